@@ -1,0 +1,178 @@
+/*
+ * pgd_amd.h - C ABI of the MI355X-native PGD fixed-point engine (libpgd_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of BAMresearch/PGDrome:
+ * PGDProblem.solve_PGD -> FP_solve -> one FEM assemble + solve per separated
+ * dimension (reference pgdrome/solver.py:306-506, 508-881).  The reference has
+ * no FFI of its own - it is pure Python that delegates every numeric step to
+ * FEniCS (dolfin/PETSc/MUMPS).  Each entry point below therefore names the
+ * reference call site(s) whose delegated native stage it replaces; the ctypes
+ * binding a maintainer would add on the reference side is in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; all objects are opaque 64-bit handles (> 0 valid);
+ *   - every function returns 0 (PGD_OK) or a negative error code, never throws
+ *     or aborts across the ABI; pgd_last_error() gives the message;
+ *   - host buffers are caller-owned, C-contiguous (f64 / i32) and are copied;
+ *     device buffers are library-owned and freed by the matching *_free;
+ *   - one context per device and process; calls on one context are serialised
+ *     by the caller; all work is enqueued on the context's single HIP stream
+ *     (the caller may hand in its own stream, e.g. torch's current stream, so
+ *     RCCL collectives issued through torch.distributed order with it);
+ *   - all arithmetic is float64, indices are int32 (nnz < 2^31 is checked).
+ */
+#ifndef PGD_AMD_H
+#define PGD_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int64_t pgd_handle;
+
+enum {
+    PGD_OK = 0,
+    PGD_ERR_INVALID = -1,   /* bad handle / argument / shape mismatch            */
+    PGD_ERR_HIP = -2,       /* a HIP runtime call failed                         */
+    PGD_ERR_NOMEM = -3,
+    PGD_ERR_LIMIT = -4,     /* a structural limit was exceeded (row too long...) */
+    PGD_ERR_SINGULAR = -5,  /* zero pivot / PCG breakdown                        */
+    PGD_ERR_NODEVICE = -6
+};
+
+/* element-matrix kinds ("atoms"); row = test, col = trial */
+enum {
+    PGD_ATOM_MASS = 0,    /* int u v                                              */
+    PGD_ATOM_STIFF = 1,   /* int grad u . grad v                                  */
+    PGD_ATOM_DUDV = 2,    /* int u_{,da} v_{,db}                                  */
+    PGD_ATOM_CONV = 3,    /* int u_{,da} v        (time derivative term)          */
+    PGD_ATOM_CONVT = 4,   /* int u v_{,db}                                        */
+    PGD_ATOM_WMASS = 5,   /* int w u v,  w a P1 vertex field                      */
+    PGD_ATOM_WSTIFF = 6   /* int w grad u . grad v                                */
+};
+
+/* ----------------------------------------------------------------- context --- */
+/* stream: NULL -> the library creates its own HIP stream; otherwise a
+ * hipStream_t owned by the caller.                                              */
+int pgd_ctx_create(int device, void *stream, pgd_handle *ctx);
+int pgd_ctx_destroy(pgd_handle ctx);
+int pgd_sync(pgd_handle ctx);
+const char *pgd_last_error(pgd_handle ctx);
+int pgd_version(void);
+int pgd_device_count(void);
+
+/* ------------------------------------------------------------------ meshes --- */
+/* Replaces dolfin's Mesh + DofMap + sparsity-pattern build behind
+ * FunctionSpace(mesh,"CG",1) (callers: tests/integration/test_heat1D.py:26-40).
+ * coords: nv x gdim row-major; cells: nc x nvpc (nvpc = gdim+1 simplices).
+ * Builds on the device: vertex->cell adjacency (sorted) and the CSR pattern of
+ * "vertices sharing a cell" with sorted columns.                                */
+int pgd_mesh_upload(pgd_handle ctx, const double *coords, int64_t nv, int gdim,
+                    const int32_t *cells, int64_t nc, int nvpc, pgd_handle *mesh);
+int pgd_mesh_info(pgd_handle ctx, pgd_handle mesh, int64_t *nv, int64_t *nc, int64_t *nnz,
+                  int32_t *max_row_len, int32_t *kl, int32_t *ku);
+int pgd_mesh_pattern_download(pgd_handle ctx, pgd_handle mesh, int32_t *row_ptr, int32_t *cols);
+int pgd_mesh_free(pgd_handle ctx, pgd_handle mesh);
+
+/* ----------------------------------------------------------------- vectors --- */
+int pgd_vec_alloc(pgd_handle ctx, int64_t n, pgd_handle *vec);
+int pgd_vec_free(pgd_handle ctx, pgd_handle vec);
+int pgd_vec_size(pgd_handle ctx, pgd_handle vec, int64_t *n);
+int pgd_vec_upload(pgd_handle ctx, pgd_handle vec, const double *host, int64_t offset, int64_t count);
+int pgd_vec_download(pgd_handle ctx, pgd_handle vec, double *host, int64_t offset, int64_t count);
+int pgd_vec_ptr(pgd_handle ctx, pgd_handle vec, void **device_ptr);
+int pgd_vec_fill(pgd_handle ctx, pgd_handle vec, double value);
+int pgd_vec_copy(pgd_handle ctx, pgd_handle dst, pgd_handle src);
+int pgd_vec_scale(pgd_handle ctx, pgd_handle vec, double a);                 /* v *= a      */
+int pgd_vec_axpy(pgd_handle ctx, pgd_handle y, double a, pgd_handle x);      /* y += a x    */
+int pgd_vec_set(pgd_handle ctx, pgd_handle vec, const int32_t *idx, const double *val, int64_t n);
+/* dot over [lo,hi) (hi < 0 -> whole vector); deterministic two-stage reduction.
+ * Replaces Vector.inner / the Euclidean residual norm of solver.py:388.         */
+int pgd_vec_dot(pgd_handle ctx, pgd_handle x, pgd_handle y, int64_t lo, int64_t hi, double *out);
+
+/* ------------------------------------------------------------------- atoms --- */
+/* Replaces FFC tabulate_tensor + dolfin Assembler for one bilinear "atom" on
+ * one separated dimension (triggered from solver.py:636,716 and from every
+ * dolfin.assemble inside the callbacks, e.g. test_heat1D.py:59-62).  Values
+ * are laid out over the mesh's CSR pattern.  wvec: vertex weights for the
+ * weighted kinds, 0 otherwise.  Deterministic (owner-computes, no atomics).     */
+int pgd_atom_assemble(pgd_handle ctx, pgd_handle mesh, int kind, int da, int db,
+                      pgd_handle wvec, pgd_handle *atom);
+int pgd_atom_upload(pgd_handle ctx, pgd_handle mesh, const double *vals, pgd_handle *atom);
+int pgd_atom_download(pgd_handle ctx, pgd_handle atom, double *vals);
+int pgd_atom_free(pgd_handle ctx, pgd_handle atom);
+
+/* --------------------------------------------------------------- operators --- */
+/* A = sum_t coefs[t] * atoms[t] with symmetric Dirichlet elimination of
+ * bc_dofs (rows and columns -> identity).  Replaces the per-solve global
+ * re-assembly + DirichletBC.apply inside LinearVariationalSolver.solve()
+ * (solver.py:627-636, 704-716).  *op == 0 allocates, otherwise the storage of
+ * the existing operator (same mesh) is reused.  The result is an atom handle.   */
+int pgd_op_combine(pgd_handle ctx, pgd_handle mesh, const pgd_handle *atoms, const double *coefs,
+                   int n, const int32_t *bc_dofs, int64_t nbc, pgd_handle *op);
+
+/* y[r0:r1) = (A x)[r0:r1)  (r1 < 0 -> all rows).  The gated kernel k_spmv_csr.  */
+int pgd_spmv(pgd_handle ctx, pgd_handle A, pgd_handle x, pgd_handle y, int64_t r0, int64_t r1);
+/* out = sum_{i in [r0,r1)} x_i (A y)_i.  Replaces assemble(F*A*G*dx) scalars
+ * (callbacks; solver.py:443, 839-841) and dolfin.norm (solver.py:342,754,837).  */
+int pgd_bilinear(pgd_handle ctx, pgd_handle A, pgd_handle x, pgd_handle y, int64_t r0, int64_t r1,
+                 double *out);
+/* out[m] = sum_i x_i (A y_m)_i for m < ny: one pass over A for a whole family of
+ * stored modes (the O(n_enr) scalar functionals of rhs_fct, test_heat1D.py:141-165). */
+int pgd_bilinear_many(pgd_handle ctx, pgd_handle A, pgd_handle x, const pgd_handle *ys, int ny,
+                      int64_t r0, int64_t r1, double *out);
+
+/* ----------------------------------------------------------------- solvers --- */
+/* Jacobi-preconditioned CG, x holds the start vector and receives the solution.
+ * Stops when ||r||_2 <= max(rtol ||b||_2, atol).  Replaces PETSc/MUMPS behind
+ * solver.solve() (solver.py:592-595, 633-636) for the SPD spatial systems.      */
+int pgd_pcg_solve(pgd_handle ctx, pgd_handle op, pgd_handle b, pgd_handle x, double rtol,
+                  double atol, int maxit, int *iters, double *relres);
+/* Banded LU with partial pivoting in one workgroup, for the small and possibly
+ * non-symmetric 1-D systems (time: u'v) and the FD-mode solve (solver.py:939).  */
+int pgd_band_solve(pgd_handle ctx, pgd_handle op, pgd_handle b, pgd_handle x);
+
+/* ------------------------------------------------- distributed PCG pieces --- */
+/* Row-sharded solve: the host drives the recurrence and places the RCCL halo
+ * exchange / all-reduce between these calls (pgdrome_amd/dist.py).  Scalars
+ * live in a device bank of PGD_NSLOTS doubles so nothing round-trips to the
+ * host inside an iteration; every kernel is a no-op once the done flag is set. */
+#define PGD_NSLOTS 64
+int pgd_slots_ptr(pgd_handle ctx, void **device_ptr);
+int pgd_slots_download(pgd_handle ctx, double *out, int first, int count);
+int pgd_slots_upload(pgd_handle ctx, const double *in, int first, int count);
+int pgd_flags_reset(pgd_handle ctx);
+int pgd_flags_download(pgd_handle ctx, int32_t *done, int32_t *iters, int32_t *status);
+int pgd_op_diag_inv(pgd_handle ctx, pgd_handle op, pgd_handle dinv);
+/* y = A x on [r0,r1), slot <- sum w_i y_i (local part)                          */
+int pgd_spmv_dot_slot(pgd_handle ctx, pgd_handle A, pgd_handle x, pgd_handle y, pgd_handle w,
+                      int64_t r0, int64_t r1, int slot);
+/* r = b - q, z = dinv r, p = z on [r0,r1); slots s..s+2 <- (r.z, r.r, b.b)       */
+int pgd_pcg_init_slot(pgd_handle ctx, pgd_handle b, pgd_handle q, pgd_handle dinv, pgd_handle r,
+                      pgd_handle z, pgd_handle p, int64_t r0, int64_t r1, int slot);
+/* tol2 slot <- max(rtol^2 S[bb], atol^2); done <- S[rr] <= tol2                  */
+int pgd_pcg_tol_slot(pgd_handle ctx, double rtol, double atol, int slot_rr, int slot_bb,
+                     int slot_tol2);
+/* alpha = S[rz]/S[pq]; x += alpha p; r -= alpha q; z = dinv r;
+ * slots out..out+1 <- (r.z, r.r)                                                */
+int pgd_pcg_xr_slot(pgd_handle ctx, pgd_handle x, pgd_handle r, pgd_handle p, pgd_handle q,
+                    pgd_handle dinv, pgd_handle z, int64_t r0, int64_t r1, int slot_rz,
+                    int slot_pq, int slot_out);
+/* iters += 1; done <- S[rr] <= S[tol2] (or breakdown)                            */
+int pgd_pcg_check_slot(pgd_handle ctx, int slot_rr, int slot_tol2);
+/* beta = S[num]/S[den]; p = z + beta p                                           */
+int pgd_pcg_p_slot(pgd_handle ctx, pgd_handle p, pgd_handle z, int64_t r0, int64_t r1,
+                   int slot_num, int slot_den);
+
+/* --------------------------------------------------------------- measuring --- */
+/* HIP-event timing of every k_spmv_csr launch on the context's stream
+ * (roofline.achieved = algorithmic bytes / launch time).  */
+int pgd_prof_enable(pgd_handle ctx, int on);
+int pgd_prof_read(pgd_handle ctx, int64_t *launches, double *seconds, double *alg_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGD_AMD_H */

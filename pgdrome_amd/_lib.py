@@ -1,0 +1,343 @@
+"""ctypes binding of include/pgd_amd.h (libpgd_amd.so).
+
+This is the whole Python <-> native boundary: plain pointers, sizes and 64-bit
+handles.  Loading never falls back to a CPU implementation: a missing library
+or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+LIB_PATH = Path(__file__).resolve().parent / "lib" / "libpgd_amd.so"
+
+H = C.c_int64
+I64 = C.c_int64
+I32 = C.c_int32
+F64 = C.c_double
+PD = C.POINTER(C.c_double)
+PI32 = C.POINTER(C.c_int32)
+PI64 = C.POINTER(C.c_int64)
+PH = C.POINTER(C.c_int64)
+VP = C.c_void_p
+
+# name -> (restype, argtypes); mirrors include/pgd_amd.h declaration by declaration
+SIGNATURES = {
+    "pgd_ctx_create": (C.c_int, [C.c_int, VP, PH]),
+    "pgd_ctx_destroy": (C.c_int, [H]),
+    "pgd_sync": (C.c_int, [H]),
+    "pgd_last_error": (C.c_char_p, [H]),
+    "pgd_version": (C.c_int, []),
+    "pgd_device_count": (C.c_int, []),
+    "pgd_mesh_upload": (C.c_int, [H, PD, I64, C.c_int, PI32, I64, C.c_int, PH]),
+    "pgd_mesh_info": (C.c_int, [H, H, PI64, PI64, PI64, PI32, PI32, PI32]),
+    "pgd_mesh_pattern_download": (C.c_int, [H, H, PI32, PI32]),
+    "pgd_mesh_free": (C.c_int, [H, H]),
+    "pgd_vec_alloc": (C.c_int, [H, I64, PH]),
+    "pgd_vec_free": (C.c_int, [H, H]),
+    "pgd_vec_size": (C.c_int, [H, H, PI64]),
+    "pgd_vec_upload": (C.c_int, [H, H, PD, I64, I64]),
+    "pgd_vec_download": (C.c_int, [H, H, PD, I64, I64]),
+    "pgd_vec_ptr": (C.c_int, [H, H, C.POINTER(VP)]),
+    "pgd_vec_fill": (C.c_int, [H, H, F64]),
+    "pgd_vec_copy": (C.c_int, [H, H, H]),
+    "pgd_vec_scale": (C.c_int, [H, H, F64]),
+    "pgd_vec_axpy": (C.c_int, [H, H, F64, H]),
+    "pgd_vec_set": (C.c_int, [H, H, PI32, PD, I64]),
+    "pgd_vec_dot": (C.c_int, [H, H, H, I64, I64, PD]),
+    "pgd_atom_assemble": (C.c_int, [H, H, C.c_int, C.c_int, C.c_int, H, PH]),
+    "pgd_atom_upload": (C.c_int, [H, H, PD, PH]),
+    "pgd_atom_download": (C.c_int, [H, H, PD]),
+    "pgd_atom_free": (C.c_int, [H, H]),
+    "pgd_op_combine": (C.c_int, [H, H, PH, PD, C.c_int, PI32, I64, PH]),
+    "pgd_spmv": (C.c_int, [H, H, H, H, I64, I64]),
+    "pgd_bilinear": (C.c_int, [H, H, H, H, I64, I64, PD]),
+    "pgd_bilinear_many": (C.c_int, [H, H, H, PH, C.c_int, I64, I64, PD]),
+    "pgd_pcg_solve": (C.c_int, [H, H, H, H, F64, F64, C.c_int, C.POINTER(C.c_int), PD]),
+    "pgd_band_solve": (C.c_int, [H, H, H, H]),
+    "pgd_slots_ptr": (C.c_int, [H, C.POINTER(VP)]),
+    "pgd_slots_download": (C.c_int, [H, PD, C.c_int, C.c_int]),
+    "pgd_slots_upload": (C.c_int, [H, PD, C.c_int, C.c_int]),
+    "pgd_flags_reset": (C.c_int, [H]),
+    "pgd_flags_download": (C.c_int, [H, PI32, PI32, PI32]),
+    "pgd_op_diag_inv": (C.c_int, [H, H, H]),
+    "pgd_spmv_dot_slot": (C.c_int, [H, H, H, H, H, I64, I64, C.c_int]),
+    "pgd_pcg_init_slot": (C.c_int, [H, H, H, H, H, H, H, I64, I64, C.c_int]),
+    "pgd_pcg_tol_slot": (C.c_int, [H, F64, F64, C.c_int, C.c_int, C.c_int]),
+    "pgd_pcg_xr_slot": (C.c_int, [H, H, H, H, H, H, H, I64, I64, C.c_int, C.c_int, C.c_int]),
+    "pgd_pcg_check_slot": (C.c_int, [H, C.c_int, C.c_int]),
+    "pgd_pcg_p_slot": (C.c_int, [H, H, H, I64, I64, C.c_int, C.c_int]),
+    "pgd_prof_enable": (C.c_int, [H, C.c_int]),
+    "pgd_prof_read": (C.c_int, [H, PI64, PD, PD]),
+}
+
+NSLOTS = 64
+
+
+class PgdError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libpgd_amd error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def load(path: Path | None = None):
+    """dlopen libpgd_amd.so and type every entry point.  Raises if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise RuntimeError(
+            f"{p} not found: build the HIP library first (python -m pgdrome_amd.build). "
+            "pgdrome_amd has no CPU fallback.")
+    lib = C.CDLL(str(p))
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def dptr(a: np.ndarray):
+    assert a.dtype == np.float64 and a.flags.c_contiguous
+    return a.ctypes.data_as(PD)
+
+
+def iptr(a: np.ndarray):
+    assert a.dtype == np.int32 and a.flags.c_contiguous
+    return a.ctypes.data_as(PI32)
+
+
+class Context:
+    """One device context; thin, checked wrappers around the C entry points."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self.lib = load()
+        if self.lib.pgd_device_count() <= 0:
+            raise RuntimeError("pgdrome_amd: no HIP device visible (no CPU fallback exists)")
+        h = H(0)
+        rc = self.lib.pgd_ctx_create(device, VP(stream) if stream else None, C.byref(h))
+        if rc != 0:
+            raise PgdError(rc, self.lib.pgd_last_error(0).decode())
+        self.h = h.value
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", 0):
+            self.lib.pgd_ctx_destroy(self.h)
+            self.h = 0
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc):
+        if rc != 0:
+            raise PgdError(rc, self.lib.pgd_last_error(self.h).decode())
+
+    def sync(self):
+        self._ck(self.lib.pgd_sync(self.h))
+
+    # ---- meshes
+    def mesh_upload(self, coords, cells):
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        if coords.ndim == 1:
+            coords = coords.reshape(-1, 1)
+        m = H(0)
+        self._ck(self.lib.pgd_mesh_upload(self.h, dptr(coords), coords.shape[0], coords.shape[1],
+                                          iptr(cells), cells.shape[0], cells.shape[1], C.byref(m)))
+        return m.value
+
+    def mesh_info(self, mesh):
+        nv, nc, nnz = I64(), I64(), I64()
+        mr, kl, ku = I32(), I32(), I32()
+        self._ck(self.lib.pgd_mesh_info(self.h, mesh, C.byref(nv), C.byref(nc), C.byref(nnz),
+                                        C.byref(mr), C.byref(kl), C.byref(ku)))
+        return dict(nv=nv.value, nc=nc.value, nnz=nnz.value, max_row=mr.value, kl=kl.value, ku=ku.value)
+
+    def mesh_pattern(self, mesh):
+        info = self.mesh_info(mesh)
+        rp = np.empty(info["nv"] + 1, dtype=np.int32)
+        cols = np.empty(max(info["nnz"], 1), dtype=np.int32)
+        self._ck(self.lib.pgd_mesh_pattern_download(self.h, mesh, iptr(rp), iptr(cols)))
+        return rp, cols[: info["nnz"]]
+
+    def mesh_free(self, mesh):
+        self._ck(self.lib.pgd_mesh_free(self.h, mesh))
+
+    # ---- vectors
+    def vec_alloc(self, n):
+        v = H(0)
+        self._ck(self.lib.pgd_vec_alloc(self.h, int(n), C.byref(v)))
+        return v.value
+
+    def vec_from(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        v = self.vec_alloc(a.size)
+        self.vec_upload(v, a)
+        return v
+
+    def vec_free(self, v):
+        self._ck(self.lib.pgd_vec_free(self.h, v))
+
+    def vec_size(self, v):
+        n = I64()
+        self._ck(self.lib.pgd_vec_size(self.h, v, C.byref(n)))
+        return n.value
+
+    def vec_upload(self, v, a, offset=0):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        self._ck(self.lib.pgd_vec_upload(self.h, v, dptr(a), int(offset), a.size))
+
+    def vec_download(self, v, offset=0, count=None):
+        if count is None:
+            count = self.vec_size(v) - offset
+        out = np.empty(count, dtype=np.float64)
+        self._ck(self.lib.pgd_vec_download(self.h, v, dptr(out), int(offset), int(count)))
+        return out
+
+    def vec_ptr(self, v):
+        p = VP()
+        self._ck(self.lib.pgd_vec_ptr(self.h, v, C.byref(p)))
+        return p.value
+
+    def vec_fill(self, v, a):
+        self._ck(self.lib.pgd_vec_fill(self.h, v, float(a)))
+
+    def vec_copy(self, dst, src):
+        self._ck(self.lib.pgd_vec_copy(self.h, dst, src))
+
+    def vec_scale(self, v, a):
+        self._ck(self.lib.pgd_vec_scale(self.h, v, float(a)))
+
+    def vec_axpy(self, y, a, x):
+        self._ck(self.lib.pgd_vec_axpy(self.h, y, float(a), x))
+
+    def vec_set(self, v, idx, val):
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        val = np.ascontiguousarray(np.broadcast_to(np.asarray(val, dtype=np.float64), idx.shape))
+        self._ck(self.lib.pgd_vec_set(self.h, v, iptr(idx), dptr(val), idx.size))
+
+    def vec_dot(self, x, y, lo=0, hi=-1):
+        out = F64()
+        self._ck(self.lib.pgd_vec_dot(self.h, x, y, int(lo), int(hi), C.byref(out)))
+        return out.value
+
+    # ---- atoms / operators
+    def atom_assemble(self, mesh, kind, da=0, db=0, w=0):
+        a = H(0)
+        self._ck(self.lib.pgd_atom_assemble(self.h, mesh, int(kind), int(da), int(db), int(w), C.byref(a)))
+        return a.value
+
+    def atom_upload(self, mesh, vals):
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        a = H(0)
+        self._ck(self.lib.pgd_atom_upload(self.h, mesh, dptr(vals), C.byref(a)))
+        return a.value
+
+    def atom_download(self, atom, nnz):
+        out = np.empty(max(nnz, 1), dtype=np.float64)
+        self._ck(self.lib.pgd_atom_download(self.h, atom, dptr(out)))
+        return out[:nnz]
+
+    def atom_free(self, a):
+        self._ck(self.lib.pgd_atom_free(self.h, a))
+
+    def op_combine(self, mesh, atoms, coefs, bc_dofs=None, op=0):
+        n = len(atoms)
+        arr = (H * n)(*[int(a) for a in atoms])
+        cf = np.ascontiguousarray(coefs, dtype=np.float64)
+        bc = np.ascontiguousarray(bc_dofs if bc_dofs is not None else [], dtype=np.int32)
+        o = H(int(op))
+        self._ck(self.lib.pgd_op_combine(self.h, mesh, arr, dptr(cf), n,
+                                         iptr(bc) if bc.size else None, bc.size, C.byref(o)))
+        return o.value
+
+    def spmv(self, A, x, y, r0=0, r1=-1):
+        self._ck(self.lib.pgd_spmv(self.h, A, x, y, int(r0), int(r1)))
+
+    def bilinear(self, A, x, y, r0=0, r1=-1):
+        out = F64()
+        self._ck(self.lib.pgd_bilinear(self.h, A, x, y, int(r0), int(r1), C.byref(out)))
+        return out.value
+
+    def bilinear_many(self, A, x, ys, r0=0, r1=-1):
+        n = len(ys)
+        out = np.zeros(max(n, 1), dtype=np.float64)
+        arr = (H * max(n, 1))(*[int(v) for v in ys])
+        self._ck(self.lib.pgd_bilinear_many(self.h, A, x, arr, n, int(r0), int(r1), dptr(out)))
+        return out[:n]
+
+    def pcg_solve(self, op, b, x, rtol=1e-10, atol=0.0, maxit=10000):
+        it = C.c_int()
+        rel = F64()
+        self._ck(self.lib.pgd_pcg_solve(self.h, op, b, x, float(rtol), float(atol), int(maxit),
+                                        C.byref(it), C.byref(rel)))
+        return it.value, rel.value
+
+    def band_solve(self, op, b, x):
+        self._ck(self.lib.pgd_band_solve(self.h, op, b, x))
+
+    # ---- distributed PCG pieces
+    def slots_ptr(self):
+        p = VP()
+        self._ck(self.lib.pgd_slots_ptr(self.h, C.byref(p)))
+        return p.value
+
+    def slots_download(self, first=0, count=NSLOTS):
+        out = np.empty(count, dtype=np.float64)
+        self._ck(self.lib.pgd_slots_download(self.h, dptr(out), int(first), int(count)))
+        return out
+
+    def slots_upload(self, vals, first=0):
+        vals = np.ascontiguousarray(vals, dtype=np.float64)
+        self._ck(self.lib.pgd_slots_upload(self.h, dptr(vals), int(first), vals.size))
+
+    def flags_reset(self):
+        self._ck(self.lib.pgd_flags_reset(self.h))
+
+    def flags(self):
+        d, i, s = I32(), I32(), I32()
+        self._ck(self.lib.pgd_flags_download(self.h, C.byref(d), C.byref(i), C.byref(s)))
+        return d.value, i.value, s.value
+
+    def op_diag_inv(self, op, dinv):
+        self._ck(self.lib.pgd_op_diag_inv(self.h, op, dinv))
+
+    def spmv_dot_slot(self, A, x, y, w, r0, r1, slot):
+        self._ck(self.lib.pgd_spmv_dot_slot(self.h, A, x, y, w, int(r0), int(r1), int(slot)))
+
+    def pcg_init_slot(self, b, q, dinv, r, z, p, lo, hi, slot):
+        self._ck(self.lib.pgd_pcg_init_slot(self.h, b, q, dinv, r, z, p, int(lo), int(hi), int(slot)))
+
+    def pcg_tol_slot(self, rtol, atol, slot_rr, slot_bb, slot_tol2):
+        self._ck(self.lib.pgd_pcg_tol_slot(self.h, float(rtol), float(atol), slot_rr, slot_bb, slot_tol2))
+
+    def pcg_xr_slot(self, x, r, p, q, dinv, z, lo, hi, slot_rz, slot_pq, slot_out):
+        self._ck(self.lib.pgd_pcg_xr_slot(self.h, x, r, p, q, dinv, z, int(lo), int(hi),
+                                          slot_rz, slot_pq, slot_out))
+
+    def pcg_check_slot(self, slot_rr, slot_tol2):
+        self._ck(self.lib.pgd_pcg_check_slot(self.h, slot_rr, slot_tol2))
+
+    def pcg_p_slot(self, p, z, lo, hi, slot_num, slot_den):
+        self._ck(self.lib.pgd_pcg_p_slot(self.h, p, z, int(lo), int(hi), slot_num, slot_den))
+
+    # ---- measuring
+    def prof_enable(self, on=True):
+        self._ck(self.lib.pgd_prof_enable(self.h, 1 if on else 0))
+
+    def prof_read(self):
+        n, s, b = I64(), F64(), F64()
+        self._ck(self.lib.pgd_prof_read(self.h, C.byref(n), C.byref(s), C.byref(b)))
+        return dict(launches=n.value, seconds=s.value, bytes=b.value)

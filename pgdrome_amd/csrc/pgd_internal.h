@@ -1,0 +1,182 @@
+// Internal declarations shared by the translation units of libpgd_amd.so.
+// gfx950 (MI355X) only: 64-lane wavefronts, 256 CUs in 8 XCDs, 160 KiB LDS/CU.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/pgd_amd.h"
+
+namespace pgd {
+
+constexpr int WAVE = 64;
+constexpr int TPB = 256;            // threads per workgroup everywhere (4 waves)
+constexpr int MAX_VEC_BLOCKS = 2048;  // grid cap of the grid-stride vector kernels (8 per CU)
+constexpr int N_XCD = 8;
+constexpr size_t PAD_BYTES = 256;   // slack after every device array (vector over-reads)
+
+// slots of the device scalar bank used by the library's own PCG loop
+enum { S_PQ = 2, S_TOL2 = 5, S_TMP = 8 /* ..15: batched functionals */ };   // 16..22: PCG r.z / r.r / b.b
+
+struct Obj {
+    enum Kind { FREE = 0, VEC, MESH, CSR } kind = FREE;
+    virtual ~Obj() {}
+};
+
+struct Vec : Obj {
+    double *d = nullptr;
+    int64_t n = 0;
+    ~Vec() override { if (d) (void)hipFree(d); }
+};
+
+struct Mesh : Obj {
+    int gdim = 0, nvpc = 0;
+    int64_t nv = 0, nc = 0, nnz = 0;
+    double *coords = nullptr;   // SoA: gdim arrays of nv doubles (coalesced per component)
+    int4 *cells = nullptr;      // one 16-byte record per cell, unused lanes = -1
+    int *v2c_ptr = nullptr;     // nv+1
+    int *v2c = nullptr;         // nc*nvpc, sorted per vertex
+    int *row_ptr = nullptr;     // nv+1
+    int *cols = nullptr;        // nnz, sorted per row
+    int max_row = 0, kl = 0, ku = 0;
+    ~Mesh() override {
+        for (void *p : {(void *)coords, (void *)cells, (void *)v2c_ptr, (void *)v2c,
+                        (void *)row_ptr, (void *)cols})
+            if (p) (void)hipFree(p);
+    }
+};
+
+struct Csr : Obj {
+    pgd_handle mesh = 0;
+    double *vals = nullptr;
+    double *dinv = nullptr;    // lazily built inverse diagonal
+    bool dinv_valid = false;
+    ~Csr() override {
+        if (vals) (void)hipFree(vals);
+        if (dinv) (void)hipFree(dinv);
+    }
+};
+
+struct Ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    std::vector<std::unique_ptr<Obj>> objs;   // handle = index + 1
+    std::vector<int64_t> free_list;
+
+    double *slots = nullptr;      // PGD_NSLOTS doubles
+    int *flags = nullptr;         // [0] done, [1] iters, [2] status
+    double *partials = nullptr;   // reduction scratch
+    int64_t partials_cap = 0;
+    double *work[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t work_cap[6] = {0, 0, 0, 0, 0, 0};
+    uint8_t *mask = nullptr;      // Dirichlet column mask scratch
+    int64_t mask_cap = 0;
+    int *ibuf = nullptr;          // small int32 scratch (bc dofs, index lists)
+    int64_t ibuf_cap = 0;
+
+    // SpMV launch timing (HIP events on `stream`)
+    bool prof = false;
+    std::vector<hipEvent_t> ev;   // pairs
+    size_t ev_used = 0;
+    int64_t prof_launches = 0;
+    double prof_seconds = 0.0, prof_bytes = 0.0;
+};
+
+// ---- helpers implemented in pgd_ctx.hip
+Ctx *get_ctx(pgd_handle h);
+int fail(Ctx *c, int code, const char *fmt, ...);
+pgd_handle put_obj(Ctx *c, Obj *o);
+Obj *get_obj(Ctx *c, pgd_handle h, Obj::Kind k);
+int free_obj(Ctx *c, pgd_handle h, Obj::Kind k);
+int dev_alloc(Ctx *c, void **p, size_t bytes);
+int ensure_partials(Ctx *c, int64_t n);
+int ensure_work(Ctx *c, int i, int64_t n);
+int ensure_mask(Ctx *c, int64_t n);
+int ensure_ibuf(Ctx *c, int64_t n);
+void prof_flush(Ctx *c);
+
+inline Vec *get_vec(Ctx *c, pgd_handle h) { return static_cast<Vec *>(get_obj(c, h, Obj::VEC)); }
+inline Mesh *get_mesh(Ctx *c, pgd_handle h) { return static_cast<Mesh *>(get_obj(c, h, Obj::MESH)); }
+inline Csr *get_csr(Ctx *c, pgd_handle h) { return static_cast<Csr *>(get_obj(c, h, Obj::CSR)); }
+
+#define PGD_CTX(c, h)                         \
+    pgd::Ctx *c = pgd::get_ctx(h);            \
+    if (!c) return PGD_ERR_INVALID;           \
+    (void)hipSetDevice(c->device)
+
+#define PGD_HIP(c, call)                                                                    \
+    do {                                                                                    \
+        hipError_t e_ = (call);                                                             \
+        if (e_ != hipSuccess)                                                               \
+            return pgd::fail(c, PGD_ERR_HIP, "%s failed: %s (%s:%d)", #call,                \
+                             hipGetErrorString(e_), __FILE__, __LINE__);                    \
+    } while (0)
+
+#define PGD_TRY(call)                \
+    do {                             \
+        int rc_ = (call);            \
+        if (rc_ != PGD_OK) return rc_; \
+    } while (0)
+
+#define PGD_LAUNCH_CHECK(c) PGD_HIP(c, hipGetLastError())
+
+inline int grid_for(int64_t n, int per_block = TPB, int cap = MAX_VEC_BLOCKS) {
+    int64_t g = (n + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (int)g;
+}
+
+// ---- launchers implemented across translation units
+// pgd_vec.hip
+int scan_exclusive_i32(Ctx *c, const int *in, int *out, int64_t n);   // out has n+1 entries
+int reduce_partials(Ctx *c, const double *partials, int nparts, int nvals, int slot0, int check_mode,
+                    int slot_rr, int slot_tol2);
+int vec_dot_range(Ctx *c, const double *x, const double *y, int64_t lo, int64_t hi, int slot);
+// pgd_spmv.hip
+int launch_spmv(Ctx *c, const Mesh *m, const double *vals, const double *x, double *y,
+                const double *w, int64_t r0, int64_t r1, bool dot, bool store, const int *flags,
+                int *nparts_out);
+int launch_spmv_multi(Ctx *c, const Mesh *m, const double *vals, const double *x,
+                      const double *const *ys, int ny, int64_t r0, int64_t r1, double *out_host);
+// pgd_pcg.hip
+int csr_diag_inv(Ctx *c, const Mesh *m, Csr *a);
+
+}  // namespace pgd
+
+// ---- device helpers --------------------------------------------------------------
+namespace pgd {
+
+// Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8 share an
+// L2).  Give every XCD one contiguous chunk of the logical tile range so that
+// neighbouring row blocks - which gather the same x planes - hit the same L2.
+// Bijective for any grid size; placement only affects speed, never results.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, rem = nblk & 7, k = bid & 7;
+    return k * q + (k < rem ? k : rem) + (bid >> 3);
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Sum over a 256-thread workgroup in a fixed order; result valid in thread 0.
+__device__ __forceinline__ double block_sum(double v, double *s_red /* >= 4 */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) s_red[wv] = v;
+    __syncthreads();
+    return (threadIdx.x == 0) ? ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) : 0.0;
+}
+
+}  // namespace pgd

@@ -1,0 +1,413 @@
+// Mesh upload, vertex->cell adjacency, CSR pattern and P1 element assembly.
+//
+// Assembly is OWNER-COMPUTES: the workgroup that owns 256 consecutive rows
+// gathers, per row, the element-matrix rows of all incident cells in a fixed
+// (sorted) order and accumulates them in an LDS image of the rows' contiguous
+// CSR segment, which is then written out with coalesced stores.  No atomics,
+// bitwise reproducible, and the nodal coordinates are read from SoA arrays so
+// that neighbouring rows read neighbouring addresses.  This is the LDS-staged
+// scatter into CSR of the north star, turned into a gather.
+#include "pgd_internal.h"
+
+namespace pgd {
+
+constexpr int MAX_ROW = 64;         // max P1 row length supported by the pattern builder
+constexpr int ASM_CAP = 6144;       // CSR entries staged per 256-row workgroup (72 KiB LDS)
+
+// ------------------------------------------------------------------ adjacency
+__global__ __launch_bounds__(TPB) void k_v2c_count(const int4 *__restrict__ cells, int64_t nc, int nvpc,
+                                                   int *__restrict__ cnt) {
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < nc; e += (int64_t)gridDim.x * TPB) {
+        const int4 c = cells[e];
+        const int v[4] = {c.x, c.y, c.z, c.w};
+        for (int j = 0; j < nvpc; ++j) atomicAdd(&cnt[v[j]], 1);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_v2c_fill(const int4 *__restrict__ cells, int64_t nc, int nvpc,
+                                                  const int *__restrict__ ptr, int *__restrict__ cursor,
+                                                  int *__restrict__ v2c) {
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < nc; e += (int64_t)gridDim.x * TPB) {
+        const int4 c = cells[e];
+        const int v[4] = {c.x, c.y, c.z, c.w};
+        for (int j = 0; j < nvpc; ++j) {
+            const int pos = atomicAdd(&cursor[v[j]], 1);
+            v2c[ptr[v[j]] + pos] = (int)e;
+        }
+    }
+}
+
+// atomics filled the lists in arrival order: sort each (short) list so that every
+// later pass sees the incident cells in ascending cell id - fixed summation order.
+__global__ __launch_bounds__(TPB) void k_v2c_sort(const int *__restrict__ ptr, int *__restrict__ v2c, int64_t nv) {
+    for (int64_t v = (int64_t)blockIdx.x * TPB + threadIdx.x; v < nv; v += (int64_t)gridDim.x * TPB) {
+        const int a = ptr[v], b = ptr[v + 1];
+        for (int i = a + 1; i < b; ++i) {
+            const int key = v2c[i];
+            int j = i - 1;
+            while (j >= a && v2c[j] > key) { v2c[j + 1] = v2c[j]; --j; }
+            v2c[j + 1] = key;
+        }
+    }
+}
+
+// --------------------------------------------------------------------- pattern
+// Sorted-unique neighbour list of one vertex into s_row (LDS, one row per thread,
+// stride MAX_ROW+1 to keep the banks apart).  Returns the length, or -1 on overflow.
+__device__ __forceinline__ int gather_row(int v, const int4 *__restrict__ cells, int nvpc,
+                                          const int *__restrict__ v2c_ptr, const int *__restrict__ v2c,
+                                          int *s_row) {
+    int len = 0;
+    const int a = v2c_ptr[v], b = v2c_ptr[v + 1];
+    for (int k = a; k < b; ++k) {
+        const int4 c = cells[v2c[k]];
+        const int u[4] = {c.x, c.y, c.z, c.w};
+        for (int j = 0; j < nvpc; ++j) {
+            const int w = u[j];
+            int pos = 0;
+            while (pos < len && s_row[pos] < w) ++pos;
+            if (pos < len && s_row[pos] == w) continue;
+            if (len >= MAX_ROW) return -1;
+            for (int t = len; t > pos; --t) s_row[t] = s_row[t - 1];
+            s_row[pos] = w;
+            ++len;
+        }
+    }
+    return len;
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(TPB) void k_pattern(const int4 *__restrict__ cells, int nvpc,
+                                                 const int *__restrict__ v2c_ptr, const int *__restrict__ v2c,
+                                                 int64_t nv, int *__restrict__ row_len,
+                                                 const int *__restrict__ row_ptr, int *__restrict__ cols,
+                                                 int *__restrict__ stats /* [0] overflow, [1] max_row, [2] kl, [3] ku */) {
+    __shared__ int s_rows[TPB * (MAX_ROW + 1)];
+    const int64_t v = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (v >= nv) return;
+    int *s_row = s_rows + threadIdx.x * (MAX_ROW + 1);
+    const int len = gather_row((int)v, cells, nvpc, v2c_ptr, v2c, s_row);
+    if (len < 0) { atomicExch(&stats[0], 1); if (!FILL) row_len[v] = 0; return; }
+    if (!FILL) {
+        row_len[v] = len;
+        atomicMax(&stats[1], len);
+        if (len > 0) {
+            atomicMax(&stats[2], (int)v - s_row[0]);
+            atomicMax(&stats[3], s_row[len - 1] - (int)v);
+        }
+    } else {
+        const int base = row_ptr[v];
+        for (int k = 0; k < len; ++k) cols[base + k] = s_row[k];
+    }
+}
+
+// -------------------------------------------------------------------- assembly
+struct AsmArgs {
+    const double *cx, *cy, *cz;   // SoA coordinates
+    const int4 *cells;
+    const int *v2c_ptr, *v2c, *row_ptr, *cols;
+    const double *w;              // vertex weights (weighted kinds)
+    double *vals;
+    int64_t nv;
+    int kind, da, db;
+};
+
+template <int D>
+__device__ __forceinline__ void p1_geometry(const AsmArgs &A, const int *u, double &vol, double g[D + 1][D]) {
+    if (D == 1) {
+        const double e = A.cx[u[1]] - A.cx[u[0]];
+        vol = fabs(e);
+        g[1][0] = 1.0 / e;
+        g[0][0] = -g[1][0];
+    } else if (D == 2) {
+        const double x0 = A.cx[u[0]], y0 = A.cy[u[0]];
+        const double ax = A.cx[u[1]] - x0, ay = A.cy[u[1]] - y0;
+        const double bx = A.cx[u[2]] - x0, by = A.cy[u[2]] - y0;
+        const double det = ax * by - ay * bx, inv = 1.0 / det;
+        vol = 0.5 * fabs(det);
+        g[1][0] = by * inv;  g[1][1] = -bx * inv;
+        g[2][0] = -ay * inv; g[2][1] = ax * inv;
+        g[0][0] = -(g[1][0] + g[2][0]);
+        g[0][1] = -(g[1][1] + g[2][1]);
+    } else {
+        const double x0 = A.cx[u[0]], y0 = A.cy[u[0]], z0 = A.cz[u[0]];
+        const double ax = A.cx[u[1]] - x0, ay = A.cy[u[1]] - y0, az = A.cz[u[1]] - z0;
+        const double bx = A.cx[u[2]] - x0, by = A.cy[u[2]] - y0, bz = A.cz[u[2]] - z0;
+        const double cx = A.cx[u[3]] - x0, cy = A.cy[u[3]] - y0, cz = A.cz[u[3]] - z0;
+        // cross products: b x c, c x a, a x b
+        const double n1x = by * cz - bz * cy, n1y = bz * cx - bx * cz, n1z = bx * cy - by * cx;
+        const double n2x = cy * az - cz * ay, n2y = cz * ax - cx * az, n2z = cx * ay - cy * ax;
+        const double n3x = ay * bz - az * by, n3y = az * bx - ax * bz, n3z = ax * by - ay * bx;
+        const double det = ax * n1x + ay * n1y + az * n1z, inv = 1.0 / det;
+        vol = fabs(det) * (1.0 / 6.0);
+        g[1][0] = n1x * inv; g[1][1] = n1y * inv; g[1][2] = n1z * inv;
+        g[2][0] = n2x * inv; g[2][1] = n2y * inv; g[2][2] = n2z * inv;
+        g[3][0] = n3x * inv; g[3][1] = n3y * inv; g[3][2] = n3z * inv;
+        for (int k = 0; k < 3; ++k) g[0][k] = -(g[1][k] + g[2][k] + g[3][k]);
+    }
+}
+
+// entry (i = test, j = trial) of the local matrix; closed forms for P1 simplices
+template <int D>
+__device__ __forceinline__ double p1_entry(int kind, int da, int db, int i, int j, double vol,
+                                           const double g[D + 1][D], const double *wl) {
+    constexpr double MFAC = 1.0 / ((D + 1) * (D + 2));
+    constexpr double WFAC = (D == 1) ? 1.0 / 24.0 : (D == 2) ? 2.0 / 120.0 : 6.0 / 720.0;   // D!/(D+3)!
+    switch (kind) {
+        case PGD_ATOM_MASS: return vol * MFAC * (i == j ? 2.0 : 1.0);
+        case PGD_ATOM_STIFF: {
+            double s = 0.0;
+            for (int k = 0; k < D; ++k) s += g[i][k] * g[j][k];
+            return vol * s;
+        }
+        case PGD_ATOM_DUDV: return vol * g[i][db] * g[j][da];
+        case PGD_ATOM_CONV: return vol * (1.0 / (D + 1)) * g[j][da];
+        case PGD_ATOM_CONVT: return vol * (1.0 / (D + 1)) * g[i][db];
+        case PGD_ATOM_WMASS: {
+            double s = 0.0;
+            for (int k = 0; k < D + 1; ++k) {
+                const double cijk = (i == j) ? (k == i ? 6.0 : 2.0) : ((k == i || k == j) ? 2.0 : 1.0);
+                s += cijk * wl[k];
+            }
+            return vol * WFAC * s;
+        }
+        case PGD_ATOM_WSTIFF: {
+            double s = 0.0, wb = 0.0;
+            for (int k = 0; k < D; ++k) s += g[i][k] * g[j][k];
+            for (int k = 0; k < D + 1; ++k) wb += wl[k];
+            return vol * (wb * (1.0 / (D + 1))) * s;
+        }
+    }
+    return 0.0;
+}
+
+template <int D>
+__global__ __launch_bounds__(TPB) void k_assemble_p1(AsmArgs A) {
+    __shared__ double s_acc[ASM_CAP];
+    __shared__ int s_cols[ASM_CAP];
+    __shared__ int s_rp[TPB + 1];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * TPB;
+    const int nr = (int)min((int64_t)TPB, A.nv - r0);
+    if (tid < nr) s_rp[tid] = A.row_ptr[r0 + tid];
+    if (tid == 0) s_rp[nr] = A.row_ptr[r0 + nr];
+    __syncthreads();
+    const int s = s_rp[0], e = s_rp[nr];
+    const bool staged = (e - s) <= ASM_CAP;   // uniform
+    if (staged) {
+        for (int k = tid; k < e - s; k += TPB) { s_acc[k] = 0.0; s_cols[k] = A.cols[s + k]; }
+    } else if (tid < nr) {
+        for (int k = s_rp[tid]; k < s_rp[tid + 1]; ++k) A.vals[k] = 0.0;
+    }
+    __syncthreads();
+    if (tid < nr) {
+        const int r = (int)(r0 + tid);
+        const int ra = s_rp[tid], len = s_rp[tid + 1] - ra;
+        double *acc = staged ? (s_acc + (ra - s)) : (A.vals + ra);
+        const int *rc = staged ? (s_cols + (ra - s)) : (A.cols + ra);
+        const int ca = A.v2c_ptr[r], cb = A.v2c_ptr[r + 1];
+        for (int k = ca; k < cb; ++k) {
+            const int4 c4 = A.cells[A.v2c[k]];
+            const int u[4] = {c4.x, c4.y, c4.z, c4.w};
+            int i = 0;
+#pragma unroll
+            for (int t = 0; t < D + 1; ++t) if (u[t] == r) i = t;
+            double vol, g[D + 1][D], wl[D + 1];
+            p1_geometry<D>(A, u, vol, g);
+#pragma unroll
+            for (int t = 0; t < D + 1; ++t) wl[t] = A.w ? A.w[u[t]] : 0.0;
+#pragma unroll
+            for (int j = 0; j < D + 1; ++j) {
+                const double val = p1_entry<D>(A.kind, A.da, A.db, i, j, vol, g, wl);
+                int pos = 0;
+                while (pos < len - 1 && rc[pos] < u[j]) ++pos;   // cols are sorted and contain u[j]
+                acc[pos] += val;
+            }
+        }
+    }
+    __syncthreads();
+    if (staged)
+        for (int k = tid; k < e - s; k += TPB) A.vals[s + k] = s_acc[k];
+}
+
+// --------------------------------------------------------------------- host side
+static int build_topology(Ctx *c, Mesh *m) {
+    void *p;
+    const int64_t nv = m->nv, nc = m->nc;
+    int *cnt = nullptr, *stats = nullptr;
+    PGD_TRY(dev_alloc(c, &p, (size_t)(nv + 1) * sizeof(int))); cnt = (int *)p;
+    PGD_TRY(dev_alloc(c, &p, (size_t)(nv + 1) * sizeof(int))); m->v2c_ptr = (int *)p;
+    PGD_TRY(dev_alloc(c, &p, (size_t)(nc * m->nvpc) * sizeof(int))); m->v2c = (int *)p;
+    PGD_TRY(dev_alloc(c, &p, 8 * sizeof(int))); stats = (int *)p;
+    auto cleanup = [&]() { (void)hipFree(cnt); (void)hipFree(stats); };
+    hipStream_t st = c->stream;
+    PGD_HIP(c, hipMemsetAsync(cnt, 0, (size_t)(nv + 1) * sizeof(int), st));
+    PGD_HIP(c, hipMemsetAsync(stats, 0, 8 * sizeof(int), st));
+    k_v2c_count<<<grid_for(nc), TPB, 0, st>>>(m->cells, nc, m->nvpc, cnt);
+    int rc = scan_exclusive_i32(c, cnt, m->v2c_ptr, nv);
+    if (rc != PGD_OK) { cleanup(); return rc; }
+    PGD_HIP(c, hipMemsetAsync(cnt, 0, (size_t)(nv + 1) * sizeof(int), st));
+    k_v2c_fill<<<grid_for(nc), TPB, 0, st>>>(m->cells, nc, m->nvpc, m->v2c_ptr, cnt, m->v2c);
+    k_v2c_sort<<<grid_for(nv), TPB, 0, st>>>(m->v2c_ptr, m->v2c, nv);
+    // pattern: count, scan, fill
+    PGD_TRY(dev_alloc(c, &p, (size_t)(nv + 1) * sizeof(int))); m->row_ptr = (int *)p;
+    const int gb = (int)((nv + TPB - 1) / TPB);
+    k_pattern<false><<<gb, TPB, 0, st>>>(m->cells, m->nvpc, m->v2c_ptr, m->v2c, nv, cnt, nullptr, nullptr, stats);
+    rc = scan_exclusive_i32(c, cnt, m->row_ptr, nv);
+    if (rc != PGD_OK) { cleanup(); return rc; }
+    int hstats[4] = {0, 0, 0, 0};
+    int total = 0;
+    PGD_HIP(c, hipMemcpyAsync(hstats, stats, sizeof hstats, hipMemcpyDeviceToHost, st));
+    PGD_HIP(c, hipMemcpyAsync(&total, m->row_ptr + nv, sizeof(int), hipMemcpyDeviceToHost, st));
+    PGD_HIP(c, hipStreamSynchronize(st));
+    if (hstats[0]) { cleanup(); return fail(c, PGD_ERR_LIMIT, "mesh: a vertex has more than %d neighbours", MAX_ROW); }
+    if (total < 0) { cleanup(); return fail(c, PGD_ERR_LIMIT, "mesh: nnz overflows int32"); }
+    m->nnz = total;
+    m->max_row = hstats[1];
+    m->kl = hstats[2];
+    m->ku = hstats[3];
+    PGD_TRY(dev_alloc(c, &p, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(int))); m->cols = (int *)p;
+    PGD_HIP(c, hipMemsetAsync(m->cols, 0, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(int) + PAD_BYTES, st));
+    k_pattern<true><<<gb, TPB, 0, st>>>(m->cells, m->nvpc, m->v2c_ptr, m->v2c, nv, nullptr, m->row_ptr, m->cols, stats);
+    PGD_HIP(c, hipStreamSynchronize(st));
+    cleanup();
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+}  // namespace pgd
+
+using namespace pgd;
+
+extern "C" {
+
+int pgd_mesh_upload(pgd_handle h, const double *coords, int64_t nv, int gdim, const int32_t *cells,
+                    int64_t nc, int nvpc, pgd_handle *out) {
+    PGD_CTX(c, h);
+    if (!coords || !cells || !out || nv < 2 || nc < 1 || gdim < 1 || gdim > 3 || nvpc != gdim + 1)
+        return fail(c, PGD_ERR_INVALID, "mesh_upload: need P1 simplices with nvpc == gdim + 1, gdim in 1..3");
+    if (nv >= (int64_t)1 << 31 || nc * nvpc >= (int64_t)1 << 31)
+        return fail(c, PGD_ERR_LIMIT, "mesh_upload: index range exceeds int32");
+    // validate connectivity on the host: an out-of-range vertex id would fault on the device
+    for (int64_t i = 0; i < nc * nvpc; ++i)
+        if (cells[i] < 0 || cells[i] >= nv) return fail(c, PGD_ERR_INVALID, "mesh_upload: cell vertex id %d out of range", cells[i]);
+    std::unique_ptr<Mesh> m(new Mesh);
+    m->kind = Obj::MESH;
+    m->gdim = gdim; m->nvpc = nvpc; m->nv = nv; m->nc = nc;
+    void *p;
+    PGD_TRY(dev_alloc(c, &p, (size_t)nv * 3 * sizeof(double))); m->coords = (double *)p;
+    PGD_TRY(dev_alloc(c, &p, (size_t)nc * sizeof(int4))); m->cells = (int4 *)p;
+    {   // host-side repack: AoS -> SoA coordinates, cells -> one int4 record each
+        std::vector<double> soa((size_t)nv * 3, 0.0);
+        for (int64_t v = 0; v < nv; ++v)
+            for (int k = 0; k < gdim; ++k) soa[(size_t)k * nv + v] = coords[v * gdim + k];
+        std::vector<int4> rec((size_t)nc);
+        for (int64_t e = 0; e < nc; ++e) {
+            int u[4] = {-1, -1, -1, -1};
+            for (int j = 0; j < nvpc; ++j) u[j] = cells[e * nvpc + j];
+            rec[e] = make_int4(u[0], u[1], u[2], u[3]);
+        }
+        PGD_HIP(c, hipMemcpyAsync(m->coords, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        PGD_HIP(c, hipMemcpyAsync(m->cells, rec.data(), rec.size() * sizeof(int4), hipMemcpyHostToDevice, c->stream));
+        PGD_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    PGD_TRY(build_topology(c, m.get()));
+    *out = put_obj(c, m.release());
+    return PGD_OK;
+}
+
+int pgd_mesh_info(pgd_handle h, pgd_handle mh, int64_t *nv, int64_t *nc, int64_t *nnz, int32_t *max_row,
+                  int32_t *kl, int32_t *ku) {
+    PGD_CTX(c, h);
+    Mesh *m = get_mesh(c, mh);
+    if (!m) return fail(c, PGD_ERR_INVALID, "mesh_info: invalid handle");
+    if (nv) *nv = m->nv;
+    if (nc) *nc = m->nc;
+    if (nnz) *nnz = m->nnz;
+    if (max_row) *max_row = m->max_row;
+    if (kl) *kl = m->kl;
+    if (ku) *ku = m->ku;
+    return PGD_OK;
+}
+
+int pgd_mesh_pattern_download(pgd_handle h, pgd_handle mh, int32_t *row_ptr, int32_t *cols) {
+    PGD_CTX(c, h);
+    Mesh *m = get_mesh(c, mh);
+    if (!m) return fail(c, PGD_ERR_INVALID, "mesh_pattern_download: invalid handle");
+    if (row_ptr) PGD_HIP(c, hipMemcpyAsync(row_ptr, m->row_ptr, (size_t)(m->nv + 1) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    if (cols && m->nnz) PGD_HIP(c, hipMemcpyAsync(cols, m->cols, (size_t)m->nnz * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    return PGD_OK;
+}
+
+int pgd_mesh_free(pgd_handle h, pgd_handle mh) {
+    PGD_CTX(c, h);
+    return free_obj(c, mh, Obj::MESH);
+}
+
+static int new_csr(Ctx *c, pgd_handle mh, Mesh *m, pgd_handle *out, Csr **res) {
+    std::unique_ptr<Csr> a(new Csr);
+    a->kind = Obj::CSR;
+    a->mesh = mh;
+    void *p;
+    PGD_TRY(dev_alloc(c, &p, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(double)));
+    a->vals = (double *)p;
+    PGD_HIP(c, hipMemsetAsync(a->vals, 0, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(double) + PAD_BYTES, c->stream));
+    *res = a.get();
+    *out = put_obj(c, a.release());
+    return PGD_OK;
+}
+
+int pgd_atom_assemble(pgd_handle h, pgd_handle mh, int kind, int da, int db, pgd_handle wh, pgd_handle *out) {
+    PGD_CTX(c, h);
+    Mesh *m = get_mesh(c, mh);
+    if (!m || !out) return fail(c, PGD_ERR_INVALID, "atom_assemble: invalid mesh handle");
+    if (kind < PGD_ATOM_MASS || kind > PGD_ATOM_WSTIFF) return fail(c, PGD_ERR_INVALID, "atom_assemble: unknown kind %d", kind);
+    if (da < 0 || da >= m->gdim || db < 0 || db >= m->gdim) return fail(c, PGD_ERR_INVALID, "atom_assemble: derivative axis out of range");
+    const double *w = nullptr;
+    if (kind == PGD_ATOM_WMASS || kind == PGD_ATOM_WSTIFF) {
+        Vec *wv = get_vec(c, wh);
+        if (!wv || wv->n != m->nv) return fail(c, PGD_ERR_INVALID, "atom_assemble: weighted kind needs a vertex weight vector");
+        w = wv->d;
+    }
+    Csr *a = nullptr;
+    PGD_TRY(new_csr(c, mh, m, out, &a));
+    AsmArgs A;
+    A.cx = m->coords; A.cy = m->coords + m->nv; A.cz = m->coords + 2 * m->nv;
+    A.cells = m->cells; A.v2c_ptr = m->v2c_ptr; A.v2c = m->v2c; A.row_ptr = m->row_ptr; A.cols = m->cols;
+    A.w = w; A.vals = a->vals; A.nv = m->nv; A.kind = kind; A.da = da; A.db = db;
+    const int gb = (int)((m->nv + TPB - 1) / TPB);
+    if (m->gdim == 1) k_assemble_p1<1><<<gb, TPB, 0, c->stream>>>(A);
+    else if (m->gdim == 2) k_assemble_p1<2><<<gb, TPB, 0, c->stream>>>(A);
+    else k_assemble_p1<3><<<gb, TPB, 0, c->stream>>>(A);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pgd_atom_upload(pgd_handle h, pgd_handle mh, const double *vals, pgd_handle *out) {
+    PGD_CTX(c, h);
+    Mesh *m = get_mesh(c, mh);
+    if (!m || !out || !vals) return fail(c, PGD_ERR_INVALID, "atom_upload: invalid arguments");
+    Csr *a = nullptr;
+    PGD_TRY(new_csr(c, mh, m, out, &a));
+    if (m->nnz) PGD_HIP(c, hipMemcpyAsync(a->vals, vals, (size_t)m->nnz * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    return PGD_OK;
+}
+
+int pgd_atom_download(pgd_handle h, pgd_handle ah, double *vals) {
+    PGD_CTX(c, h);
+    Csr *a = get_csr(c, ah);
+    Mesh *m = a ? get_mesh(c, a->mesh) : nullptr;
+    if (!a || !m || !vals) return fail(c, PGD_ERR_INVALID, "atom_download: invalid handle");
+    if (m->nnz) PGD_HIP(c, hipMemcpyAsync(vals, a->vals, (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    return PGD_OK;
+}
+
+int pgd_atom_free(pgd_handle h, pgd_handle ah) {
+    PGD_CTX(c, h);
+    return free_obj(c, ah, Obj::CSR);
+}
+
+}  // extern "C"

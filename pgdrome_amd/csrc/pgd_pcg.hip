@@ -1,0 +1,438 @@
+// Operator build (A = sum_t c_t A_t with symmetric Dirichlet elimination), the
+// Jacobi-PCG recurrence and the small banded direct solve.
+//
+// PCG iteration = 3 streaming kernels + 2 one-workgroup reductions:
+//   k_spmv_csr<dot>   q = A p, partial p.q                  (12 nnz + 28 n bytes)
+//   k_pcg_xr          x += a p; r -= a q; z = r/diag; partial r.z, r.r   (56 n bytes)
+//   k_pcg_p           p = z + b p                            (24 n bytes)
+// alpha and beta never leave the device: each kernel forms them from the scalar
+// bank, and a `done` flag turns every later launch into a no-op, so the host
+// only looks at the flag every CHECK_EVERY iterations.  All reductions are
+// wavefront-shuffle -> LDS -> fixed-order final pass: bitwise reproducible.
+#include "pgd_internal.h"
+
+namespace pgd {
+
+constexpr int MAXT = 8;          // atoms per combine launch
+constexpr int CHECK_EVERY = 16;  // PCG iterations enqueued between two host looks at the flag
+
+struct CombineArgs {
+    const double *in[MAXT];
+    double coef[MAXT];
+    int n;
+};
+
+// out[k] = sum_t c_t in_t[k]; entries in a Dirichlet column are zeroed
+__global__ __launch_bounds__(TPB) void k_combine(CombineArgs A, double *__restrict__ out, const int *__restrict__ cols,
+                                                 const uint8_t *__restrict__ colmask, int64_t nnz) {
+    for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < nnz; k += (int64_t)gridDim.x * TPB) {
+        double s = 0.0;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            if (t < A.n) s = fma(A.coef[t], A.in[t][k], s);
+        if (colmask && colmask[cols[k]]) s = 0.0;
+        out[k] = s;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_mask_set(uint8_t *__restrict__ mask, const int *__restrict__ dofs, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) mask[dofs[i]] = 1;
+}
+
+// Dirichlet rows -> identity rows
+__global__ __launch_bounds__(TPB) void k_dirichlet_rows(const int *__restrict__ dofs, int64_t n,
+                                                        const int *__restrict__ row_ptr, const int *__restrict__ cols,
+                                                        double *__restrict__ vals) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const int r = dofs[i];
+        for (int k = row_ptr[r]; k < row_ptr[r + 1]; ++k) vals[k] = (cols[k] == r) ? 1.0 : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_diag_inv(const int *__restrict__ row_ptr, const int *__restrict__ cols,
+                                                  const double *__restrict__ vals, double *__restrict__ dinv, int64_t n) {
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < n; r += (int64_t)gridDim.x * TPB) {
+        double d = 0.0;
+        for (int k = row_ptr[r]; k < row_ptr[r + 1]; ++k)
+            if (cols[k] == (int)r) d = vals[k];
+        dinv[r] = 1.0 / d;
+    }
+}
+
+// r = b - q; z = dinv r; p = z; partials (r.z, r.r, b.b)
+__global__ __launch_bounds__(TPB) void k_pcg_init(const double *__restrict__ b, const double *__restrict__ q,
+                                                  const double *__restrict__ dinv, double *__restrict__ r,
+                                                  double *__restrict__ z, double *__restrict__ p, int64_t lo,
+                                                  int64_t hi, double *__restrict__ partials) {
+    __shared__ double s_red[4];
+    double rz = 0.0, rr = 0.0, bb = 0.0;
+    for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB) {
+        const double bi = b[i], ri = bi - q[i], zi = dinv[i] * ri;
+        r[i] = ri; z[i] = zi; p[i] = zi;
+        rz = fma(ri, zi, rz); rr = fma(ri, ri, rr); bb = fma(bi, bi, bb);
+    }
+    rz = block_sum(rz, s_red);
+    rr = block_sum(rr, s_red);
+    bb = block_sum(bb, s_red);
+    if (threadIdx.x == 0) {
+        partials[3 * blockIdx.x + 0] = rz;
+        partials[3 * blockIdx.x + 1] = rr;
+        partials[3 * blockIdx.x + 2] = bb;
+    }
+}
+
+__global__ void k_pcg_tol(double *__restrict__ slots, int *__restrict__ flags, double rtol, double atol, int slot_rr,
+                          int slot_bb, int slot_tol2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double t1 = rtol * rtol * slots[slot_bb], t2 = atol * atol;
+    const double tol2 = t1 > t2 ? t1 : t2;
+    slots[slot_tol2] = tol2;
+    const double rr = slots[slot_rr];
+    if (!(rr == rr)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; }
+    else if (rr <= tol2) flags[0] = 1;
+}
+
+__global__ void k_pcg_check(const double *__restrict__ slots, int *__restrict__ flags, int slot_rr, int slot_tol2) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || flags[0]) return;
+    const double rr = slots[slot_rr];
+    flags[1] += 1;
+    if (!(rr == rr)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; }
+    else if (rr <= slots[slot_tol2]) flags[0] = 1;
+}
+
+__global__ __launch_bounds__(TPB) void k_pcg_xr(double *__restrict__ x, double *__restrict__ r,
+                                                const double *__restrict__ p, const double *__restrict__ q,
+                                                const double *__restrict__ dinv, double *__restrict__ z, int64_t lo,
+                                                int64_t hi, const double *__restrict__ slots, int slot_rz, int slot_pq,
+                                                double *__restrict__ partials, const int *__restrict__ flags) {
+    if (flags[0]) return;
+    __shared__ double s_red[4];
+    const double alpha = slots[slot_rz] / slots[slot_pq];
+    double rz = 0.0, rr = 0.0;
+    for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB) {
+        x[i] = fma(alpha, p[i], x[i]);
+        const double ri = fma(-alpha, q[i], r[i]), zi = dinv[i] * ri;
+        r[i] = ri; z[i] = zi;
+        rz = fma(ri, zi, rz); rr = fma(ri, ri, rr);
+    }
+    rz = block_sum(rz, s_red);
+    rr = block_sum(rr, s_red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = rz; partials[2 * blockIdx.x + 1] = rr; }
+}
+
+__global__ __launch_bounds__(TPB) void k_pcg_p(double *__restrict__ p, const double *__restrict__ z, int64_t lo,
+                                               int64_t hi, const double *__restrict__ slots, int slot_num, int slot_den,
+                                               const int *__restrict__ flags) {
+    if (flags[0]) return;
+    const double beta = slots[slot_num] / slots[slot_den];
+    for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB)
+        p[i] = fma(beta, p[i], z[i]);
+}
+
+// ---------------------------------------------------------------- banded LU (small systems)
+// One workgroup; the band lives in LDS when it fits.  ab(i,j) is stored at
+// W[(i - j + kl + ku) + j * ld], ld = 2 kl + ku + 1 (LAPACK dgbtrf layout: kl extra
+// super-diagonals for the fill of partial pivoting).  The elimination itself is a
+// dependency chain of n steps with O(kl (kl+ku)) work each: one lane does it.
+constexpr int BAND_LDS_DOUBLES = 16384;   // 128 KiB
+
+__global__ __launch_bounds__(TPB) void k_band_solve(const int *__restrict__ row_ptr, const int *__restrict__ cols,
+                                                    const double *__restrict__ vals, const double *__restrict__ b,
+                                                    double *__restrict__ x, int n, int kl, int ku,
+                                                    double *__restrict__ gwork, int use_lds, int *__restrict__ flags) {
+    __shared__ double s_w[BAND_LDS_DOUBLES];
+    const int ld = 2 * kl + ku + 1;
+    double *W = use_lds ? s_w : gwork;          // n*ld band entries, then n rhs entries
+    double *rhs = W + (int64_t)n * ld;
+    for (int64_t k = threadIdx.x; k < (int64_t)n * ld; k += TPB) W[k] = 0.0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += TPB) {
+        rhs[i] = b[i];
+        for (int k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+            const int j = cols[k];
+            W[(i - j + kl + ku) + (int64_t)j * ld] = vals[k];
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int kv = kl + ku;
+        int singular = 0;
+        for (int j = 0; j < n; ++j) {
+            const int imax = min(j + kl, n - 1), cmax = min(j + kv, n - 1);
+            int piv = j;
+            double best = fabs(W[kv + (int64_t)j * ld]);
+            for (int i = j + 1; i <= imax; ++i) {
+                const double t = fabs(W[(i - j + kv) + (int64_t)j * ld]);
+                if (t > best) { best = t; piv = i; }
+            }
+            if (best == 0.0) { singular = 1; break; }
+            if (piv != j) {
+                for (int cc = j; cc <= cmax; ++cc) {
+                    const int64_t a1 = (j - cc + kv) + (int64_t)cc * ld, a2 = (piv - cc + kv) + (int64_t)cc * ld;
+                    const double t = W[a1]; W[a1] = W[a2]; W[a2] = t;
+                }
+                const double t = rhs[j]; rhs[j] = rhs[piv]; rhs[piv] = t;
+            }
+            const double dinv = 1.0 / W[kv + (int64_t)j * ld];
+            for (int i = j + 1; i <= imax; ++i) {
+                const double l = W[(i - j + kv) + (int64_t)j * ld] * dinv;
+                if (l != 0.0) {
+                    for (int cc = j + 1; cc <= cmax; ++cc)
+                        W[(i - cc + kv) + (int64_t)cc * ld] -= l * W[(j - cc + kv) + (int64_t)cc * ld];
+                    rhs[i] -= l * rhs[j];
+                }
+            }
+        }
+        if (!singular) {
+            for (int j = n - 1; j >= 0; --j) {
+                const int cmax = min(j + kv, n - 1);
+                double s = rhs[j];
+                for (int cc = j + 1; cc <= cmax; ++cc) s -= W[(j - cc + kv) + (int64_t)cc * ld] * rhs[cc];
+                rhs[j] = s / W[kv + (int64_t)j * ld];
+            }
+        } else {
+            flags[2] = PGD_ERR_SINGULAR;
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += TPB) x[i] = rhs[i];
+}
+
+int csr_diag_inv(Ctx *c, const Mesh *m, Csr *a) {
+    if (a->dinv_valid) return PGD_OK;
+    if (!a->dinv) {
+        void *p;
+        PGD_TRY(dev_alloc(c, &p, (size_t)m->nv * sizeof(double)));
+        a->dinv = (double *)p;
+    }
+    k_diag_inv<<<grid_for(m->nv), TPB, 0, c->stream>>>(m->row_ptr, m->cols, a->vals, a->dinv, m->nv);
+    PGD_LAUNCH_CHECK(c);
+    a->dinv_valid = true;
+    return PGD_OK;
+}
+
+// shared by pgd_pcg_solve and the *_slot entry points
+static int pcg_init(Ctx *c, const double *b, const double *q, const double *dinv, double *r, double *z, double *p,
+                    int64_t lo, int64_t hi, int slot) {
+    const int g = grid_for(hi - lo);
+    PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS));
+    k_pcg_init<<<g, TPB, 0, c->stream>>>(b, q, dinv, r, z, p, lo, hi, c->partials);
+    PGD_LAUNCH_CHECK(c);
+    return reduce_partials(c, c->partials, g, 3, slot, -1, 0, 0);
+}
+
+static int pcg_xr(Ctx *c, double *x, double *r, const double *p, const double *q, const double *dinv, double *z,
+                  int64_t lo, int64_t hi, int slot_rz, int slot_pq, int slot_out, int check_mode, int slot_tol2) {
+    const int g = grid_for(hi - lo);
+    PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS));
+    k_pcg_xr<<<g, TPB, 0, c->stream>>>(x, r, p, q, dinv, z, lo, hi, c->slots, slot_rz, slot_pq, c->partials, c->flags);
+    PGD_LAUNCH_CHECK(c);
+    return reduce_partials(c, c->partials, g, 2, slot_out, check_mode, slot_out + 1, slot_tol2);
+}
+
+}  // namespace pgd
+
+using namespace pgd;
+
+extern "C" {
+
+int pgd_op_combine(pgd_handle h, pgd_handle mh, const pgd_handle *atoms, const double *coefs, int n,
+                   const int32_t *bc_dofs, int64_t nbc, pgd_handle *op) {
+    PGD_CTX(c, h);
+    Mesh *m = get_mesh(c, mh);
+    if (!m || !atoms || !coefs || !op || n < 1 || nbc < 0 || (nbc > 0 && !bc_dofs))
+        return fail(c, PGD_ERR_INVALID, "op_combine: invalid arguments");
+    std::vector<const double *> in((size_t)n);
+    for (int t = 0; t < n; ++t) {
+        Csr *a = get_csr(c, atoms[t]);
+        if (!a || a->mesh != mh) return fail(c, PGD_ERR_INVALID, "op_combine: atom %d is not on this mesh", t);
+        if (*op && atoms[t] == *op) return fail(c, PGD_ERR_INVALID, "op_combine: output aliases an input");
+        in[t] = a->vals;
+    }
+    for (int64_t i = 0; i < nbc; ++i)
+        if (bc_dofs[i] < 0 || bc_dofs[i] >= m->nv) return fail(c, PGD_ERR_INVALID, "op_combine: bc dof out of range");
+    Csr *o = nullptr;
+    if (*op) {
+        o = get_csr(c, *op);
+        if (!o || o->mesh != mh) return fail(c, PGD_ERR_INVALID, "op_combine: *op is not an operator on this mesh");
+    } else {
+        std::unique_ptr<Csr> a(new Csr);
+        a->kind = Obj::CSR;
+        a->mesh = mh;
+        void *p;
+        PGD_TRY(dev_alloc(c, &p, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(double)));
+        a->vals = (double *)p;
+        PGD_HIP(c, hipMemsetAsync(a->vals, 0, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(double) + PAD_BYTES, c->stream));
+        o = a.get();
+        *op = put_obj(c, a.release());
+    }
+    o->dinv_valid = false;
+    const uint8_t *mask = nullptr;
+    if (nbc > 0) {
+        PGD_TRY(ensure_mask(c, m->nv));
+        PGD_TRY(ensure_ibuf(c, nbc));
+        PGD_HIP(c, hipMemsetAsync(c->mask, 0, (size_t)m->nv, c->stream));
+        PGD_HIP(c, hipMemcpyAsync(c->ibuf, bc_dofs, (size_t)nbc * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        k_mask_set<<<grid_for(nbc), TPB, 0, c->stream>>>(c->mask, c->ibuf, nbc);
+        mask = c->mask;
+    }
+    const int g = grid_for(m->nnz, TPB, 4 * MAX_VEC_BLOCKS);
+    for (int t = 0, pass = 0; t < n; ++pass) {
+        // up to MAXT inputs per launch; later launches accumulate onto the running output
+        CombineArgs A;
+        int cnt = 0;
+        if (pass > 0) { A.in[0] = o->vals; A.coef[0] = 1.0; cnt = 1; }
+        while (t < n && cnt < MAXT) { A.in[cnt] = in[t]; A.coef[cnt] = coefs[t]; ++cnt; ++t; }
+        for (int k = cnt; k < MAXT; ++k) { A.in[k] = in[0]; A.coef[k] = 0.0; }
+        A.n = cnt;
+        k_combine<<<g, TPB, 0, c->stream>>>(A, o->vals, m->cols, (t >= n) ? mask : nullptr, m->nnz);
+    }
+    if (nbc > 0) k_dirichlet_rows<<<grid_for(nbc), TPB, 0, c->stream>>>(c->ibuf, nbc, m->row_ptr, m->cols, o->vals);
+    PGD_LAUNCH_CHECK(c);
+    PGD_HIP(c, hipStreamSynchronize(c->stream));   // bc_dofs is caller-owned
+    return PGD_OK;
+}
+
+int pgd_op_diag_inv(pgd_handle h, pgd_handle oh, pgd_handle dh) {
+    PGD_CTX(c, h);
+    Csr *o = get_csr(c, oh);
+    Mesh *m = o ? get_mesh(c, o->mesh) : nullptr;
+    Vec *d = get_vec(c, dh);
+    if (!o || !m || !d || d->n != m->nv) return fail(c, PGD_ERR_INVALID, "op_diag_inv: invalid handles");
+    k_diag_inv<<<grid_for(m->nv), TPB, 0, c->stream>>>(m->row_ptr, m->cols, o->vals, d->d, m->nv);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, double rtol, double atol, int maxit,
+                  int *iters, double *relres) {
+    PGD_CTX(c, h);
+    Csr *o = get_csr(c, oh);
+    Mesh *m = o ? get_mesh(c, o->mesh) : nullptr;
+    Vec *b = get_vec(c, bh), *x = get_vec(c, xh);
+    if (!o || !m || !b || !x || b->n != m->nv || x->n != m->nv || b == x || maxit < 0)
+        return fail(c, PGD_ERR_INVALID, "pcg_solve: invalid handles or size mismatch");
+    const int64_t n = m->nv;
+    PGD_TRY(csr_diag_inv(c, m, o));
+    for (int i = 0; i < 4; ++i) PGD_TRY(ensure_work(c, i, n));
+    double *r = c->work[0], *z = c->work[1], *p = c->work[2], *q = c->work[3];
+    PGD_HIP(c, hipMemsetAsync(c->flags, 0, 8 * sizeof(int), c->stream));
+    // r0 = b - A x0; (r.z, r.r, b.b) land in slots 20..22
+    constexpr int S_INIT = 20, S_PAIR = 16;   // r.z / r.r of iteration k live in slots 16 + 2 (k & 1), +1
+    PGD_TRY(launch_spmv(c, m, o->vals, x->d, q, nullptr, 0, n, false, true, nullptr, nullptr));
+    PGD_TRY(pcg_init(c, b->d, q, o->dinv, r, z, p, 0, n, S_INIT));
+    k_pcg_tol<<<1, 64, 0, c->stream>>>(c->slots, c->flags, rtol, atol, S_INIT + 1, S_INIT + 2, S_TOL2);
+    PGD_LAUNCH_CHECK(c);
+    int f[4] = {0, 0, 0, 0};
+    int rz_old = S_INIT;
+    int enq = 0;
+    while (true) {
+        PGD_HIP(c, hipMemcpyAsync(f, c->flags, sizeof f, hipMemcpyDeviceToHost, c->stream));
+        PGD_HIP(c, hipStreamSynchronize(c->stream));
+        if (f[0] || enq >= maxit) break;
+        const int chunk = (maxit - enq < CHECK_EVERY) ? maxit - enq : CHECK_EVERY;
+        for (int k = 0; k < chunk; ++k) {
+            const int out = S_PAIR + 2 * ((enq + k) & 1);
+            int nparts = 0;
+            PGD_TRY(launch_spmv(c, m, o->vals, p, q, p, 0, n, true, true, c->flags, &nparts));
+            PGD_TRY(reduce_partials(c, c->partials, nparts, 1, S_PQ, 0, 0, 0));
+            // x, r, z update; the final reduction also runs the convergence test on r.r
+            PGD_TRY(pcg_xr(c, x->d, r, p, q, o->dinv, z, 0, n, rz_old, S_PQ, out, 1, S_TOL2));
+            k_pcg_p<<<grid_for(n), TPB, 0, c->stream>>>(p, z, 0, n, c->slots, out, rz_old, c->flags);
+            rz_old = out;
+        }
+        PGD_LAUNCH_CHECK(c);
+        enq += chunk;
+    }
+    double s[PGD_NSLOTS];
+    PGD_HIP(c, hipMemcpyAsync(s, c->slots, sizeof s, hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    if (iters) *iters = f[1];
+    const double rr = (f[1] > 0) ? s[S_PAIR + 2 * ((f[1] - 1) & 1) + 1] : s[S_INIT + 1];
+    const double bb = s[S_INIT + 2];
+    if (relres) *relres = (bb > 0.0) ? sqrt(rr / bb) : 0.0;
+    if (f[2] != 0) return fail(c, f[2], "pcg_solve: breakdown (NaN residual) after %d iterations", f[1]);
+    return PGD_OK;
+}
+
+int pgd_band_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh) {
+    PGD_CTX(c, h);
+    Csr *o = get_csr(c, oh);
+    Mesh *m = o ? get_mesh(c, o->mesh) : nullptr;
+    Vec *b = get_vec(c, bh), *x = get_vec(c, xh);
+    if (!o || !m || !b || !x || b->n != m->nv || x->n != m->nv)
+        return fail(c, PGD_ERR_INVALID, "band_solve: invalid handles or size mismatch");
+    const int64_t n = m->nv, ld = 2 * (int64_t)m->kl + m->ku + 1;
+    const int64_t need = n * ld + n;
+    if (need > ((int64_t)1 << 27)) return fail(c, PGD_ERR_LIMIT, "band_solve: system too large for the direct path (n=%lld, band=%lld)", (long long)n, (long long)ld);
+    const int use_lds = need <= BAND_LDS_DOUBLES;
+    if (!use_lds) PGD_TRY(ensure_work(c, 4, need));
+    PGD_HIP(c, hipMemsetAsync(c->flags, 0, 8 * sizeof(int), c->stream));
+    k_band_solve<<<1, TPB, 0, c->stream>>>(m->row_ptr, m->cols, o->vals, b->d, x->d, (int)n, m->kl, m->ku,
+                                           use_lds ? nullptr : c->work[4], use_lds, c->flags);
+    PGD_LAUNCH_CHECK(c);
+    int f[4];
+    PGD_HIP(c, hipMemcpyAsync(f, c->flags, sizeof f, hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    if (f[2] != 0) return fail(c, PGD_ERR_SINGULAR, "band_solve: zero pivot");
+    return PGD_OK;
+}
+
+// ---------------------------------------------------------- distributed PCG pieces
+static int get3(Ctx *c, pgd_handle a, pgd_handle b, pgd_handle d, Vec **A, Vec **B, Vec **D) {
+    *A = get_vec(c, a); *B = get_vec(c, b); *D = get_vec(c, d);
+    return (*A && *B && *D && (*A)->n == (*B)->n && (*A)->n == (*D)->n) ? PGD_OK : PGD_ERR_INVALID;
+}
+
+static int range_ok(int64_t n, int64_t &lo, int64_t &hi) {
+    if (hi < 0) hi = n;
+    return lo >= 0 && lo <= hi && hi <= n;
+}
+
+int pgd_pcg_init_slot(pgd_handle h, pgd_handle bh, pgd_handle qh, pgd_handle dh, pgd_handle rh, pgd_handle zh,
+                      pgd_handle ph, int64_t lo, int64_t hi, int slot) {
+    PGD_CTX(c, h);
+    Vec *b, *q, *d, *r, *z, *p;
+    if (get3(c, bh, qh, dh, &b, &q, &d) != PGD_OK || get3(c, rh, zh, ph, &r, &z, &p) != PGD_OK || b->n != r->n ||
+        !range_ok(b->n, lo, hi) || slot < 0 || slot + 3 > PGD_NSLOTS)
+        return fail(c, PGD_ERR_INVALID, "pcg_init_slot: invalid arguments");
+    if (hi == lo) return PGD_OK;
+    return pcg_init(c, b->d, q->d, d->d, r->d, z->d, p->d, lo, hi, slot);
+}
+
+int pgd_pcg_tol_slot(pgd_handle h, double rtol, double atol, int slot_rr, int slot_bb, int slot_tol2) {
+    PGD_CTX(c, h);
+    k_pcg_tol<<<1, 64, 0, c->stream>>>(c->slots, c->flags, rtol, atol, slot_rr, slot_bb, slot_tol2);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pgd_pcg_xr_slot(pgd_handle h, pgd_handle xh, pgd_handle rh, pgd_handle ph, pgd_handle qh, pgd_handle dh,
+                    pgd_handle zh, int64_t lo, int64_t hi, int slot_rz, int slot_pq, int slot_out) {
+    PGD_CTX(c, h);
+    Vec *x, *r, *p, *q, *d, *z;
+    if (get3(c, xh, rh, ph, &x, &r, &p) != PGD_OK || get3(c, qh, dh, zh, &q, &d, &z) != PGD_OK || x->n != q->n ||
+        !range_ok(x->n, lo, hi) || slot_out < 0 || slot_out + 2 > PGD_NSLOTS)
+        return fail(c, PGD_ERR_INVALID, "pcg_xr_slot: invalid arguments");
+    if (hi == lo) return PGD_OK;
+    return pcg_xr(c, x->d, r->d, p->d, q->d, d->d, z->d, lo, hi, slot_rz, slot_pq, slot_out, 0, 0);
+}
+
+int pgd_pcg_check_slot(pgd_handle h, int slot_rr, int slot_tol2) {
+    PGD_CTX(c, h);
+    k_pcg_check<<<1, 64, 0, c->stream>>>(c->slots, c->flags, slot_rr, slot_tol2);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pgd_pcg_p_slot(pgd_handle h, pgd_handle ph, pgd_handle zh, int64_t lo, int64_t hi, int slot_num, int slot_den) {
+    PGD_CTX(c, h);
+    Vec *p = get_vec(c, ph), *z = get_vec(c, zh);
+    if (!p || !z || p->n != z->n || !range_ok(p->n, lo, hi)) return fail(c, PGD_ERR_INVALID, "pcg_p_slot: invalid arguments");
+    if (hi == lo) return PGD_OK;
+    k_pcg_p<<<grid_for(hi - lo), TPB, 0, c->stream>>>(p->d, z->d, lo, hi, c->slots, slot_num, slot_den, c->flags);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,232 @@
+// Vector kernels: fill / scale / axpy / scatter-set, the deterministic two-stage
+// dot (wavefront shuffle -> LDS -> fixed-order final pass), and an int32 scan.
+// All are HBM-bound streams: 8 B/lane loads, grid capped at 8 workgroups per CU
+// with a grid-stride loop (guide: Guideline 11).
+#include "pgd_internal.h"
+
+namespace pgd {
+
+__global__ __launch_bounds__(TPB) void k_fill(double *__restrict__ v, double a, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) v[i] = a;
+}
+
+__global__ __launch_bounds__(TPB) void k_scale(double *__restrict__ v, double a, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) v[i] *= a;
+}
+
+__global__ __launch_bounds__(TPB) void k_axpy(double *__restrict__ y, double a, const double *__restrict__ x, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
+        y[i] = fma(a, x[i], y[i]);
+}
+
+__global__ __launch_bounds__(TPB) void k_set(double *__restrict__ v, const int *__restrict__ idx,
+                                             const double *__restrict__ val, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) v[idx[i]] = val[i];
+}
+
+// partial[b] = sum over the block's grid-stride share of x_i y_i (fixed order)
+__global__ __launch_bounds__(TPB) void k_dot(const double *__restrict__ x, const double *__restrict__ y,
+                                             int64_t lo, int64_t hi, double *__restrict__ partials) {
+    __shared__ double s_red[4];
+    double acc = 0.0;
+    for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB)
+        acc = fma(x[i], y[i], acc);
+    acc = block_sum(acc, s_red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+// Final pass of every reduction: one 1024-thread workgroup adds `nparts` partial
+// sums per value in a fixed order and writes slots[slot0 + v].  check_mode 1 adds
+// the PCG convergence test (library-driven loop): iters += 1, done <- rr <= tol2.
+__global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restrict__ partials, int nparts,
+                                                          int nvals, double *__restrict__ slots, int slot0,
+                                                          int check_mode, int slot_rr, int slot_tol2,
+                                                          int *__restrict__ flags) {
+    __shared__ double s_w[16];
+    if (flags && check_mode >= 0 && flags[0]) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int v = 0; v < nvals; ++v) {
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < nparts; i += 1024) acc += partials[(int64_t)i * nvals + v];
+        acc = wave_sum(acc);
+        __syncthreads();
+        if (lane == 0) s_w[wv] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += s_w[k];
+            slots[slot0 + v] = t;
+        }
+    }
+    if (check_mode == 1 && threadIdx.x == 0) {
+        __threadfence_block();
+        const double rr = slots[slot_rr], tol2 = slots[slot_tol2];
+        flags[1] += 1;
+        if (!(rr == rr)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; }   // NaN: breakdown
+        else if (rr <= tol2) flags[0] = 1;
+    }
+}
+
+// ---- int32 exclusive scan (setup only): 1024 items per workgroup, recursive on block sums
+constexpr int SCAN_ITEMS = 4;   // per thread
+
+__global__ __launch_bounds__(TPB) void k_scan_block(const int *__restrict__ in, int *__restrict__ out,
+                                                    int *__restrict__ block_sums, int64_t n) {
+    __shared__ int s_wave[4];
+    const int64_t base = ((int64_t)blockIdx.x * TPB + threadIdx.x) * SCAN_ITEMS;
+    int v[SCAN_ITEMS], run = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0;
+        run += v[k];
+    }
+    // inclusive scan of `run` across the wave, then across the 4 waves
+    int inc = run;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += t;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < wv; ++w) wave_off += s_wave[w];
+    int excl = wave_off + inc - run;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        if (base + k < n) out[base + k] = excl;
+        excl += v[k];
+    }
+    if (threadIdx.x == TPB - 1 && block_sums) block_sums[blockIdx.x] = wave_off + inc;
+}
+
+__global__ __launch_bounds__(TPB) void k_scan_add(int *__restrict__ out, const int *__restrict__ block_off, int64_t n) {
+    const int64_t base = ((int64_t)blockIdx.x * TPB + threadIdx.x) * SCAN_ITEMS;
+    const int off = block_off[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k)
+        if (base + k < n) out[base + k] += off;
+}
+
+__global__ void k_scan_total(const int *__restrict__ in, int *__restrict__ out, int64_t n) {
+    // out[n] = out[n-1] + in[n-1]  (total), single thread
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[n] = (n > 0) ? out[n - 1] + in[n - 1] : 0;
+}
+
+static int scan_rec(Ctx *c, const int *in, int *out, int64_t n) {
+    const int64_t per_block = (int64_t)TPB * SCAN_ITEMS;
+    const int64_t nb = (n + per_block - 1) / per_block;
+    if (nb <= 1) {
+        k_scan_block<<<1, TPB, 0, c->stream>>>(in, out, nullptr, n);
+        PGD_LAUNCH_CHECK(c);
+        return PGD_OK;
+    }
+    int *sums = nullptr, *offs = nullptr;
+    void *p;
+    PGD_TRY(dev_alloc(c, &p, (size_t)nb * sizeof(int)));
+    sums = (int *)p;
+    if (dev_alloc(c, &p, (size_t)(nb + 1) * sizeof(int)) != PGD_OK) { (void)hipFree(sums); return PGD_ERR_NOMEM; }
+    offs = (int *)p;
+    k_scan_block<<<(int)nb, TPB, 0, c->stream>>>(in, out, sums, n);
+    int rc = scan_rec(c, sums, offs, nb);
+    if (rc == PGD_OK) k_scan_add<<<(int)nb, TPB, 0, c->stream>>>(out, offs, n);
+    hipError_t e = hipStreamSynchronize(c->stream);
+    (void)hipFree(sums);
+    (void)hipFree(offs);
+    if (rc != PGD_OK) return rc;
+    if (e != hipSuccess) return fail(c, PGD_ERR_HIP, "scan: %s", hipGetErrorString(e));
+    return PGD_OK;
+}
+
+int scan_exclusive_i32(Ctx *c, const int *in, int *out, int64_t n) {
+    if (n > 0) PGD_TRY(scan_rec(c, in, out, n));
+    k_scan_total<<<1, 64, 0, c->stream>>>(in, out, n);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int reduce_partials(Ctx *c, const double *partials, int nparts, int nvals, int slot0, int check_mode,
+                    int slot_rr, int slot_tol2) {
+    k_reduce_partials<<<1, 1024, 0, c->stream>>>(partials, nparts, nvals, c->slots, slot0, check_mode,
+                                                 slot_rr, slot_tol2, c->flags);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int vec_dot_range(Ctx *c, const double *x, const double *y, int64_t lo, int64_t hi, int slot) {
+    const int g = grid_for(hi - lo);
+    PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS));
+    k_dot<<<g, TPB, 0, c->stream>>>(x, y, lo, hi, c->partials);
+    PGD_LAUNCH_CHECK(c);
+    return reduce_partials(c, c->partials, g, 1, slot, -1, 0, 0);
+}
+
+}  // namespace pgd
+
+using namespace pgd;
+
+extern "C" {
+
+int pgd_vec_fill(pgd_handle h, pgd_handle vh, double a) {
+    PGD_CTX(c, h);
+    Vec *v = get_vec(c, vh);
+    if (!v) return fail(c, PGD_ERR_INVALID, "vec_fill: invalid handle");
+    if (v->n == 0) return PGD_OK;
+    k_fill<<<grid_for(v->n), TPB, 0, c->stream>>>(v->d, a, v->n);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pgd_vec_scale(pgd_handle h, pgd_handle vh, double a) {
+    PGD_CTX(c, h);
+    Vec *v = get_vec(c, vh);
+    if (!v) return fail(c, PGD_ERR_INVALID, "vec_scale: invalid handle");
+    if (v->n == 0) return PGD_OK;
+    k_scale<<<grid_for(v->n), TPB, 0, c->stream>>>(v->d, a, v->n);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pgd_vec_axpy(pgd_handle h, pgd_handle yh, double a, pgd_handle xh) {
+    PGD_CTX(c, h);
+    Vec *y = get_vec(c, yh), *x = get_vec(c, xh);
+    if (!x || !y || x->n != y->n) return fail(c, PGD_ERR_INVALID, "vec_axpy: invalid handles or size mismatch");
+    if (y->n == 0) return PGD_OK;
+    k_axpy<<<grid_for(y->n), TPB, 0, c->stream>>>(y->d, a, x->d, y->n);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pgd_vec_set(pgd_handle h, pgd_handle vh, const int32_t *idx, const double *val, int64_t n) {
+    PGD_CTX(c, h);
+    Vec *v = get_vec(c, vh);
+    if (!v || n < 0 || (n > 0 && (!idx || !val))) return fail(c, PGD_ERR_INVALID, "vec_set: bad arguments");
+    if (n == 0) return PGD_OK;
+    for (int64_t i = 0; i < n; ++i)
+        if (idx[i] < 0 || idx[i] >= v->n) return fail(c, PGD_ERR_INVALID, "vec_set: index %d out of range", idx[i]);
+    PGD_TRY(ensure_ibuf(c, n));
+    PGD_TRY(ensure_work(c, 5, n));
+    PGD_HIP(c, hipMemcpyAsync(c->ibuf, idx, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+    PGD_HIP(c, hipMemcpyAsync(c->work[5], val, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+    k_set<<<grid_for(n), TPB, 0, c->stream>>>(v->d, c->ibuf, c->work[5], n);
+    PGD_LAUNCH_CHECK(c);
+    PGD_HIP(c, hipStreamSynchronize(c->stream));   // host buffers are caller-owned
+    return PGD_OK;
+}
+
+int pgd_vec_dot(pgd_handle h, pgd_handle xh, pgd_handle yh, int64_t lo, int64_t hi, double *out) {
+    PGD_CTX(c, h);
+    Vec *x = get_vec(c, xh), *y = get_vec(c, yh);
+    if (!x || !y || x->n != y->n || !out) return fail(c, PGD_ERR_INVALID, "vec_dot: invalid handles or size mismatch");
+    if (hi < 0) hi = x->n;
+    if (lo < 0 || lo > hi || hi > x->n) return fail(c, PGD_ERR_INVALID, "vec_dot: bad range");
+    if (hi == lo) { *out = 0.0; return PGD_OK; }
+    PGD_TRY(vec_dot_range(c, x->d, y->d, lo, hi, S_TMP));
+    PGD_HIP(c, hipMemcpyAsync(out, c->slots + S_TMP, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    return PGD_OK;
+}
+
+}  // extern "C"

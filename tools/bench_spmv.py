@@ -1,0 +1,78 @@
+"""Micro-benchmark of k_spmv_csr and the PCG vector kernels on an n^3 P1 BoxMesh.
+
+    python tools/bench_spmv.py [n ...]      (default: 128 256)
+
+Prints achieved algorithmic GB/s (12 nnz + 20 n bytes per launch).
+"""
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+from oracle import fem_numpy as F          # mesh generator only (test infrastructure)
+from pgdrome_amd import _lib
+
+
+def main():
+    sizes = [int(a) for a in sys.argv[1:]] or [128, 256]
+    ctx = _lib.Context(0)
+    for n in sizes:
+        t0 = time.time()
+        coords, cells = F.box_mesh((0, 0, 0), (1, 1, 1), n - 1, n - 1, n - 1)
+        t1 = time.time()
+        mesh = ctx.mesh_upload(coords, cells)
+        ctx.sync()
+        t2 = time.time()
+        info = ctx.mesh_info(mesh)
+        nv, nnz = info["nv"], info["nnz"]
+        del coords, cells
+        ak = ctx.atom_assemble(mesh, F.STIFF)
+        am = ctx.atom_assemble(mesh, F.MASS)
+        ctx.sync()
+        t3 = time.time()
+        op = ctx.op_combine(mesh, [ak, am], [1.0, 1.0])
+        ctx.sync()
+        t4 = time.time()
+        print(f"n={n}^3 nv={nv} nnz={nnz} (formula {F.nnz_p1_box(n)}) host mesh {t1-t0:.2f}s upload+topology {t2-t1:.2f}s "
+              f"2 atoms {t3-t2:.3f}s combine {t4-t3:.3f}s", flush=True)
+        x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, nv))
+        y = ctx.vec_alloc(nv)
+        for _ in range(5):
+            ctx.spmv(op, x, y)
+        ctx.sync()
+        ctx.prof_enable(True)
+        reps = 50
+        t0 = time.time()
+        for _ in range(reps):
+            ctx.spmv(op, x, y)
+        ctx.sync()
+        wall = time.time() - t0
+        pr = ctx.prof_read()
+        ctx.prof_enable(False)
+        alg = F.spmv_bytes(nv, nnz)
+        print(f"  spmv: {pr['seconds']/pr['launches']*1e6:.1f} us/launch (events) {wall/reps*1e6:.1f} us (wall) "
+              f"-> {alg/(pr['seconds']/pr['launches'])/1e9:.0f} GB/s algorithmic = {alg/(pr['seconds']/pr['launches'])/8e12*100:.1f}% of 8 TB/s", flush=True)
+        # bilinear (spmv + dot), and a full PCG solve
+        t0 = time.time()
+        for _ in range(20):
+            ctx.bilinear(op, x, x)
+        print(f"  bilinear (host round trip each): {(time.time()-t0)/20*1e6:.1f} us", flush=True)
+        b = ctx.vec_alloc(nv)
+        ctx.spmv(op, x, b)
+        ctx.vec_fill(y, 0.0)
+        t0 = time.time()
+        it, rel = ctx.pcg_solve(op, b, y, rtol=1e-8, maxit=2000)
+        dt = time.time() - t0
+        print(f"  pcg: {it} iterations, relres {rel:.2e}, {dt*1e3:.1f} ms -> {dt/max(it,1)*1e6:.1f} us/iteration "
+              f"({(alg + 88*nv)/ (dt/max(it,1))/1e9:.0f} GB/s of 12nnz+108n)", flush=True)
+        for v in (x, y, b):
+            ctx.vec_free(v)
+        for a in (ak, am, op):
+            ctx.atom_free(a)
+        ctx.mesh_free(mesh)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
