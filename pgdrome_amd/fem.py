@@ -1,0 +1,1669 @@
+"""Host-side form frontend: the subset of the dolfin/UFL surface that PGDrome's
+weak-form callbacks and ``PGDProblem`` use, captured
+as *operator atoms* and executed by the HIP engine through the C-ABI.
+
+The reference callbacks build every form from one rigid grammar
+(/root/reference/tests/integration/test_heat1D.py:55-266,
+test_laplace.py:73-366):
+
+    Constant(assemble(F*A*G*dx(m_j)) * ...) * param * u[.dx(0)] * v[.dx(0)] * dx(m_d)
+
+so an integrand is a sum of monomials  coef * prod(factors)  with factors
+``field`` or ``field.dx(i)`` (or ``inner(grad f, grad g)``), fields being the
+trial / test function or coefficient Functions.  Each monomial maps onto one
+P1 atom (mass, stiffness, directional derivative, convection, weighted mass)
+that is assembled ONCE per mesh on the GPU and cached; a bilinear form is then
+``sum_t c_t A_t`` (one k_combine launch), a linear form ``sum_s c_s A_s g_s``
+(SpMV + axpy) and a functional ``f^T A g`` (fused SpMV-dot).
+
+Numbering: device vectors are kept in mesh-vertex order.  ``Function.vector()``
+exposes dof order; as in serial dolfin 2019.1.0 the P1 dofs of an IntervalMesh
+run opposite to the vertices (pinned by /root/reference/tests/unit/test_FD.py:69,
+76-79), for 2-D/3-D meshes dof == vertex (dolfin's reordering there is not
+pinned by anything in the reference tree; compare in vertex order).
+
+There is no CPU implementation in this package: the default backend is the HIP
+library and creating it without a GPU raises.  Tests inject the oracle backend
+explicitly with ``set_backend``.
+"""
+from __future__ import annotations
+
+import logging
+import math
+import numbers
+import re
+
+import numpy as np
+
+LOG = logging.getLogger("pgdrome_amd.fem")
+
+MASS, STIFF, DUDV, CONV, CONVT, WMASS, WSTIFF = range(7)   # == include/pgd_amd.h PGD_ATOM_*
+
+# --------------------------------------------------------------------------- backend
+_backend = None
+
+
+def set_backend(be):
+    """Install a backend object (see hip_backend.HipBackend for the interface)."""
+    global _backend
+    _backend = be
+    return be
+
+
+def get_backend():
+    global _backend
+    if _backend is None:
+        from .hip_backend import HipBackend   # raises without the HIP library or a GPU
+        _backend = HipBackend()
+    return _backend
+
+
+# ------------------------------------------------------------------- logging shims
+class LogLevel:
+    DEBUG, TRACE, PROGRESS, INFO, WARNING, ERROR, CRITICAL = 10, 13, 16, 20, 30, 40, 50
+
+
+def set_log_level(level):
+    LOG.setLevel(level)
+
+
+parameters = {"form_compiler": {"optimize": True, "cpp_optimize": True, "quadrature_degree": -1},
+              "linear_algebra_backend": "pgd_amd"}
+
+DOLFIN_EPS = 3.0e-16
+
+
+def near(x, x0, eps=DOLFIN_EPS):
+    return abs(x - x0) < eps
+
+
+class Point:
+    def __init__(self, *xs):
+        if len(xs) == 1 and hasattr(xs[0], "__len__"):
+            xs = tuple(xs[0])
+        self._x = tuple(float(v) for v in xs)
+
+    def __getitem__(self, i):
+        return self._x[i]
+
+    def __len__(self):
+        return len(self._x)
+
+    def x(self):
+        return self._x[0]
+
+    def y(self):
+        return self._x[1] if len(self._x) > 1 else 0.0
+
+    def z(self):
+        return self._x[2] if len(self._x) > 2 else 0.0
+
+    def array(self):
+        return np.array(self._x + (0.0,) * (3 - len(self._x)))
+
+
+# ---------------------------------------------------------------------------- meshes
+class _Topology:
+    def __init__(self, d):
+        self._d = d
+
+    def dim(self):
+        return self._d
+
+
+class _Geometry(_Topology):
+    pass
+
+
+class Partition:
+    """Row-sharding of a mesh across ranks (pgdrome_amd/dist.py).  The local mesh
+    holds the owned vertices [own0, own1) plus one layer of ghost vertices on
+    either side; all local vectors have the extended length."""
+
+    def __init__(self, comm, own0, own1, n_global, lo_ghost, hi_ghost, global_offset):
+        self.comm = comm
+        self.own0, self.own1 = own0, own1
+        self.n_global = n_global
+        self.lo_ghost, self.hi_ghost = lo_ghost, hi_ghost   # ghost counts before / after
+        self.global_offset = global_offset                    # global id of local vertex 0
+
+
+class Mesh:
+    _CELL_NAMES = {1: "interval", 2: "triangle", 3: "tetrahedron"}
+
+    def __init__(self, coords, cells, part=None):
+        coords = np.ascontiguousarray(coords, dtype=np.float64)
+        if coords.ndim == 1:
+            coords = coords.reshape(-1, 1)
+        self._coords = coords
+        self._cells = np.ascontiguousarray(cells, dtype=np.int32)
+        self._gdim = coords.shape[1]
+        self.part = part
+        self._handles = {}       # backend id -> mesh handle
+        self._atoms = {}         # (backend id, key) -> atom handle
+        self._on_boundary = None
+        self._ones = None
+
+    def coordinates(self):
+        return self._coords
+
+    def cells(self):
+        return self._cells
+
+    def num_vertices(self):
+        return self._coords.shape[0]
+
+    def num_cells(self):
+        return self._cells.shape[0]
+
+    def topology(self):
+        return _Topology(self._gdim)
+
+    def geometry(self):
+        return _Geometry(self._gdim)
+
+    def ufl_cell(self):
+        return self._CELL_NAMES[self._gdim]
+
+    def hmin(self):
+        X = self._coords[self._cells]
+        return float(np.linalg.norm(X[:, 1:] - X[:, :1], axis=2).min())
+
+    # rows a rank owns (whole mesh when not sharded)
+    def owned_range(self):
+        return (self.part.own0, self.part.own1) if self.part else (0, self.num_vertices())
+
+    def handle(self):
+        be = get_backend()
+        h = self._handles.get(id(be))
+        if h is None:
+            h = be.mesh(self._coords, self._cells)
+            self._handles[id(be)] = h
+        return h
+
+    def atom(self, kind, da=0, db=0, weight=None):
+        """Cached device atom; weighted atoms are keyed by the weight's identity+version."""
+        be = get_backend()
+        if self._gdim == 1 and kind == DUDV:
+            kind = STIFF
+        wkey = None if weight is None else (id(weight), weight.version)
+        key = (id(be), kind, da if kind in (DUDV, CONV) else 0, db if kind in (DUDV, CONVT) else 0, wkey)
+        a = self._atoms.get(key)
+        if a is None:
+            if weight is not None:   # drop stale versions of the same weight
+                for k in [k for k in self._atoms if k[0] == id(be) and k[1] == kind and k[4] and k[4][0] == id(weight)]:
+                    be.atom_free(self._atoms.pop(k))
+            a = be.atom(self.handle(), kind, key[2], key[3], weight.dev() if weight is not None else 0)
+            self._atoms[key] = a
+        return a
+
+    def vertex_on_boundary(self):
+        """Vertices on exterior facets (facets that belong to exactly one cell)."""
+        if self._on_boundary is None:
+            nv = self.num_vertices()
+            flag = np.zeros(nv, dtype=bool)
+            c = self._cells
+            if self._gdim == 1:
+                cnt = np.bincount(c.ravel(), minlength=nv)
+                flag = cnt == 1
+            else:
+                k = c.shape[1]
+                facets = np.concatenate([np.delete(c, j, axis=1) for j in range(k)], axis=0)
+                facets = np.sort(facets, axis=1)
+                uniq, counts = np.unique(facets, axis=0, return_counts=True)
+                flag[uniq[counts == 1].ravel()] = True
+            if self.part is not None:
+                # cut faces of a slab are not physical boundary: only keep vertices on the
+                # global hull, which for slabs is decided by the caller-provided box
+                flag &= self.part.comm.hull_mask(self)
+            self._on_boundary = flag
+        return self._on_boundary
+
+
+def IntervalMesh(n, a, b):
+    n = int(n)
+    coords = (a + (b - a) * np.arange(n + 1, dtype=np.float64) / n).reshape(-1, 1)
+    cells = np.stack([np.arange(n), np.arange(1, n + 1)], axis=1)
+    return Mesh(coords, cells)
+
+
+def UnitIntervalMesh(n):
+    return IntervalMesh(n, 0.0, 1.0)
+
+
+def _grid_axis(a, b, n):
+    return a + (b - a) * np.arange(n + 1, dtype=np.float64) / n
+
+
+def RectangleMesh(p0, p1, nx, ny, diagonal="right"):
+    nx, ny = int(nx), int(ny)
+    xs, ys = _grid_axis(p0[0], p1[0], nx), _grid_axis(p0[1], p1[1], ny)
+    X, Y = np.meshgrid(xs, ys, indexing="xy")
+    coords = np.stack([X.ravel(), Y.ravel()], axis=1)
+    ix, iy = np.meshgrid(np.arange(nx), np.arange(ny), indexing="xy")
+    v0 = (iy * (nx + 1) + ix).ravel()
+    v1, v2, v3 = v0 + 1, v0 + nx + 1, v0 + nx + 2
+    if diagonal == "right":
+        tris = ((v0, v1, v3), (v0, v2, v3))
+    elif diagonal == "left":
+        tris = ((v0, v1, v2), (v1, v2, v3))
+    else:
+        raise NotImplementedError("RectangleMesh diagonal=%r (only 'right'/'left')" % (diagonal,))
+    cells = np.empty((2 * nx * ny, 3), dtype=np.int32)
+    for k, t in enumerate(tris):
+        cells[k::2] = np.stack(t, axis=1)
+    return Mesh(coords, cells)
+
+
+def UnitSquareMesh(nx, ny, diagonal="right"):
+    return RectangleMesh(Point(0, 0), Point(1, 1), nx, ny, diagonal)
+
+
+def box_mesh_arrays(p0, p1, nx, ny, nz, z_first=0, z_last=None):
+    """Vertices / tetrahedra of dolfin.BoxMesh restricted to the vertex planes
+    z_first..z_last (inclusive) - the slab a rank holds when the mesh is sharded."""
+    z_last = nz if z_last is None else z_last
+    xs, ys, zs = _grid_axis(p0[0], p1[0], nx), _grid_axis(p0[1], p1[1], ny), _grid_axis(p0[2], p1[2], nz)
+    zs = zs[z_first:z_last + 1]
+    Z, Y, X = np.meshgrid(zs, ys, xs, indexing="ij")
+    coords = np.stack([X.ravel(), Y.ravel(), Z.ravel()], axis=1)
+    nzl = z_last - z_first
+    sx, sy = nx + 1, (nx + 1) * (ny + 1)
+    iz, iy, ix = np.meshgrid(np.arange(nzl), np.arange(ny), np.arange(nx), indexing="ij")
+    v0 = (iz * sy + iy * sx + ix).ravel().astype(np.int32)
+    v1, v2, v3 = v0 + 1, v0 + sx, v0 + sx + 1
+    v4, v5, v6, v7 = v0 + sy, v1 + sy, v2 + sy, v3 + sy
+    tets = ((v0, v1, v3, v7), (v0, v1, v7, v5), (v0, v5, v7, v4),
+            (v0, v3, v2, v7), (v0, v6, v4, v7), (v0, v2, v6, v7))
+    cells = np.empty((6 * nx * ny * nzl, 4), dtype=np.int32)
+    for k, t in enumerate(tets):
+        cells[k::6] = np.stack(t, axis=1)
+    return coords, cells
+
+
+def BoxMesh(p0, p1, nx, ny, nz):
+    coords, cells = box_mesh_arrays(p0, p1, int(nx), int(ny), int(nz))
+    return Mesh(coords, cells)
+
+
+def UnitCubeMesh(nx, ny, nz):
+    return BoxMesh(Point(0, 0, 0), Point(1, 1, 1), nx, ny, nz)
+
+
+# ------------------------------------------------------------------- function spaces
+class _Element:
+    def __init__(self, cell, degree):
+        self._cell, self._degree = cell, degree
+
+    def __str__(self):
+        return "FiniteElement('Lagrange', %s, %d)" % (self._cell, self._degree)
+
+    __repr__ = __str__
+
+    def degree(self):
+        return self._degree
+
+    def family(self):
+        return "Lagrange"
+
+
+class _DofMap:
+    def __init__(self, V):
+        self._V = V
+
+    def dofs(self):
+        return np.arange(self._V.dim())
+
+
+class FunctionSpace:
+    def __init__(self, mesh, family="CG", degree=1):
+        if str(family) not in ("CG", "P", "Lagrange"):
+            raise NotImplementedError("FunctionSpace family %r: only Lagrange ('CG'/'P')" % (family,))
+        if int(degree) != 1:
+            raise NotImplementedError("FunctionSpace degree %r: only P1 is built so far (P2: SURVEY 8(f4))" % (degree,))
+        self._mesh = mesh
+        self._element = _Element(mesh.ufl_cell(), 1)
+        n = mesh.num_vertices()
+        # dof -> vertex; self-inverse reversal on intervals, identity otherwise
+        self._d2v = np.arange(n - 1, -1, -1) if mesh.topology().dim() == 1 else None
+
+    def mesh(self):
+        return self._mesh
+
+    def dim(self):
+        return self._mesh.num_vertices()
+
+    def ufl_element(self):
+        return self._element
+
+    def ufl_function_space(self):
+        return self
+
+    def dofmap(self):
+        return _DofMap(self)
+
+    def tabulate_dof_coordinates(self):
+        return self.to_dof_order(self._mesh.coordinates())
+
+    def to_dof_order(self, a):
+        return a if self._d2v is None else a[self._d2v]
+
+    def to_vertex_order(self, a):
+        return a if self._d2v is None else a[self._d2v]     # the reversal is its own inverse
+
+    def dof_to_vertex(self, dofs):
+        return dofs if self._d2v is None else self._d2v[dofs]
+
+    def __eq__(self, other):
+        return self is other
+
+    def __hash__(self):
+        return id(self)
+
+
+def vertex_to_dof_map(V):
+    n = V.dim()
+    return np.arange(n) if V._d2v is None else V._d2v.copy()
+
+
+dof_to_vertex_map = vertex_to_dof_map
+
+
+# ----------------------------------------------------------------------------- vectors
+class Vector:
+    """A dof vector resident on the device, with a lazily synchronised host mirror.
+
+    Storage is in VERTEX order on both sides; indexing (``v[:]``, ``v[i]``) is in
+    DOF order like dolfin's GenericVector."""
+
+    def __init__(self, V, host=None):
+        self.V = V
+        self.n = V.dim()
+        self._host = np.zeros(self.n) if host is None else np.array(host, dtype=np.float64)
+        self._dev = None
+        self._host_ok = True
+        self._dev_ok = False
+        self.version = 0
+
+    # -- residency
+    def host(self):
+        if not self._host_ok:
+            self._host = get_backend().vec_to_host(self._dev)
+            self._host_ok = True
+        return self._host
+
+    def dev(self):
+        be = get_backend()
+        if self._dev is None:
+            self._dev = be.vec_zeros(self.n)
+            if self._host_ok and not np.any(self._host):
+                self._dev_ok = True
+        if not self._dev_ok:
+            be.vec_upload(self._dev, self._host)
+            self._dev_ok = True
+        return self._dev
+
+    def touched_host(self):
+        self._host_ok, self._dev_ok = True, False
+        self.version += 1
+
+    def touched_dev(self):
+        self._dev_ok, self._host_ok = True, False
+        self.version += 1
+
+    def __del__(self):
+        try:
+            if self._dev is not None and _backend is not None:
+                _backend.vec_free(self._dev)
+        except Exception:
+            pass
+
+    # -- GenericVector surface
+    def __len__(self):
+        return self.n
+
+    def size(self):
+        return self.n
+
+    local_size = size
+
+    def get_local(self):
+        return self.V.to_dof_order(self.host()).copy()
+
+    def set_local(self, a):
+        self._host = np.array(self.V.to_vertex_order(np.asarray(a, dtype=np.float64)), dtype=np.float64)
+        self.touched_host()
+
+    def apply(self, mode=""):
+        pass
+
+    def __getitem__(self, key):
+        return self.V.to_dof_order(self.host())[key].copy() if isinstance(key, slice) \
+            else self.V.to_dof_order(self.host())[key]
+
+    def __setitem__(self, key, val):
+        a = self.get_local()
+        a[key] = val.get_local() if isinstance(val, Vector) else val
+        self.set_local(a)
+
+    def __array__(self, dtype=None, copy=None):
+        return self.get_local()
+
+    def zero(self):
+        self._host = np.zeros(self.n)
+        self.touched_host()
+
+    def copy(self):
+        out = Vector(self.V)
+        out.assign_from(self)
+        return out
+
+    def assign_from(self, other):
+        if self._small() or not other._dev_ok:
+            self._host = other.host().copy()
+            self.touched_host()
+        else:
+            get_backend().vec_copy(self.dev_for_write(), other.dev())
+            self.touched_dev()
+
+    def dev_for_write(self):
+        """Device handle whose content is about to be overwritten (skips the upload)."""
+        if self._dev is None:
+            self._dev = get_backend().vec_zeros(self.n)
+        return self._dev
+
+    def _small(self):
+        return self.n <= 4096
+
+    def scale(self, a):
+        if self._dev_ok and not self._small():
+            get_backend().vec_scale(self._dev, float(a))
+            self.touched_dev()
+        else:
+            self._host = self.host() * float(a)
+            self.touched_host()
+
+    def axpy(self, a, x):
+        if not self._small() and (self._dev_ok or x._dev_ok):
+            get_backend().vec_axpy(self.dev(), float(a), x.dev())
+            self.touched_dev()
+        else:
+            self._host = self.host() + float(a) * x.host()
+            self.touched_host()
+
+    def __imul__(self, a):
+        self.scale(a)
+        return self
+
+    def __itruediv__(self, a):
+        self.scale(1.0 / a)
+        return self
+
+    def __iadd__(self, x):
+        self.axpy(1.0, x)
+        return self
+
+    def __isub__(self, x):
+        self.axpy(-1.0, x)
+        return self
+
+    def inner(self, other):
+        lo, hi = self.V.mesh().owned_range()
+        if self._small() and self.V.mesh().part is None:
+            return float(self.host() @ other.host())
+        return _allreduce_sum(self.V.mesh(), get_backend().vec_dot(self.dev(), other.dev(), lo, hi))
+
+    def norm(self, kind="l2"):
+        if kind.lower() == "l2":
+            return math.sqrt(self.inner(self))
+        if kind.lower() == "linf":
+            return float(np.abs(self.host()).max())
+        raise NotImplementedError(kind)
+
+    def max(self):
+        return float(self.host().max())
+
+    def min(self):
+        return float(self.host().min())
+
+    def sum(self):
+        return float(self.host().sum())
+
+
+def _allreduce_sum(mesh, value):
+    if mesh.part is None:
+        return value
+    return mesh.part.comm.allreduce_sum(value)
+
+
+# ------------------------------------------------------------------ symbolic algebra
+class Expr:
+    """Anything that can stand in an integrand; normalises to a polynomial (list of Terms)."""
+
+    def _poly(self):
+        raise NotImplementedError
+
+    def __mul__(self, o):
+        if isinstance(o, Measure):
+            return Form([(t, o) for t in self._poly()])
+        return Poly(_pmul(self._poly(), _as_poly(o)))
+
+    def __rmul__(self, o):
+        return Poly(_pmul(_as_poly(o), self._poly()))
+
+    def __add__(self, o):
+        return Poly(self._poly() + _as_poly(o))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return Poly(self._poly() + _pscale(_as_poly(o), -1.0))
+
+    def __rsub__(self, o):
+        return Poly(_as_poly(o) + _pscale(self._poly(), -1.0))
+
+    def __neg__(self):
+        return Poly(_pscale(self._poly(), -1.0))
+
+    def __truediv__(self, o):
+        return Poly(_pscale(self._poly(), 1.0 / _as_float(o)))
+
+    def dx(self, *axes):
+        p = self._poly()
+        if len(axes) != 1:
+            raise NotImplementedError("only first derivatives .dx(i)")
+        out = []
+        for t in p:
+            if len(t.factors) != 1 or t.factors[0].deriv is not None:
+                raise NotImplementedError(".dx() of a product / second derivative")
+            f = t.factors[0]
+            out.append(Term(t.coef, (Factor(f.leaf, int(axes[0])),)))
+        return Poly(out)
+
+
+class Factor:
+    __slots__ = ("leaf", "deriv", "other")
+
+    def __init__(self, leaf, deriv=None, other=None):
+        self.leaf, self.deriv, self.other = leaf, deriv, other   # deriv: None | axis | "grad" (dot with `other`)
+
+
+class Term:
+    __slots__ = ("coef", "factors")
+
+    def __init__(self, coef, factors):
+        self.coef, self.factors = float(coef), tuple(factors)
+
+
+class Poly(Expr):
+    def __init__(self, terms):
+        self.terms = list(terms)
+
+    def _poly(self):
+        return self.terms
+
+
+def _as_float(o):
+    if isinstance(o, Constant):
+        return float(o)
+    if isinstance(o, numbers.Real):
+        return float(o)
+    if isinstance(o, np.ndarray) and o.ndim == 0:
+        return float(o)
+    raise TypeError("expected a scalar, got %r" % (type(o),))
+
+
+def _as_poly(o):
+    if isinstance(o, Expr):
+        return o._poly()
+    return [Term(_as_float(o), ())]
+
+
+def _pmul(a, b):
+    return [Term(s.coef * t.coef, s.factors + t.factors) for s in a for t in b]
+
+
+def _pscale(a, c):
+    return [Term(t.coef * c, t.factors) for t in a]
+
+
+class Constant(Expr):
+    def __init__(self, value, cell=None, name=None):
+        if isinstance(value, (tuple, list, np.ndarray)) and np.ndim(value) > 0:
+            raise NotImplementedError("vector/tensor Constant (vector-valued spaces: SURVEY 8(f4))")
+        self._v = float(value)
+
+    def assign(self, v):
+        self._v = float(v)
+
+    def values(self):
+        return np.array([self._v])
+
+    def __float__(self):
+        return self._v
+
+    def _poly(self):
+        return [Term(self._v, ())]
+
+    def __call__(self, *a):
+        return self._v
+
+
+class Grad:
+    """grad(f): only meaningful inside inner()/dot()."""
+
+    def __init__(self, f):
+        p = _as_poly(f)
+        if len(p) != 1 or len(p[0].factors) != 1 or p[0].factors[0].deriv is not None:
+            raise NotImplementedError("grad() of anything but a plain function")
+        self.coef, self.leaf = p[0].coef, p[0].factors[0].leaf
+
+
+def grad(f):
+    return Grad(f)
+
+
+nabla_grad = grad
+
+
+def inner(a, b):
+    if isinstance(a, Grad) and isinstance(b, Grad):
+        return Poly([Term(a.coef * b.coef, (Factor(a.leaf, "grad", b.leaf),))])
+    if isinstance(a, Grad) or isinstance(b, Grad):
+        raise NotImplementedError("inner(grad f, g) with a non-gradient g")
+    return Poly(_pmul(_as_poly(a), _as_poly(b)))
+
+
+dot = inner
+
+
+class Measure:
+    def __init__(self, kind="dx", domain=None, subdomain_data=None, subdomain_id=None):
+        if kind != "dx":
+            raise NotImplementedError("Measure %r: only cell integrals dx (ds: SURVEY 8(f4))" % (kind,))
+        self.kind, self.mesh = kind, domain
+        if subdomain_id is not None or subdomain_data is not None:
+            raise NotImplementedError("subdomain integrals (SURVEY 8(f4))")
+
+    def __call__(self, *args, **kw):
+        mesh = kw.get("domain")
+        for a in args:
+            if isinstance(a, Mesh):
+                mesh = a
+            elif a is not None:
+                raise NotImplementedError("dx(subdomain id) (SURVEY 8(f4))")
+        return Measure(self.kind, mesh)
+
+    def __rmul__(self, o):
+        return Form([(t, self) for t in _as_poly(o)])
+
+
+dx = Measure("dx")
+
+
+class Form:
+    """Sum of (Term, Measure) integrals."""
+
+    def __init__(self, integrals):
+        self.integrals = list(integrals)
+
+    def __add__(self, o):
+        if isinstance(o, numbers.Real) and o == 0:
+            return self
+        return Form(self.integrals + o.integrals)
+
+    __radd__ = __add__
+
+    def __neg__(self):
+        return Form([(Term(-t.coef, t.factors), m) for t, m in self.integrals])
+
+    def __sub__(self, o):
+        if isinstance(o, numbers.Real) and o == 0:
+            return self
+        return self + (-o)
+
+    def __rsub__(self, o):
+        return (-self) + o
+
+    def __mul__(self, c):
+        c = _as_float(c)
+        return Form([(Term(t.coef * c, t.factors), m) for t, m in self.integrals])
+
+    __rmul__ = __mul__
+
+    def __truediv__(self, c):
+        return self * (1.0 / _as_float(c))
+
+    def __eq__(self, o):
+        return Equation(self, o)
+
+    __hash__ = None
+
+    def mesh(self):
+        for t, m in self.integrals:
+            if m.mesh is not None:
+                return m.mesh
+            for f in t.factors:
+                V = getattr(f.leaf, "_V", None)
+                if V is not None:
+                    return V.mesh()
+        raise ValueError("cannot determine the integration domain of this form")
+
+    def rank(self):
+        r = set()
+        for t, _ in self.integrals:
+            r.add(sum(1 for f in t.factors if isinstance(f.leaf, Argument)) +
+                  sum(1 for f in t.factors if f.deriv == "grad" and isinstance(f.other, Argument)))
+        if len(r) > 1:
+            raise ValueError("form mixes integrands of different arity: %s" % sorted(r))
+        return r.pop() if r else 0
+
+
+class Equation:
+    def __init__(self, lhs, rhs):
+        self.lhs, self.rhs = lhs, rhs
+
+
+class Argument(Expr):
+    def __init__(self, V, number):
+        self._V, self.number = V, number
+
+    def function_space(self):
+        return self._V
+
+    def _poly(self):
+        return [Term(1.0, (Factor(self),))]
+
+
+def TestFunction(V):
+    return Argument(V, 0)
+
+
+def TrialFunction(V):
+    return Argument(V, 1)
+
+
+# --------------------------------------------------------------------------- functions
+class Function(Expr):
+    def __init__(self, V, src=None, name=None):
+        if isinstance(V, Function):       # copy constructor
+            src, V = V, V._V
+        self._V = V
+        self._vec = Vector(V)
+        self._name = name or "f"
+        if isinstance(src, Function):
+            self._vec.assign_from(src._vec)
+        elif isinstance(src, Vector):
+            self._vec.assign_from(src)
+
+    def function_space(self):
+        return self._V
+
+    def vector(self):
+        return self._vec
+
+    def name(self):
+        return self._name
+
+    def rename(self, name, label=None):
+        self._name = name
+
+    def ufl_element(self):
+        return self._V.ufl_element()
+
+    def compute_vertex_values(self, mesh=None):
+        return self._vec.host().copy()
+
+    def copy(self, deepcopy=False):
+        return Function(self._V, self) if deepcopy else self
+
+    def assign(self, other):
+        if isinstance(other, Function):
+            self._vec.assign_from(other._vec)
+        else:
+            self._vec._host = interpolate(other, self._V)._vec.host().copy()
+            self._vec.touched_host()
+
+    def interpolate(self, other):
+        self.assign(other)
+
+    def _poly(self):
+        return [Term(1.0, (Factor(self),))]
+
+    def __call__(self, *x):
+        if len(x) == 1 and hasattr(x[0], "__len__"):
+            x = tuple(x[0])
+        return _point_eval(self, np.array([float(v) for v in x]))
+
+
+def _point_eval(f, x):
+    mesh = f._V.mesh()
+    X, cells, vals = mesh.coordinates(), mesh.cells(), f._vec.host()
+    if mesh.topology().dim() == 1:
+        xs = X[:, 0]
+        if x[0] < xs.min() - 1e-12 or x[0] > xs.max() + 1e-12:
+            raise RuntimeError("point %r outside the mesh" % (x,))
+        order = np.argsort(xs)
+        return float(np.interp(x[0], xs[order], vals[order]))
+    # simplices: barycentric coordinates of x in every cell, take the one containing it
+    P = X[cells]
+    T = np.transpose(P[:, 1:, :] - P[:, :1, :], (0, 2, 1))
+    lam = np.linalg.solve(T, (x[None, :] - P[:, 0, :])[:, :, None])[:, :, 0]
+    lam0 = 1.0 - lam.sum(axis=1)
+    L = np.concatenate([lam0[:, None], lam], axis=1)
+    k = int(np.argmax(L.min(axis=1)))
+    if L[k].min() < -1e-10:
+        raise RuntimeError("point %r outside the mesh" % (x,))
+    return float(L[k] @ vals[cells[k]])
+
+
+_EXPR_FUNCS = {
+    "pow": np.power, "exp": np.exp, "sqrt": np.sqrt, "sin": np.sin, "cos": np.cos, "tan": np.tan,
+    "fabs": np.abs, "abs": np.abs, "log": np.log, "log10": np.log10, "sinh": np.sinh, "cosh": np.cosh,
+    "tanh": np.tanh, "atan": np.arctan, "atan2": np.arctan2, "asin": np.arcsin, "acos": np.arccos,
+    "floor": np.floor, "ceil": np.ceil, "fmin": np.minimum, "fmax": np.maximum, "min": np.minimum,
+    "max": np.maximum, "erf": None, "pi": math.pi, "DOLFIN_PI": math.pi, "DOLFIN_EPS": DOLFIN_EPS,
+    "where": np.where, "logical_and": np.logical_and, "logical_or": np.logical_or,
+    "logical_not": np.logical_not,
+}
+
+
+def _split_top(s, op):
+    """Split s at top-level occurrences of the operator string `op`."""
+    out, depth, last, i = [], 0, 0, 0
+    while i < len(s):
+        c = s[i]
+        if c in "([":
+            depth += 1
+        elif c in ")]":
+            depth -= 1
+        elif depth == 0 and s.startswith(op, i):
+            out.append(s[last:i])
+            i += len(op)
+            last = i
+            continue
+        i += 1
+    out.append(s[last:])
+    return out
+
+
+def _c_to_py(s):
+    """Translate the C++ expression dialect of dolfin.Expression to numpy-evaluable Python."""
+    s = s.strip()
+    # ternary  c ? a : b  (right-associative, lowest precedence)
+    depth = 0
+    for i, ch in enumerate(s):
+        if ch in "([":
+            depth += 1
+        elif ch in ")]":
+            depth -= 1
+        elif ch == "?" and depth == 0:
+            cond, rest = s[:i], s[i + 1:]
+            d2, nest = 0, 0
+            for j, cj in enumerate(rest):
+                if cj in "([":
+                    d2 += 1
+                elif cj in ")]":
+                    d2 -= 1
+                elif cj == "?" and d2 == 0:
+                    nest += 1
+                elif cj == ":" and d2 == 0:
+                    if nest == 0:
+                        return "where(%s, %s, %s)" % (_c_to_py(cond), _c_to_py(rest[:j]), _c_to_py(rest[j + 1:]))
+                    nest -= 1
+            raise ValueError("malformed ternary in Expression: %r" % s)
+    parts = _split_top(s, "||")
+    if len(parts) > 1:
+        out = _c_to_py(parts[0])
+        for p in parts[1:]:
+            out = "logical_or(%s, %s)" % (out, _c_to_py(p))
+        return out
+    parts = _split_top(s, "&&")
+    if len(parts) > 1:
+        out = _c_to_py(parts[0])
+        for p in parts[1:]:
+            out = "logical_and(%s, %s)" % (out, _c_to_py(p))
+        return out
+    # recurse into parenthesised groups / call arguments that may contain the operators above
+    if "?" in s or "&&" in s or "||" in s:
+        out, i = "", 0
+        while i < len(s):
+            if s[i] == "(":
+                depth, j = 1, i + 1
+                while j < len(s) and depth:
+                    depth += s[j] == "("
+                    depth -= s[j] == ")"
+                    j += 1
+                inner_s = s[i + 1:j - 1]
+                out += "(" + ", ".join(_c_to_py(a) for a in _split_top(inner_s, ",")) + ")"
+                i = j
+            else:
+                out += s[i]
+                i += 1
+        return out
+    return s
+
+
+class Expression(Expr):
+    """dolfin.Expression("C++ string", degree=k, **parameters), scalar valued.
+
+    Used as a form coefficient it is interpolated into the P1 space of the
+    integration mesh (exact for the degree <= 1 data of the benchmark configs;
+    for higher ``degree`` FFC would integrate a degree-k interpolant instead -
+    documented deviation)."""
+
+    def __init__(self, code=None, degree=None, element=None, cell=None, domain=None, name=None, **params):
+        if isinstance(code, (tuple, list)):
+            raise NotImplementedError("vector-valued Expression (SURVEY 8(f4))")
+        object.__setattr__(self, "_params", dict(params))
+        self._code = code
+        self._py = compile(_c_to_py(code), "<Expression %r>" % (code,), "eval") if code is not None else None
+        self._degree = degree
+        self._cache = {}
+
+    def __setattr__(self, k, v):
+        if k in self.__dict__.get("_params", {}):
+            self._params[k] = v
+            self._cache.clear()
+        else:
+            object.__setattr__(self, k, v)
+
+    def __getattr__(self, k):
+        p = self.__dict__.get("_params", {})
+        if k in p:
+            return p[k]
+        raise AttributeError(k)
+
+    def _param_values(self):
+        out = {}
+        for k, v in self._params.items():
+            if isinstance(v, Function):
+                raise NotImplementedError("Function-valued Expression parameter")
+            out[k] = float(v)
+        return out
+
+    def eval_at(self, coords):
+        """Vectorised evaluation at points (n x gdim) -> (n,)."""
+        coords = np.asarray(coords, dtype=np.float64)
+        if coords.ndim == 1:
+            coords = coords.reshape(1, -1)
+        ns = dict(_EXPR_FUNCS)
+        ns.update(self._param_values())
+        ns["x"] = [coords[:, k] for k in range(coords.shape[1])]
+        val = eval(self._py, {"__builtins__": {}}, ns)
+        return np.broadcast_to(np.asarray(val, dtype=np.float64), (coords.shape[0],)).copy()
+
+    def __call__(self, *x):
+        if len(x) == 1 and hasattr(x[0], "__len__"):
+            x = tuple(x[0])
+        return float(self.eval_at(np.array([[float(v) for v in x]]))[0])
+
+    def as_function(self, mesh):
+        key = (id(mesh), tuple(sorted(self._param_values().items())))
+        f = self._cache.get(key)
+        if f is None:
+            V = _p1_space(mesh)
+            f = Function(V)
+            f._vec._host = self.eval_at(mesh.coordinates())
+            f._vec.touched_host()
+            self._cache = {key: f}
+        return f
+
+    def _poly(self):
+        return [Term(1.0, (Factor(self),))]
+
+
+_P1_SPACES = {}
+
+
+def _p1_space(mesh):
+    V = _P1_SPACES.get(id(mesh))
+    if V is None or V.mesh() is not mesh:
+        V = FunctionSpace(mesh, "CG", 1)
+        _P1_SPACES[id(mesh)] = V
+    return V
+
+
+def interpolate(v, V):
+    f = Function(V)
+    if isinstance(v, Function):
+        if v._V.mesh() is V.mesh():
+            f._vec.assign_from(v._vec)
+        else:
+            f._vec._host = np.array([v(x) for x in V.mesh().coordinates()])
+            f._vec.touched_host()
+    elif isinstance(v, Expression):
+        f._vec._host = v.eval_at(V.mesh().coordinates())
+        f._vec.touched_host()
+    elif isinstance(v, (Constant, numbers.Real)):
+        f._vec._host = np.full(V.dim(), float(v))
+        f._vec.touched_host()
+    else:
+        raise TypeError("cannot interpolate %r" % (type(v),))
+    return f
+
+
+def project(v, V, bcs=None, **kw):
+    """L2 projection onto P1.  With P1-interpolated data the projection of the
+    interpolant is the interpolant itself."""
+    return interpolate(v, V)
+
+
+# ----------------------------------------------------------------- boundary conditions
+class SubDomain:
+    def inside(self, x, on_boundary):
+        raise NotImplementedError
+
+    def mark(self, meshfunction, value):
+        raise NotImplementedError("MeshFunction marking (SURVEY 8(f4))")
+
+
+def _eval_marker(marker, mesh):
+    """Vertices selected by a dolfin-style marker ``f(x, on_boundary)``.
+
+    First tried vectorised (x[k] are coordinate arrays), which numpy-friendly
+    markers accept; otherwise vertex by vertex as dolfin does."""
+    fn = marker.inside if isinstance(marker, SubDomain) else marker
+    X, onb = mesh.coordinates(), mesh.vertex_on_boundary()
+    try:
+        res = fn([X[:, k] for k in range(X.shape[1])], onb)
+        res = np.asarray(res)
+        if res.shape == (X.shape[0],) and res.dtype == bool:
+            return res
+    except (ValueError, TypeError):
+        pass
+    return np.array([bool(fn(X[i], bool(onb[i]))) for i in range(X.shape[0])], dtype=bool)
+
+
+class DirichletBC:
+    def __init__(self, V, value, marker, tag=None, method="topological"):
+        if tag is not None:
+            raise NotImplementedError("DirichletBC(V, g, meshfunction, tag) (SURVEY 8(f4))")
+        self._V, self._value = V, value
+        mask = _eval_marker(marker, V.mesh())
+        self._vertices = np.where(mask)[0].astype(np.int32)
+        self._vals = self._values_at(self._vertices)
+
+    def _values_at(self, verts):
+        g, X = self._value, self._V.mesh().coordinates()
+        if isinstance(g, (numbers.Real, Constant)):
+            return np.full(verts.size, float(g))
+        if isinstance(g, Expression):
+            return g.eval_at(X[verts])
+        if isinstance(g, Function):
+            return g._vec.host()[verts]
+        raise TypeError("unsupported Dirichlet value %r" % (type(g),))
+
+    def function_space(self):
+        return self._V
+
+    def vertices(self):
+        return self._vertices
+
+    def vertex_values(self):
+        return self._vals
+
+    def get_boundary_values(self):
+        inv = vertex_to_dof_map(self._V)
+        return {int(inv[v]): float(g) for v, g in zip(self._vertices, self._vals)}
+
+    def homogeneous(self):
+        return not np.any(self._vals)
+
+    def apply(self, *args):
+        for a in args:
+            if isinstance(a, Vector):
+                if a._small() or not a._dev_ok:
+                    h = a.host()
+                    h[self._vertices] = self._vals
+                    a.touched_host()
+                else:
+                    get_backend().vec_set(a.dev(), self._vertices, self._vals)
+                    a.touched_dev()
+            elif isinstance(a, Matrix):
+                a.apply_dirichlet(self)
+            else:
+                raise TypeError("DirichletBC.apply(%r)" % (type(a),))
+
+
+def _bc_list(bcs):
+    if bcs is None or (isinstance(bcs, numbers.Real) and bcs == 0):
+        return []
+    return list(bcs) if isinstance(bcs, (list, tuple)) else [bcs]
+
+
+def _bc_vertices(bcs):
+    """Merged (vertices, values) of several conditions; later ones win like dolfin."""
+    bcs = _bc_list(bcs)
+    if not bcs:
+        return np.zeros(0, dtype=np.int32), np.zeros(0)
+    d = {}
+    for bc in bcs:
+        for v, g in zip(bc.vertices(), bc.vertex_values()):
+            d[int(v)] = float(g)
+    verts = np.array(sorted(d), dtype=np.int32)
+    return verts, np.array([d[int(v)] for v in verts])
+
+
+# ---------------------------------------------------------------------------- assembly
+class _AtomRef:
+    """One atom of one mesh with a scalar coefficient."""
+    __slots__ = ("coef", "kind", "da", "db", "weight")
+
+    def __init__(self, coef, kind, da=0, db=0, weight=None):
+        self.coef, self.kind, self.da, self.db, self.weight = coef, kind, da, db, weight
+
+
+def _coef_vec(leaf, mesh):
+    """Device-resident P1 representation of a coefficient leaf on `mesh`."""
+    if isinstance(leaf, Function):
+        if leaf._V.mesh() is not mesh:
+            raise ValueError("coefficient lives on a different mesh than the integral")
+        return leaf._vec
+    if isinstance(leaf, Expression):
+        return leaf.as_function(mesh)._vec
+    raise TypeError("unsupported coefficient %r" % (type(leaf),))
+
+
+def _atom_for(test, trial, weights, mesh):
+    """Map (test factor, trial factor, extra undifferentiated weights) to an atom."""
+    if test.deriv == "grad" or trial.deriv == "grad":
+        raise AssertionError("grad factors are handled by the caller")
+    if len(weights) > 1:
+        raise NotImplementedError("more than one weight function in one integrand")
+    w = _coef_vec(weights[0].leaf, mesh) if weights else None
+    if weights and weights[0].deriv is not None:
+        raise NotImplementedError("differentiated weight function")
+    dt, du = test.deriv, trial.deriv
+    if dt is None and du is None:
+        return (WMASS, 0, 0, w) if w is not None else (MASS, 0, 0, None)
+    if w is not None:
+        if dt is not None and du is not None and mesh.topology().dim() == 1:
+            return (WSTIFF, 0, 0, w)
+        raise NotImplementedError("weighted derivative atoms beyond w u' v' in 1-D")
+    if dt is not None and du is not None:
+        return (DUDV, du, dt, None)
+    if du is not None:
+        return (CONV, du, 0, None)
+    return (CONVT, 0, dt, None)
+
+
+def _classify(term, mesh):
+    """Split a Term into (test factor, trial factor, coefficient factors, graddot factor)."""
+    test = trial = gd = None
+    coefs = []
+    for f in term.factors:
+        if f.deriv == "grad":
+            if gd is not None:
+                raise NotImplementedError("two inner(grad, grad) factors in one integrand")
+            gd = f
+        elif isinstance(f.leaf, Argument):
+            if f.leaf.number == 0:
+                if test is not None:
+                    raise ValueError("two test functions in one integrand")
+                test = f
+            else:
+                if trial is not None:
+                    raise ValueError("two trial functions in one integrand")
+                trial = f
+        else:
+            coefs.append(f)
+    return test, trial, coefs, gd
+
+
+_SCALAR_MEMO = {}
+_SCALAR_MEMO_MAX = 4096
+_MV_CACHE = {}        # (atom handle, id(vec)) -> (version, result Vector)   A @ g for immutable g
+
+
+def _matvec_cached(mesh, atom, g):
+    """A g as a Vector; cached while g is unchanged (stored modes and loads never change)."""
+    key = (atom, id(g))
+    hit = _MV_CACHE.get(key)
+    if hit is not None and hit[0] == g.version and hit[2] is g:
+        return hit[1]
+    be = get_backend()
+    out = Vector(g.V)
+    _halo(mesh, g)
+    lo, hi = mesh.owned_range()
+    be.spmv(atom, g.dev(), out.dev_for_write(), lo, hi)
+    out.touched_dev()
+    if len(_MV_CACHE) > 4096:
+        _MV_CACHE.clear()
+    _MV_CACHE[key] = (g.version, out, g)
+    return out
+
+
+def _halo(mesh, vec):
+    if mesh.part is not None:
+        mesh.part.comm.halo_exchange(mesh, vec)
+
+
+def _bilinear_scalar(mesh, atom, f, g):
+    """f^T A g with memoisation on (atom, vector identity, vector version)."""
+    key = (atom, id(f), f.version, id(g), g.version)
+    hit = _SCALAR_MEMO.get(key)
+    if hit is not None and hit[1] is f and hit[2] is g:
+        return hit[0]
+    be = get_backend()
+    lo, hi = mesh.owned_range()
+    _halo(mesh, g)
+    val = _allreduce_sum(mesh, be.bilinear(atom, f.dev(), g.dev(), lo, hi))
+    if len(_SCALAR_MEMO) > _SCALAR_MEMO_MAX:
+        _SCALAR_MEMO.clear()
+    _SCALAR_MEMO[key] = (val, f, g)
+    return val
+
+
+def _ones(mesh):
+    if mesh._ones is None:
+        v = Vector(_p1_space(mesh), np.ones(mesh.num_vertices()))
+        mesh._ones = v
+    return mesh._ones
+
+
+def _term_scalar(term, mesh):
+    test, trial, coefs, gd = _classify(term, mesh)
+    if test is not None or trial is not None:
+        raise ValueError("scalar assemble of a form with arguments")
+    if gd is not None:
+        if isinstance(gd.leaf, Argument) or isinstance(gd.other, Argument):
+            raise ValueError("scalar assemble of a form with arguments")
+        if len(coefs) > 1:
+            raise NotImplementedError("weighted inner(grad, grad) functional with several weights")
+        f, g = _coef_vec(gd.leaf, mesh), _coef_vec(gd.other, mesh)
+        if coefs:
+            atom = mesh.atom(WSTIFF, 0, 0, _coef_vec(coefs[0].leaf, mesh))
+        else:
+            atom = mesh.atom(STIFF)
+        return term.coef * _bilinear_scalar(mesh, atom, f, g)
+    if len(coefs) == 0:
+        one = _ones(mesh)
+        return term.coef * _bilinear_scalar(mesh, mesh.atom(MASS), one, one)
+    if len(coefs) == 1:
+        c = coefs[0]
+        kind, da, db, w = _atom_for(Factor(None, None), Factor(None, c.deriv), [], mesh)
+        return term.coef * _bilinear_scalar(mesh, mesh.atom(kind, da, db, w), _ones(mesh), _coef_vec(c.leaf, mesh))
+    # f (test side) is the first factor, g (trial side) the second, further undifferentiated ones weight
+    der = [c for c in coefs if c.deriv is not None]
+    plain = [c for c in coefs if c.deriv is None]
+    if len(der) > 2:
+        raise NotImplementedError("more than two differentiated factors in a functional")
+    ordered = der + plain
+    f, g, rest = ordered[0], ordered[1], ordered[2:]
+    kind, da, db, w = _atom_for(Factor(None, f.deriv), Factor(None, g.deriv), rest, mesh)
+    return term.coef * _bilinear_scalar(mesh, mesh.atom(kind, da, db, w), _coef_vec(f.leaf, mesh), _coef_vec(g.leaf, mesh))
+
+
+def _term_vector(term, mesh):
+    """(coef, atom handle, coefficient Vector g) with  b += coef * A g."""
+    test, trial, coefs, gd = _classify(term, mesh)
+    if trial is not None:
+        raise ValueError("linear form with a trial function")
+    if gd is not None:
+        a, b = gd.leaf, gd.other
+        if isinstance(b, Argument):
+            a, b = b, a
+        if not isinstance(a, Argument) or a.number != 0 or isinstance(b, Argument):
+            raise ValueError("linear form: inner(grad, grad) needs exactly one test function")
+        if test is not None:
+            raise ValueError("two test functions in one integrand")
+        if len(coefs) > 1:
+            raise NotImplementedError("several weights on inner(grad, grad)")
+        atom = mesh.atom(WSTIFF, 0, 0, _coef_vec(coefs[0].leaf, mesh)) if coefs else mesh.atom(STIFF)
+        return term.coef, atom, _coef_vec(b, mesh)
+    if test is None:
+        raise ValueError("linear form without a test function")
+    if not coefs:
+        return term.coef, mesh.atom(MASS), _ones(mesh)
+    der = [c for c in coefs if c.deriv is not None]
+    plain = [c for c in coefs if c.deriv is None]
+    if len(der) > 1:
+        raise NotImplementedError("two differentiated coefficients in a linear form")
+    ordered = der + plain
+    g, rest = ordered[0], ordered[1:]
+    kind, da, db, w = _atom_for(test, Factor(None, g.deriv), rest, mesh)
+    return term.coef, mesh.atom(kind, da, db, w), _coef_vec(g.leaf, mesh)
+
+
+def _term_matrix(term, mesh):
+    test, trial, coefs, gd = _classify(term, mesh)
+    if gd is not None:
+        a, b = gd.leaf, gd.other
+        if not (isinstance(a, Argument) and isinstance(b, Argument) and {a.number, b.number} == {0, 1}):
+            raise ValueError("bilinear form: inner(grad, grad) needs the trial and the test function")
+        if test is not None or trial is not None:
+            raise ValueError("too many arguments in one integrand")
+        if len(coefs) > 1 or (coefs and coefs[0].deriv is not None):
+            raise NotImplementedError("several / differentiated weights on inner(grad, grad)")
+        w = _coef_vec(coefs[0].leaf, mesh) if coefs else None
+        return _AtomRef(term.coef, WSTIFF if w is not None else STIFF, 0, 0, w)
+    if test is None or trial is None:
+        raise ValueError("bilinear form needs a trial and a test function")
+    kind, da, db, w = _atom_for(test, trial, coefs, mesh)
+    return _AtomRef(term.coef, kind, da, db, w)
+
+
+class AssembledVector(Vector):
+    """Result of assemble(linear form)."""
+
+
+class Matrix:
+    """sum_t c_t A_t on one mesh, optionally with Dirichlet rows/columns eliminated."""
+
+    def __init__(self, V, refs):
+        self.V, self.refs = V, refs
+        self.bc_vertices = np.zeros(0, dtype=np.int32)
+        self._op = 0
+
+    def mesh(self):
+        return self.V.mesh()
+
+    def is_symmetric(self):
+        return all(r.kind in (MASS, STIFF, WMASS, WSTIFF) or (r.kind == DUDV and r.da == r.db) for r in self.refs)
+
+    def apply_dirichlet(self, bc):
+        self.bc_vertices = np.union1d(self.bc_vertices, bc.vertices()).astype(np.int32)
+        self._op = 0
+
+    def merged(self):
+        """Atoms with equal keys summed: (handles, coefs)."""
+        mesh, acc = self.mesh(), {}
+        for r in self.refs:
+            h = mesh.atom(r.kind, r.da, r.db, r.weight)
+            acc[h] = acc.get(h, 0.0) + r.coef
+        return list(acc), [acc[h] for h in acc]
+
+    def op(self, reuse=0):
+        handles, coefs = self.merged()
+        return get_backend().combine(self.mesh().handle(), handles, coefs, self.bc_vertices, reuse)
+
+    def array(self):
+        """Dense copy in dof order (small systems / tests only)."""
+        be, mesh = get_backend(), self.mesh()
+        op = self.op()
+        rp, cols = be.mesh_pattern(mesh.handle())
+        vals = be.atom_values(op, cols.size)
+        be.atom_free(op)
+        n = mesh.num_vertices()
+        A = np.zeros((n, n))
+        rows = np.repeat(np.arange(n), np.diff(rp))
+        A[rows, cols] = vals
+        p = vertex_to_dof_map(self.V)
+        return A[np.ix_(p, p)]
+
+
+def assemble(form, tensor=None, **kw):
+    """Scalar, vector or matrix of a Form - dolfin.assemble."""
+    if isinstance(form, numbers.Real):
+        return float(form)
+    rank = form.rank()
+    if rank == 0:
+        total = 0.0
+        for t, m in form.integrals:
+            mesh = m.mesh if m.mesh is not None else Form([(t, m)]).mesh()
+            total += _term_scalar(t, mesh)
+        return total
+    mesh = form.mesh()
+    V = _argument_space(form, 0)
+    if rank == 1:
+        out = AssembledVector(V)
+        _assemble_vector_into(form, mesh, out)
+        return out
+    return Matrix(V, [_term_matrix(t, m.mesh or mesh) for t, m in form.integrals])
+
+
+def _argument_space(form, number):
+    for t, _ in form.integrals:
+        for f in t.factors:
+            for leaf in (f.leaf, f.other):
+                if isinstance(leaf, Argument) and leaf.number == number:
+                    return leaf._V
+    raise ValueError("form has no argument %d" % number)
+
+
+def _assemble_vector_into(form, mesh, out):
+    """out = sum_s c_s A_s g_s.  Small systems on the host mirror, large ones by axpy on the device."""
+    pieces = [_term_vector(t, m.mesh or mesh) for t, m in form.integrals]
+    merged = {}
+    for c, atom, g in pieces:
+        key = (atom, id(g))
+        if key in merged:
+            merged[key][0] += c
+        else:
+            merged[key] = [c, atom, g]
+    be = get_backend()
+    if out._small() and mesh.part is None:
+        acc = np.zeros(out.n)
+        for c, atom, g in merged.values():
+            acc += c * _matvec_cached(mesh, atom, g).host()
+        out._host = acc
+        out.touched_host()
+        return
+    be.vec_fill(out.dev_for_write(), 0.0)
+    out.touched_dev()
+    for c, atom, g in merged.values():
+        if c != 0.0:
+            be.vec_axpy(out.dev(), c, _matvec_cached(mesh, atom, g).dev())
+    out.touched_dev()
+
+
+def norm(f, norm_type="L2", mesh=None):
+    """dolfin.norm: L2 norm of a Function (consistent mass), l2 of a Vector."""
+    if isinstance(f, Vector):
+        return f.norm("l2")
+    kind = norm_type.lower()
+    m = f._V.mesh()
+    if kind == "l2":
+        return math.sqrt(abs(_bilinear_scalar(m, m.atom(MASS), f._vec, f._vec)))
+    if kind in ("h10", "h1"):
+        s = _bilinear_scalar(m, m.atom(STIFF), f._vec, f._vec)
+        if kind == "h1":
+            s += _bilinear_scalar(m, m.atom(MASS), f._vec, f._vec)
+        return math.sqrt(abs(s))
+    raise NotImplementedError("norm type %r" % (norm_type,))
+
+
+def errornorm(u, uh, norm_type="L2", degree_rise=3, mesh=None):
+    """L2 distance between two P1 functions (or an Expression and a function) on uh's mesh."""
+    V = uh._V
+    a = interpolate(u, V) if not (isinstance(u, Function) and u._V is V) else u
+    d = Function(V)
+    d._vec._host = a._vec.host() - uh._vec.host()
+    d._vec.touched_host()
+    return norm(d, norm_type)
+
+
+# --------------------------------------------------------------------- variational solvers
+def derivative(form, u, du=None):
+    """Gateaux derivative of a form that is LINEAR in the Function `u`:
+    integrands containing `u` get it replaced by a trial function, the rest vanish."""
+    trial = du if du is not None else TrialFunction(u._V)
+    out = []
+    for t, m in form.integrals:
+        hits = [i for i, f in enumerate(t.factors) if f.leaf is u or f.other is u]
+        if not hits:
+            continue
+        if len(hits) > 1:
+            raise NotImplementedError("form is nonlinear in the unknown (u appears twice in an integrand)")
+        i = hits[0]
+        f = t.factors[i]
+        nf = Factor(trial if f.leaf is u else f.leaf, f.deriv, trial if f.other is u else f.other)
+        out.append((Term(t.coef, t.factors[:i] + (nf,) + t.factors[i + 1:]), m))
+    return Form(out)
+
+
+class _Params(dict):
+    """Nested solver-parameter dictionary accepting any key (settings are forwarded verbatim)."""
+
+    def __missing__(self, k):
+        v = _Params()
+        self[k] = v
+        return v
+
+
+SMALL_DIRECT_N = 20000   # systems up to this size on 1-D meshes take the banded direct path
+
+
+def _solve_linear(A, b, x, prm):
+    """Solve A x = b on the device.  A: Matrix (BCs already registered), b: Vector (BC values set).
+
+    1-D meshes (time / parameter dimensions, possibly non-symmetric) use the banded
+    LU kernel - the counterpart of the reference's MUMPS solve; larger SPD systems
+    use Jacobi-PCG with `relative_tolerance` (default 1e-10) from the settings."""
+    be, mesh = get_backend(), A.mesh()
+    method = str(prm.get("linear_solver", "default"))
+    n = mesh.num_vertices()
+    op = A.op()
+    info = {}
+    try:
+        use_direct = mesh.topology().dim() == 1 and n <= SMALL_DIRECT_N and mesh.part is None
+        if not use_direct and not A.is_symmetric():
+            raise NotImplementedError("non-symmetric operator on a large mesh: only SPD systems go to PCG")
+        if use_direct:
+            be.band_solve(op, b.dev(), x.dev_for_write())
+            x.touched_dev()
+            info.update(method="band_lu", iterations=1)
+        else:
+            rtol = float(prm.get("relative_tolerance", 1e-10)) if not isinstance(prm.get("relative_tolerance"), _Params) else 1e-10
+            atol = float(prm.get("absolute_tolerance", 0.0)) if not isinstance(prm.get("absolute_tolerance"), _Params) else 0.0
+            maxit = int(prm.get("maximum_iterations", 20000)) if not isinstance(prm.get("maximum_iterations"), _Params) else 20000
+            if mesh.part is not None:
+                it, rel = mesh.part.comm.pcg(mesh, op, b, x, rtol, atol, maxit)
+            else:
+                xd = x.dev()      # start vector (warm start when the caller filled it)
+                it, rel = be.pcg(op, b.dev(), xd, rtol, atol, maxit)
+                x.touched_dev()
+            info.update(method="jacobi_pcg", iterations=it, relres=rel)
+            if rel > max(rtol, 1e-14) * 1.0001 and it >= maxit:
+                LOG.error("PCG did not reach rtol %g in %d iterations (relres %g)", rtol, it, rel)
+        LOG.debug("linear solve (%s requested): %s", method, info)
+    finally:
+        be.atom_free(op)
+    STATS["linear_solves"] += 1
+    STATS["pcg_iterations"] += info.get("iterations", 0) if info.get("method") == "jacobi_pcg" else 0
+    return info
+
+
+STATS = {"linear_solves": 0, "pcg_iterations": 0}
+
+
+def _apply_bcs_system(A, b, bcs):
+    """Symmetric elimination: lift non-zero values, then identity rows/cols + b[bc] = g."""
+    verts, vals = _bc_vertices(bcs)
+    if verts.size == 0:
+        return
+    mesh = A.mesh()
+    if np.any(vals):
+        g = Vector(A.V)
+        g.host()[verts] = vals
+        g.touched_host()
+        handles, coefs = A.merged()
+        for h, c in zip(handles, coefs):
+            b.axpy(-c, _matvec_cached(mesh, h, g))
+    for bc in _bc_list(bcs):
+        A.apply_dirichlet(bc)
+    tmp = DirichletBC.__new__(DirichletBC)
+    tmp._vertices, tmp._vals = verts, vals
+    tmp.apply(b)
+
+
+class LinearVariationalProblem:
+    def __init__(self, a, L, u, bcs=None, form_compiler_parameters=None):
+        self.a, self.L, self.u, self.bcs = a, L, u, _bc_list(bcs)
+
+
+class LinearVariationalSolver:
+    def __init__(self, problem):
+        self.problem = problem
+        self.parameters = _Params(linear_solver="default")
+        self.info = {}
+
+    def solve(self):
+        p = self.problem
+        A = assemble(p.a)
+        b = assemble(p.L)
+        _apply_bcs_system(A, b, p.bcs)
+        self.info = _solve_linear(A, b, p.u.vector(), self.parameters)
+        return self.info
+
+
+class NonlinearVariationalProblem:
+    def __init__(self, F, u, bcs=None, J=None, form_compiler_parameters=None):
+        self.F, self.u, self.bcs = F, u, _bc_list(bcs)
+        self.J = J if J is not None else derivative(F, u)
+
+
+class NonlinearVariationalSolver:
+    """Newton's method.  The forms PGDrome's callbacks can express are linear in
+    the unknown, so the first step solves the problem and the second residual
+    evaluation confirms it (solver.py:579-595, 651-674)."""
+
+    def __init__(self, problem):
+        self.problem = problem
+        self.parameters = _Params()
+        ns = self.parameters["newton_solver"]
+        ns.update(linear_solver="default", maximum_iterations=50, relative_tolerance=1e-9,
+                  absolute_tolerance=1e-10)
+        self.info = {}
+
+    def _residual(self, bcs_h):
+        p = self.problem
+        r = assemble(p.F)          # F(u; v): u enters as a coefficient
+        for bc in bcs_h:
+            bc.apply(r)
+        return r
+
+    def solve(self):
+        p, ns = self.problem, self.parameters["newton_solver"]
+        u = p.u.vector()
+        # start from a state that satisfies the Dirichlet values; updates are homogeneous there
+        for bc in p.bcs:
+            bc.apply(u)
+        bcs_h = []
+        for bc in p.bcs:
+            h = DirichletBC.__new__(DirichletBC)
+            h._V, h._vertices, h._vals = bc._V, bc._vertices, np.zeros_like(bc._vals)
+            bcs_h.append(h)
+        lin = _Params({k: v for k, v in ns.items() if k in ("linear_solver", "preconditioner")})
+        lin["relative_tolerance"] = ns.get("krylov_relative_tolerance", 1e-10) \
+            if not isinstance(ns.get("krylov_relative_tolerance"), _Params) else 1e-10
+        rtol, atol, maxit = float(ns["relative_tolerance"]), float(ns["absolute_tolerance"]), int(ns["maximum_iterations"])
+        r = self._residual(bcs_h)
+        r0 = r.norm("l2")
+        it = 0
+        res = r0
+        while it < maxit and res > atol and (it == 0 or res > rtol * r0):
+            A = assemble(p.J)
+            for bc in bcs_h:
+                A.apply_dirichlet(bc)
+            r.scale(-1.0)
+            du = Vector(u.V)
+            _solve_linear(A, r, du, lin)
+            u.axpy(1.0, du)
+            it += 1
+            r = self._residual(bcs_h)
+            res = r.norm("l2")
+        self.info = {"newton_iterations": it, "residual": res, "residual0": r0}
+        return it, res <= atol or res <= rtol * r0
+
+
+def solve(eq, u, bcs=None, solver_parameters=None, **kw):
+    """solve(a == L, u, bcs) for linear problems."""
+    if not isinstance(eq, Equation):
+        raise TypeError("solve() expects `a == L`")
+    if isinstance(eq.rhs, numbers.Real):
+        prob = NonlinearVariationalProblem(eq.lhs, u, bcs)
+        s = NonlinearVariationalSolver(prob)
+        if solver_parameters:
+            s.parameters["newton_solver"].update(solver_parameters.get("newton_solver", {}))
+        return s.solve()
+    s = LinearVariationalSolver(LinearVariationalProblem(eq.lhs, eq.rhs, u, bcs))
+    if solver_parameters:
+        s.parameters.update(solver_parameters)
+    return s.solve()
+
+
+def clear_caches():
+    _SCALAR_MEMO.clear()
+    _MV_CACHE.clear()
