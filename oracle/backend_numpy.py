@@ -1,0 +1,235 @@
+"""Oracle (TEST INFRASTRUCTURE): the numpy FEM restatement as a backend of the
+host-side form frontend (pgdrome_amd.fem).  It lets the ``-m "not gpu"`` tests
+run the host logic (form capture, PGDProblem control flow, sharding) on CPU and
+lets tests/golden/make_fixtures.py drive the reference's own solve_PGD.
+
+It is never installed by the product: tests inject it with fem.set_backend().
+Same interface as pgdrome_amd.hip_backend.HipBackend.
+"""
+from __future__ import annotations
+
+import numpy as np
+import scipy.sparse as sps
+
+from . import fem_numpy as F
+
+NSLOTS = 64
+
+
+class _Mesh:
+    def __init__(self, coords, cells):
+        self.coords, self.cells = coords, cells
+        self.rp, self.cols = F.csr_pattern(coords.shape[0], cells)
+        self.n = coords.shape[0]
+        rows = np.repeat(np.arange(self.n), np.diff(self.rp))
+        self.kl = int((rows - self.cols).max())
+        self.ku = int((self.cols - rows).max())
+
+
+class NumpyBackend:
+    name = "oracle-numpy"
+
+    def __init__(self):
+        self._obj = {}
+        self._next = 1
+        self.slots = np.zeros(NSLOTS)
+        self._flags = [0, 0, 0]
+        self.spmv_calls = 0
+
+    def _put(self, o):
+        h = self._next
+        self._next += 1
+        self._obj[h] = o
+        return h
+
+    # ---- meshes
+    def mesh(self, coords, cells):
+        return self._put(_Mesh(np.asarray(coords, dtype=np.float64), np.asarray(cells, dtype=np.int32)))
+
+    def mesh_info(self, mh):
+        m = self._obj[mh]
+        return dict(nv=m.n, nc=m.cells.shape[0], nnz=int(m.rp[-1]), kl=m.kl, ku=m.ku,
+                    max_row=int(np.diff(m.rp).max()))
+
+    def mesh_pattern(self, mh):
+        m = self._obj[mh]
+        return m.rp, m.cols
+
+    def mesh_free(self, mh):
+        self._obj.pop(mh, None)
+
+    # ---- vectors
+    def vec_zeros(self, n):
+        return self._put(np.zeros(int(n)))
+
+    def vec_from(self, a):
+        return self._put(np.array(a, dtype=np.float64))
+
+    def vec_to_host(self, v):
+        return self._obj[v].copy()
+
+    def vec_upload(self, v, a):
+        self._obj[v][:] = a
+
+    def vec_free(self, v):
+        self._obj.pop(v, None)
+
+    def vec_copy(self, dst, src):
+        self._obj[dst][:] = self._obj[src]
+
+    def vec_scale(self, v, a):
+        self._obj[v] *= a
+
+    def vec_axpy(self, y, a, x):
+        self._obj[y] += a * self._obj[x]
+
+    def vec_fill(self, v, a):
+        self._obj[v][:] = a
+
+    def vec_set(self, v, idx, vals):
+        self._obj[v][np.asarray(idx)] = vals
+
+    def vec_dot(self, x, y, lo=0, hi=-1):
+        a, b = self._obj[x], self._obj[y]
+        hi = a.size if hi < 0 else hi
+        return float(a[lo:hi] @ b[lo:hi])
+
+    # ---- atoms and operators
+    def atom(self, mh, kind, da, db, w):
+        m = self._obj[mh]
+        A = F.assemble_atom(m.coords, m.cells, kind, da, db, self._obj[w] if w else None)
+        return self._put((mh, A))
+
+    def atom_values(self, a, nnz):
+        mh, A = self._obj[a]
+        m = self._obj[mh]
+        full = sps.csr_matrix((np.ones(m.cols.size), m.cols, m.rp), shape=(m.n, m.n))
+        out = np.zeros(m.cols.size)
+        # align A's stored entries with the mesh pattern (A may have dropped structural zeros)
+        A = A.tocsr()
+        A.sort_indices()
+        if A.nnz == m.cols.size:
+            return A.data.copy()
+        pos = {}
+        for i in range(m.n):
+            for k in range(m.rp[i], m.rp[i + 1]):
+                pos[(i, m.cols[k])] = k
+        C = A.tocoo()
+        for i, j, v in zip(C.row, C.col, C.data):
+            out[pos[(i, j)]] = v
+        return out
+
+    def atom_free(self, a):
+        self._obj.pop(a, None)
+
+    def combine(self, mh, atoms, coefs, bc_vertices=None, reuse=0):
+        m = self._obj[mh]
+        A = None
+        for a, c in zip(atoms, coefs):
+            t = c * self._obj[a][1]
+            A = t if A is None else A + t
+        if bc_vertices is not None and len(bc_vertices):
+            A, _ = F.apply_dirichlet(A, np.zeros(m.n), np.asarray(bc_vertices))
+        if reuse:
+            self._obj[reuse] = (mh, A.tocsr())
+            return reuse
+        return self._put((mh, A.tocsr()))
+
+    def spmv(self, A, x, y, r0=0, r1=-1):
+        M = self._obj[A][1]
+        r1 = M.shape[0] if r1 < 0 else r1
+        self._obj[y][r0:r1] = (M[r0:r1] @ self._obj[x])
+        self.spmv_calls += 1
+
+    def bilinear(self, A, x, y, r0=0, r1=-1):
+        M = self._obj[A][1]
+        r1 = M.shape[0] if r1 < 0 else r1
+        return float(self._obj[x][r0:r1] @ (M[r0:r1] @ self._obj[y]))
+
+    def bilinear_many(self, A, x, ys, r0=0, r1=-1):
+        return np.array([self.bilinear(A, x, y, r0, r1) for y in ys])
+
+    # ---- solvers
+    def pcg(self, op, b, x, rtol, atol, maxit):
+        sol, it, rel = F.pcg_jacobi(self._obj[op][1], self._obj[b], self._obj[x], rtol, atol, maxit)
+        self._obj[x][:] = sol
+        return it, rel
+
+    def band_solve(self, op, b, x):
+        self._obj[x][:] = F.direct_solve(self._obj[op][1], self._obj[b])
+
+    # ---- pieces of the row-sharded PCG, eager numpy versions of the *_slot kernels
+    def slots_tensor(self):
+        import torch
+        return torch.from_numpy(self.slots)
+
+    def vec_tensor(self, v):
+        import torch
+        return torch.from_numpy(self._obj[v])
+
+    def slots_get(self, first=0, count=NSLOTS):
+        return self.slots[first:first + count].copy()
+
+    def flags_reset(self):
+        self._flags = [0, 0, 0]
+
+    def flags(self):
+        return tuple(self._flags)
+
+    def op_diag_inv(self, op, dinv):
+        self._obj[dinv][:] = 1.0 / self._obj[op][1].diagonal()
+
+    def spmv_dot_slot(self, A, x, y, w, r0, r1, slot):
+        if self._flags[0]:
+            return
+        self.spmv(A, x, y, r0, r1)
+        self.slots[slot] = float(self._obj[w][r0:r1] @ self._obj[y][r0:r1])
+
+    def pcg_init_slot(self, b, q, dinv, r, z, p, lo, hi, slot):
+        o = self._obj
+        o[r][lo:hi] = o[b][lo:hi] - o[q][lo:hi]
+        o[z][lo:hi] = o[dinv][lo:hi] * o[r][lo:hi]
+        o[p][lo:hi] = o[z][lo:hi]
+        self.slots[slot] = float(o[r][lo:hi] @ o[z][lo:hi])
+        self.slots[slot + 1] = float(o[r][lo:hi] @ o[r][lo:hi])
+        self.slots[slot + 2] = float(o[b][lo:hi] @ o[b][lo:hi])
+
+    def pcg_tol_slot(self, rtol, atol, s_rr, s_bb, s_tol2):
+        tol2 = max(rtol * rtol * self.slots[s_bb], atol * atol)
+        self.slots[s_tol2] = tol2
+        if self.slots[s_rr] <= tol2:
+            self._flags[0] = 1
+
+    def pcg_xr_slot(self, x, r, p, q, dinv, z, lo, hi, s_rz, s_pq, s_out):
+        if self._flags[0]:
+            return
+        o = self._obj
+        alpha = self.slots[s_rz] / self.slots[s_pq]
+        o[x][lo:hi] += alpha * o[p][lo:hi]
+        o[r][lo:hi] -= alpha * o[q][lo:hi]
+        o[z][lo:hi] = o[dinv][lo:hi] * o[r][lo:hi]
+        self.slots[s_out] = float(o[r][lo:hi] @ o[z][lo:hi])
+        self.slots[s_out + 1] = float(o[r][lo:hi] @ o[r][lo:hi])
+
+    def pcg_check_slot(self, s_rr, s_tol2):
+        if self._flags[0]:
+            return
+        self._flags[1] += 1
+        if self.slots[s_rr] <= self.slots[s_tol2]:
+            self._flags[0] = 1
+
+    def pcg_p_slot(self, p, z, lo, hi, s_num, s_den):
+        if self._flags[0]:
+            return
+        o = self._obj
+        beta = self.slots[s_num] / self.slots[s_den]
+        o[p][lo:hi] = o[z][lo:hi] + beta * o[p][lo:hi]
+
+    def sync(self):
+        pass
+
+    def prof_enable(self, on=True):
+        pass
+
+    def prof_read(self):
+        return dict(launches=0, seconds=0.0, bytes=0.0)

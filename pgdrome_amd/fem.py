@@ -213,9 +213,7 @@ class Mesh:
                 uniq, counts = np.unique(facets, axis=0, return_counts=True)
                 flag[uniq[counts == 1].ravel()] = True
             if self.part is not None:
-                # cut faces of a slab are not physical boundary: only keep vertices on the
-                # global hull, which for slabs is decided by the caller-provided box
-                flag &= self.part.comm.hull_mask(self)
+                raise RuntimeError("a sharded mesh must be given its hull mask by its builder")
             self._on_boundary = flag
         return self._on_boundary
 
@@ -252,7 +250,10 @@ def RectangleMesh(p0, p1, nx, ny, diagonal="right"):
     cells = np.empty((2 * nx * ny, 3), dtype=np.int32)
     for k, t in enumerate(tris):
         cells[k::2] = np.stack(t, axis=1)
-    return Mesh(coords, cells)
+    mesh = Mesh(coords, cells)
+    jx, jy = np.meshgrid(np.arange(nx + 1), np.arange(ny + 1), indexing="xy")
+    mesh._on_boundary = ((jx == 0) | (jx == nx) | (jy == 0) | (jy == ny)).ravel()   # structured: no facet search
+    return mesh
 
 
 def UnitSquareMesh(nx, ny, diagonal="right"):
@@ -281,9 +282,19 @@ def box_mesh_arrays(p0, p1, nx, ny, nz, z_first=0, z_last=None):
     return coords, cells
 
 
+def box_hull_mask(nx, ny, nz, z_first=0, z_last=None):
+    """Vertices of the (sub-)grid that lie on the hull of the whole box."""
+    z_last = nz if z_last is None else z_last
+    jz, jy, jx = np.meshgrid(np.arange(z_first, z_last + 1), np.arange(ny + 1), np.arange(nx + 1), indexing="ij")
+    return ((jx == 0) | (jx == nx) | (jy == 0) | (jy == ny) | (jz == 0) | (jz == nz)).ravel()
+
+
 def BoxMesh(p0, p1, nx, ny, nz):
-    coords, cells = box_mesh_arrays(p0, p1, int(nx), int(ny), int(nz))
-    return Mesh(coords, cells)
+    nx, ny, nz = int(nx), int(ny), int(nz)
+    coords, cells = box_mesh_arrays(p0, p1, nx, ny, nz)
+    mesh = Mesh(coords, cells)
+    mesh._on_boundary = box_hull_mask(nx, ny, nz)
+    return mesh
 
 
 def UnitCubeMesh(nx, ny, nz):
@@ -546,6 +557,8 @@ class Expr:
     def __mul__(self, o):
         if isinstance(o, Measure):
             return Form([(t, o) for t in self._poly()])
+        if isinstance(o, Form):
+            return o * _scalar_of(self)
         return Poly(_pmul(self._poly(), _as_poly(o)))
 
     def __rmul__(self, o):
@@ -603,7 +616,17 @@ class Poly(Expr):
         return self.terms
 
 
+def _scalar_of(e):
+    """Value of an expression that contains no fields (products of Constants and floats)."""
+    p = e._poly()
+    if any(t.factors for t in p):
+        raise TypeError("only scalars can multiply an integrated form")
+    return sum(t.coef for t in p)
+
+
 def _as_float(o):
+    if isinstance(o, Poly):
+        return _scalar_of(o)
     if isinstance(o, Constant):
         return float(o)
     if isinstance(o, numbers.Real):

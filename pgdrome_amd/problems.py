@@ -1,0 +1,206 @@
+"""Synthetic separable problems of BASELINE.json's configs, written exactly the
+way a PGDrome user writes a problem: meshes + FunctionSpaces, a ``bc_fct`` and
+the two weak-form callbacks ``lhs_fct`` / ``rhs_fct`` that dispatch on ``typ``
+(callback contract: /root/reference/pgdrome/solver.py:547-569; grammar modelled
+on /root/reference/tests/integration/test_laplace.py:73-366 and
+test_heat1D.py:55-266).  ``bench.py`` and the parity tests run them through
+``PGDProblem``; tests/golden/make_fixtures.py runs the same callbacks through
+the reference's own ``PGDProblem``.
+
+All loads and coefficients are P1 (interpolated), so the closed-form P1 atoms
+integrate every form exactly.  Markers are written with numpy-friendly logic so
+they evaluate vectorised on multi-million-vertex meshes.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import fem
+
+
+def _on_boundary(x, on_boundary):
+    return on_boundary
+
+
+# ------------------------------------------------------------------ config 1: 1D x 1D Poisson
+def poisson_1d1d(n=32):
+    """-Laplace(u) = 1 on (0,1)^2, u = 0 on the boundary, u = sum X(x) Y(y)."""
+    meshes = [fem.IntervalMesh(n - 1, 0.0, 1.0) for _ in range(2)]
+    Vs = [fem.FunctionSpace(m, "CG", 1) for m in meshes]
+    load = [[fem.interpolate(fem.Expression("1.0", degree=1), V)] for V in Vs]
+
+    def bc_fct(Vs, dom, param):
+        return [fem.DirichletBC(Vs[0], 0, _on_boundary), fem.DirichletBC(Vs[1], 0, _on_boundary)]
+
+    def lhs_fct(u, v, Fs, meshes, dom, param, typ, dim):
+        d, o = (0, 1) if typ == "r" else (1, 0)
+        return (fem.Constant(fem.assemble(Fs[o] * Fs[o] * fem.dx(meshes[o]))) * u.dx(0) * v.dx(0) * fem.dx(meshes[d])
+                + fem.Constant(fem.assemble(Fs[o].dx(0) * Fs[o].dx(0) * fem.dx(meshes[o]))) * u * v * fem.dx(meshes[d]))
+
+    def rhs_fct(u, v, Fs, meshes, dom, param, Q, PGD_func, typ, nE, dim):
+        d, o = (0, 1) if typ == "r" else (1, 0)
+        l = fem.Constant(fem.assemble(Q[o][0] * Fs[o] * fem.dx(meshes[o]))) * Q[d][0] * v * fem.dx(meshes[d])
+        for old in range(nE):
+            l += (-fem.Constant(fem.assemble(PGD_func[o][old] * Fs[o] * fem.dx(meshes[o])))
+                  * PGD_func[d][old].dx(0) * v.dx(0) * fem.dx(meshes[d])
+                  - fem.Constant(fem.assemble(PGD_func[o][old].dx(0) * Fs[o].dx(0) * fem.dx(meshes[o])))
+                  * PGD_func[d][old] * v * fem.dx(meshes[d]))
+        return l
+
+    return dict(name="poisson_1d1d", name_coord=["X", "Y"], modes_info=["U", "Node", "Scalar"], Vs=Vs,
+                bc_fct=bc_fct, load=load, param={}, rhs_fct=rhs_fct, lhs_fct=lhs_fct, probs=["r", "s"],
+                PGD_nmax=3, PGD_tol=1e-10)
+
+
+# ------------------------------------- configs 2 and 4: -Laplace(u) + mu u = 1, u(x; mu)
+def reaction_diffusion(space_mesh, n_mu=128, mu_range=(1.0, 10.0), PGD_nmax=10, PGD_tol=1e-8):
+    """Space (2-D or 3-D, P1) x 1-D parameter mu: atoms K_x (x) M_mu + M_x (x) Mw_mu, w = mu."""
+    mu_mesh = fem.IntervalMesh(n_mu - 1, mu_range[0], mu_range[1])
+    meshes = [space_mesh, mu_mesh]
+    Vs = [fem.FunctionSpace(m, "CG", 1) for m in meshes]
+    load = [[fem.interpolate(fem.Expression("1.0", degree=1), Vs[0])],
+            [fem.interpolate(fem.Expression("1.0", degree=1), Vs[1])]]
+    param = {"mu": fem.interpolate(fem.Expression("x[0]", degree=1), Vs[1])}
+
+    def bc_fct(Vs, dom, param):
+        return [fem.DirichletBC(Vs[0], 0, _on_boundary), 0]
+
+    def lhs_fct(u, v, Fs, meshes, dom, param, typ, dim):
+        mu = param["mu"]
+        if typ == "x":
+            return (fem.Constant(fem.assemble(Fs[1] * Fs[1] * fem.dx(meshes[1])))
+                    * fem.inner(fem.grad(u), fem.grad(v)) * fem.dx(meshes[0])
+                    + fem.Constant(fem.assemble(mu * Fs[1] * Fs[1] * fem.dx(meshes[1])))
+                    * u * v * fem.dx(meshes[0]))
+        return (fem.Constant(fem.assemble(fem.inner(fem.grad(Fs[0]), fem.grad(Fs[0])) * fem.dx(meshes[0])))
+                * u * v * fem.dx(meshes[1])
+                + fem.Constant(fem.assemble(Fs[0] * Fs[0] * fem.dx(meshes[0])))
+                * mu * u * v * fem.dx(meshes[1]))
+
+    def rhs_fct(u, v, Fs, meshes, dom, param, Q, PGD_func, typ, nE, dim):
+        mu = param["mu"]
+        if typ == "x":
+            l = fem.Constant(fem.assemble(Q[1][0] * Fs[1] * fem.dx(meshes[1]))) * Q[0][0] * v * fem.dx(meshes[0])
+            for old in range(nE):
+                l += (-fem.Constant(fem.assemble(PGD_func[1][old] * Fs[1] * fem.dx(meshes[1])))
+                      * fem.inner(fem.grad(PGD_func[0][old]), fem.grad(v)) * fem.dx(meshes[0])
+                      - fem.Constant(fem.assemble(mu * PGD_func[1][old] * Fs[1] * fem.dx(meshes[1])))
+                      * PGD_func[0][old] * v * fem.dx(meshes[0]))
+            return l
+        l = fem.Constant(fem.assemble(Q[0][0] * Fs[0] * fem.dx(meshes[0]))) * Q[1][0] * v * fem.dx(meshes[1])
+        for old in range(nE):
+            l += (-fem.Constant(fem.assemble(fem.inner(fem.grad(PGD_func[0][old]), fem.grad(Fs[0])) * fem.dx(meshes[0])))
+                  * PGD_func[1][old] * v * fem.dx(meshes[1])
+                  - fem.Constant(fem.assemble(PGD_func[0][old] * Fs[0] * fem.dx(meshes[0])))
+                  * mu * PGD_func[1][old] * v * fem.dx(meshes[1]))
+        return l
+
+    return dict(name="reaction_diffusion", name_coord=["X", "mu"], modes_info=["U", "Node", "Scalar"], Vs=Vs,
+                bc_fct=bc_fct, load=load, param=param, rhs_fct=rhs_fct, lhs_fct=lhs_fct, probs=["x", "m"],
+                PGD_nmax=PGD_nmax, PGD_tol=PGD_tol)
+
+
+# ----------------- configs 3 and 5: rho c dT/dt - k Laplace(T) = q(x) (x) 1(t) [(x) params]
+def transient_heat(space_mesh, n_t=256, n_p=0, rho_c=1.0, k=0.1, p_range=(0.5, 2.0), PGD_nmax=20,
+                   PGD_tol=1e-6):
+    """Space x time [x two material parameters]:  mu1 rho c dT/dt - mu2 k Laplace(T) = q.
+
+    T = 0 on the spatial boundary, T(t=0) = 0 as a Dirichlet condition on the
+    time dimension (as test_heat1D.py:43-52 does).  Atoms:
+    M_x (x) C_t [(x) Mw_1 (x) M_2]  +  K_x (x) M_t [(x) M_1 (x) Mw_2];  the time
+    problem is non-symmetric (u'v) and goes to the banded direct solve."""
+    gdim = space_mesh.geometry().dim()
+    t_mesh = fem.IntervalMesh(n_t - 1, 0.0, 1.0)
+    meshes = [space_mesh, t_mesh]
+    names, probs = ["X", "t"], ["x", "t"]
+    if n_p:
+        meshes += [fem.IntervalMesh(n_p - 1, p_range[0], p_range[1]) for _ in range(2)]
+        names += ["mu1", "mu2"]
+        probs += ["p1", "p2"]
+    Vs = [fem.FunctionSpace(m, "CG", 1) for m in meshes]
+    D = len(meshes)
+    r2 = " + ".join("pow(x[%d]-0.5, 2)" % i for i in range(gdim))
+    q_x = fem.interpolate(fem.Expression("exp(-(%s)/0.02)" % r2, degree=1), Vs[0])
+    load = [[q_x]] + [[fem.interpolate(fem.Expression("1.0", degree=1), V)] for V in Vs[1:]]
+    param = {"rho_c": rho_c, "k": k}
+    if n_p:
+        param["w1"] = fem.interpolate(fem.Expression("x[0]", degree=1), Vs[2])
+        param["w2"] = fem.interpolate(fem.Expression("x[0]", degree=1), Vs[3])
+
+    def bc_fct(Vs, dom, param):
+        def t0(x, on_boundary):
+            return x[0] < 1e-10
+        return [fem.DirichletBC(Vs[0], 0, _on_boundary), fem.DirichletBC(Vs[1], 0, t0)] + [0] * (len(Vs) - 2)
+
+    # per term (0: capacity, 1: conduction) and dimension, the functional G^T A F of the other dims
+    def other(term, d, G, F, meshes, param):
+        m = meshes[d]
+        if d == 0:
+            return fem.assemble(G * F * fem.dx(m)) if term == 0 else \
+                fem.assemble(fem.inner(fem.grad(G), fem.grad(F)) * fem.dx(m))
+        if d == 1:
+            # the trial side (old mode or the iterate itself) carries the time derivative
+            return fem.assemble(G.dx(0) * F * fem.dx(m)) if term == 0 else fem.assemble(G * F * fem.dx(m))
+        w = param["w1"] if d == 2 else param["w2"]
+        weighted = (term == 0 and d == 2) or (term == 1 and d == 3)
+        return fem.assemble(w * G * F * fem.dx(m)) if weighted else fem.assemble(G * F * fem.dx(m))
+
+    def own(term, d, u, v, meshes, param):
+        m = meshes[d]
+        if d == 0:
+            return u * v * fem.dx(m) if term == 0 else fem.inner(fem.grad(u), fem.grad(v)) * fem.dx(m)
+        if d == 1:
+            return u.dx(0) * v * fem.dx(m) if term == 0 else u * v * fem.dx(m)
+        w = param["w1"] if d == 2 else param["w2"]
+        weighted = (term == 0 and d == 2) or (term == 1 and d == 3)
+        return w * u * v * fem.dx(m) if weighted else u * v * fem.dx(m)
+
+    def lhs_fct(u, v, Fs, meshes, dom, param, typ, dim):
+        d = probs.index(typ)
+        a = 0
+        for term, phys in ((0, param["rho_c"]), (1, param["k"])):
+            c = phys
+            for j in range(D):
+                if j != d:
+                    c *= other(term, j, Fs[j], Fs[j], meshes, param)
+            a += fem.Constant(c) * own(term, d, u, v, meshes, param)
+        return a
+
+    def rhs_fct(u, v, Fs, meshes, dom, param, Q, PGD_func, typ, nE, dim):
+        d = probs.index(typ)
+        c = 1.0
+        for j in range(D):
+            if j != d:
+                c *= fem.assemble(Q[j][0] * Fs[j] * fem.dx(meshes[j]))
+        l = fem.Constant(c) * Q[d][0] * v * fem.dx(meshes[d])
+        for old in range(nE):
+            for term, phys in ((0, param["rho_c"]), (1, param["k"])):
+                c = phys
+                for j in range(D):
+                    if j != d:
+                        c *= other(term, j, PGD_func[j][old], Fs[j], meshes, param)
+                l += -fem.Constant(c) * own(term, d, PGD_func[d][old], v, meshes, param)
+        return l
+
+    return dict(name="transient_heat", name_coord=names, modes_info=["T", "Node", "Scalar"], Vs=Vs,
+                bc_fct=bc_fct, load=load, param=param, rhs_fct=rhs_fct, lhs_fct=lhs_fct, probs=probs,
+                PGD_nmax=PGD_nmax, PGD_tol=PGD_tol)
+
+
+def make_problem(spec, cls):
+    """PGDProblem(**spec) for either implementation of the class."""
+    return cls(**spec)
+
+
+CONFIGS = {
+    # name -> (builder, description); the sizes of BASELINE.json's configs
+    "cfg1": (lambda: poisson_1d1d(32), "1Dx1D separated Poisson, 32 P1 dofs per dimension, 3 modes"),
+    "cfg2": (lambda: reaction_diffusion(fem.RectangleMesh(fem.Point(0, 0), fem.Point(1, 1), 255, 255), 128,
+                                        PGD_nmax=10), "2D-space 256^2 P1 x 1D-parameter (128), 10 modes"),
+    "cfg3": (lambda: transient_heat(fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), 127, 127, 127), 256,
+                                    PGD_nmax=20), "3D-space 128^3 P1 x 1D-time (256), 20 modes"),
+    "cfg4": (lambda: reaction_diffusion(fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), 255, 255, 255), 128,
+                                        PGD_nmax=10), "3D-space 256^3 P1 x 1D-parameter (128)"),
+    "cfg5": (lambda: transient_heat(fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), 255, 255, 255), 256, 64,
+                                    PGD_nmax=50), "3D-space 256^3 P1 x time (256) x 2 parameters (64), 50 modes"),
+}

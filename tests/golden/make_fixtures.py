@@ -1,0 +1,112 @@
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own
+``PGDProblem.solve_PGD`` (imported from /root/reference, build container only).
+
+    python tests/golden/make_fixtures.py
+
+What is reference and what is not, precisely:
+  * the enrichment loop, the fixed-point loop, both stop tests, the mode
+    normalisation, the residual pre-check and all bookkeeping are executed by
+    the unmodified /root/reference/pgdrome/solver.py;
+  * ``FD_matrices`` values come straight from the reference function;
+  * the FEM arithmetic underneath (what the reference delegates to FEniCS
+    2019.1.0, which is not installable here) is supplied by the repository's
+    form frontend running on the numpy ORACLE backend, registered under the
+    module name ``dolfin`` for the duration of this script.
+So these fixtures pin the control flow and bookkeeping against the reference
+itself; the FEM arithmetic is pinned separately by analytic known answers
+(tests/test_oracle.py).  Only numbers are written - no reference source.
+"""
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference")
+
+from oracle.backend_numpy import NumpyBackend   # noqa: E402
+from pgdrome_amd import fem, problems           # noqa: E402
+
+fem.set_backend(NumpyBackend())
+sys.modules["dolfin"] = fem
+sys.modules["h5py"] = types.ModuleType("h5py")
+
+from pgdrome.solver import FD_matrices as ref_FD_matrices   # noqa: E402
+from pgdrome.solver import PGDProblem as RefPGDProblem      # noqa: E402
+
+
+def case_specs():
+    P = fem.Point
+    return {
+        "cfg1": lambda: problems.poisson_1d1d(32),
+        "cfg2_small": lambda: problems.reaction_diffusion(fem.RectangleMesh(P(0, 0), P(1, 1), 8, 8), 9, PGD_nmax=4),
+        "cfg4_small": lambda: problems.reaction_diffusion(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), 4, 4, 4), 9, PGD_nmax=4),
+        "cfg3_small": lambda: problems.transient_heat(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), 4, 4, 4), 9, PGD_nmax=5),
+        "cfg5_small": lambda: problems.transient_heat(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), 4, 4, 4), 9, 5, PGD_nmax=5),
+    }
+
+
+RUNS = [
+    # (case, _problem, norm_modes, stop_fp, extra knobs)
+    ("cfg1", "linear", "stiff", "norm", {}),
+    ("cfg1", "linear", "l2", "norm", {}),
+    ("cfg1", "nonlinear", "stiff", "norm", {}),
+    ("cfg1", "linear", "no", "delta", {"tol_fp_it": 1e-4}),
+    ("cfg1", "linear", "stiff", "norm", {"max_fp_it": 2}),        # exercises "NOT converged, continue"
+    ("cfg2_small", "linear", "stiff", "norm", {}),
+    ("cfg4_small", "linear", "stiff", "norm", {}),
+    ("cfg4_small", "nonlinear", "l2", "norm", {"PGD_nmax": 3}),
+    ("cfg3_small", "linear", "stiff", "norm", {}),
+    ("cfg5_small", "linear", "stiff", "norm", {}),
+]
+
+
+def run_reference(case, prob_kind, norm_modes, stop_fp, knobs):
+    spec = case_specs()[case]()
+    p = RefPGDProblem(**spec)
+    p.norm_modes, p.stop_fp = norm_modes, stop_fp
+    for k, v in knobs.items():
+        setattr(p, k, v)
+    p.solve_PGD(_problem=prob_kind)
+    modes = [[f.compute_vertex_values().tolist() for f in p.PGD_func[d]] for d in range(p.num_pgd_var)]
+    err = [np.asarray(e, dtype=float).tolist() for e in p.err_fp_it]
+    return {
+        "case": case, "problem": prob_kind, "norm_modes": norm_modes, "stop_fp": stop_fp, "knobs": knobs,
+        "dims": [V.dim() for V in spec["Vs"]],
+        "PGD_modes": int(p.PGD_modes), "num_fp_it": [int(v) for v in p.num_fp_it], "err_fp_it": err,
+        "amplitude": [float(v) for v in p.amplitude], "alpha": [float(v) for v in p.alpha],
+        "modes_vertex_values": modes,
+        "not_converged_logged": p.simulation_info.count("NOT converged"),
+    }
+
+
+def fd_fixture():
+    out = []
+    rng = np.random.default_rng(42)
+    for x in (np.linspace(0, 1, 5), np.linspace(-1, 3, 2), np.sort(rng.uniform(0, 2, 9))):
+        M, D2, D1 = ref_FD_matrices(x)
+        out.append({"x": x.tolist(), "M": M.toarray().tolist(), "D2": D2.toarray().tolist(),
+                    "D1_up": D1.toarray().tolist()})
+    return out
+
+
+def main():
+    runs = [run_reference(*r) for r in RUNS]
+    with open(os.path.join(HERE, "reference_runs.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_fixtures.py",
+                   "reference": "BAMresearch/PGDrome @ 2024_10_08, pgdrome/solver.py solve_PGD/FP_solve",
+                   "arithmetic": "oracle numpy backend (FEniCS absent)", "runs": runs}, f)
+    with open(os.path.join(HERE, "fd_matrices.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_fixtures.py", "source": "pgdrome/solver.py:947-988 FD_matrices",
+                   "cases": fd_fixture()}, f)
+    for r in runs:
+        print(r["case"], r["problem"], r["norm_modes"], r["stop_fp"], r["knobs"], "->", r["PGD_modes"], "modes, fp",
+              r["num_fp_it"], "amp", ["%.4e" % a for a in r["amplitude"]])
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,107 @@
+"""Pin the oracle: analytic known answers for the P1 arithmetic, the values the
+reference's own tests hold, and the reference-generated fixtures."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fem_numpy as F
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_interval_element_matrices_closed_form():
+    c, e = F.interval_mesh(4, 0.0, 1.0)      # h = 1/4
+    K = F.assemble_atom(c, e, F.STIFF).toarray()
+    M = F.assemble_atom(c, e, F.MASS).toarray()
+    C = F.assemble_atom(c, e, F.CONV).toarray()
+    h = 0.25
+    assert np.allclose(K[1, :3], [-1 / h, 2 / h, -1 / h]) and np.isclose(K[0, 0], 1 / h)
+    assert np.allclose(M[1, :3], [h / 6, 4 * h / 6, h / 6]) and np.isclose(M[0, 0], h / 3)
+    assert np.allclose(C[1, :3], [-0.5, 0.0, 0.5]) and np.allclose(C[0, :2], [-0.5, 0.5])
+
+
+def test_triangle_and_tet_reference_elements():
+    c = np.array([[0.0, 0.0], [1.0, 0.0], [0.0, 1.0]])
+    e = np.array([[0, 1, 2]], dtype=np.int32)
+    K = F.element_matrices(c, e, F.STIFF)[0]
+    assert np.allclose(K, [[1.0, -0.5, -0.5], [-0.5, 0.5, 0.0], [-0.5, 0.0, 0.5]])
+    M = F.element_matrices(c, e, F.MASS)[0]
+    assert np.allclose(M, (np.ones((3, 3)) + np.eye(3)) / 24.0)
+    c3 = np.array([[0.0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]])
+    e3 = np.array([[0, 1, 2, 3]], dtype=np.int32)
+    M3 = F.element_matrices(c3, e3, F.MASS)[0]
+    assert np.allclose(M3, (np.ones((4, 4)) + np.eye(4)) / 120.0)
+    K3 = F.element_matrices(c3, e3, F.STIFF)[0]
+    assert np.allclose(K3[0], [0.5, -1 / 6, -1 / 6, -1 / 6]) and np.allclose(np.diag(K3)[1:], 1 / 6)
+
+
+@pytest.mark.parametrize("mesh", ["interval", "rect", "box"])
+def test_polynomial_integrals_are_exact(mesh):
+    c, e = {"interval": lambda: F.interval_mesh(7, 0.0, 2.0),
+            "rect": lambda: F.rectangle_mesh((0, 0), (2, 1), 5, 4),
+            "box": lambda: F.box_mesh((0, 0, 0), (2, 1, 1), 3, 4, 2)}[mesh]()
+    one, x = np.ones(c.shape[0]), c[:, 0]
+    vol = 2.0
+    M, K = F.assemble_atom(c, e, F.MASS), F.assemble_atom(c, e, F.STIFF)
+    assert np.isclose(one @ (M @ one), vol)
+    assert np.isclose(x @ (M @ x), vol * 4.0 / 3.0)          # int x^2 over [0,2] x unit cross-section
+    assert np.isclose(x @ (K @ x), vol) and abs(K @ one).max() < 1e-12
+    assert np.isclose(one @ (F.assemble_atom(c, e, F.CONV, a=0) @ x), vol)
+    assert np.isclose(x @ (F.assemble_atom(c, e, F.WMASS, w=x) @ x), vol * 2.0)   # int x^3 = 4 -> 4 * 1
+    assert np.isclose(x @ (F.assemble_atom(c, e, F.WSTIFF, w=x) @ x), vol * 1.0)  # int x = 2
+    D = F.assemble_atom(c, e, F.DUDV, a=0, b=0)
+    assert np.isclose(x @ (D @ x), vol)
+    assert abs(F.assemble_atom(c, e, F.CONVT, b=0) - F.assemble_atom(c, e, F.CONV, a=0).T).max() < 1e-14
+
+
+def test_pattern_sizes():
+    for n in (2, 3, 8):
+        c, e = F.box_mesh((0, 0, 0), (1, 1, 1), n - 1, n - 1, n - 1)
+        assert F.csr_pattern(c.shape[0], e)[0][-1] == F.nnz_p1_box(n)
+        c, e = F.rectangle_mesh((0, 0), (1, 1), n - 1, n - 1)
+        assert F.csr_pattern(c.shape[0], e)[0][-1] == F.nnz_p1_rect(n)
+    assert F.nnz_p1_box(256) == 250_088_446 and F.nnz_p1_box(128) == 31_065_598
+    assert F.nnz_p1_rect(256) == 456_706
+    assert F.spmv_bytes(16_777_216, 250_088_446) == 3_336_605_672
+
+
+def test_analytic_truss_known_answer():
+    """u = p/(2E) (x - x^2): the analytic solution the reference checks its elastic
+    test against (tests/integration/test_elastic.py:294-303) is reproduced at the nodes."""
+    c, e = F.interval_mesh(50, 0.0, 1.0)
+    K, M = F.assemble_atom(c, e, F.STIFF), F.assemble_atom(c, e, F.MASS)
+    E, p = 3.0, 2.0
+    A, b = F.apply_dirichlet(E * K, M @ np.full(51, p), [0, 50])
+    u = F.direct_solve(A, b)
+    assert np.abs(u - p / (2 * E) * (c[:, 0] - c[:, 0] ** 2)).max() < 1e-12
+
+
+def test_dirichlet_lifting_and_pcg():
+    c, e = F.rectangle_mesh((0, 0), (1, 1), 12, 12)
+    K = F.assemble_atom(c, e, F.STIFF)
+    bnd = np.where((c[:, 0] == 0) | (c[:, 0] == 1) | (c[:, 1] == 0) | (c[:, 1] == 1))[0]
+    g = 1.0 + 2.0 * c[:, 0] - c[:, 1]            # harmonic: the discrete solution is g itself
+    A, b = F.apply_dirichlet(K, np.zeros(c.shape[0]), bnd, g[bnd])
+    assert abs(A - A.T).max() < 1e-14
+    u = F.direct_solve(A, b)
+    assert np.abs(u - g).max() < 1e-12
+    x, it, rel = F.pcg_jacobi(A, b, rtol=1e-12)
+    assert rel <= 1e-12 and np.abs(x - g).max() < 1e-9 and 0 < it < 200
+
+
+def test_fd_matrices_match_reference_fixture():
+    from pgdrome_amd.solver import FD_matrices
+    with open(os.path.join(GOLDEN, "fd_matrices.json")) as f:
+        cases = json.load(f)["cases"]
+    assert len(cases) == 3
+    for cs in cases:
+        M, D2, D1 = FD_matrices(np.array(cs["x"]))
+        assert np.array_equal(M.toarray(), np.array(cs["M"]))
+        assert np.array_equal(D2.toarray(), np.array(cs["D2"]))
+        assert np.array_equal(D1.toarray(), np.array(cs["D1_up"]))
+    # the values SURVEY section 8(c) quotes for linspace(0, 1, 5)
+    M, D2, D1 = FD_matrices(np.linspace(0, 1, 5))
+    assert np.allclose(M.diagonal(), [.125, .25, .25, .25, .125])
+    assert np.allclose(D2.toarray()[1, :3], [4, -8, 4]) and np.allclose(D1.toarray()[1, :2], [-1, 1])

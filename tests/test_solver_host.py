@@ -1,0 +1,153 @@
+"""Host logic on CPU: the form frontend and PGDProblem control flow, with the numpy
+oracle injected as the backend, against the fixtures captured from the reference's
+own solve_PGD (tests/golden/reference_runs.json)."""
+import numpy as np
+import pytest
+
+from oracle.backend_numpy import NumpyBackend
+from pgdrome_amd import fem
+from tests import pgd_cases
+
+
+@pytest.fixture(autouse=True)
+def oracle_backend():
+    old = fem._backend
+    fem.set_backend(NumpyBackend())
+    fem.clear_caches()
+    yield
+    fem.set_backend(old)
+    fem.clear_caches()
+
+
+RUNS = pgd_cases.load_runs()
+
+
+@pytest.mark.parametrize("run", RUNS, ids=lambda r: "%s-%s-%s-%s%s" % (
+    r["case"], r["problem"], r["norm_modes"], r["stop_fp"], "-" + "_".join(r["knobs"]) if r["knobs"] else ""))
+def test_pgdproblem_reproduces_reference_run(run):
+    p = pgd_cases.run_case(run)
+    # same arithmetic (oracle) under a different loop implementation; the PCG start vector differs
+    # (warm start) so solves agree to the PCG tolerance (rtol 1e-10), not to rounding
+    pgd_cases.check_against_golden(p, run, mode_tol=1e-6, scalar_rtol=1e-7)
+
+
+def test_config1_matches_survey_appendix_e():
+    run = [r for r in RUNS if r["case"] == "cfg1" and r["norm_modes"] == "stiff" and r["problem"] == "linear"
+           and not r["knobs"]][0]
+    assert run["num_fp_it"] == [4, 3, 3]
+    np.testing.assert_allclose(run["amplitude"], [1.0, 9.05230929e-03, 5.41470445e-04], rtol=1e-8)
+    np.testing.assert_allclose(run["alpha"], [0.18722322, 0.00605851, 0.00070933], rtol=5e-6)   # quoted to 8 decimals
+
+
+def test_stiff_and_l2_store_the_same_modes():
+    a = [r for r in RUNS if r["case"] == "cfg1" and r["norm_modes"] == "stiff" and r["problem"] == "linear" and not r["knobs"]][0]
+    b = [r for r in RUNS if r["case"] == "cfg1" and r["norm_modes"] == "l2"][0]
+    for d in range(2):
+        for m in range(3):
+            assert np.abs(np.array(a["modes_vertex_values"][d][m]) - np.array(b["modes_vertex_values"][d][m])).max() < 1e-14
+
+
+def test_interval_dofs_run_against_the_vertices():
+    """tests/unit/test_FD.py:69,76-79 of the reference: t = 0 is the LAST dof."""
+    V = fem.FunctionSpace(fem.IntervalMesh(4, 0.0, 1.0), "CG", 1)
+    x = V.tabulate_dof_coordinates().flatten()
+    assert np.allclose(x, [1.0, 0.75, 0.5, 0.25, 0.0])
+    f = fem.interpolate(fem.Expression("x[0]", degree=1), V)
+    assert np.allclose(f.vector()[:], x) and np.allclose(f.compute_vertex_values(), x[::-1])
+    idx = np.argsort(x)
+    assert np.array_equal(idx[idx], np.arange(5))          # the sort permutation is self-inverse
+    f.vector()[:] = np.arange(5.0)
+    assert np.allclose(f.compute_vertex_values(), [4, 3, 2, 1, 0]) and f.vector()[-1] == 4.0
+
+
+def test_form_algebra_and_assemble_ranks():
+    mesh = fem.IntervalMesh(10, 0.0, 2.0)
+    V = fem.FunctionSpace(mesh, "P", 1)
+    u, v = fem.TrialFunction(V), fem.TestFunction(V)
+    f = fem.interpolate(fem.Expression("x[0]", degree=1), V)
+    g = fem.interpolate(fem.Expression("1.0 - 0.5*x[0]", degree=1), V)
+    assert np.isclose(fem.assemble(f * g * fem.dx(mesh)), 2.0 - 0.5 * 8.0 / 3.0)
+    assert np.isclose(fem.assemble(f.dx(0) * g * fem.dx(mesh)), 1.0)
+    assert np.isclose(fem.assemble(f.dx(0) * g.dx(0) * fem.dx(mesh)), -1.0)
+    assert np.isclose(fem.assemble(fem.Constant(3.0) * 2.0 * f * f * f * fem.dx(mesh)), 6.0 * 4.0)
+    assert np.isclose(fem.assemble(fem.inner(fem.grad(f), fem.grad(g)) * fem.dx(mesh)), -1.0)
+    b = fem.assemble(2.0 * f * v * fem.dx(mesh) - g.dx(0) * v.dx(0) * fem.dx(mesh))
+    assert np.isclose(b[:].sum(), 2.0 * 2.0)                 # K g has zero row sums
+    A = fem.assemble(fem.Constant(2.0) * u.dx(0) * v.dx(0) * fem.dx(mesh) + u * v * fem.dx(mesh)).array()
+    h = 0.2
+    assert np.isclose(A[5, 5], 2 * 2 / h + 4 * h / 6) and np.isclose(A[5, 4], -2 / h + h / 6)
+    l = 0
+    l += f * v * fem.dx(mesh)
+    l += -(g * v * fem.dx(mesh))
+    assert np.isclose(fem.assemble(l)[:].sum(), 2.0 - 1.0)
+    with pytest.raises(NotImplementedError):
+        fem.FunctionSpace(mesh, "CG", 2)
+
+
+def test_expression_dialect():
+    X = np.array([[0.2], [1.7]])
+    assert np.allclose(fem.Expression("x[0]<L/2 ? 1.0 : 0", degree=1, L=3.0).eval_at(X), [1.0, 0.0])
+    assert np.allclose(fem.Expression("x[0]*Q", Q=2.5, degree=1).eval_at(X), [0.5, 4.25])
+    assert np.allclose(fem.Expression("(x[0] > 0.1 && x[0] < 1.0) ? pow(x[0], 2) : exp(-x[0])", degree=1).eval_at(X),
+                       [0.04, np.exp(-1.7)])
+    e = fem.Expression("a*x[0]", a=1.0, degree=1)
+    e.a = 3.0
+    assert np.isclose(e(2.0), 6.0)
+
+
+def test_dirichlet_and_linear_solve_1d():
+    mesh = fem.IntervalMesh(16, 0.0, 1.0)
+    V = fem.FunctionSpace(mesh, "CG", 1)
+    u, v = fem.TrialFunction(V), fem.TestFunction(V)
+
+    def ends(x, on_boundary):
+        return on_boundary
+    bc = fem.DirichletBC(V, fem.Expression("1.0 + x[0]", degree=1), ends)
+    w = fem.Function(V)
+    fem.solve(u.dx(0) * v.dx(0) * fem.dx(mesh) == fem.Constant(0.0) * v * fem.dx(mesh), w, bc)
+    assert np.allclose(w.compute_vertex_values(), 1.0 + mesh.coordinates()[:, 0])       # lifting of g != 0
+    assert np.isclose(w(0.33), 1.33)
+    # non-symmetric first-order problem u' = 1, u(0) = 0 (time dimension)
+    def t0(x, on_boundary):
+        return x[0] < 1e-12
+    w2 = fem.Function(V)
+    one = fem.interpolate(fem.Constant(1.0), V)
+    fem.solve(u.dx(0) * v * fem.dx(mesh) == one * v * fem.dx(mesh), w2, fem.DirichletBC(V, 0.0, t0))
+    assert np.allclose(w2.compute_vertex_values(), mesh.coordinates()[:, 0], atol=1e-12)
+
+
+def test_per_vertex_marker_fallback_and_near():
+    mesh = fem.RectangleMesh(fem.Point(0, 0), fem.Point(3, 3), 6, 6)
+    V = fem.FunctionSpace(mesh, "CG", 1)
+
+    def leftright(x, on_boundary):     # python `and`/`or`: not vectorisable, falls back to the vertex loop
+        return on_boundary and fem.near(x[0], 0.0, 1e-6) or fem.near(x[0], 3.0, 1e-6)
+    bc = fem.DirichletBC(V, 0, leftright)
+    X = mesh.coordinates()
+    assert set(bc.vertices()) == set(np.where((X[:, 0] == 0) | (X[:, 0] == 3))[0])
+
+
+def test_nonconvergence_is_logged_not_raised():
+    run = [r for r in RUNS if r["knobs"].get("max_fp_it") == 2][0]
+    p = pgd_cases.run_case(run)
+    assert p.num_fp_it == [2, 2, 2] and p.simulation_info.count("NOT converged") == 3
+    p.stop_fp = "bogus"
+    with pytest.raises(ValueError):
+        p.solve_PGD(_problem="linear")
+
+
+def test_second_solve_keeps_alpha_history():
+    """Quirk Q3: alpha / num_fp_it are not cleared by a second solve_PGD, PGD_func is."""
+    run = RUNS[0]
+    p = pgd_cases.run_case(run)
+    p.solve_PGD(_problem="linear")
+    assert len(p.alpha) == 6 and len(p.num_fp_it) == 6 and p.PGD_modes == 3 and len(p.amplitude) == 3
+
+
+def test_return_pgd_and_evaluate():
+    p = pgd_cases.run_case(RUNS[0])
+    sol = p.return_PGD()
+    assert sol.numModes == 3 and sol.problem is p and sol.mesh[0].numNodes == 32
+    u = sol.evaluate(0, [1], [0.5], 0)
+    # -Laplace u = 1 on the unit square: u(0.5, 0.5) = 0.0736713...
+    assert abs(u(0.5) - 0.0736713) < 2e-3
