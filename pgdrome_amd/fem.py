@@ -192,7 +192,9 @@ class Mesh:
         if a is None:
             if weight is not None:   # drop stale versions of the same weight
                 for k in [k for k in self._atoms if k[0] == id(be) and k[1] == kind and k[4] and k[4][0] == id(weight)]:
-                    be.atom_free(self._atoms.pop(k))
+                    stale = self._atoms.pop(k)
+                    _purge_atom(stale)       # the library recycles handle numbers: forget everything keyed by it
+                    be.atom_free(stale)
             a = be.atom(self.handle(), kind, key[2], key[3], weight.dev() if weight is not None else 0)
             self._atoms[key] = a
         return a
@@ -392,6 +394,7 @@ class Vector:
         self.n = V.dim()
         self._host = np.zeros(self.n) if host is None else np.array(host, dtype=np.float64)
         self._dev = None
+        self._be = None          # backend that owns _dev
         self._host_ok = True
         self._dev_ok = False
         self.version = 0
@@ -399,16 +402,30 @@ class Vector:
     # -- residency
     def host(self):
         if not self._host_ok:
-            self._host = get_backend().vec_to_host(self._dev)
+            self._host = self._be.vec_to_host(self._dev)
             self._host_ok = True
         return self._host
 
-    def dev(self):
+    def _alloc_dev(self):
         be = get_backend()
+        if self._dev is not None and self._be is not be:     # backend was swapped (tests): start over there
+            self.host()
+            self._drop_dev()
         if self._dev is None:
-            self._dev = be.vec_zeros(self.n)
-            if self._host_ok and not np.any(self._host):
-                self._dev_ok = True
+            self._dev, self._be = be.vec_zeros(self.n), be
+            self._dev_ok = bool(self._host_ok and not np.any(self._host))
+        return be
+
+    def _drop_dev(self):
+        if self._dev is not None:
+            try:
+                self._be.vec_free(self._dev)
+            except Exception:
+                pass
+        self._dev, self._be, self._dev_ok = None, None, False
+
+    def dev(self):
+        be = self._alloc_dev()
         if not self._dev_ok:
             be.vec_upload(self._dev, self._host)
             self._dev_ok = True
@@ -423,11 +440,7 @@ class Vector:
         self.version += 1
 
     def __del__(self):
-        try:
-            if self._dev is not None and _backend is not None:
-                _backend.vec_free(self._dev)
-        except Exception:
-            pass
+        self._drop_dev()
 
     # -- GenericVector surface
     def __len__(self):
@@ -479,8 +492,7 @@ class Vector:
 
     def dev_for_write(self):
         """Device handle whose content is about to be overwritten (skips the upload)."""
-        if self._dev is None:
-            self._dev = get_backend().vec_zeros(self.n)
+        self._alloc_dev()
         return self._dev
 
     def _small(self):
@@ -1239,6 +1251,13 @@ _SCALAR_MEMO_MAX = 4096
 _MV_CACHE = {}        # (atom handle, id(vec)) -> (version, result Vector)   A @ g for immutable g
 
 
+def _purge_atom(atom):
+    for k in [k for k in _MV_CACHE if k[0] == atom]:
+        del _MV_CACHE[k]
+    for k in [k for k in _SCALAR_MEMO if k[0] == atom]:
+        del _SCALAR_MEMO[k]
+
+
 def _matvec_cached(mesh, atom, g):
     """A g as a Vector; cached while g is unchanged (stored modes and loads never change)."""
     key = (atom, id(g))
@@ -1343,6 +1362,9 @@ def _term_vector(term, mesh):
     plain = [c for c in coefs if c.deriv is None]
     if len(der) > 1:
         raise NotImplementedError("two differentiated coefficients in a linear form")
+    if not der and len(plain) == 2:
+        # w g v is symmetric in (w, g): weight the atom with the coefficient that changes less often
+        plain.sort(key=lambda c: -_coef_vec(c.leaf, mesh).version)
     ordered = der + plain
     g, rest = ordered[0], ordered[1:]
     kind, da, db, w = _atom_for(test, Factor(None, g.deriv), rest, mesh)
