@@ -167,8 +167,9 @@ int pgd_pcg_p_slot(pgd_handle ctx, pgd_handle p, pgd_handle z, int64_t r0, int64
                    int slot_num, int slot_den);
 
 /* --------------------------------------------------------------- measuring --- */
-/* HIP-event timing of every k_spmv_csr launch on the context's stream
- * (roofline.achieved = algorithmic bytes / launch time).  */
+/* HIP-event timing of k_spmv_csr launches on the context's stream (SURVEY.md
+ * section 8d: roofline.achieved = algorithmic bytes / launch time).
+ * on = 1: every launch; on = 2: only the PCG instance (fused dot, stores y).     */
 int pgd_prof_enable(pgd_handle ctx, int on);
 int pgd_prof_read(pgd_handle ctx, int64_t *launches, double *seconds, double *alg_bytes);
 

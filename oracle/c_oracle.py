@@ -20,6 +20,9 @@ def load():
         lib = C.CDLL(str(so))
         PD, PI = C.POINTER(C.c_double), C.POINTER(C.c_int32)
         lib.orc_num_threads.restype = C.c_int
+        lib.orc_set_threads.argtypes = [C.c_int]
+        lib.orc_set_threads.restype = None
+        lib.orc_set_threads(usable_cpus())
         lib.orc_spmv.argtypes = [C.c_int64, PI, PI, PD, PD, PD]
         lib.orc_spmv.restype = None
         lib.orc_pcg_jacobi.argtypes = [C.c_int64, PI, PI, PD, PD, PD, C.c_double, C.c_double, C.c_int,
@@ -27,6 +30,20 @@ def load():
         lib.orc_pcg_jacobi.restype = C.c_int
         _lib = lib
     return _lib
+
+
+def usable_cpus():
+    """CPUs this process may run on: affinity mask capped by the cgroup CPU quota."""
+    import os
+    n = len(os.sched_getaffinity(0))
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return n
 
 
 def _d(a):

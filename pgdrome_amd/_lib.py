@@ -335,7 +335,7 @@ class Context:
 
     # ---- measuring
     def prof_enable(self, on=True):
-        self._ck(self.lib.pgd_prof_enable(self.h, 1 if on else 0))
+        self._ck(self.lib.pgd_prof_enable(self.h, int(on)))
 
     def prof_read(self):
         n, s, b = I64(), F64(), F64()

@@ -281,6 +281,7 @@ int pgd_prof_enable(pgd_handle h, int on) {
     PGD_CTX(c, h);
     prof_flush(c);
     c->prof = on != 0;
+    c->prof_pcg_only = on == 2;
     if (on) {
         c->prof_launches = 0;
         c->prof_seconds = 0.0;

@@ -83,6 +83,7 @@ struct Ctx {
 
     // SpMV launch timing (HIP events on `stream`)
     bool prof = false;
+    bool prof_pcg_only = false;   // time only the PCG instance k_spmv_csr<dot,store>
     std::vector<hipEvent_t> ev;   // pairs
     size_t ev_used = 0;
     int64_t prof_launches = 0;
