@@ -215,6 +215,7 @@ class NumpyBackend:
         if self._flags[0]:
             return
         self._flags[1] += 1
+        self.slots[6] = self.slots[s_rr]
         if self.slots[s_rr] <= self.slots[s_tol2]:
             self._flags[0] = 1
 

@@ -86,7 +86,7 @@ struct Ctx {
     bool prof_pcg_only = false;   // time only the PCG instance k_spmv_csr<dot,store>
     std::vector<hipEvent_t> ev;   // pairs
     size_t ev_used = 0;
-    int64_t prof_launches = 0;
+    int64_t prof_launches = 0, prof_seen = 0;
     double prof_seconds = 0.0, prof_bytes = 0.0;
 };
 

@@ -92,9 +92,10 @@ __global__ void k_pcg_tol(double *__restrict__ slots, int *__restrict__ flags, d
     else if (rr <= tol2) flags[0] = 1;
 }
 
-__global__ void k_pcg_check(const double *__restrict__ slots, int *__restrict__ flags, int slot_rr, int slot_tol2) {
+__global__ void k_pcg_check(double *__restrict__ slots, int *__restrict__ flags, int slot_rr, int slot_tol2) {
     if (threadIdx.x != 0 || blockIdx.x != 0 || flags[0]) return;
     const double rr = slots[slot_rr];
+    slots[6] = rr;      // last live r.r: later all-reduces of the (frozen) pair slots cannot disturb it
     flags[1] += 1;
     if (!(rr == rr)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; }
     else if (rr <= slots[slot_tol2]) flags[0] = 1;

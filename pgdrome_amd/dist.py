@@ -1,0 +1,193 @@
+"""Row-sharding of the large spatial dimension across the GPUs of one node.
+
+The reference has no distributed path; this is the
+engine's own.  The structured vertex grid of the spatial mesh is cut into
+z-slabs, one per rank (one process per GPU).  A rank holds its owned vertex
+planes plus ONE ghost plane on either side and all cells between those planes,
+so every owned row of every atom is complete locally; all local vectors have
+the extended length and live in local (slab) vertex order:
+
+        [ lo ghost plane | owned planes ............ | hi ghost plane ]
+          0 .. own0        own0 .. own1                own1 .. n_ext
+
+Exchange steps (the only collectives on the data path):
+  * halo: before an operator is applied to a vector, each rank sends its first /
+    last owned plane to the lower / upper neighbour and receives their planes
+    into its ghost planes - contiguous slices, no pack kernels, point-to-point
+    (2 of the 7 xGMI links per GPU; 512 KiB per face at 256^3);
+  * fp64 all-reduce of 1-3 scalars for every dot product.
+Both go through ``torch.distributed`` (backend "nccl" = RCCL on ROCm; "gloo" in
+the CPU tests), on torch's current stream, which is also the stream the HIP
+library enqueues on - so kernels and collectives are ordered without host
+synchronisation.  The small time/parameter dimensions are replicated.
+
+The PCG recurrence is driven from here with the same kernels as the single-GPU
+``pgd_pcg_solve`` (device-resident scalars, a done flag, a host look at the
+flag every CHECK_EVERY iterations).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import fem
+
+CHECK_EVERY = 16
+# slots of the device scalar bank (shared convention with csrc/pgd_pcg.hip)
+S_PQ, S_TOL2, S_FINAL_RR, S_INIT, S_PAIR = 2, 5, 6, 20, 16
+
+
+class TorchComm:
+    """Communication + sharded-solve driver on top of torch.distributed."""
+
+    def __init__(self, dist, backend):
+        import torch
+        self.torch, self.dist, self.be = torch, dist, backend
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self._slots = None
+        self._work = {}
+        self._views = {}
+        self.stats = {"halo": 0, "allreduce": 0}
+
+    # ---- scalars
+    def _scalar_device(self):
+        return self.slots().device
+
+    def slots(self):
+        if self._slots is None:
+            self._slots = self.be.slots_tensor()
+        return self._slots
+
+    def allreduce_sum(self, value):
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self._scalar_device())
+        self.dist.all_reduce(t)
+        self.stats["allreduce"] += 1
+        return float(t.item())
+
+    def allreduce_slots(self, first, count):
+        self.dist.all_reduce(self.slots()[first:first + count])
+        self.stats["allreduce"] += 1
+
+    # ---- halo exchange
+    def _view(self, handle):
+        v = self._views.get(handle)
+        if v is None:
+            v = self.be.vec_tensor(handle)
+            self._views[handle] = v
+        return v
+
+    def halo_exchange_raw(self, mesh, handle, cache_view=False):
+        part = mesh.part
+        t = self._view(handle) if cache_view else self.be.vec_tensor(handle)
+        P2P, d = self.dist.P2POp, self.dist
+        ops = []
+        if part.lo_ghost:
+            g = part.lo_ghost
+            ops.append(P2P(d.isend, t[part.own0:part.own0 + g], self.rank - 1))
+            ops.append(P2P(d.irecv, t[0:g], self.rank - 1))
+        if part.hi_ghost:
+            g = part.hi_ghost
+            ops.append(P2P(d.isend, t[part.own1 - g:part.own1], self.rank + 1))
+            ops.append(P2P(d.irecv, t[part.own1:part.own1 + g], self.rank + 1))
+        if ops:
+            for req in d.batch_isend_irecv(ops):
+                req.wait()
+        self.stats["halo"] += 1
+
+    def halo_exchange(self, mesh, vec):
+        """Refresh the ghost planes of a frontend Vector (skipped while it is unchanged)."""
+        if getattr(vec, "_halo_version", None) == vec.version:
+            return
+        h = vec.dev()
+        self.halo_exchange_raw(mesh, h)
+        vec._host_ok = False           # ghost entries changed on the device only
+        vec._halo_version = vec.version
+
+    # ---- sharded Jacobi-PCG
+    def _workvec(self, n, name):
+        key = (n, name)
+        h = self._work.get(key)
+        if h is None:
+            h = self.be.vec_zeros(n)
+            self._work[key] = h
+        return h
+
+    def pcg(self, mesh, op, b, x, rtol, atol, maxit):
+        be, part = self.be, mesh.part
+        lo, hi, n = part.own0, part.own1, mesh.num_vertices()
+        r, z, p, q, dinv = (self._workvec(n, k) for k in ("r", "z", "p", "q", "dinv"))
+        xh, bh = x.dev(), b.dev()
+        be.flags_reset()
+        be.op_diag_inv(op, dinv)
+        self.halo_exchange_raw(mesh, xh)
+        be.spmv(op, xh, q, lo, hi)
+        be.pcg_init_slot(bh, q, dinv, r, z, p, lo, hi, S_INIT)          # local (r.z, r.r, b.b)
+        self.allreduce_slots(S_INIT, 3)
+        be.pcg_tol_slot(rtol, atol, S_INIT + 1, S_INIT + 2, S_TOL2)
+        rz_old, k = S_INIT, 0
+        while True:
+            done, iters, status = be.flags()          # the only host synchronisation of the loop
+            if done or k >= maxit:
+                break
+            for _ in range(min(CHECK_EVERY, maxit - k)):
+                out = S_PAIR + 2 * (k & 1)
+                self.halo_exchange_raw(mesh, p, cache_view=True)
+                be.spmv_dot_slot(op, p, q, p, lo, hi, S_PQ)             # q = A p, local p.q
+                self.allreduce_slots(S_PQ, 1)
+                be.pcg_xr_slot(xh, r, p, q, dinv, z, lo, hi, rz_old, S_PQ, out)
+                self.allreduce_slots(out, 2)                             # (r.z, r.r)
+                be.pcg_check_slot(out + 1, S_TOL2)
+                be.pcg_p_slot(p, z, lo, hi, out, rz_old)
+                rz_old = out
+                k += 1
+        if status != 0:
+            raise RuntimeError("sharded PCG breakdown (NaN residual) after %d iterations" % iters)
+        s = be.slots_get(0, 24)
+        bb = s[S_INIT + 2]
+        rr = s[S_FINAL_RR] if iters > 0 else s[S_INIT + 1]
+        x.touched_dev()
+        self.halo_exchange(mesh, x)
+        return iters, (np.sqrt(rr / bb) if bb > 0 else 0.0)
+
+
+def slab_ranges(n_planes, world):
+    """Owned vertex planes [z0, z1) of every rank: as even as possible, every rank >= 1 plane."""
+    if world > n_planes:
+        raise ValueError("more ranks (%d) than vertex planes (%d)" % (world, n_planes))
+    base, rem = divmod(n_planes, world)
+    out, z = [], 0
+    for r in range(world):
+        k = base + (1 if r < rem else 0)
+        out.append((z, z + k))
+        z += k
+    return out
+
+
+def sharded_box_mesh(comm, p0, p1, nx, ny, nz):
+    """This rank's slab of dolfin.BoxMesh(p0, p1, nx, ny, nz) as a frontend Mesh with a Partition."""
+    nx, ny, nz = int(nx), int(ny), int(nz)
+    z0, z1 = slab_ranges(nz + 1, comm.world)[comm.rank]
+    zf = z0 - 1 if comm.rank > 0 else z0                       # first local plane (ghost below)
+    zl = z1 if comm.rank < comm.world - 1 else z1 - 1          # last local plane (ghost above)
+    coords, cells = fem.box_mesh_arrays(p0, p1, nx, ny, nz, zf, zl)
+    plane = (nx + 1) * (ny + 1)
+    lo_g = plane if comm.rank > 0 else 0
+    hi_g = plane if comm.rank < comm.world - 1 else 0
+    own0 = lo_g
+    own1 = own0 + (z1 - z0) * plane
+    part = fem.Partition(comm, own0, own1, plane * (nz + 1), lo_g, hi_g, zf * plane)
+    mesh = fem.Mesh(coords, cells, part)
+    mesh._on_boundary = fem.box_hull_mask(nx, ny, nz, zf, zl)
+    assert mesh.num_vertices() == own1 + hi_g
+    return mesh
+
+
+def gather_owned(comm, mesh, local_values):
+    """All ranks' owned entries concatenated in global vertex order (tests / output only)."""
+    torch, dist = comm.torch, comm.dist
+    part = mesh.part
+    mine = np.ascontiguousarray(local_values[part.own0:part.own1])
+    sizes = [None] * comm.world
+    dist.all_gather_object(sizes, int(mine.size))
+    out = [None] * comm.world
+    dist.all_gather_object(out, mine)
+    return np.concatenate(out)

@@ -1172,12 +1172,13 @@ def _bc_vertices(bcs):
     bcs = _bc_list(bcs)
     if not bcs:
         return np.zeros(0, dtype=np.int32), np.zeros(0)
-    d = {}
-    for bc in bcs:
-        for v, g in zip(bc.vertices(), bc.vertex_values()):
-            d[int(v)] = float(g)
-    verts = np.array(sorted(d), dtype=np.int32)
-    return verts, np.array([d[int(v)] for v in verts])
+    if len(bcs) == 1:
+        return bcs[0].vertices(), bcs[0].vertex_values()
+    verts = np.concatenate([bc.vertices() for bc in bcs])
+    vals = np.concatenate([bc.vertex_values() for bc in bcs])
+    # keep the LAST occurrence of every vertex: unique on the reversed arrays keeps the first it meets
+    uniq, first = np.unique(verts[::-1], return_index=True)
+    return uniq.astype(np.int32), vals[::-1][first]
 
 
 # ---------------------------------------------------------------------------- assembly

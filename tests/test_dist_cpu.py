@@ -1,0 +1,99 @@
+"""The N > 1 path on CPU: world_size 2 and 3 over gloo, oracle backend for the local
+arithmetic.  Checks that the z-slab sharding (halo exchange + all-reduced dots + the
+host-driven PCG recurrence) reproduces the unsharded run of the same host code."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem(space, n_mu=9):
+    from pgdrome_amd import problems
+    return problems.reaction_diffusion(space, n_mu, PGD_nmax=3)
+
+
+def _worker(rank, world, port, shape, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.backend_numpy import NumpyBackend
+        from pgdrome_amd import dist as pdist, fem
+        from pgdrome_amd.solver import PGDProblem
+        be = fem.set_backend(NumpyBackend())
+        comm = pdist.TorchComm(dist, be)
+        P = fem.Point
+        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+        p = PGDProblem(**_problem(mesh))
+        p.solve_PGD(_problem="linear")
+        modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values()) for f in p.PGD_func[0]]
+        modes_mu = [f.compute_vertex_values() for f in p.PGD_func[1]]
+        # halo consistency: after the solve every ghost plane equals the neighbour's owned plane
+        f = p.PGD_func[0][0]
+        comm.halo_exchange(mesh, f.vector())
+        loc = f.compute_vertex_values()
+        glob = modes_x[0]
+        part = mesh.part
+        assert np.array_equal(loc, glob[part.global_offset:part.global_offset + loc.size])
+        if rank == 0:
+            q.put(dict(num_fp_it=p.num_fp_it, amplitude=p.amplitude, alpha=p.alpha, modes_x=modes_x,
+                       modes_mu=modes_mu, stats=dict(comm.stats)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape", [(2, (4, 3, 5)), (3, (3, 4, 6))])
+def test_sharded_solve_equals_single_process(world, shape):
+    from oracle.backend_numpy import NumpyBackend
+    from pgdrome_amd import fem
+    from pgdrome_amd.solver import PGDProblem
+    old = fem._backend
+    fem.set_backend(NumpyBackend())
+    fem.clear_caches()
+    try:
+        P = fem.Point
+        ref = PGDProblem(**_problem(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape)))
+        ref.solve_PGD(_problem="linear")
+        ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
+        ref_mu = [f.compute_vertex_values() for f in ref.PGD_func[1]]
+    finally:
+        fem.set_backend(old)
+        fem.clear_caches()
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    out = q.get(timeout=240)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert out["num_fp_it"] == ref.num_fp_it
+    np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
+    np.testing.assert_allclose(out["alpha"], ref.alpha, rtol=1e-8)
+    for m in range(ref.PGD_modes):
+        assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
+        assert np.linalg.norm(out["modes_mu"][m] - ref_mu[m]) <= 1e-7 * np.linalg.norm(ref_mu[m])
+    assert out["stats"]["halo"] > 0 and out["stats"]["allreduce"] > 0
+
+
+def test_slab_ranges_cover_all_planes():
+    from pgdrome_amd.dist import slab_ranges
+    for n, w in ((256, 8), (256, 3), (7, 7), (10, 4)):
+        r = slab_ranges(n, w)
+        assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
+        assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+    with pytest.raises(ValueError):
+        slab_ranges(3, 4)

@@ -1,0 +1,66 @@
+"""The host-driven (sharded) PCG recurrence on the GPU with world_size 1 over RCCL:
+exercises the *_slot kernels, the zero-copy torch views of library-owned device
+memory, the shared HIP stream and an in-stream all-reduce.  (Two ranks cannot
+share one GPU under RCCL; the N > 1 exchange logic is covered by tests/test_dist_cpu.py.)"""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_sharded_driver_world1_matches_library_pcg():
+    import torch
+    import torch.distributed as dist
+    from pgdrome_amd import dist as pdist, fem, problems
+    from pgdrome_amd.hip_backend import HipBackend
+    from pgdrome_amd.solver import PGDProblem
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    old = fem._backend
+    try:
+        P = fem.Point
+        shape = (24, 20, 28)
+        # library-driven PCG
+        be1 = fem.set_backend(HipBackend(0))
+        fem.clear_caches()
+        ref = PGDProblem(**problems.reaction_diffusion(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape), 17, PGD_nmax=3))
+        ref.solve_PGD(_problem="linear")
+        ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
+        its_ref = fem.STATS["pcg_iterations"]
+        # host-driven PCG on torch's stream, scalars all-reduced through RCCL
+        be2 = fem.set_backend(HipBackend(0, torch.cuda.current_stream().cuda_stream))
+        fem.clear_caches()
+        comm = pdist.TorchComm(dist, be2)
+        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+        assert mesh.part.lo_ghost == 0 and mesh.part.hi_ghost == 0
+        p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=3))
+        fem.STATS["pcg_iterations"] = 0
+        p.solve_PGD(_problem="linear")
+        assert p.num_fp_it == ref.num_fp_it
+        np.testing.assert_allclose(p.amplitude, ref.amplitude, rtol=1e-9)
+        for m in range(ref.PGD_modes):
+            got = p.PGD_func[0][m].compute_vertex_values()
+            assert np.linalg.norm(got - ref_x[m]) <= 1e-8 * np.linalg.norm(ref_x[m])
+        assert comm.stats["allreduce"] > 100
+        # zero-copy view really aliases the library's memory
+        v = be2.vec_from(np.arange(5.0))
+        t = be2.vec_tensor(v)
+        t += 1.0
+        torch.cuda.synchronize()
+        assert np.array_equal(be2.vec_to_host(v), np.arange(5.0) + 1.0)
+    finally:
+        fem.set_backend(old)
+        fem.clear_caches()
+        dist.destroy_process_group()
