@@ -166,6 +166,14 @@ int pgd_pcg_check_slot(pgd_handle ctx, int slot_rr, int slot_tol2);
 int pgd_pcg_p_slot(pgd_handle ctx, pgd_handle p, pgd_handle z, int64_t r0, int64_t r1,
                    int slot_num, int slot_den);
 
+/* ------------------------------------------------------------------ tuning --- */
+/* Launch-shape knobs; they change speed (and the order of the dot's partial
+ * sums), never which result is computed.                                        */
+enum {
+    PGD_TUNE_SPMV_ROWS = 1   /* rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256 */
+};
+int pgd_tune(pgd_handle ctx, int knob, int64_t value);
+
 /* --------------------------------------------------------------- measuring --- */
 /* HIP-event timing of k_spmv_csr launches on the context's stream (SURVEY.md
  * section 8d: roofline.achieved = algorithmic bytes / launch time).

@@ -69,6 +69,7 @@ SIGNATURES = {
     "pgd_pcg_xr_slot": (C.c_int, [H, H, H, H, H, H, H, I64, I64, C.c_int, C.c_int, C.c_int]),
     "pgd_pcg_check_slot": (C.c_int, [H, C.c_int, C.c_int]),
     "pgd_pcg_p_slot": (C.c_int, [H, H, H, I64, I64, C.c_int, C.c_int]),
+    "pgd_tune": (C.c_int, [H, C.c_int, I64]),
     "pgd_prof_enable": (C.c_int, [H, C.c_int]),
     "pgd_prof_read": (C.c_int, [H, PI64, PD, PD]),
 }
@@ -332,6 +333,9 @@ class Context:
 
     def pcg_p_slot(self, p, z, lo, hi, slot_num, slot_den):
         self._ck(self.lib.pgd_pcg_p_slot(self.h, p, z, int(lo), int(hi), slot_num, slot_den))
+
+    def tune(self, knob, value):
+        self._ck(self.lib.pgd_tune(self.h, int(knob), int(value)))
 
     # ---- measuring
     def prof_enable(self, on=True):

@@ -116,6 +116,12 @@ int pgd_ctx_create(int device, void *stream, pgd_handle *out) {
     if (hipSetDevice(device) != hipSuccess) return fail(nullptr, PGD_ERR_HIP, "hipSetDevice failed");
     std::unique_ptr<Ctx> c(new Ctx);
     c->device = device;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) {
+            c->num_cu = prop.multiProcessorCount;
+        }
+    }
     if (stream) {
         c->stream = (hipStream_t)stream;
     } else {

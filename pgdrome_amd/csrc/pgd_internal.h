@@ -81,6 +81,9 @@ struct Ctx {
     int *ibuf = nullptr;          // small int32 scratch (bc dofs, index lists)
     int64_t ibuf_cap = 0;
 
+    int num_cu = 256;
+    int spmv_rows = 64;           // rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256
+
     // SpMV launch timing (HIP events on `stream`)
     bool prof = false;
     bool prof_pcg_only = false;   // time only the PCG instance k_spmv_csr<dot,store>
@@ -168,6 +171,23 @@ __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
     return v;
+}
+
+// Sum over an NW-wave workgroup in a fixed order; result valid in thread 0.
+template <int NW>
+__device__ __forceinline__ double block_sum_n(double v, double *s_red /* >= NW */) {
+    v = wave_sum(v);
+    if (NW == 1) return v;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) s_red[wv] = v;
+    __syncthreads();
+    double t = 0.0;
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NW; ++k) t += s_red[k];
+    }
+    return t;
 }
 
 // Sum over a 256-thread workgroup in a fixed order; result valid in thread 0.

@@ -21,9 +21,9 @@
 
 namespace pgd {
 
-constexpr int SPMV_CAP = 4096;                       // staged entries per workgroup
-constexpr int SPMV_VROUNDS = SPMV_CAP / (TPB * 2);   // double2 loads per lane (8)
-constexpr int SPMV_CROUNDS = SPMV_CAP / (TPB * 4);   // int4 loads per lane (4)
+constexpr int SPMV_CAP = 4096;                       // staged entries per 256-row workgroup (k_spmv_multi)
+constexpr int SPMV_VROUNDS = 8;                      // double2 loads per lane: 16 entries per row
+constexpr int SPMV_CROUNDS = 4;                      // int4 loads per lane
 constexpr int MAXY = 8;                              // vectors per pass of k_spmv_multi
 
 struct SpmvArgs {
@@ -34,26 +34,31 @@ struct SpmvArgs {
     int row_begin, row_end;
 };
 
-template <bool DOT, bool STORE>
-__global__ __launch_bounds__(TPB) void k_spmv_csr(SpmvArgs A) {
+typedef double d2_t __attribute__((ext_vector_type(2)));
+typedef int i4_t __attribute__((ext_vector_type(4)));
+
+// R = rows (= threads) per workgroup; the staging capacity scales with it (16 entries per row).
+template <bool DOT, bool STORE, int R>
+__global__ __launch_bounds__(R) void k_spmv_csr(SpmvArgs A) {
+    constexpr int CAP = 16 * R;
     if (A.flags && A.flags[0]) return;   // PCG already converged: uniform early exit
-    __shared__ __align__(16) double s_vals[SPMV_CAP + 2];
-    __shared__ __align__(16) int s_cols[SPMV_CAP + 4];
-    __shared__ int s_rp[TPB + 1];
-    __shared__ double s_red[4];
+    __shared__ __align__(16) double s_vals[CAP + 2];
+    __shared__ __align__(16) int s_cols[CAP + 4];
+    __shared__ int s_rp[R + 1];
+    __shared__ double s_red[R / 64];
     const int tid = threadIdx.x;
     const int b = xcd_remap(blockIdx.x, gridDim.x);
-    const int r0 = A.row_begin + b * TPB;
-    const int nr = min(TPB, A.row_end - r0);
+    const int r0 = A.row_begin + b * R;
+    const int nr = min(R, A.row_end - r0);
     if (tid < nr) s_rp[tid] = A.row_ptr[r0 + tid];
     if (tid == 0) s_rp[nr] = A.row_ptr[r0 + nr];
     __syncthreads();
     const int s = s_rp[0], e = s_rp[nr];
     const int sv = s & ~1, sc = s & ~3;     // 16-byte aligned starts of the two streams
     double acc = 0.0;
-    if (e - sc <= SPMV_CAP) {
-        double2 v[SPMV_VROUNDS];
-        int4 c[SPMV_CROUNDS];
+    if (e - sc <= CAP) {
+        d2_t v[SPMV_VROUNDS];
+        i4_t c[SPMV_CROUNDS];
         const double *gv = A.vals + sv;
         const int *gc = A.cols + sc;
         const int nvv = e - sv, ncc = e - sc;
@@ -62,22 +67,22 @@ __global__ __launch_bounds__(TPB) void k_spmv_csr(SpmvArgs A) {
         // the segment are in flight before the first LDS store
 #pragma unroll
         for (int i = 0; i < SPMV_VROUNDS; ++i) {
-            const int k = (tid + i * TPB) * 2;
-            v[i] = *reinterpret_cast<const double2 *>(gv + (k < nvv ? k : 0));
+            const int k = (tid + i * R) * 2;
+            v[i] = *reinterpret_cast<const d2_t *>(gv + (k < nvv ? k : 0));
         }
 #pragma unroll
         for (int i = 0; i < SPMV_CROUNDS; ++i) {
-            const int k = (tid + i * TPB) * 4;
-            c[i] = *reinterpret_cast<const int4 *>(gc + (k < ncc ? k : 0));
+            const int k = (tid + i * R) * 4;
+            c[i] = *reinterpret_cast<const i4_t *>(gc + (k < ncc ? k : 0));
         }
         // stores are unconditional as well (slots past the segment are never read): the
         // staging phase is straight-line code, 12 loads then 12 LDS stores
 #pragma unroll
         for (int i = 0; i < SPMV_VROUNDS; ++i)
-            *reinterpret_cast<double2 *>(s_vals + (tid + i * TPB) * 2) = v[i];
+            *reinterpret_cast<d2_t *>(s_vals + (tid + i * R) * 2) = v[i];
 #pragma unroll
         for (int i = 0; i < SPMV_CROUNDS; ++i)
-            *reinterpret_cast<int4 *>(s_cols + (tid + i * TPB) * 4) = c[i];
+            *reinterpret_cast<i4_t *>(s_cols + (tid + i * R) * 4) = c[i];
         __syncthreads();
         if (tid < nr) {
             const int a = s_rp[tid], bnd = s_rp[tid + 1];
@@ -105,7 +110,7 @@ __global__ __launch_bounds__(TPB) void k_spmv_csr(SpmvArgs A) {
     if (STORE && tid < nr) A.y[r0 + tid] = acc;
     if (DOT) {
         const double t = (tid < nr) ? acc * A.w[r0 + tid] : 0.0;
-        const double sum = block_sum(t, s_red);
+        const double sum = block_sum_n<R / 64>(t, s_red);
         if (tid == 0) A.partials[b] = sum;
     }
 }
@@ -170,7 +175,8 @@ int launch_spmv(Ctx *c, const Mesh *m, const double *vals, const double *x, doub
     if (r1 < 0) r1 = m->nv;
     if (r0 < 0 || r0 > r1 || r1 > m->nv) return fail(c, PGD_ERR_INVALID, "spmv: bad row range");
     const int64_t nrows = r1 - r0;
-    const int nblk = (int)((nrows + TPB - 1) / TPB);
+    const int R = c->spmv_rows;
+    const int nblk = (int)((nrows + R - 1) / R);
     if (nparts_out) *nparts_out = nblk;
     if (nblk == 0) return PGD_OK;
     if (dot) PGD_TRY(ensure_partials(c, (int64_t)nblk > 4 * MAX_VEC_BLOCKS ? nblk : 4 * MAX_VEC_BLOCKS));
@@ -184,9 +190,16 @@ int launch_spmv(Ctx *c, const Mesh *m, const double *vals, const double *x, doub
         if (c->ev_used + 2 > c->ev.size()) prof_flush(c);
         PGD_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
     }
-    if (dot && store) k_spmv_csr<true, true><<<nblk, TPB, 0, c->stream>>>(A);
-    else if (dot) k_spmv_csr<true, false><<<nblk, TPB, 0, c->stream>>>(A);
-    else k_spmv_csr<false, true><<<nblk, TPB, 0, c->stream>>>(A);
+#define PGD_SPMV_LAUNCH(D, S)                                                                    \
+    do {                                                                                         \
+        if (R == 256) k_spmv_csr<D, S, 256><<<nblk, 256, 0, c->stream>>>(A);                     \
+        else if (R == 128) k_spmv_csr<D, S, 128><<<nblk, 128, 0, c->stream>>>(A);                \
+        else k_spmv_csr<D, S, 64><<<nblk, 64, 0, c->stream>>>(A);                                \
+    } while (0)
+    if (dot && store) PGD_SPMV_LAUNCH(true, true);
+    else if (dot) PGD_SPMV_LAUNCH(true, false);
+    else PGD_SPMV_LAUNCH(false, true);
+#undef PGD_SPMV_LAUNCH
     if (timed) {
         PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
         c->ev_used += 2;
@@ -226,6 +239,12 @@ int launch_spmv_multi(Ctx *c, const Mesh *m, const double *vals, const double *x
 using namespace pgd;
 
 extern "C" {
+
+int pgd_tune(pgd_handle h, int knob, int64_t value) {
+    PGD_CTX(c, h);
+    if (knob == PGD_TUNE_SPMV_ROWS && (value == 64 || value == 128 || value == 256)) { c->spmv_rows = (int)value; return PGD_OK; }
+    return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
+}
 
 int pgd_spmv(pgd_handle h, pgd_handle ah, pgd_handle xh, pgd_handle yh, int64_t r0, int64_t r1) {
     PGD_CTX(c, h);

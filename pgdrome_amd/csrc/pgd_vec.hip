@@ -155,8 +155,35 @@ int scan_exclusive_i32(Ctx *c, const int *in, int *out, int64_t n) {
     return PGD_OK;
 }
 
+// First stage for long partial lists (a 64-row-per-workgroup SpMV leaves 262 144 of them):
+// workgroup b adds partials [1024 b, 1024 b + 1024) of every value in a fixed order.
+__global__ __launch_bounds__(TPB) void k_reduce_stage1(const double *__restrict__ partials, int nparts, int nvals,
+                                                       double *__restrict__ out, const int *__restrict__ flags,
+                                                       int check_mode) {
+    if (flags && check_mode >= 0 && flags[0]) return;
+    __shared__ double s_red[4];
+    const int base = blockIdx.x * 1024;
+    for (int v = 0; v < nvals; ++v) {
+        double a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = base + threadIdx.x + u * TPB;
+            a[u] = (i < nparts) ? partials[(int64_t)i * nvals + v] : 0.0;
+        }
+        const double t = block_sum((a[0] + a[1]) + (a[2] + a[3]), s_red);
+        if (threadIdx.x == 0) out[(int64_t)blockIdx.x * nvals + v] = t;
+    }
+}
+
 int reduce_partials(Ctx *c, const double *partials, int nparts, int nvals, int slot0, int check_mode,
                     int slot_rr, int slot_tol2) {
+    if (nparts > 8192) {
+        const int nb = (nparts + 1023) / 1024;
+        PGD_TRY(ensure_work(c, 5, (int64_t)nb * nvals > 4096 ? (int64_t)nb * nvals : 4096));
+        k_reduce_stage1<<<nb, TPB, 0, c->stream>>>(partials, nparts, nvals, c->work[5], c->flags, check_mode);
+        partials = c->work[5];
+        nparts = nb;
+    }
     k_reduce_partials<<<1, 1024, 0, c->stream>>>(partials, nparts, nvals, c->slots, slot0, check_mode,
                                                  slot_rr, slot_tol2, c->flags);
     PGD_LAUNCH_CHECK(c);

@@ -138,6 +138,32 @@ def test_spmv_bilinear_dot(ctx, mesh):
     ctx.atom_free(a)
 
 
+@pytest.mark.parametrize("rows", [64, 128, 256])
+def test_spmv_workgroup_shapes_agree(ctx, rows):
+    """Every tile height of k_spmv_csr gives the same product (only the dot's partial order differs)."""
+    coords, cells = F.box_mesh((0, 0, 0), (1, 1, 1), 30, 17, 23)
+    h = ctx.mesh_upload(coords, cells)
+    n = coords.shape[0]
+    K = F.assemble_atom(coords, cells, F.STIFF)
+    a = ctx.atom_upload(h, K.data)
+    x = np.random.default_rng(8).uniform(-1, 1, n)
+    xv, yv = ctx.vec_from(x), ctx.vec_alloc(n)
+    from pgdrome_amd._lib import PgdError
+    with pytest.raises(PgdError):
+        ctx.tune(1, 100)
+    ctx.tune(1, rows)
+    try:
+        ctx.spmv(a, xv, yv)
+        y = ctx.vec_download(yv)
+        assert np.all(np.abs(y - K @ x) <= 4e-15 * (np.abs(K) @ np.abs(x)))
+        r0, r1 = 1000, n - 777
+        bl = ctx.bilinear(a, xv, xv, r0, r1)
+        assert abs(bl - x[r0:r1] @ (K @ x)[r0:r1]) <= 1e-12 * (np.abs(x) @ (np.abs(K) @ np.abs(x)))
+    finally:
+        ctx.tune(1, 64)
+    ctx.mesh_free(h)
+
+
 def test_vector_ops(ctx):
     rng = np.random.default_rng(5)
     for n in (1, 63, 64, 257, 100_003):

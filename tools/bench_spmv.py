@@ -38,21 +38,22 @@ def main():
               f"2 atoms {t3-t2:.3f}s combine {t4-t3:.3f}s", flush=True)
         x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, nv))
         y = ctx.vec_alloc(nv)
-        for _ in range(5):
-            ctx.spmv(op, x, y)
-        ctx.sync()
-        ctx.prof_enable(True)
-        reps = 50
-        t0 = time.time()
-        for _ in range(reps):
-            ctx.spmv(op, x, y)
-        ctx.sync()
-        wall = time.time() - t0
-        pr = ctx.prof_read()
-        ctx.prof_enable(False)
         alg = F.spmv_bytes(nv, nnz)
-        print(f"  spmv: {pr['seconds']/pr['launches']*1e6:.1f} us/launch (events) {wall/reps*1e6:.1f} us (wall) "
-              f"-> {alg/(pr['seconds']/pr['launches'])/1e9:.0f} GB/s algorithmic = {alg/(pr['seconds']/pr['launches'])/8e12*100:.1f}% of 8 TB/s", flush=True)
+        variants = [(256, 0), (128, 0), (64, 0)]
+        for rnd in range(3):                      # interleaved rounds in one process
+            for var, grid in variants:
+                ctx.tune(1, var)
+                for _ in range(3):
+                    ctx.spmv(op, x, y)
+                ctx.sync()
+                reps = 40
+                t0 = time.time()
+                for _ in range(reps):
+                    ctx.spmv(op, x, y)
+                ctx.sync()
+                wall = (time.time() - t0) / reps
+                print(f"  round {rnd} rows/workgroup {var}: {wall*1e6:.1f} us (wall) -> {alg/wall/1e9:.0f} GB/s = {alg/wall/8e12*100:.1f}% of 8 TB/s", flush=True)
+        ctx.tune(1, 64)
         # bilinear (spmv + dot), and a full PCG solve
         t0 = time.time()
         for _ in range(20):
