@@ -28,6 +28,7 @@ int fail(Ctx *c, int code, const char *fmt, ...) {
 }
 
 pgd_handle put_obj(Ctx *c, Obj *o) {
+    o->ctx = c;
     if (!c->free_list.empty()) {
         int64_t i = c->free_list.back();
         c->free_list.pop_back();
@@ -47,15 +48,41 @@ Obj *get_obj(Ctx *c, pgd_handle h, Obj::Kind k) {
 
 int free_obj(Ctx *c, pgd_handle h, Obj::Kind k) {
     if (!get_obj(c, h, k)) return fail(c, PGD_ERR_INVALID, "free: invalid handle %lld", (long long)h);
-    (void)hipStreamSynchronize(c->stream);
+    if (k == Obj::MESH) (void)hipStreamSynchronize(c->stream);   // mesh arrays go straight back to HIP
     c->objs[h - 1].reset();
     c->free_list.push_back(h - 1);
     return PGD_OK;
 }
 
+void dev_release(Ctx *c, void *p, size_t bytes) {
+    if (!p) return;
+    if (c && bytes >= ((size_t)1 << 16) && c->pool_bytes + bytes <= Ctx::POOL_MAX) {
+        c->pool.emplace(bytes, p);
+        c->pool_bytes += bytes;
+        return;
+    }
+    (void)hipFree(p);
+}
+
 int dev_alloc(Ctx *c, void **p, size_t bytes) {
     *p = nullptr;
+    if (c) {
+        auto it = c->pool.find(bytes);
+        if (it != c->pool.end()) {
+            *p = it->second;
+            c->pool_bytes -= bytes;
+            c->pool.erase(it);
+            return PGD_OK;
+        }
+    }
     hipError_t e = hipMalloc(p, bytes + PAD_BYTES);
+    if (e != hipSuccess && c && !c->pool.empty()) {      // out of memory: give the pooled buffers back and retry
+        (void)hipStreamSynchronize(c->stream);
+        for (auto &kv : c->pool) (void)hipFree(kv.second);
+        c->pool.clear();
+        c->pool_bytes = 0;
+        e = hipMalloc(p, bytes + PAD_BYTES);
+    }
     if (e != hipSuccess) {
         *p = nullptr;
         return fail(c, PGD_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
@@ -149,6 +176,8 @@ int pgd_ctx_destroy(pgd_handle h) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     c->objs.clear();
+    for (auto &kv : c->pool) (void)hipFree(kv.second);
+    c->pool.clear();
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (void *p : {(void *)c->slots, (void *)c->flags, (void *)c->partials, (void *)c->mask,
                     (void *)c->ibuf})

@@ -6,6 +6,7 @@
 
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <memory>
 #include <string>
 #include <vector>
@@ -23,15 +24,19 @@ constexpr size_t PAD_BYTES = 256;   // slack after every device array (vector ov
 // slots of the device scalar bank used by the library's own PCG loop
 enum { S_PQ = 2, S_TOL2 = 5, S_TMP = 8 /* ..15: batched functionals */ };   // 16..22: PCG r.z / r.r / b.b
 
+struct Ctx;
+void dev_release(Ctx *c, void *p, size_t bytes);   // back to the context's buffer pool
+
 struct Obj {
     enum Kind { FREE = 0, VEC, MESH, CSR } kind = FREE;
+    Ctx *ctx = nullptr;
     virtual ~Obj() {}
 };
 
 struct Vec : Obj {
     double *d = nullptr;
     int64_t n = 0;
-    ~Vec() override { if (d) (void)hipFree(d); }
+    ~Vec() override { if (d) dev_release(ctx, d, (size_t)(n > 0 ? n : 1) * sizeof(double)); }
 };
 
 struct Mesh : Obj {
@@ -56,9 +61,10 @@ struct Csr : Obj {
     double *vals = nullptr;
     double *dinv = nullptr;    // lazily built inverse diagonal
     bool dinv_valid = false;
+    size_t vals_bytes = 0, dinv_bytes = 0;
     ~Csr() override {
-        if (vals) (void)hipFree(vals);
-        if (dinv) (void)hipFree(dinv);
+        if (vals) dev_release(ctx, vals, vals_bytes);
+        if (dinv) dev_release(ctx, dinv, dinv_bytes);
     }
 };
 
@@ -69,6 +75,13 @@ struct Ctx {
     std::string err;
     std::vector<std::unique_ptr<Obj>> objs;   // handle = index + 1
     std::vector<int64_t> free_list;
+
+    // Stream-ordered buffer pool: per-solve operators (2 GB) and work vectors (134 MB) are recycled
+    // instead of paying hipMalloc/hipFree (~7 ms each) in every fixed-point pass.  Safe because all
+    // work of a context is ordered on its one stream.
+    std::multimap<size_t, void *> pool;
+    size_t pool_bytes = 0;
+    static constexpr size_t POOL_MAX = (size_t)24 << 30;
 
     double *slots = nullptr;      // PGD_NSLOTS doubles
     int *flags = nullptr;         // [0] done, [1] iters, [2] status

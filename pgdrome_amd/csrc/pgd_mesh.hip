@@ -350,7 +350,8 @@ static int new_csr(Ctx *c, pgd_handle mh, Mesh *m, pgd_handle *out, Csr **res) {
     a->kind = Obj::CSR;
     a->mesh = mh;
     void *p;
-    PGD_TRY(dev_alloc(c, &p, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(double)));
+    a->vals_bytes = (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(double);
+    PGD_TRY(dev_alloc(c, &p, a->vals_bytes));
     a->vals = (double *)p;
     PGD_HIP(c, hipMemsetAsync(a->vals, 0, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(double) + PAD_BYTES, c->stream));
     *res = a.get();

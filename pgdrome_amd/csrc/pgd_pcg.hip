@@ -203,7 +203,8 @@ int csr_diag_inv(Ctx *c, const Mesh *m, Csr *a) {
     if (a->dinv_valid) return PGD_OK;
     if (!a->dinv) {
         void *p;
-        PGD_TRY(dev_alloc(c, &p, (size_t)m->nv * sizeof(double)));
+        a->dinv_bytes = (size_t)m->nv * sizeof(double);
+        PGD_TRY(dev_alloc(c, &p, a->dinv_bytes));
         a->dinv = (double *)p;
     }
     k_diag_inv<<<grid_for(m->nv), TPB, 0, c->stream>>>(m->row_ptr, m->cols, a->vals, a->dinv, m->nv);
@@ -261,7 +262,8 @@ int pgd_op_combine(pgd_handle h, pgd_handle mh, const pgd_handle *atoms, const d
         a->kind = Obj::CSR;
         a->mesh = mh;
         void *p;
-        PGD_TRY(dev_alloc(c, &p, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(double)));
+        a->vals_bytes = (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(double);
+        PGD_TRY(dev_alloc(c, &p, a->vals_bytes));
         a->vals = (double *)p;
         PGD_HIP(c, hipMemsetAsync(a->vals, 0, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(double) + PAD_BYTES, c->stream));
         o = a.get();

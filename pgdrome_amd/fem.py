@@ -498,6 +498,15 @@ class Vector:
     def _small(self):
         return self.n <= 4096
 
+    def fill(self, a):
+        """All entries (ghosts included) = a; on the device for large vectors (no 134 MB upload)."""
+        if self._small():
+            self._host = np.full(self.n, float(a))
+            self.touched_host()
+        else:
+            get_backend().vec_fill(self.dev_for_write(), float(a))
+            self.touched_dev()
+
     def scale(self, a):
         if self._dev_ok and not self._small():
             get_backend().vec_scale(self._dev, float(a))
@@ -1017,6 +1026,9 @@ class Expression(Expr):
             out[k] = float(v)
         return out
 
+    def is_constant(self):
+        return "x[" not in self._code
+
     def eval_at(self, coords):
         """Vectorised evaluation at points (n x gdim) -> (n,)."""
         coords = np.asarray(coords, dtype=np.float64)
@@ -1068,11 +1080,13 @@ def interpolate(v, V):
             f._vec._host = np.array([v(x) for x in V.mesh().coordinates()])
             f._vec.touched_host()
     elif isinstance(v, Expression):
-        f._vec._host = v.eval_at(V.mesh().coordinates())
-        f._vec.touched_host()
+        if v.is_constant():
+            f._vec.fill(v.eval_at(np.zeros((1, V.mesh().geometry().dim())))[0])
+        else:
+            f._vec._host = v.eval_at(V.mesh().coordinates())
+            f._vec.touched_host()
     elif isinstance(v, (Constant, numbers.Real)):
-        f._vec._host = np.full(V.dim(), float(v))
-        f._vec.touched_host()
+        f._vec.fill(float(v))
     else:
         raise TypeError("cannot interpolate %r" % (type(v),))
     return f
