@@ -149,6 +149,12 @@ def main():
                      "launches": prof["launches"], "avg_launch_us": 1e6 * prof["seconds"] / max(prof["launches"], 1),
                      "algorithmic_bytes_per_launch": prof["bytes"] / max(prof["launches"], 1)},
     }
+    pmc = os.path.join(ROOT, "profiles", "pmc_spmv_latest.json")
+    if n == 256 and os.path.exists(pmc):
+        # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
+        # correction + WRITE_SIZE); collected with tools/pmc_spmv.py, not in this process
+        with open(pmc) as f:
+            out["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(prob, spec, be, pcg_its / K, args)
     if rank == 0:

@@ -1,0 +1,42 @@
+"""Run one BASELINE config end to end on the GPU and print what happened.
+
+    python tools/run_config.py cfg3 [--modes 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pgdrome_amd import fem, problems
+from pgdrome_amd.hip_backend import HipBackend
+from pgdrome_amd.solver import PGDProblem
+
+ap = argparse.ArgumentParser()
+ap.add_argument("config")
+ap.add_argument("--modes", type=int, default=0)
+ap.add_argument("--problem", default="linear")
+ap.add_argument("--rtol", type=float, default=1e-10)
+args = ap.parse_args()
+
+be = fem.set_backend(HipBackend(0))
+t0 = time.time()
+builder, desc = problems.CONFIGS[args.config]
+spec = builder()
+if args.modes:
+    spec["PGD_nmax"] = args.modes
+p = PGDProblem(**spec)
+be.sync()
+t1 = time.time()
+p.solve_PGD(_problem=args.problem, settings={"linear_solver": "cg", "preconditioner": "jacobi",
+                                             "relative_tolerance": args.rtol})
+be.sync()
+t2 = time.time()
+print(json.dumps({
+    "config": args.config, "description": desc, "dims": [V.dim() for V in spec["Vs"]],
+    "setup_s": t1 - t0, "solve_s": t2 - t1, "modes": p.PGD_modes, "num_fp_it": p.num_fp_it,
+    "fp_passes": p.fp_passes, "fp_it_per_s": p.fp_passes / (t2 - t1),
+    "amplitude": p.amplitude, "err_fp_it": [float(e) for e in p.err_fp_it],
+    "linear_solves": fem.STATS["linear_solves"], "pcg_iterations": fem.STATS["pcg_iterations"],
+    "not_converged": p.simulation_info.count("NOT converged")}))
