@@ -94,7 +94,47 @@ def fd_fixture():
     return out
 
 
+def heat1d_fixture():
+    """The reference's own integration test module (tests/integration/test_heat1D.py), loaded as
+    is: its create_meshes / create_bc / problem_assemble_* / create_PGD run the reference PGDProblem
+    (heating case of test_heating; the parameter values below are that test's setUp data)."""
+    import contextlib
+    import importlib.util
+    import io
+    import logging
+    spec = importlib.util.spec_from_file_location("ref_test_heat1D", "/root/reference/tests/integration/test_heat1D.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = []
+    for typ in ("FEM", "FDtime"):
+        param = {"rho": 1, "cp": 1, "k": 0.5, "Tamb": 25, "Q": 1, "af": 0.2, "ar": 0.2, "xc": 0.5, "lx": 1, "lt": 1}
+        ranges = [[0.0, 1.0], [0.0, 1.0], [0.5, 1.0]]
+        ff = 6 * np.sqrt(3) / ((param["af"] + param["ar"]) * param["af"] * param["af"] * np.pi ** 1.5)
+        q = fem.Expression("ff* exp(-3*(pow(x[0]-xc,2)/pow(af,2)))", degree=4, ff=ff, af=param["af"],
+                           ar=param["ar"], xc=param["xc"])
+        param["IC_t"] = fem.Expression("Tamb", degree=1, Tamb=param["Tamb"])
+        param["IC_x"] = fem.Expression("1.0", degree=1)
+        param["IC_q"] = fem.Expression("1.0", degree=1)
+        meshes, vs = mod.create_meshes([15, 10, 10], [1, 1, 1], ranges)
+        logging.disable(logging.CRITICAL)
+        with contextlib.redirect_stdout(io.StringIO()):
+            sol, param = mod.create_PGD(param=param, vs=vs, q=q, _type=typ)
+        logging.disable(logging.NOTSET)
+        p = sol.problem
+        out.append({"variant": typ, "PGD_modes": int(p.PGD_modes), "num_fp_it": [int(v) for v in p.num_fp_it],
+                    "err_fp_it": [float(e) for e in p.err_fp_it], "amplitude": [float(a) for a in p.amplitude],
+                    "alpha": [float(a) for a in p.alpha],
+                    "not_converged_logged": p.simulation_info.count("NOT converged"),
+                    "modes_vertex_values": [[f.compute_vertex_values().tolist() for f in p.PGD_func[d]] for d in range(3)]})
+        print("heat1D", typ, "->", p.PGD_modes, "modes, fp", p.num_fp_it)
+    return out
+
+
 def main():
+    with open(os.path.join(HERE, "reference_heat1d.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_fixtures.py",
+                   "source": "reference tests/integration/test_heat1D.py run unchanged (create_PGD, heating case)",
+                   "arithmetic": "oracle numpy backend (FEniCS absent)", "runs": heat1d_fixture()}, f)
     runs = [run_reference(*r) for r in RUNS]
     with open(os.path.join(HERE, "reference_runs.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_fixtures.py",

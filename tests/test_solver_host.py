@@ -151,3 +151,23 @@ def test_return_pgd_and_evaluate():
     u = sol.evaluate(0, [1], [0.5], 0)
     # -Laplace u = 1 on the unit square: u(0.5, 0.5) = 0.0736713...
     assert abs(u(0.5) - 0.0736713) < 2e-3
+
+
+@pytest.mark.parametrize("variant", ["FEM", "FDtime"])
+def test_reference_heat1d_integration_case(variant):
+    """The reference's test_heat1D problem (mixed FEM / FD-in-time, initial-condition lifting, 20
+    enrichment steps, three fixed-point loops that do NOT converge and are logged, not raised)."""
+    import json, os
+    from pgdrome_amd.solver import PGDProblem, FD_matrices
+    from tests import heat1d_problem
+    with open(os.path.join(pgd_cases.GOLDEN, "reference_heat1d.json")) as f:
+        ref = [r for r in json.load(f)["runs"] if r["variant"] == variant][0]
+    p = heat1d_problem.run(fem, PGDProblem, FD_matrices, fd_time=(variant == "FDtime"))
+    assert p.PGD_modes == ref["PGD_modes"] and [int(v) for v in p.num_fp_it] == ref["num_fp_it"]
+    assert p.simulation_info.count("NOT converged") == ref["not_converged_logged"] == (3 if variant == "FEM" else 0)
+    np.testing.assert_allclose(p.amplitude, ref["amplitude"], rtol=1e-6)
+    np.testing.assert_allclose(p.alpha, ref["alpha"], rtol=1e-6)
+    for d in range(3):
+        for m in range(p.PGD_modes):
+            r = np.array(ref["modes_vertex_values"][d][m])
+            assert np.linalg.norm(p.PGD_func[d][m].compute_vertex_values() - r) <= 1e-6 * np.linalg.norm(r)
