@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--n-mu", type=int, default=128)
     ap.add_argument("--rtol", type=float, default=1e-10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dist-driver", action="store_true",
+                    help="N=1 only: run the row-sharded (host-driven, RCCL) solver path with one rank")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -60,8 +62,10 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    sharded = world > 1 or args.dist_driver
+    if sharded:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     from pgdrome_amd import fem, problems
@@ -69,13 +73,13 @@ def main():
     from pgdrome_amd.solver import PGDProblem
 
     # the library enqueues on torch's current stream so RCCL collectives order with the kernels
-    stream = torch.cuda.current_stream().cuda_stream if world > 1 else None
+    stream = torch.cuda.current_stream().cuda_stream if sharded else None
     be = fem.set_backend(HipBackend(local_rank, stream))
 
     n = args.n
     t_setup = time.time()
     P = fem.Point
-    if world > 1:
+    if sharded:
         from pgdrome_amd import dist as pdist
         comm = pdist.TorchComm(dist, be)
         space = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), n - 1, n - 1, n - 1)
@@ -141,7 +145,7 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "cfg4: 3D-space %d^3 P1 (BoxMesh, 6 tets/cube) x 1D-parameter %d P1, "
                                "-Laplace(u)+mu*u=1, Jacobi-PCG rtol %g" % (n, args.n_mu, args.rtol),
-                   "spatial_dofs": n_sp, "nnz": nnz, "parallelism": "z-slab row sharding x%d" % world if world > 1 else "single GPU",
+                   "spatial_dofs": n_sp, "nnz": nnz, "parallelism": "z-slab row sharding x%d" % world if sharded else "single GPU",
                    "pcg_iterations_per_step": pcg_its / K, "modes_completed": len(prob.num_fp_it),
                    "setup_seconds_untimed": t_setup},
         "roofline": {"bound": "hbm", "kernel": "k_spmv_csr", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
@@ -159,7 +163,7 @@ def main():
         out["cpu_baseline"] = cpu_baseline(prob, spec, be, pcg_its / K, args)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if sharded:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -68,17 +68,8 @@ class TorchComm:
         self.stats["allreduce"] += 1
 
     # ---- halo exchange
-    def _view(self, handle):
-        v = self._views.get(handle)
-        if v is None:
-            v = self.be.vec_tensor(handle)
-            self._views[handle] = v
-        return v
-
-    def halo_exchange_raw(self, mesh, handle, cache_view=False):
-        part = mesh.part
-        t = self._view(handle) if cache_view else self.be.vec_tensor(handle)
-        P2P, d = self.dist.P2POp, self.dist
+    def _halo_ops(self, mesh, t):
+        part, P2P, d = mesh.part, self.dist.P2POp, self.dist
         ops = []
         if part.lo_ghost:
             g = part.lo_ghost
@@ -88,8 +79,20 @@ class TorchComm:
             g = part.hi_ghost
             ops.append(P2P(d.isend, t[part.own1 - g:part.own1], self.rank + 1))
             ops.append(P2P(d.irecv, t[part.own1:part.own1 + g], self.rank + 1))
+        return ops
+
+    def halo_exchange_raw(self, mesh, handle, cache_view=False):
+        """Neighbour planes -> ghost planes of a device vector (contiguous slices, grouped send/recv).
+        For the PCG work vectors the tensor view and the P2P descriptors are built once and reused."""
+        if cache_view:
+            ops = self._views.get(handle)
+            if ops is None:
+                ops = self._halo_ops(mesh, self.be.vec_tensor(handle))
+                self._views[handle] = ops
+        else:
+            ops = self._halo_ops(mesh, self.be.vec_tensor(handle))
         if ops:
-            for req in d.batch_isend_irecv(ops):
+            for req in self.dist.batch_isend_irecv(ops):
                 req.wait()
         self.stats["halo"] += 1
 
