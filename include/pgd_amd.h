@@ -74,6 +74,9 @@ int pgd_mesh_upload(pgd_handle ctx, const double *coords, int64_t nv, int gdim,
 int pgd_mesh_info(pgd_handle ctx, pgd_handle mesh, int64_t *nv, int64_t *nc, int64_t *nnz,
                   int32_t *max_row_len, int32_t *kl, int32_t *ku);
 int pgd_mesh_pattern_download(pgd_handle ctx, pgd_handle mesh, int32_t *row_ptr, int32_t *cols);
+/* number of distinct relative column patterns held in the mesh's column dictionary
+ * (0: the pattern is too irregular, SpMV streams the column ids)                   */
+int pgd_mesh_dict_count(pgd_handle ctx, pgd_handle mesh, int32_t *count);
 int pgd_mesh_free(pgd_handle ctx, pgd_handle mesh);
 
 /* ----------------------------------------------------------------- vectors --- */
@@ -170,7 +173,9 @@ int pgd_pcg_p_slot(pgd_handle ctx, pgd_handle p, pgd_handle z, int64_t r0, int64
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed.                                        */
 enum {
-    PGD_TUNE_SPMV_ROWS = 1   /* rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256 */
+    PGD_TUNE_SPMV_ROWS = 1,  /* rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256 */
+    PGD_TUNE_SPMV_DICT = 2   /* 1 (default): decode column ids from the mesh's relative-pattern
+                                dictionary when it has one (k_spmv_csr_dict); 0: always stream them */
 };
 int pgd_tune(pgd_handle ctx, int knob, int64_t value);
 

@@ -34,6 +34,7 @@ SIGNATURES = {
     "pgd_mesh_upload": (C.c_int, [H, PD, I64, C.c_int, PI32, I64, C.c_int, PH]),
     "pgd_mesh_info": (C.c_int, [H, H, PI64, PI64, PI64, PI32, PI32, PI32]),
     "pgd_mesh_pattern_download": (C.c_int, [H, H, PI32, PI32]),
+    "pgd_mesh_dict_count": (C.c_int, [H, H, PI32]),
     "pgd_mesh_free": (C.c_int, [H, H]),
     "pgd_vec_alloc": (C.c_int, [H, I64, PH]),
     "pgd_vec_free": (C.c_int, [H, H]),
@@ -172,6 +173,11 @@ class Context:
         cols = np.empty(max(info["nnz"], 1), dtype=np.int32)
         self._ck(self.lib.pgd_mesh_pattern_download(self.h, mesh, iptr(rp), iptr(cols)))
         return rp, cols[: info["nnz"]]
+
+    def mesh_dict_count(self, mesh):
+        n = I32()
+        self._ck(self.lib.pgd_mesh_dict_count(self.h, mesh, C.byref(n)))
+        return n.value
 
     def mesh_free(self, mesh):
         self._ck(self.lib.pgd_mesh_free(self.h, mesh))

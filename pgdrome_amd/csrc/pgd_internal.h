@@ -19,6 +19,8 @@ constexpr int WAVE = 64;
 constexpr int TPB = 256;            // threads per workgroup everywhere (4 waves)
 constexpr int MAX_VEC_BLOCKS = 2048;  // grid cap of the grid-stride vector kernels (8 per CU)
 constexpr int N_XCD = 8;
+constexpr int DICT_MAXP = 256;      // patterns a mesh may have for the column dictionary
+constexpr int DICT_DLEN = 32;       // max row length representable (ints per pattern, 128 B)
 constexpr size_t PAD_BYTES = 256;   // slack after every device array (vector over-reads)
 
 // slots of the device scalar bank used by the library's own PCG loop
@@ -49,9 +51,15 @@ struct Mesh : Obj {
     int *row_ptr = nullptr;     // nv+1
     int *cols = nullptr;        // nnz, sorted per row
     int max_row = 0, kl = 0, ku = 0;
+    // Column-index dictionary (lossless): FEM rows repeat a handful of RELATIVE column patterns
+    // (cols[k] - row); when a mesh has <= DICT_MAXP of them every row stores a 2-byte pattern id
+    // and k_spmv_csr_dict rebuilds its column ids from the table instead of streaming 4 B/entry.
+    uint16_t *pids = nullptr;    // nv
+    int *dict_off = nullptr;     // dict_count x DICT_DLEN relative offsets
+    int dict_count = 0;          // 0: dictionary not available (irregular pattern) -> plain CSR kernel
     ~Mesh() override {
         for (void *p : {(void *)coords, (void *)cells, (void *)v2c_ptr, (void *)v2c,
-                        (void *)row_ptr, (void *)cols})
+                        (void *)row_ptr, (void *)cols, (void *)pids, (void *)dict_off})
             if (p) (void)hipFree(p);
     }
 };
@@ -95,6 +103,7 @@ struct Ctx {
     int64_t ibuf_cap = 0;
 
     int num_cu = 256;
+    int spmv_dict = 1;            // use the column dictionary when the mesh has one
     int spmv_rows = 64;           // rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256
 
     // SpMV launch timing (HIP events on `stream`)

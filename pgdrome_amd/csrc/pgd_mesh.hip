@@ -275,6 +275,132 @@ static int build_topology(Ctx *c, Mesh *m) {
     return PGD_OK;
 }
 
+
+// ---------------------------------------------------------------- column dictionary
+constexpr int DICT_TABLE = 4096;   // open-addressing table of 64-bit pattern hashes
+
+__device__ __forceinline__ unsigned long long row_hash(const int *__restrict__ row_ptr,
+                                                       const int *__restrict__ cols, int r) {
+    const int a = row_ptr[r], b = row_ptr[r + 1];
+    unsigned long long h = 1469598103934665603ULL ^ (unsigned)(b - a);
+    h *= 1099511628211ULL;
+    for (int k = a; k < b; ++k) { h ^= (unsigned)(cols[k] - r); h *= 1099511628211ULL; }
+    return h ? h : 1ULL;
+}
+
+__device__ __forceinline__ int dict_find(const unsigned long long *keys, unsigned long long h) {
+    int slot = (int)(h & (DICT_TABLE - 1));
+    for (int probe = 0; probe < DICT_TABLE; ++probe) {
+        const unsigned long long cur = keys[slot];
+        if (cur == h) return slot;
+        if (cur == 0ULL) return -1;
+        slot = (slot + 1) & (DICT_TABLE - 1);
+    }
+    return -1;
+}
+
+// pass A: every distinct hash gets a table slot (ids are handed out after the kernel boundary)
+__global__ __launch_bounds__(TPB) void k_dict_insert(const int *__restrict__ row_ptr, const int *__restrict__ cols,
+                                                     int64_t nv, unsigned long long *keys, int *flags) {
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nv; r += (int64_t)gridDim.x * TPB) {
+        if (row_ptr[r + 1] - row_ptr[r] > DICT_DLEN) { flags[0] = 1; continue; }
+        const unsigned long long h = row_hash(row_ptr, cols, (int)r);
+        int slot = (int)(h & (DICT_TABLE - 1));
+        bool done = false;
+        for (int probe = 0; probe < DICT_TABLE && !done; ++probe) {
+            unsigned long long cur = keys[slot];          // cheap look first: almost always already there
+            if (cur == 0ULL) cur = atomicCAS(&keys[slot], 0ULL, h);
+            if (cur == 0ULL || cur == h) done = true;
+            else slot = (slot + 1) & (DICT_TABLE - 1);
+        }
+        if (!done) flags[0] = 1;                          // table full: far too many patterns
+    }
+}
+
+// pass B: number the occupied slots
+__global__ void k_dict_ids(const unsigned long long *keys, int *ids, int *count) {
+    const int slot = blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot < DICT_TABLE) ids[slot] = keys[slot] ? atomicAdd(count, 1) : -1;
+}
+
+// pass C: pattern id per row + the lowest row of every pattern as its representative
+__global__ __launch_bounds__(TPB) void k_dict_assign(const int *__restrict__ row_ptr, const int *__restrict__ cols,
+                                                     int64_t nv, const unsigned long long *keys, const int *ids,
+                                                     uint16_t *pids, int *rep, int *flags) {
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nv; r += (int64_t)gridDim.x * TPB) {
+        const int slot = dict_find(keys, row_hash(row_ptr, cols, (int)r));
+        const int id = slot >= 0 ? ids[slot] : -1;
+        if (id < 0 || id >= DICT_MAXP) { flags[0] = 1; pids[r] = 0; continue; }
+        pids[r] = (uint16_t)id;
+        if (rep[id] > (int)r) atomicMin(&rep[id], (int)r);
+    }
+}
+
+// pass D: the table of relative offsets, from the representatives
+__global__ void k_dict_build(const int *__restrict__ row_ptr, const int *__restrict__ cols, const int *rep,
+                             int count, int *dict_off) {
+    const int id = blockIdx.x, k = threadIdx.x;       // DICT_DLEN threads
+    if (id >= count) return;
+    const int r = rep[id], a = row_ptr[r], len = row_ptr[r + 1] - a;
+    dict_off[id * DICT_DLEN + k] = (k < len) ? cols[a + k] - r : 0;
+}
+
+// pass E: every row must decode to exactly its column ids (guards against hash collisions)
+__global__ __launch_bounds__(TPB) void k_dict_verify(const int *__restrict__ row_ptr, const int *__restrict__ cols,
+                                                     int64_t nv, const uint16_t *pids, const int *dict_off, int *flags) {
+    for (int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x; r < nv; r += (int64_t)gridDim.x * TPB) {
+        const int a = row_ptr[r], len = row_ptr[r + 1] - a;
+        const int *off = dict_off + (int)pids[r] * DICT_DLEN;
+        bool ok = len <= DICT_DLEN;
+        for (int k = 0; ok && k < len; ++k) ok = (cols[a + k] == (int)r + off[k]);
+        if (!ok) flags[0] = 1;
+    }
+}
+
+static int build_dictionary(Ctx *c, Mesh *m) {
+    m->dict_count = 0;
+    if (m->nnz == 0 || m->max_row > DICT_DLEN) return PGD_OK;
+    void *p;
+    unsigned long long *keys = nullptr;
+    int *ibuf = nullptr;   // ids[DICT_TABLE], rep[DICT_MAXP], count, flags
+    PGD_TRY(dev_alloc(c, &p, DICT_TABLE * sizeof(unsigned long long))); keys = (unsigned long long *)p;
+    PGD_TRY(dev_alloc(c, &p, (DICT_TABLE + DICT_MAXP + 8) * sizeof(int))); ibuf = (int *)p;
+    int *ids = ibuf, *rep = ibuf + DICT_TABLE, *count = rep + DICT_MAXP, *flags = count + 1;
+    PGD_TRY(dev_alloc(c, &p, (size_t)m->nv * sizeof(uint16_t))); m->pids = (uint16_t *)p;
+    PGD_TRY(dev_alloc(c, &p, (size_t)DICT_MAXP * DICT_DLEN * sizeof(int))); m->dict_off = (int *)p;
+    hipStream_t st = c->stream;
+    PGD_HIP(c, hipMemsetAsync(keys, 0, DICT_TABLE * sizeof(unsigned long long), st));
+    PGD_HIP(c, hipMemsetAsync(ibuf, 0x7f, (DICT_TABLE + DICT_MAXP) * sizeof(int), st));   // rep = large
+    PGD_HIP(c, hipMemsetAsync(count, 0, 8 * sizeof(int), st));
+    PGD_HIP(c, hipMemsetAsync(m->dict_off, 0, (size_t)DICT_MAXP * DICT_DLEN * sizeof(int), st));
+    const int g = grid_for(m->nv);
+    k_dict_insert<<<g, TPB, 0, st>>>(m->row_ptr, m->cols, m->nv, keys, flags);
+    k_dict_ids<<<DICT_TABLE / TPB, TPB, 0, st>>>(keys, ids, count);
+    int h[2] = {0, 0};
+    PGD_HIP(c, hipMemcpyAsync(h, count, sizeof h, hipMemcpyDeviceToHost, st));
+    PGD_HIP(c, hipStreamSynchronize(st));
+    bool ok = h[1] == 0 && h[0] >= 1 && h[0] <= DICT_MAXP;
+    if (ok) {
+        k_dict_assign<<<g, TPB, 0, st>>>(m->row_ptr, m->cols, m->nv, keys, ids, m->pids, rep, flags);
+        k_dict_build<<<h[0], DICT_DLEN, 0, st>>>(m->row_ptr, m->cols, rep, h[0], m->dict_off);
+        k_dict_verify<<<g, TPB, 0, st>>>(m->row_ptr, m->cols, m->nv, m->pids, m->dict_off, flags);
+        int f = 1;
+        PGD_HIP(c, hipMemcpyAsync(&f, flags, sizeof f, hipMemcpyDeviceToHost, st));
+        PGD_HIP(c, hipStreamSynchronize(st));
+        ok = f == 0;
+    }
+    (void)hipFree(keys);
+    (void)hipFree(ibuf);
+    if (ok) {
+        m->dict_count = h[0];
+    } else {
+        (void)hipFree(m->pids); m->pids = nullptr;
+        (void)hipFree(m->dict_off); m->dict_off = nullptr;
+    }
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
 }  // namespace pgd
 
 using namespace pgd;
@@ -312,6 +438,7 @@ int pgd_mesh_upload(pgd_handle h, const double *coords, int64_t nv, int gdim, co
         PGD_HIP(c, hipStreamSynchronize(c->stream));
     }
     PGD_TRY(build_topology(c, m.get()));
+    PGD_TRY(build_dictionary(c, m.get()));
     *out = put_obj(c, m.release());
     return PGD_OK;
 }
@@ -337,6 +464,14 @@ int pgd_mesh_pattern_download(pgd_handle h, pgd_handle mh, int32_t *row_ptr, int
     if (row_ptr) PGD_HIP(c, hipMemcpyAsync(row_ptr, m->row_ptr, (size_t)(m->nv + 1) * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     if (cols && m->nnz) PGD_HIP(c, hipMemcpyAsync(cols, m->cols, (size_t)m->nnz * sizeof(int), hipMemcpyDeviceToHost, c->stream));
     PGD_HIP(c, hipStreamSynchronize(c->stream));
+    return PGD_OK;
+}
+
+int pgd_mesh_dict_count(pgd_handle h, pgd_handle mh, int32_t *count) {
+    PGD_CTX(c, h);
+    Mesh *m = get_mesh(c, mh);
+    if (!m || !count) return fail(c, PGD_ERR_INVALID, "mesh_dict_count: invalid handle");
+    *count = m->dict_count;
     return PGD_OK;
 }
 

@@ -115,6 +115,73 @@ __global__ __launch_bounds__(R) void k_spmv_csr(SpmvArgs A) {
     }
 }
 
+// Column-dictionary form of the same product (Mesh::pids / dict_off, pgd_internal.h): the
+// values are staged exactly as above, but no column id is read from HBM - a row decodes its
+// columns as row + dict_off[pattern][k].  A wave of interior rows shares one pattern, so the
+// table reads are L1 broadcasts.  Traffic per row drops from 180 + 20 B to 120 + 22 B; the
+// result is bit-identical to k_spmv_csr (same products, same order).
+template <bool DOT, bool STORE, int R>
+__global__ __launch_bounds__(R) void k_spmv_csr_dict(SpmvArgs A, const uint16_t *__restrict__ pids,
+                                                      const int *__restrict__ dict_off) {
+    constexpr int CAP = 16 * R;
+    if (A.flags && A.flags[0]) return;
+    __shared__ __align__(16) double s_vals[CAP + 2];
+    __shared__ int s_rp[R + 1];
+    __shared__ double s_red[R / 64];
+    const int tid = threadIdx.x;
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int r0 = A.row_begin + b * R;
+    const int nr = min(R, A.row_end - r0);
+    if (tid < nr) s_rp[tid] = A.row_ptr[r0 + tid];
+    if (tid == 0) s_rp[nr] = A.row_ptr[r0 + nr];
+    const int pid = (tid < nr) ? (int)pids[r0 + tid] : 0;
+    __syncthreads();
+    const int s = s_rp[0], e = s_rp[nr];
+    const int sv = s & ~1;
+    const bool staged = (e - sv) <= CAP;
+    if (staged) {
+        d2_t v[SPMV_VROUNDS];
+        const double *gv = A.vals + sv;
+        const int nvv = e - sv;
+#pragma unroll
+        for (int i = 0; i < SPMV_VROUNDS; ++i) {
+            const int k = (tid + i * R) * 2;
+            v[i] = *reinterpret_cast<const d2_t *>(gv + (k < nvv ? k : 0));
+        }
+#pragma unroll
+        for (int i = 0; i < SPMV_VROUNDS; ++i) *reinterpret_cast<d2_t *>(s_vals + (tid + i * R) * 2) = v[i];
+    }
+    __syncthreads();
+    double acc = 0.0;
+    if (tid < nr) {
+        const int a = s_rp[tid], len = s_rp[tid + 1] - a, r = r0 + tid;
+        const int *off = dict_off + pid * DICT_DLEN;
+        for (int k0 = 0; k0 < len; k0 += 8) {
+            // 8 entries per round: two 16-byte table reads, 8 gathers in flight
+            const i4_t o0 = *reinterpret_cast<const i4_t *>(off + k0);
+            const i4_t o1 = *reinterpret_cast<const i4_t *>(off + k0 + 4);
+            const int oo[8] = {o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w};
+            double vv[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const bool ok = k0 + u < len;
+                const int kk = ok ? k0 + u : len - 1;
+                const double tv = staged ? s_vals[a + kk - sv] : A.vals[a + kk];
+                vv[u] = ok ? tv : 0.0;
+                xv[u] = A.x[r + (ok ? oo[u] : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = fma(vv[u], xv[u], acc);
+        }
+    }
+    if (STORE && tid < nr) A.y[r0 + tid] = acc;
+    if (DOT) {
+        const double t = (tid < nr) ? acc * A.w[r0 + tid] : 0.0;
+        const double sum = block_sum_n<R / 64>(t, s_red);
+        if (tid == 0) A.partials[b] = sum;
+    }
+}
+
 // out partial[b*ny + m] = sum over the block's rows of x_i (A y_m)_i : one pass
 // over the matrix for up to MAXY stored modes (batched scalar functionals).
 struct SpmvMultiArgs {
@@ -190,11 +257,18 @@ int launch_spmv(Ctx *c, const Mesh *m, const double *vals, const double *x, doub
         if (c->ev_used + 2 > c->ev.size()) prof_flush(c);
         PGD_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
     }
-#define PGD_SPMV_LAUNCH(D, S)                                                                    \
-    do {                                                                                         \
-        if (R == 256) k_spmv_csr<D, S, 256><<<nblk, 256, 0, c->stream>>>(A);                     \
-        else if (R == 128) k_spmv_csr<D, S, 128><<<nblk, 128, 0, c->stream>>>(A);                \
-        else k_spmv_csr<D, S, 64><<<nblk, 64, 0, c->stream>>>(A);                                \
+    const bool use_dict = c->spmv_dict && m->dict_count > 0;
+#define PGD_SPMV_LAUNCH(D, S)                                                                             \
+    do {                                                                                                  \
+        if (use_dict) {                                                                                   \
+            if (R == 256) k_spmv_csr_dict<D, S, 256><<<nblk, 256, 0, c->stream>>>(A, m->pids, m->dict_off);      \
+            else if (R == 128) k_spmv_csr_dict<D, S, 128><<<nblk, 128, 0, c->stream>>>(A, m->pids, m->dict_off); \
+            else k_spmv_csr_dict<D, S, 64><<<nblk, 64, 0, c->stream>>>(A, m->pids, m->dict_off);                \
+        } else {                                                                                          \
+            if (R == 256) k_spmv_csr<D, S, 256><<<nblk, 256, 0, c->stream>>>(A);                          \
+            else if (R == 128) k_spmv_csr<D, S, 128><<<nblk, 128, 0, c->stream>>>(A);                     \
+            else k_spmv_csr<D, S, 64><<<nblk, 64, 0, c->stream>>>(A);                                     \
+        }                                                                                                 \
     } while (0)
     if (dot && store) PGD_SPMV_LAUNCH(true, true);
     else if (dot) PGD_SPMV_LAUNCH(true, false);
@@ -243,6 +317,7 @@ extern "C" {
 int pgd_tune(pgd_handle h, int knob, int64_t value) {
     PGD_CTX(c, h);
     if (knob == PGD_TUNE_SPMV_ROWS && (value == 64 || value == 128 || value == 256)) { c->spmv_rows = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_DICT && (value == 0 || value == 1)) { c->spmv_dict = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }
 

@@ -164,6 +164,49 @@ def test_spmv_workgroup_shapes_agree(ctx, rows):
     ctx.mesh_free(h)
 
 
+def test_column_dictionary_is_lossless(ctx):
+    """k_spmv_csr_dict (column ids decoded from the relative-pattern dictionary) is bit-identical to the
+    streaming kernel; an irregularly numbered mesh has no dictionary and takes the plain kernel."""
+    rng = np.random.default_rng(21)
+    for name, (coords, cells) in {"box": F.box_mesh((0, 0, 0), (1, 1, 1), 21, 13, 17),
+                                  "rect": F.rectangle_mesh((0, 0), (1, 1), 50, 37),
+                                  "interval": F.interval_mesh(1000, 0.0, 1.0)}.items():
+        h = ctx.mesh_upload(coords, cells)
+        n = coords.shape[0]
+        count = ctx.mesh_dict_count(h)
+        assert 1 <= count <= 64, (name, count)        # interior pattern + boundary variants
+        K = F.assemble_atom(coords, cells, F.STIFF) + F.assemble_atom(coords, cells, F.MASS)
+        a = ctx.atom_upload(h, K.data)
+        x = rng.uniform(-1, 1, n)
+        xv, y1, y2 = ctx.vec_from(x), ctx.vec_alloc(n), ctx.vec_alloc(n)
+        out = {}
+        for rows in (64, 128, 256):
+            ctx.tune(1, rows)
+            for d in (1, 0):
+                ctx.tune(2, d)
+                ctx.spmv(a, xv, y1)
+                out[(rows, d)] = (ctx.vec_download(y1), ctx.bilinear(a, xv, xv, 3, n - 2))
+            assert np.array_equal(out[(rows, 1)][0], out[(rows, 0)][0])
+            assert out[(rows, 1)][1] == out[(rows, 0)][1]
+        ctx.tune(1, 64)
+        ctx.tune(2, 1)
+        assert np.all(np.abs(out[(64, 1)][0] - K @ x) <= 4e-15 * (np.abs(K) @ np.abs(x)))
+        ctx.mesh_free(h)
+    # random renumbering of the vertices: every row has its own relative pattern -> no dictionary
+    coords, cells = F.box_mesh((0, 0, 0), (1, 1, 1), 9, 9, 9)
+    perm = rng.permutation(coords.shape[0])
+    inv = np.argsort(perm)
+    h = ctx.mesh_upload(coords[perm], inv[cells].astype(np.int32))
+    assert ctx.mesh_dict_count(h) == 0
+    K = F.assemble_atom(coords[perm], inv[cells].astype(np.int32), F.STIFF)
+    a = ctx.atom_assemble(h, F.STIFF)
+    x = rng.uniform(-1, 1, coords.shape[0])
+    xv, yv = ctx.vec_from(x), ctx.vec_alloc(coords.shape[0])
+    ctx.spmv(a, xv, yv)
+    assert np.all(np.abs(ctx.vec_download(yv) - K @ x) <= 1e-13 * (np.abs(K) @ np.abs(x)))
+    ctx.mesh_free(h)
+
+
 def test_vector_ops(ctx):
     rng = np.random.default_rng(5)
     for n in (1, 63, 64, 257, 100_003):

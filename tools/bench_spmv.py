@@ -39,10 +39,11 @@ def main():
         x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, nv))
         y = ctx.vec_alloc(nv)
         alg = F.spmv_bytes(nv, nnz)
-        variants = [(256, 0), (128, 0), (64, 0)]
+        variants = [(64, 0), (64, 1), (128, 1), (256, 1)]
         for rnd in range(3):                      # interleaved rounds in one process
             for var, grid in variants:
                 ctx.tune(1, var)
+                ctx.tune(2, grid)
                 for _ in range(3):
                     ctx.spmv(op, x, y)
                 ctx.sync()
@@ -52,8 +53,10 @@ def main():
                     ctx.spmv(op, x, y)
                 ctx.sync()
                 wall = (time.time() - t0) / reps
-                print(f"  round {rnd} rows/workgroup {var}: {wall*1e6:.1f} us (wall) -> {alg/wall/1e9:.0f} GB/s = {alg/wall/8e12*100:.1f}% of 8 TB/s", flush=True)
+                print(f"  round {rnd} rows/workgroup {var} dict {grid}: {wall*1e6:.1f} us (wall) -> {alg/wall/1e9:.0f} GB/s = {alg/wall/8e12*100:.1f}% of 8 TB/s", flush=True)
         ctx.tune(1, 64)
+        ctx.tune(2, 1)
+        print('  dictionary patterns:', ctx.mesh_dict_count(mesh), flush=True)
         # bilinear (spmv + dot), and a full PCG solve
         t0 = time.time()
         for _ in range(20):
