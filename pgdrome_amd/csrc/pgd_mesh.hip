@@ -114,12 +114,12 @@ struct AsmArgs {
 
 template <int D>
 __device__ __forceinline__ void p1_geometry(const AsmArgs &A, const int *u, double &vol, double g[D + 1][D]) {
-    if (D == 1) {
+    if constexpr (D == 1) {
         const double e = A.cx[u[1]] - A.cx[u[0]];
         vol = fabs(e);
         g[1][0] = 1.0 / e;
         g[0][0] = -g[1][0];
-    } else if (D == 2) {
+    } else if constexpr (D == 2) {
         const double x0 = A.cx[u[0]], y0 = A.cy[u[0]];
         const double ax = A.cx[u[1]] - x0, ay = A.cy[u[1]] - y0;
         const double bx = A.cx[u[2]] - x0, by = A.cy[u[2]] - y0;

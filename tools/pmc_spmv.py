@@ -12,7 +12,7 @@ from oracle import fem_numpy as F          # mesh generator only
 from pgdrome_amd import _lib
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-variant = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+use_dict = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = _lib.Context(0)
 coords, cells = F.box_mesh((0, 0, 0), (1, 1, 1), n - 1, n - 1, n - 1)
 mesh = ctx.mesh_upload(coords, cells)
@@ -22,8 +22,8 @@ op = ctx.op_combine(mesh, [ak, am], [1.0, 1.0])
 nv = ctx.mesh_info(mesh)["nv"]
 x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, nv))
 y = ctx.vec_alloc(nv)
-ctx.tune(1, variant)
+ctx.tune(2, use_dict)     # 1: k_spmv_csr_dict (default), 0: k_spmv_csr
 for _ in range(6):
     ctx.spmv(op, x, y)
 ctx.sync()
-print("done", n, variant)
+print("done", n, "dict", use_dict, "patterns", ctx.mesh_dict_count(mesh))
