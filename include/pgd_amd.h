@@ -91,6 +91,9 @@ int pgd_vec_copy(pgd_handle ctx, pgd_handle dst, pgd_handle src);
 int pgd_vec_scale(pgd_handle ctx, pgd_handle vec, double a);                 /* v *= a      */
 int pgd_vec_axpy(pgd_handle ctx, pgd_handle y, double a, pgd_handle x);      /* y += a x    */
 int pgd_vec_set(pgd_handle ctx, pgd_handle vec, const int32_t *idx, const double *val, int64_t n);
+/* y = sum_k coefs[k] * xs[k]: the online reconstruction u = sum_k c_k F^k of a PGD solution
+ * on its large dimension (replaces the numpy loop of model.py:822-842).            */
+int pgd_vec_lincomb(pgd_handle ctx, pgd_handle y, const pgd_handle *xs, const double *coefs, int k);
 /* dot over [lo,hi) (hi < 0 -> whole vector); deterministic two-stage reduction.
  * Replaces Vector.inner / the Euclidean residual norm of solver.py:388.         */
 int pgd_vec_dot(pgd_handle ctx, pgd_handle x, pgd_handle y, int64_t lo, int64_t hi, double *out);

@@ -86,6 +86,12 @@ class NumpyBackend:
     def vec_fill(self, v, a):
         self._obj[v][:] = a
 
+    def vec_lincomb(self, y, xs, coefs):
+        acc = np.zeros_like(self._obj[y])
+        for x, c in zip(xs, coefs):
+            acc += c * self._obj[x]
+        self._obj[y][:] = acc
+
     def vec_set(self, v, idx, vals):
         self._obj[v][np.asarray(idx)] = vals
 

@@ -47,6 +47,7 @@ SIGNATURES = {
     "pgd_vec_scale": (C.c_int, [H, H, F64]),
     "pgd_vec_axpy": (C.c_int, [H, H, F64, H]),
     "pgd_vec_set": (C.c_int, [H, H, PI32, PD, I64]),
+    "pgd_vec_lincomb": (C.c_int, [H, H, PH, PD, C.c_int]),
     "pgd_vec_dot": (C.c_int, [H, H, H, I64, I64, PD]),
     "pgd_atom_assemble": (C.c_int, [H, H, C.c_int, C.c_int, C.c_int, H, PH]),
     "pgd_atom_upload": (C.c_int, [H, H, PD, PH]),
@@ -229,6 +230,12 @@ class Context:
 
     def vec_axpy(self, y, a, x):
         self._ck(self.lib.pgd_vec_axpy(self.h, y, float(a), x))
+
+    def vec_lincomb(self, y, xs, coefs):
+        k = len(xs)
+        arr = (H * max(k, 1))(*[int(x) for x in xs])
+        cf = np.ascontiguousarray(coefs, dtype=np.float64)
+        self._ck(self.lib.pgd_vec_lincomb(self.h, y, arr, dptr(cf) if k else None, k))
 
     def vec_set(self, v, idx, val):
         idx = np.ascontiguousarray(idx, dtype=np.int32)

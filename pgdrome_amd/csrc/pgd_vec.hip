@@ -24,6 +24,26 @@ __global__ __launch_bounds__(TPB) void k_set(double *__restrict__ v, const int *
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) v[idx[i]] = val[i];
 }
 
+// y = sum_k c_k x_k for up to 8 vectors per pass (one write per pass instead of one per term):
+// the online reconstruction u(x) = sum_k [prod_i F_i^k(mu_i)] F_x^k of a PGD solution
+// (reference model.py:805-842) is this tall-skinny product; 8 (K + 1) n bytes per call.
+struct LincombArgs {
+    const double *x[8];
+    double c[8];
+    int k;
+    int accumulate;   // 1: y += ..., 0: y = ...
+};
+
+__global__ __launch_bounds__(TPB) void k_lincomb(double *__restrict__ y, LincombArgs A, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        double s = A.accumulate ? y[i] : 0.0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < A.k) s = fma(A.c[t], A.x[t][i], s);
+        y[i] = s;
+    }
+}
+
 // partial[b] = sum over the block's grid-stride share of x_i y_i (fixed order)
 __global__ __launch_bounds__(TPB) void k_dot(const double *__restrict__ x, const double *__restrict__ y,
                                              int64_t lo, int64_t hi, double *__restrict__ partials) {
@@ -230,6 +250,33 @@ int pgd_vec_axpy(pgd_handle h, pgd_handle yh, double a, pgd_handle xh) {
     if (!x || !y || x->n != y->n) return fail(c, PGD_ERR_INVALID, "vec_axpy: invalid handles or size mismatch");
     if (y->n == 0) return PGD_OK;
     k_axpy<<<grid_for(y->n), TPB, 0, c->stream>>>(y->d, a, x->d, y->n);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pgd_vec_lincomb(pgd_handle h, pgd_handle yh, const pgd_handle *xs, const double *coefs, int k) {
+    PGD_CTX(c, h);
+    Vec *y = get_vec(c, yh);
+    if (!y || k < 0 || (k > 0 && (!xs || !coefs))) return fail(c, PGD_ERR_INVALID, "vec_lincomb: bad arguments");
+    std::vector<const double *> px((size_t)k);
+    for (int t = 0; t < k; ++t) {
+        Vec *x = get_vec(c, xs[t]);
+        if (!x || x->n != y->n || x == y) return fail(c, PGD_ERR_INVALID, "vec_lincomb: vector %d invalid, of another size or aliasing y", t);
+        px[t] = x->d;
+    }
+    if (y->n == 0) return PGD_OK;
+    if (k == 0) {
+        k_fill<<<grid_for(y->n), TPB, 0, c->stream>>>(y->d, 0.0, y->n);
+        PGD_LAUNCH_CHECK(c);
+        return PGD_OK;
+    }
+    for (int first = 0; first < k; first += 8) {
+        LincombArgs A;
+        A.k = (k - first < 8) ? k - first : 8;
+        A.accumulate = first > 0;
+        for (int t = 0; t < 8; ++t) { A.x[t] = px[first + (t < A.k ? t : 0)]; A.c[t] = (t < A.k) ? coefs[first + t] : 0.0; }
+        k_lincomb<<<grid_for(y->n), TPB, 0, c->stream>>>(y->d, A, y->n);
+    }
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
 }

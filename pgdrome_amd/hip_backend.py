@@ -59,6 +59,9 @@ class HipBackend:
     def vec_fill(self, v, a):
         self.ctx.vec_fill(v, a)
 
+    def vec_lincomb(self, y, xs, coefs):
+        self.ctx.vec_lincomb(y, xs, coefs)
+
     def vec_set(self, v, idx, vals):
         self.ctx.vec_set(v, idx, vals)
 

@@ -126,6 +126,25 @@ def heat1d_fixture():
                     "alpha": [float(a) for a in p.alpha],
                     "not_converged_logged": p.simulation_info.count("NOT converged"),
                     "modes_vertex_values": [[f.compute_vertex_values().tolist() for f in p.PGD_func[d]] for d in range(3)]})
+        if typ == "FEM":
+            # online evaluation and error computation of the reference's own model.PGD on this solution
+            from pgdrome.model import PGDErrorComputation as RefErr
+            ev = sol.evaluate(0, [1, 2], [0.9, 1.0], 0)
+            xs = sol.mesh[0].dataX if hasattr(sol.mesh[0], "dataX") else vs[0].mesh().coordinates()[:, 0]
+            xs = np.asarray(xs, dtype=float).reshape(-1)
+
+            def fom(smp):
+                return np.cos(3.0 * xs) * smp[0] + smp[1]
+            err = RefErr(fixed_dim=[0], n_samples=5, FOM_model=fom, PGD_model=sol)
+            samples = err.sampling_LHS()
+            errs, mean_e, max_e = err.evaluate_error()
+            for d in (1, 2):
+                sol.mesh[d].attributes[0].interpolationInfo = {"name": 0, "kind": "linear"}
+                sol.mesh[d].attributes[0].interpolationfct = []
+            ev_interp = sol.evaluate(0, [1, 2], [0.37, 0.81], 0)
+            out[-1]["model"] = {"evaluate_0.9_1.0": ev.compute_vertex_values().tolist(),
+                                "evaluate_interp1d_0.37_0.81": np.asarray(ev_interp).reshape(-1).tolist(),
+                                "lhs_samples": samples, "errors": errs.tolist(), "mean": float(mean_e), "max": float(max_e)}
         print("heat1D", typ, "->", p.PGD_modes, "modes, fp", p.num_fp_it)
     return out
 

@@ -229,6 +229,25 @@ def test_vector_ops(ctx):
         ctx.vec_free(yv)
 
 
+def test_lincomb(ctx):
+    """y = sum_k c_k x_k (online reconstruction): exact against the same fma chain in numpy order."""
+    rng = np.random.default_rng(17)
+    n = 100_003
+    X = rng.standard_normal((11, n))
+    xs = [ctx.vec_from(X[k]) for k in range(11)]
+    y = ctx.vec_from(rng.standard_normal(n))
+    for k in (0, 1, 8, 11):
+        c = rng.uniform(-2, 2, k)
+        ctx.vec_lincomb(y, xs[:k], c)
+        ref = (c[:, None] * X[:k]).sum(axis=0) if k else np.zeros(n)
+        assert np.abs(ctx.vec_download(y) - ref).max() <= 1e-14 * max(1.0, np.abs(ref).max()) * max(k, 1)
+    from pgdrome_amd._lib import PgdError
+    with pytest.raises(PgdError):
+        ctx.vec_lincomb(y, [y], [1.0])
+    for v in xs + [y]:
+        ctx.vec_free(v)
+
+
 def boundary_dofs(coords):
     lo, hi = coords.min(axis=0), coords.max(axis=0)
     return np.where(np.any((coords <= lo + 1e-12) | (coords >= hi - 1e-12), axis=1))[0].astype(np.int32)

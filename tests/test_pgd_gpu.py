@@ -127,3 +127,16 @@ def test_reference_heat1d_integration_case_on_gpu(variant):
         assert p.PGD_modes == ref["PGD_modes"] and [int(v) for v in p.num_fp_it] == ref["num_fp_it"]
         assert p.amplitude[-1] < 1e-5
     print(variant, p.PGD_modes, p.num_fp_it)
+
+
+def test_online_evaluation_runs_on_the_device():
+    """PGD.evaluate on a fixed dimension large enough for the lincomb kernel equals the host sum."""
+    mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), 40, 40, 40)      # 68 921 dofs
+    p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=3))
+    p.solve_PGD(_problem="linear")
+    sol = p.return_PGD()
+    u = sol.evaluate(0, [1], [4.2], 0)
+    c = sol.mode_factors([1], [4.2], 0)
+    ref = sum(c[k] * p.PGD_func[0][k].compute_vertex_values() for k in range(3))
+    assert np.linalg.norm(u.compute_vertex_values() - ref) <= 1e-13 * np.linalg.norm(ref)
+    assert sol.evaluate_max(0, [1], [4.2], 0) > 0
