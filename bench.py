@@ -72,8 +72,15 @@ def main():
     from pgdrome_amd.hip_backend import HipBackend
     from pgdrome_amd.solver import PGDProblem
 
-    # the library enqueues on torch's current stream so RCCL collectives order with the kernels
-    stream = torch.cuda.current_stream().cuda_stream if sharded else None
+    # Sharded runs: the library enqueues on torch's CURRENT stream so that RCCL collectives (which torch
+    # orders against the current stream) and the kernels form one sequence.  The legacy default stream
+    # has handle 0, which the C ABI reads as "create your own", so make an explicit stream current.
+    stream = None
+    if sharded:
+        tstream = torch.cuda.Stream(device=local_rank)
+        torch.cuda.set_stream(tstream)
+        stream = tstream.cuda_stream
+        assert stream, "expected a non-default HIP stream"
     be = fem.set_backend(HipBackend(local_rank, stream))
 
     n = args.n

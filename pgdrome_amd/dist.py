@@ -43,10 +43,20 @@ class TorchComm:
         import torch
         self.torch, self.dist, self.be = torch, dist, backend
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self._check_stream()
         self._slots = None
         self._work = {}
         self._views = {}
         self.stats = {"halo": 0, "allreduce": 0}
+
+    def _check_stream(self):
+        """Collectives are ordered against torch's current stream: the HIP library must enqueue on it too."""
+        if getattr(self.be, "name", "") != "hip":
+            return
+        cur = self.torch.cuda.current_stream().cuda_stream
+        if not self.be.stream or self.be.stream != cur:
+            raise RuntimeError("sharded runs need HipBackend(device, stream) with stream == torch's current "
+                               "(non-default) stream; got backend stream %r, torch current %r" % (self.be.stream, cur))
 
     # ---- scalars
     def _scalar_device(self):
@@ -58,13 +68,25 @@ class TorchComm:
         return self._slots
 
     def allreduce_sum(self, value):
-        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=self._scalar_device())
+        dev = "cpu" if self.dist.get_backend() == "gloo" else self._scalar_device()
+        t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=dev)
         self.dist.all_reduce(t)
         self.stats["allreduce"] += 1
         return float(t.item())
 
+    def _staged(self, t):
+        """gloo cannot move device memory: stage through the host (test configuration: several ranks
+        sharing one GPU over gloo; production runs use RCCL and never take this path)."""
+        return t.is_cuda and self.dist.get_backend() == "gloo"
+
     def allreduce_slots(self, first, count):
-        self.dist.all_reduce(self.slots()[first:first + count])
+        t = self.slots()[first:first + count]
+        if self._staged(t):
+            h = t.cpu()
+            self.dist.all_reduce(h)
+            t.copy_(h)
+        else:
+            self.dist.all_reduce(t)
         self.stats["allreduce"] += 1
 
     # ---- halo exchange
@@ -91,7 +113,15 @@ class TorchComm:
                 self._views[handle] = ops
         else:
             ops = self._halo_ops(mesh, self.be.vec_tensor(handle))
-        if ops:
+        if ops and self._staged(ops[0].tensor):
+            host = [(op, op.tensor.cpu()) for op in ops]
+            reqs = self.dist.batch_isend_irecv([self.dist.P2POp(op.op, h, op.peer) for op, h in host])
+            for req in reqs:
+                req.wait()
+            for op, h in host:
+                if op.op is self.dist.irecv:
+                    op.tensor.copy_(h)
+        elif ops:
             for req in self.dist.batch_isend_irecv(ops):
                 req.wait()
         self.stats["halo"] += 1
@@ -116,6 +146,7 @@ class TorchComm:
 
     def pcg(self, mesh, op, b, x, rtol, atol, maxit):
         be, part = self.be, mesh.part
+        self._check_stream()
         lo, hi, n = part.own0, part.own1, mesh.num_vertices()
         r, z, p, q, dinv = (self._workvec(n, k) for k in ("r", "z", "p", "q", "dinv"))
         xh, bh = x.dev(), b.dev()

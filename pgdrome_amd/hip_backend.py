@@ -17,6 +17,7 @@ class HipBackend:
     def __init__(self, device: int = 0, stream: int | None = None):
         self.ctx = _lib.Context(device, stream)
         self.device = device
+        self.stream = stream          # external HIP stream handle (None: the library's own stream)
 
     # ---- meshes
     def mesh(self, coords, cells):

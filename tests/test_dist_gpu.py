@@ -40,7 +40,11 @@ def test_sharded_driver_world1_matches_library_pcg():
         ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
         its_ref = fem.STATS["pcg_iterations"]
         # host-driven PCG on torch's stream, scalars all-reduced through RCCL
-        be2 = fem.set_backend(HipBackend(0, torch.cuda.current_stream().cuda_stream))
+        with pytest.raises(RuntimeError):          # default stream (handle 0) = library's own stream: refused
+            pdist.TorchComm(dist, HipBackend(0, torch.cuda.current_stream().cuda_stream or None))
+        tstream = torch.cuda.Stream(device=0)
+        torch.cuda.set_stream(tstream)
+        be2 = fem.set_backend(HipBackend(0, tstream.cuda_stream))
         fem.clear_caches()
         comm = pdist.TorchComm(dist, be2)
         mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
@@ -61,6 +65,73 @@ def test_sharded_driver_world1_matches_library_pcg():
         torch.cuda.synchronize()
         assert np.array_equal(be2.vec_to_host(v), np.arange(5.0) + 1.0)
     finally:
+        torch.cuda.set_stream(torch.cuda.default_stream(0))
         fem.set_backend(old)
         fem.clear_caches()
         dist.destroy_process_group()
+
+
+def _shared_gpu_worker(rank, world, port, shape, q):
+    """One of several ranks that all use GPU 0: HIP kernels for the local arithmetic, gloo (staged
+    through the host) for the exchange steps."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pgdrome_amd import dist as pdist, fem, problems
+        from pgdrome_amd.hip_backend import HipBackend
+        from pgdrome_amd.solver import PGDProblem
+        torch.cuda.set_device(0)
+        tstream = torch.cuda.Stream(device=0)
+        torch.cuda.set_stream(tstream)
+        be = fem.set_backend(HipBackend(0, tstream.cuda_stream))
+        comm = pdist.TorchComm(dist, be)
+        P = fem.Point
+        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+        p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=3))
+        p.solve_PGD(_problem="linear")
+        modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values()) for f in p.PGD_func[0]]
+        if rank == 0:
+            q.put(dict(num_fp_it=p.num_fp_it, amplitude=p.amplitude, modes_x=modes_x, stats=dict(comm.stats)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_solve_with_real_halos_on_one_gpu(world):
+    """Row-sharded solve with the HIP kernels and REAL halo exchanges: `world` processes share GPU 0
+    and exchange through gloo.  Must reproduce the unsharded GPU run (same modes, same iteration counts)."""
+    import torch.multiprocessing as mp
+    from pgdrome_amd import fem, problems
+    from pgdrome_amd.hip_backend import HipBackend
+    from pgdrome_amd.solver import PGDProblem
+    shape = (24, 20, 29)
+    old = fem._backend
+    fem.set_backend(HipBackend(0))
+    fem.clear_caches()
+    try:
+        P = fem.Point
+        ref = PGDProblem(**problems.reaction_diffusion(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape), 17, PGD_nmax=3))
+        ref.solve_PGD(_problem="linear")
+        ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
+    finally:
+        fem.set_backend(old)
+        fem.clear_caches()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    out = q.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert out["num_fp_it"] == ref.num_fp_it
+    np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
+    for m in range(ref.PGD_modes):
+        assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
+    assert out["stats"]["halo"] > 100
