@@ -28,7 +28,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
 
 
 class _Done(Exception):
@@ -141,7 +140,7 @@ def main():
         elapsed = float(t.item())
 
     n_sp = n ** 3
-    from pgdrome_amd.sizes import nnz_p1_box, spmv_bytes
+    from pgdrome_amd.sizes import nnz_p1_box
     nnz = nnz_p1_box(n)
     pcg_its = state["its1"] - state["its0"]
     achieved = prof["bytes"] / prof["seconds"] / 1e9 if prof["seconds"] > 0 else 0.0

@@ -13,8 +13,6 @@ from __future__ import annotations
 
 import time
 
-import numpy as np
-
 from . import c_oracle
 
 

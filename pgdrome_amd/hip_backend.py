@@ -6,8 +6,6 @@ package computes on the CPU in its place.
 """
 from __future__ import annotations
 
-import numpy as np
-
 from . import _lib
 
 
@@ -101,11 +99,9 @@ class HipBackend:
     # ---- pieces of the row-sharded PCG (pgdrome_amd/dist.py)
     def slots_tensor(self):
         """The device scalar bank as a torch tensor (zero copy) for RCCL all-reduces."""
-        import torch
         return _as_torch(self.ctx.slots_ptr(), _lib.NSLOTS, self.device)
 
     def vec_tensor(self, v):
-        import torch
         return _as_torch(self.ctx.vec_ptr(v), self.ctx.vec_size(v), self.device)
 
     def slots_get(self, first=0, count=_lib.NSLOTS):

@@ -13,8 +13,6 @@ they evaluate vectorised on multi-million-vertex meshes.
 """
 from __future__ import annotations
 
-import numpy as np
-
 from . import fem
 
 
