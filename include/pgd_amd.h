@@ -172,6 +172,17 @@ int pgd_pcg_check_slot(pgd_handle ctx, int slot_rr, int slot_tol2);
 int pgd_pcg_p_slot(pgd_handle ctx, pgd_handle p, pgd_handle z, int64_t r0, int64_t r1,
                    int slot_num, int slot_den);
 
+/* Single-reduction (Chronopoulos-Gear) form of the same recurrence: one all-reduce of
+ * S[base..base+4] = (r.u, r.r, w.u interior / low / high boundary rows) per iteration.
+ * S[base+5] alpha, S[base+6] beta, S[base+7] previous r.u, S[base+8] b.b.              */
+int pgd_cg_init_slot(pgd_handle ctx, pgd_handle b, pgd_handle q, pgd_handle dinv, pgd_handle r,
+                     pgd_handle u, pgd_handle p, pgd_handle s, int64_t r0, int64_t r1, int base);
+/* p = u + beta p; s = w + beta s; x += alpha p; r -= alpha s; u = dinv r; S[base..+1] <- (r.u, r.r) */
+int pgd_cg_update_slot(pgd_handle ctx, pgd_handle x, pgd_handle r, pgd_handle u, pgd_handle w,
+                       pgd_handle p, pgd_handle s, pgd_handle dinv, int64_t r0, int64_t r1, int base);
+/* after the all-reduce: next alpha/beta, iteration count, done <- r.r <= tol2 (init: also sets tol2) */
+int pgd_cg_scalars_slot(pgd_handle ctx, int base, int init, double rtol, double atol);
+
 /* ------------------------------------------------------------------ tuning --- */
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed.                                        */

@@ -188,6 +188,9 @@ class NumpyBackend:
     def spmv_dot_slot(self, A, x, y, w, r0, r1, slot):
         if self._flags[0]:
             return
+        if r1 == r0:
+            self.slots[slot] = 0.0
+            return
         self.spmv(A, x, y, r0, r1)
         self.slots[slot] = float(self._obj[w][r0:r1] @ self._obj[y][r0:r1])
 
@@ -231,6 +234,50 @@ class NumpyBackend:
         o = self._obj
         beta = self.slots[s_num] / self.slots[s_den]
         o[p][lo:hi] = o[z][lo:hi] + beta * o[p][lo:hi]
+
+    def cg_init_slot(self, b, q, dinv, r, u, p, s, lo, hi, base):
+        o = self._obj
+        o[r][lo:hi] = o[b][lo:hi] - o[q][lo:hi]
+        o[u][lo:hi] = o[dinv][lo:hi] * o[r][lo:hi]
+        o[p][lo:hi] = 0.0
+        o[s][lo:hi] = 0.0
+        self.slots[base] = float(o[r][lo:hi] @ o[u][lo:hi])
+        self.slots[base + 1] = float(o[r][lo:hi] @ o[r][lo:hi])
+        self.slots[base + 8] = float(o[b][lo:hi] @ o[b][lo:hi])
+
+    def cg_update_slot(self, x, r, u, w, p, s, dinv, lo, hi, base):
+        if self._flags[0]:
+            return
+        o = self._obj
+        alpha, beta = self.slots[base + 5], self.slots[base + 6]
+        o[p][lo:hi] = o[u][lo:hi] + beta * o[p][lo:hi]
+        o[s][lo:hi] = o[w][lo:hi] + beta * o[s][lo:hi]
+        o[x][lo:hi] += alpha * o[p][lo:hi]
+        o[r][lo:hi] -= alpha * o[s][lo:hi]
+        o[u][lo:hi] = o[dinv][lo:hi] * o[r][lo:hi]
+        self.slots[base] = float(o[r][lo:hi] @ o[u][lo:hi])
+        self.slots[base + 1] = float(o[r][lo:hi] @ o[r][lo:hi])
+
+    def cg_scalars_slot(self, base, init, rtol, atol):
+        if self._flags[0]:
+            return
+        S = self.slots
+        g, rr, d = S[base], S[base + 1], S[base + 2] + S[base + 3] + S[base + 4]
+        if init:
+            S[5] = max(rtol * rtol * S[base + 8], atol * atol)
+        else:
+            self._flags[1] += 1
+        S[6] = rr
+        if rr <= S[5]:
+            self._flags[0] = 1
+            return
+        beta = 0.0 if init else g / S[base + 7]
+        alpha = g / d if init else g / (d - beta * g / S[base + 5])
+        S[base + 5], S[base + 6], S[base + 7] = alpha, beta, g
+
+    def slots_set(self, vals, first=0):
+        vals = np.asarray(vals, dtype=np.float64)
+        self.slots[first:first + vals.size] = vals
 
     def sync(self):
         pass

@@ -71,6 +71,9 @@ SIGNATURES = {
     "pgd_pcg_xr_slot": (C.c_int, [H, H, H, H, H, H, H, I64, I64, C.c_int, C.c_int, C.c_int]),
     "pgd_pcg_check_slot": (C.c_int, [H, C.c_int, C.c_int]),
     "pgd_pcg_p_slot": (C.c_int, [H, H, H, I64, I64, C.c_int, C.c_int]),
+    "pgd_cg_init_slot": (C.c_int, [H, H, H, H, H, H, H, H, I64, I64, C.c_int]),
+    "pgd_cg_update_slot": (C.c_int, [H, H, H, H, H, H, H, H, I64, I64, C.c_int]),
+    "pgd_cg_scalars_slot": (C.c_int, [H, C.c_int, C.c_int, F64, F64]),
     "pgd_tune": (C.c_int, [H, C.c_int, I64]),
     "pgd_prof_enable": (C.c_int, [H, C.c_int]),
     "pgd_prof_read": (C.c_int, [H, PI64, PD, PD]),
@@ -346,6 +349,15 @@ class Context:
 
     def pcg_p_slot(self, p, z, lo, hi, slot_num, slot_den):
         self._ck(self.lib.pgd_pcg_p_slot(self.h, p, z, int(lo), int(hi), slot_num, slot_den))
+
+    def cg_init_slot(self, b, q, dinv, r, u, p, s, lo, hi, base):
+        self._ck(self.lib.pgd_cg_init_slot(self.h, b, q, dinv, r, u, p, s, int(lo), int(hi), int(base)))
+
+    def cg_update_slot(self, x, r, u, w, p, s, dinv, lo, hi, base):
+        self._ck(self.lib.pgd_cg_update_slot(self.h, x, r, u, w, p, s, dinv, int(lo), int(hi), int(base)))
+
+    def cg_scalars_slot(self, base, init, rtol, atol):
+        self._ck(self.lib.pgd_cg_scalars_slot(self.h, int(base), int(init), float(rtol), float(atol)))
 
     def tune(self, knob, value):
         self._ck(self.lib.pgd_tune(self.h, int(knob), int(value)))

@@ -130,6 +130,77 @@ __global__ __launch_bounds__(TPB) void k_pcg_p(double *__restrict__ p, const dou
         p[i] = fma(beta, p[i], z[i]);
 }
 
+
+// ---- single-reduction (Chronopoulos-Gear) form of the same Jacobi-PCG, used by the row-sharded
+// solve: ONE all-reduce per iteration instead of two.  Scalars: S[b+0..4] = (r.u, r.r, w.u interior,
+// w.u low boundary rows, w.u high boundary rows) - reduced across ranks together - then
+// S[b+5] alpha, S[b+6] beta, S[b+7] previous r.u, S[b+8] b.b.
+//   p = u + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s;  u = dinv r;  partial (r.u, r.r)
+__global__ __launch_bounds__(TPB) void k_cg_update(double *__restrict__ x, double *__restrict__ r, double *__restrict__ u,
+                                                   const double *__restrict__ w, double *__restrict__ p,
+                                                   double *__restrict__ s, const double *__restrict__ dinv, int64_t lo,
+                                                   int64_t hi, const double *__restrict__ slots, int base,
+                                                   double *__restrict__ partials, const int *__restrict__ flags) {
+    if (flags[0]) return;
+    __shared__ double s_red[4];
+    const double alpha = slots[base + 5], beta = slots[base + 6];
+    double ru = 0.0, rr = 0.0;
+    for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB) {
+        const double pi = fma(beta, p[i], u[i]), si = fma(beta, s[i], w[i]);
+        p[i] = pi; s[i] = si;
+        x[i] = fma(alpha, pi, x[i]);
+        const double ri = fma(-alpha, si, r[i]), ui = dinv[i] * ri;
+        r[i] = ri; u[i] = ui;
+        ru = fma(ri, ui, ru); rr = fma(ri, ri, rr);
+    }
+    ru = block_sum(ru, s_red);
+    rr = block_sum(rr, s_red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = ru; partials[2 * blockIdx.x + 1] = rr; }
+}
+
+// r = b - q; u = dinv r; p = s = 0; partials (r.u, r.r, b.b)
+__global__ __launch_bounds__(TPB) void k_cg_init(const double *__restrict__ b, const double *__restrict__ q,
+                                                 const double *__restrict__ dinv, double *__restrict__ r,
+                                                 double *__restrict__ u, double *__restrict__ p, double *__restrict__ s,
+                                                 int64_t lo, int64_t hi, double *__restrict__ partials) {
+    __shared__ double s_red[4];
+    double ru = 0.0, rr = 0.0, bb = 0.0;
+    for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB) {
+        const double bi = b[i], ri = bi - q[i], ui = dinv[i] * ri;
+        r[i] = ri; u[i] = ui; p[i] = 0.0; s[i] = 0.0;
+        ru = fma(ri, ui, ru); rr = fma(ri, ri, rr); bb = fma(bi, bi, bb);
+    }
+    ru = block_sum(ru, s_red);
+    rr = block_sum(rr, s_red);
+    bb = block_sum(bb, s_red);
+    if (threadIdx.x == 0) {
+        partials[3 * blockIdx.x + 0] = ru;
+        partials[3 * blockIdx.x + 1] = rr;
+        partials[3 * blockIdx.x + 2] = bb;
+    }
+}
+
+// after the all-reduce: next alpha / beta, iteration count, convergence
+__global__ void k_cg_scalars(double *__restrict__ slots, int *__restrict__ flags, int base, int init, double rtol,
+                             double atol) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || flags[0]) return;
+    const double g = slots[base], rr = slots[base + 1], d = slots[base + 2] + slots[base + 3] + slots[base + 4];
+    if (init) {
+        const double t1 = rtol * rtol * slots[base + 8], t2 = atol * atol;
+        slots[S_TOL2] = t1 > t2 ? t1 : t2;
+    } else {
+        flags[1] += 1;
+    }
+    slots[6] = rr;
+    if (!(rr == rr) || !(d == d)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; return; }
+    if (rr <= slots[S_TOL2]) { flags[0] = 1; return; }
+    const double beta = init ? 0.0 : g / slots[base + 7];
+    const double alpha = init ? g / d : g / (d - beta * g / slots[base + 5]);
+    slots[base + 5] = alpha;
+    slots[base + 6] = beta;
+    slots[base + 7] = g;
+}
+
 // ---------------------------------------------------------------- banded LU (small systems)
 // One workgroup; the band lives in LDS when it fits.  ab(i,j) is stored at
 // W[(i - j + kl + ku) + j * ld], ld = 2 kl + ku + 1 (LAPACK dgbtrf layout: kl extra
@@ -434,6 +505,51 @@ int pgd_pcg_p_slot(pgd_handle h, pgd_handle ph, pgd_handle zh, int64_t lo, int64
     if (!p || !z || p->n != z->n || !range_ok(p->n, lo, hi)) return fail(c, PGD_ERR_INVALID, "pcg_p_slot: invalid arguments");
     if (hi == lo) return PGD_OK;
     k_pcg_p<<<grid_for(hi - lo), TPB, 0, c->stream>>>(p->d, z->d, lo, hi, c->slots, slot_num, slot_den, c->flags);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pgd_cg_init_slot(pgd_handle h, pgd_handle bh, pgd_handle qh, pgd_handle dh, pgd_handle rh, pgd_handle uh,
+                     pgd_handle ph, pgd_handle sh, int64_t lo, int64_t hi, int base) {
+    PGD_CTX(c, h);
+    Vec *b, *q, *d, *r, *u, *p;
+    Vec *s = get_vec(c, sh);
+    if (get3(c, bh, qh, dh, &b, &q, &d) != PGD_OK || get3(c, rh, uh, ph, &r, &u, &p) != PGD_OK || !s ||
+        b->n != r->n || s->n != b->n || !range_ok(b->n, lo, hi) || base < 0 || base + 9 > PGD_NSLOTS)
+        return fail(c, PGD_ERR_INVALID, "cg_init_slot: invalid arguments");
+    if (hi == lo) return PGD_OK;
+    const int g = grid_for(hi - lo);
+    PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS));
+    k_cg_init<<<g, TPB, 0, c->stream>>>(b->d, q->d, d->d, r->d, u->d, p->d, s->d, lo, hi, c->partials);
+    PGD_LAUNCH_CHECK(c);
+    // (r.u, r.r) -> S[base], S[base+1]; b.b -> S[base+8]: reduce 3 values to a scratch triple, then place b.b
+    PGD_TRY(reduce_partials(c, c->partials, g, 3, 40, -1, 0, 0));
+    PGD_HIP(c, hipMemcpyAsync(c->slots + base, c->slots + 40, 2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    PGD_HIP(c, hipMemcpyAsync(c->slots + base + 8, c->slots + 42, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return PGD_OK;
+}
+
+int pgd_cg_update_slot(pgd_handle h, pgd_handle xh, pgd_handle rh, pgd_handle uh, pgd_handle wh, pgd_handle ph,
+                       pgd_handle sh, pgd_handle dh, int64_t lo, int64_t hi, int base) {
+    PGD_CTX(c, h);
+    Vec *x, *r, *u, *w, *p, *s;
+    Vec *d = get_vec(c, dh);
+    if (get3(c, xh, rh, uh, &x, &r, &u) != PGD_OK || get3(c, wh, ph, sh, &w, &p, &s) != PGD_OK || !d ||
+        x->n != w->n || d->n != x->n || !range_ok(x->n, lo, hi) || base < 0 || base + 9 > PGD_NSLOTS)
+        return fail(c, PGD_ERR_INVALID, "cg_update_slot: invalid arguments");
+    if (hi == lo) return PGD_OK;
+    const int g = grid_for(hi - lo);
+    PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS));
+    k_cg_update<<<g, TPB, 0, c->stream>>>(x->d, r->d, u->d, w->d, p->d, s->d, d->d, lo, hi, c->slots, base,
+                                          c->partials, c->flags);
+    PGD_LAUNCH_CHECK(c);
+    return reduce_partials(c, c->partials, g, 2, base, 0, 0, 0);
+}
+
+int pgd_cg_scalars_slot(pgd_handle h, int base, int init, double rtol, double atol) {
+    PGD_CTX(c, h);
+    if (base < 0 || base + 9 > PGD_NSLOTS) return fail(c, PGD_ERR_INVALID, "cg_scalars_slot: bad slot base");
+    k_cg_scalars<<<1, 64, 0, c->stream>>>(c->slots, c->flags, base, init, rtol, atol);
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
 }

@@ -376,7 +376,10 @@ int pgd_spmv_dot_slot(pgd_handle h, pgd_handle ah, pgd_handle xh, pgd_handle yh,
         return fail(c, PGD_ERR_INVALID, "spmv_dot_slot: invalid handles, sizes or slot");
     int nparts = 0;
     PGD_TRY(launch_spmv(c, m, a->vals, x->d, y->d, w->d, r0, r1, true, true, c->flags, &nparts));
-    if (nparts == 0) return PGD_OK;
+    if (nparts == 0) {   // empty row range: its partial is 0 (callers all-reduce the slot unconditionally)
+        PGD_HIP(c, hipMemsetAsync(c->slots + slot, 0, sizeof(double), c->stream));
+        return PGD_OK;
+    }
     return reduce_partials(c, c->partials, nparts, 1, slot, 0, 0, 0);
 }
 

@@ -39,11 +39,14 @@ S_PQ, S_TOL2, S_FINAL_RR, S_INIT, S_PAIR = 2, 5, 6, 20, 16
 class TorchComm:
     """Communication + sharded-solve driver on top of torch.distributed."""
 
-    def __init__(self, dist, backend):
+    def __init__(self, dist, backend, single_reduction=None):
         import torch
         self.torch, self.dist, self.be = torch, dist, backend
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self._check_stream()
+        # more than one rank: the single-reduction recurrence (one all-reduce per iteration, halo
+        # overlapped with the interior rows); one rank: the textbook two-reduction form
+        self.single_reduction = (dist.get_world_size() > 1) if single_reduction is None else single_reduction
         self._slots = None
         self._work = {}
         self._views = {}
@@ -144,7 +147,75 @@ class TorchComm:
             self._work[key] = h
         return h
 
+    def _halo_begin(self, mesh, handle):
+        """Start the halo exchange of a PCG work vector; returns a callable that completes it."""
+        ops = self._views.get(handle)
+        if ops is None:
+            ops = self._halo_ops(mesh, self.be.vec_tensor(handle))
+            self._views[handle] = ops
+        self.stats["halo"] += 1
+        if not ops:
+            return lambda: None
+        if self._staged(ops[0].tensor):
+            self.stats["halo"] -= 1
+            self.halo_exchange_raw(mesh, handle, cache_view=True)
+            return lambda: None
+        reqs = self.dist.batch_isend_irecv(ops)
+        return lambda: [req.wait() for req in reqs]
+
+    def _spmv_dot_overlapped(self, mesh, op, u, w, base):
+        """w = A u on the owned rows with S[base..base+2] <- local (w.u) of the interior / low / high
+        boundary rows.  The interior rows do not touch ghost entries, so they run while the planes travel."""
+        be, part = self.be, mesh.part
+        lo, hi, glo, ghi = part.own0, part.own1, part.lo_ghost, part.hi_ghost
+        finish = self._halo_begin(mesh, u)
+        if hi - lo < glo + ghi:          # a rank that owns a single plane: nothing to overlap
+            glo, ghi = hi - lo, 0
+        # all three slots are written every time (an empty range writes 0): they are all-reduced together
+        be.spmv_dot_slot(op, u, w, u, lo + glo, hi - ghi, base)
+        finish()
+        be.spmv_dot_slot(op, u, w, u, lo, lo + glo, base + 1)
+        be.spmv_dot_slot(op, u, w, u, hi - ghi, hi, base + 2)
+
+    def pcg_single_reduction(self, mesh, op, b, x, rtol, atol, maxit):
+        """Chronopoulos-Gear Jacobi-PCG: the same Krylov iterates as `pcg`, one all-reduce per iteration."""
+        be, part = self.be, mesh.part
+        self._check_stream()
+        lo, hi, n = part.own0, part.own1, mesh.num_vertices()
+        r, u, w, p, s, q, dinv = (self._workvec(n, k) for k in ("r", "z", "w", "p", "s", "q", "dinv"))
+        xh, bh = x.dev(), b.dev()
+        B = 24
+        be.flags_reset()
+        be.slots_set(np.zeros(9), B)
+        be.op_diag_inv(op, dinv)
+        self.halo_exchange_raw(mesh, xh)
+        be.spmv(op, xh, q, lo, hi)
+        be.cg_init_slot(bh, q, dinv, r, u, p, s, lo, hi, B)            # local (r.u, r.r) and b.b
+        self._spmv_dot_overlapped(mesh, op, u, w, B + 2)
+        self.allreduce_slots(B, 9)                                        # alpha/beta/old r.u are still 0
+        be.cg_scalars_slot(B, 1, rtol, atol)
+        k = 0
+        while True:
+            done, iters, status = be.flags()
+            if done or k >= maxit:
+                break
+            for _ in range(min(CHECK_EVERY, maxit - k)):
+                be.cg_update_slot(xh, r, u, w, p, s, dinv, lo, hi, B)
+                self._spmv_dot_overlapped(mesh, op, u, w, B + 2)
+                self.allreduce_slots(B, 5)                                # (r.u, r.r, w.u x 3) in one call
+                be.cg_scalars_slot(B, 0, rtol, atol)
+                k += 1
+        if status != 0:
+            raise RuntimeError("sharded PCG breakdown (NaN) after %d iterations" % iters)
+        sl = be.slots_get(0, 40)
+        bb, rr = sl[B + 8], sl[S_FINAL_RR]
+        x.touched_dev()
+        self.halo_exchange(mesh, x)
+        return iters, (np.sqrt(rr / bb) if bb > 0 else 0.0)
+
     def pcg(self, mesh, op, b, x, rtol, atol, maxit):
+        if self.single_reduction:
+            return self.pcg_single_reduction(mesh, op, b, x, rtol, atol, maxit)
         be, part = self.be, mesh.part
         self._check_stream()
         lo, hi, n = part.own0, part.own1, mesh.num_vertices()

@@ -134,6 +134,18 @@ class HipBackend:
     def pcg_p_slot(self, p, z, lo, hi, s_num, s_den):
         self.ctx.pcg_p_slot(p, z, lo, hi, s_num, s_den)
 
+    def cg_init_slot(self, b, q, dinv, r, u, p, s, lo, hi, base):
+        self.ctx.cg_init_slot(b, q, dinv, r, u, p, s, lo, hi, base)
+
+    def cg_update_slot(self, x, r, u, w, p, s, dinv, lo, hi, base):
+        self.ctx.cg_update_slot(x, r, u, w, p, s, dinv, lo, hi, base)
+
+    def cg_scalars_slot(self, base, init, rtol, atol):
+        self.ctx.cg_scalars_slot(base, init, rtol, atol)
+
+    def slots_set(self, vals, first=0):
+        self.ctx.slots_upload(vals, first)
+
     def sync(self):
         self.ctx.sync()
 

@@ -20,7 +20,7 @@ def _problem(space, n_mu=9):
     return problems.reaction_diffusion(space, n_mu, PGD_nmax=3)
 
 
-def _worker(rank, world, port, shape, q):
+def _worker(rank, world, port, shape, q, single_reduction=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -30,7 +30,7 @@ def _worker(rank, world, port, shape, q):
         from pgdrome_amd import dist as pdist, fem
         from pgdrome_amd.solver import PGDProblem
         be = fem.set_backend(NumpyBackend())
-        comm = pdist.TorchComm(dist, be)
+        comm = pdist.TorchComm(dist, be, single_reduction)
         P = fem.Point
         mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
         p = PGDProblem(**_problem(mesh))
@@ -52,8 +52,11 @@ def _worker(rank, world, port, shape, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shape", [(2, (4, 3, 5)), (3, (3, 4, 6))])
-def test_sharded_solve_equals_single_process(world, shape):
+@pytest.mark.parametrize("world,shape,single_reduction", [(2, (4, 3, 5), True), (3, (3, 4, 6), True),
+                                                          (2, (4, 3, 5), False), (4, (3, 3, 4), True)])
+def test_sharded_solve_equals_single_process(world, shape, single_reduction):
+    """Both recurrences of the sharded solve (two-reduction PCG, single-reduction Chronopoulos-Gear with
+    halo/interior overlap; (4, (3,3,4)) has ranks that own a single plane)."""
     from oracle.backend_numpy import NumpyBackend
     from pgdrome_amd import fem
     from pgdrome_amd.solver import PGDProblem
@@ -73,7 +76,7 @@ def test_sharded_solve_equals_single_process(world, shape):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, q, single_reduction)) for r in range(world)]
     for pr in procs:
         pr.start()
     out = q.get(timeout=240)
