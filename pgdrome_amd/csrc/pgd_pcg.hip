@@ -15,6 +15,7 @@ namespace pgd {
 
 constexpr int MAXT = 8;          // atoms per combine launch
 constexpr int CHECK_EVERY = 16;  // PCG iterations enqueued between two host looks at the flag
+constexpr int64_t GRAPH_MAX_ROWS = 1 << 21;   // systems up to this size replay their chunks as a hipGraph
 
 struct CombineArgs {
     const double *in[MAXT];
@@ -391,33 +392,64 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     for (int i = 0; i < 4; ++i) PGD_TRY(ensure_work(c, i, n));
     double *r = c->work[0], *z = c->work[1], *p = c->work[2], *q = c->work[3];
     PGD_HIP(c, hipMemsetAsync(c->flags, 0, 8 * sizeof(int), c->stream));
-    // r0 = b - A x0; (r.z, r.r, b.b) land in slots 20..22
-    constexpr int S_INIT = 20, S_PAIR = 16;   // r.z / r.r of iteration k live in slots 16 + 2 (k & 1), +1
+    // r0 = b - A x0; (r.z, r.r, b.b) land in slots 18..20.  r.z / r.r of iteration k live in slots
+    // 16 + 2 (k & 1), +1, so iteration 0 finds "the previous r.z" in slot 18 like every even iteration:
+    // all 16-iteration chunks are identical and can be replayed as one hipGraph.
+    constexpr int S_INIT = 18, S_PAIR = 16;
     PGD_TRY(launch_spmv(c, m, o->vals, x->d, q, nullptr, 0, n, false, true, nullptr, nullptr));
     PGD_TRY(pcg_init(c, b->d, q, o->dinv, r, z, p, 0, n, S_INIT));
     k_pcg_tol<<<1, 64, 0, c->stream>>>(c->slots, c->flags, rtol, atol, S_INIT + 1, S_INIT + 2, S_TOL2);
     PGD_LAUNCH_CHECK(c);
-    int f[4] = {0, 0, 0, 0};
-    int rz_old = S_INIT;
-    int enq = 0;
-    while (true) {
-        PGD_HIP(c, hipMemcpyAsync(f, c->flags, sizeof f, hipMemcpyDeviceToHost, c->stream));
-        PGD_HIP(c, hipStreamSynchronize(c->stream));
-        if (f[0] || enq >= maxit) break;
-        const int chunk = (maxit - enq < CHECK_EVERY) ? maxit - enq : CHECK_EVERY;
-        for (int k = 0; k < chunk; ++k) {
-            const int out = S_PAIR + 2 * ((enq + k) & 1);
+
+    auto enqueue = [&](int start, int count) -> int {
+        for (int k = 0; k < count; ++k) {
+            const int out = S_PAIR + 2 * ((start + k) & 1), rz_old = S_PAIR + 2 * ((start + k + 1) & 1);
             int nparts = 0;
             PGD_TRY(launch_spmv(c, m, o->vals, p, q, p, 0, n, true, true, c->flags, &nparts));
             PGD_TRY(reduce_partials(c, c->partials, nparts, 1, S_PQ, 0, 0, 0));
             // x, r, z update; the final reduction also runs the convergence test on r.r
             PGD_TRY(pcg_xr(c, x->d, r, p, q, o->dinv, z, 0, n, rz_old, S_PQ, out, 1, S_TOL2));
             k_pcg_p<<<grid_for(n), TPB, 0, c->stream>>>(p, z, 0, n, c->slots, out, rz_old, c->flags);
-            rz_old = out;
         }
-        PGD_LAUNCH_CHECK(c);
+        return PGD_OK;
+    };
+
+    // Small systems are launch-bound (5 launches of a few microseconds per iteration): replay the
+    // chunk as a graph.  Large ones gain nothing and keep eager launches (and their event timing).
+    hipGraphExec_t gexec = nullptr;
+    if (!c->prof && n <= GRAPH_MAX_ROWS && maxit >= CHECK_EVERY) {
+        // everything a chunk allocates lazily must exist before the capture starts
+        PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS > (n + 63) / 64 ? 4 * (int64_t)MAX_VEC_BLOCKS : (n + 63) / 64));
+        PGD_TRY(ensure_work(c, 5, 4096));
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+            const int rc = enqueue(0, CHECK_EVERY);
+            const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+            if (rc != PGD_OK || e != hipSuccess || !graph ||
+                hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess)
+                gexec = nullptr;
+            if (graph) (void)hipGraphDestroy(graph);
+            (void)hipGetLastError();
+        }
+    }
+    int f[4] = {0, 0, 0, 0};
+    int enq = 0, rc_loop = PGD_OK;
+    while (true) {
+        hipError_t e = hipMemcpyAsync(f, c->flags, sizeof f, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) { rc_loop = fail(c, PGD_ERR_HIP, "pcg_solve: %s", hipGetErrorString(e)); break; }
+        if (f[0] || enq >= maxit) break;
+        const int chunk = (maxit - enq < CHECK_EVERY) ? maxit - enq : CHECK_EVERY;
+        if (gexec && chunk == CHECK_EVERY) {
+            if (hipGraphLaunch(gexec, c->stream) != hipSuccess) { rc_loop = fail(c, PGD_ERR_HIP, "pcg_solve: hipGraphLaunch failed"); break; }
+        } else if ((rc_loop = enqueue(enq, chunk)) != PGD_OK) {
+            break;
+        }
         enq += chunk;
     }
+    if (gexec) (void)hipGraphExecDestroy(gexec);
+    if (rc_loop != PGD_OK) return rc_loop;
+    PGD_LAUNCH_CHECK(c);
     double s[PGD_NSLOTS];
     PGD_HIP(c, hipMemcpyAsync(s, c->slots, sizeof s, hipMemcpyDeviceToHost, c->stream));
     PGD_HIP(c, hipStreamSynchronize(c->stream));
