@@ -66,7 +66,8 @@ int pgd_device_count(void);
 /* ------------------------------------------------------------------ meshes --- */
 /* Replaces dolfin's Mesh + DofMap + sparsity-pattern build behind
  * FunctionSpace(mesh,"CG",1) (callers: tests/integration/test_heat1D.py:26-40).
- * coords: nv x gdim row-major; cells: nc x nvpc (nvpc = gdim+1 simplices).
+ * coords: nv x gdim row-major; cells: nc x nvpc.  P1: nvpc = gdim+1 simplex vertices.  P2 on
+ * intervals: gdim = 1, nvpc = 3, nodes = vertices and cell midpoints, cell = (v0, v1, mid).
  * Builds on the device: vertex->cell adjacency (sorted) and the CSR pattern of
  * "vertices sharing a cell" with sorted columns.                                */
 int pgd_mesh_upload(pgd_handle ctx, const double *coords, int64_t nv, int gdim,

@@ -108,8 +108,52 @@ def _geometry(coords, cells):
     return vol, g
 
 
+# 4-point Gauss-Legendre on [0, 1]: exact to degree 7 (P2 x P2 x P2 weights need 6)
+_GQ = np.polynomial.legendre.leggauss(4)
+GAUSS_X, GAUSS_W = 0.5 * (_GQ[0] + 1.0), 0.5 * _GQ[1]
+
+
+def p2_interval_nodes(coords, cells):
+    """Node coordinates and cell -> node table of the P2 space on an interval mesh: nodes ordered along
+    the interval (vertex i -> 2 i, midpoint of cell i -> 2 i + 1), cell record (v0, v1, mid)."""
+    x = coords[:, 0]
+    nodes = np.empty(2 * x.size - 1)
+    nodes[0::2] = x
+    nodes[1::2] = 0.5 * (x[:-1] + x[1:])
+    tab = np.stack([2 * cells[:, 0], 2 * cells[:, 1], 2 * cells[:, 0] + 1], axis=1).astype(np.int32)
+    return nodes.reshape(-1, 1), tab
+
+
+def element_matrices_p2_interval(coords, cells, kind, w=None):
+    """3x3 local matrices of quadratic Lagrange elements on intervals by Gauss quadrature (exact for
+    the polynomial integrands): N0 = (1-s)(1-2s), N1 = s(2s-1), N2 = 4s(1-s) on s in [0,1] from v0 to v1."""
+    hs = coords[cells[:, 1], 0] - coords[cells[:, 0], 0]          # signed length
+    s_ = GAUSS_X
+    N = np.stack([(1 - s_) * (1 - 2 * s_), s_ * (2 * s_ - 1), 4 * s_ * (1 - s_)])      # (3, nq)
+    dN = np.stack([4 * s_ - 3, 4 * s_ - 1, 4 - 8 * s_])                               # d/ds
+    nc = cells.shape[0]
+    wq = np.ones((nc, s_.size))
+    if kind in (WMASS, WSTIFF):
+        if w is None:
+            raise ValueError("weighted atom needs nodal weights")
+        wq = np.asarray(w, dtype=np.float64)[cells] @ N                               # w at the quadrature points
+    jac = np.abs(hs)[:, None] * GAUSS_W[None, :] * wq                                 # (nc, nq)
+    if kind in (MASS, WMASS):
+        return np.einsum("cq,iq,jq->cij", jac, N, N)
+    if kind in (STIFF, DUDV, WSTIFF):
+        return np.einsum("cq,iq,jq->cij", jac / (hs ** 2)[:, None], dN, dN)
+    if kind == CONV:
+        return np.einsum("cq,iq,jq->cij", jac / hs[:, None], N, dN)
+    if kind == CONVT:
+        return np.einsum("cq,iq,jq->cij", jac / hs[:, None], dN, N)
+    raise ValueError(f"unknown atom kind {kind}")
+
+
 def element_matrices(coords, cells, kind, a=0, b=0, w=None):
-    """Local (D+1)x(D+1) matrices, row = test index i, column = trial index j."""
+    """Local matrices, row = test index i, column = trial index j (P1 simplices, or P2 intervals when
+    the cell records carry three nodes on a 1-D mesh)."""
+    if coords.shape[1] == 1 and cells.shape[1] == 3:
+        return element_matrices_p2_interval(coords, cells, kind, w)
     vol, g = _geometry(coords, cells)
     nc, nv, D = g.shape
     if kind == MASS:

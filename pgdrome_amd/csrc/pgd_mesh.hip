@@ -230,6 +230,51 @@ __global__ __launch_bounds__(TPB) void k_assemble_p1(AsmArgs A) {
         for (int k = tid; k < e - s; k += TPB) A.vals[s + k] = s_acc[k];
 }
 
+
+// Quadratic Lagrange elements on intervals (cell record = v0, v1, midpoint node): owner-computes like
+// the P1 kernel, local 3x3 entries by 4-point Gauss quadrature (exact to degree 7).  These systems are
+// small (time / parameter dimensions), so every lane accumulates straight into its own CSR row.
+__global__ __launch_bounds__(TPB) void k_assemble_p2_interval(AsmArgs A) {
+    const double GX[4] = {0.06943184420297371, 0.33000947820757187, 0.6699905217924281, 0.9305681557970262};
+    const double GW[4] = {0.17392742256872692, 0.32607257743127305, 0.32607257743127305, 0.17392742256872692};
+    const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (r >= A.nv) return;
+    const int ra = A.row_ptr[r], len = A.row_ptr[r + 1] - ra;
+    for (int k = 0; k < len; ++k) A.vals[ra + k] = 0.0;
+    for (int k = A.v2c_ptr[r]; k < A.v2c_ptr[r + 1]; ++k) {
+        const int4 c4 = A.cells[A.v2c[k]];
+        const int u[3] = {c4.x, c4.y, c4.z};
+        const int i = (u[0] == (int)r) ? 0 : (u[1] == (int)r) ? 1 : 2;
+        const double hs = A.cx[u[1]] - A.cx[u[0]], inv = 1.0 / hs, ah = fabs(hs);
+        double wl[3] = {1.0, 1.0, 1.0};
+        const bool weighted = A.kind == PGD_ATOM_WMASS || A.kind == PGD_ATOM_WSTIFF;
+        if (weighted) { wl[0] = A.w[u[0]]; wl[1] = A.w[u[1]]; wl[2] = A.w[u[2]]; }
+        double loc[3] = {0.0, 0.0, 0.0};
+        for (int q = 0; q < 4; ++q) {
+            const double s = GX[q];
+            const double N[3] = {(1 - s) * (1 - 2 * s), s * (2 * s - 1), 4 * s * (1 - s)};
+            const double dN[3] = {(4 * s - 3) * inv, (4 * s - 1) * inv, (4 - 8 * s) * inv};
+            double jac = ah * GW[q];
+            if (weighted) jac *= wl[0] * N[0] + wl[1] * N[1] + wl[2] * N[2];
+            for (int j = 0; j < 3; ++j) {
+                double f;
+                switch (A.kind) {
+                    case PGD_ATOM_MASS: case PGD_ATOM_WMASS: f = N[i] * N[j]; break;
+                    case PGD_ATOM_CONV: f = N[i] * dN[j]; break;
+                    case PGD_ATOM_CONVT: f = dN[i] * N[j]; break;
+                    default: f = dN[i] * dN[j]; break;      // STIFF, DUDV(0,0), WSTIFF
+                }
+                loc[j] = fma(jac, f, loc[j]);
+            }
+        }
+        for (int j = 0; j < 3; ++j) {
+            int pos = 0;
+            while (pos < len - 1 && A.cols[ra + pos] < u[j]) ++pos;
+            A.vals[ra + pos] += loc[j];
+        }
+    }
+}
+
 // --------------------------------------------------------------------- host side
 static int build_topology(Ctx *c, Mesh *m) {
     void *p;
@@ -410,8 +455,9 @@ extern "C" {
 int pgd_mesh_upload(pgd_handle h, const double *coords, int64_t nv, int gdim, const int32_t *cells,
                     int64_t nc, int nvpc, pgd_handle *out) {
     PGD_CTX(c, h);
-    if (!coords || !cells || !out || nv < 2 || nc < 1 || gdim < 1 || gdim > 3 || nvpc != gdim + 1)
-        return fail(c, PGD_ERR_INVALID, "mesh_upload: need P1 simplices with nvpc == gdim + 1, gdim in 1..3");
+    const bool p2_interval = gdim == 1 && nvpc == 3;   // quadratic elements: cell record (v0, v1, midpoint)
+    if (!coords || !cells || !out || nv < 2 || nc < 1 || gdim < 1 || gdim > 3 || (nvpc != gdim + 1 && !p2_interval))
+        return fail(c, PGD_ERR_INVALID, "mesh_upload: need P1 simplices (nvpc == gdim + 1, gdim in 1..3) or P2 intervals (gdim 1, nvpc 3)");
     if (nv >= (int64_t)1 << 31 || nc * nvpc >= (int64_t)1 << 31)
         return fail(c, PGD_ERR_LIMIT, "mesh_upload: index range exceeds int32");
     // validate connectivity on the host: an out-of-range vertex id would fault on the device
@@ -513,7 +559,8 @@ int pgd_atom_assemble(pgd_handle h, pgd_handle mh, int kind, int da, int db, pgd
     A.cells = m->cells; A.v2c_ptr = m->v2c_ptr; A.v2c = m->v2c; A.row_ptr = m->row_ptr; A.cols = m->cols;
     A.w = w; A.vals = a->vals; A.nv = m->nv; A.kind = kind; A.da = da; A.db = db;
     const int gb = (int)((m->nv + TPB - 1) / TPB);
-    if (m->gdim == 1) k_assemble_p1<1><<<gb, TPB, 0, c->stream>>>(A);
+    if (m->gdim == 1 && m->nvpc == 3) k_assemble_p2_interval<<<gb, TPB, 0, c->stream>>>(A);
+    else if (m->gdim == 1) k_assemble_p1<1><<<gb, TPB, 0, c->stream>>>(A);
     else if (m->gdim == 2) k_assemble_p1<2><<<gb, TPB, 0, c->stream>>>(A);
     else k_assemble_p1<3><<<gb, TPB, 0, c->stream>>>(A);
     PGD_LAUNCH_CHECK(c);

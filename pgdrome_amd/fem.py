@@ -138,10 +138,8 @@ class Mesh:
         self._cells = np.ascontiguousarray(cells, dtype=np.int32)
         self._gdim = coords.shape[1]
         self.part = part
-        self._handles = {}       # backend id -> mesh handle
-        self._atoms = {}         # (backend id, key) -> atom handle
+        self._layouts = {}       # degree -> DofLayout
         self._on_boundary = None
-        self._ones = None
 
     def coordinates(self):
         return self._coords
@@ -172,31 +170,19 @@ class Mesh:
     def owned_range(self):
         return (self.part.own0, self.part.own1) if self.part else (0, self.num_vertices())
 
+    def layout(self, degree=1):
+        """Degrees of freedom of the Lagrange space of this degree on the mesh (created once)."""
+        lay = self._layouts.get(degree)
+        if lay is None:
+            lay = DofLayout(self, degree)
+            self._layouts[degree] = lay
+        return lay
+
     def handle(self):
-        be = get_backend()
-        h = self._handles.get(id(be))
-        if h is None:
-            h = be.mesh(self._coords, self._cells)
-            self._handles[id(be)] = h
-        return h
+        return self.layout(1).handle()
 
     def atom(self, kind, da=0, db=0, weight=None):
-        """Cached device atom; weighted atoms are keyed by the weight's identity+version."""
-        be = get_backend()
-        if self._gdim == 1 and kind == DUDV:
-            kind = STIFF
-        wkey = None if weight is None else (id(weight), weight.version)
-        key = (id(be), kind, da if kind in (DUDV, CONV) else 0, db if kind in (DUDV, CONVT) else 0, wkey)
-        a = self._atoms.get(key)
-        if a is None:
-            if weight is not None:   # drop stale versions of the same weight
-                for k in [k for k in self._atoms if k[0] == id(be) and k[1] == kind and k[4] and k[4][0] == id(weight)]:
-                    stale = self._atoms.pop(k)
-                    _purge_atom(stale)       # the library recycles handle numbers: forget everything keyed by it
-                    be.atom_free(stale)
-            a = be.atom(self.handle(), kind, key[2], key[3], weight.dev() if weight is not None else 0)
-            self._atoms[key] = a
-        return a
+        return self.layout(1).atom(kind, da, db, weight)
 
     def vertex_on_boundary(self):
         """Vertices on exterior facets (facets that belong to exactly one cell)."""
@@ -217,6 +203,85 @@ class Mesh:
                 raise RuntimeError("a sharded mesh must be given its hull mask by its builder")
             self._on_boundary = flag
         return self._on_boundary
+
+
+class DofLayout:
+    """The degrees of freedom of a Lagrange space as the device sees them: node coordinates, cell -> node
+    connectivity (uploaded as a "dof mesh"), and the cache of assembled atoms.
+
+    degree 1: nodes = mesh vertices.  degree 2 (intervals only so far): nodes ordered along the interval,
+    vertex i -> node 2 i, midpoint of cell i -> node 2 i + 1, cell record (v0, v1, mid)."""
+
+    def __init__(self, mesh, degree):
+        self.mesh, self.degree = mesh, int(degree)
+        if self.degree == 1:
+            self.coords, self.cells = mesh.coordinates(), mesh.cells()
+            self.vertex_nodes = None
+        elif self.degree == 2 and mesh.topology().dim() == 1:
+            if mesh.part is not None:
+                raise NotImplementedError("P2 on a sharded mesh")
+            X, C = mesh.coordinates()[:, 0], mesh.cells()
+            if not (np.all(np.diff(X) > 0) and np.array_equal(C[:, 0] + 1, C[:, 1])):
+                raise NotImplementedError("P2 needs an interval mesh with vertices in increasing order")
+            nv = X.size
+            nodes = np.empty(2 * nv - 1)
+            nodes[0::2] = X
+            nodes[1::2] = 0.5 * (X[:-1] + X[1:])
+            self.coords = nodes.reshape(-1, 1)
+            self.cells = np.stack([2 * C[:, 0], 2 * C[:, 1], 2 * C[:, 0] + 1], axis=1).astype(np.int32)
+            self.vertex_nodes = np.arange(0, 2 * nv - 1, 2)
+        else:
+            raise NotImplementedError("Lagrange degree %d on %s cells: P1 everywhere, P2 on intervals "
+                                      "(SURVEY 8(f4))" % (self.degree, mesh.ufl_cell()))
+        self.n = self.coords.shape[0]
+        self._handles, self._atoms = {}, {}
+        self._ones = self._space = None
+
+    @property
+    def part(self):
+        return self.mesh.part
+
+    def owned_range(self):
+        return self.mesh.owned_range() if self.degree == 1 else (0, self.n)
+
+    def on_boundary(self):
+        onb = self.mesh.vertex_on_boundary()
+        if self.vertex_nodes is None:
+            return onb
+        flags = np.zeros(self.n, dtype=bool)
+        flags[self.vertex_nodes] = onb
+        return flags
+
+    def space(self):
+        if self._space is None:
+            self._space = FunctionSpace(self.mesh, "CG", self.degree)
+        return self._space
+
+    def handle(self):
+        be = get_backend()
+        h = self._handles.get(id(be))
+        if h is None:
+            h = be.mesh(self.coords, self.cells)
+            self._handles[id(be)] = h
+        return h
+
+    def atom(self, kind, da=0, db=0, weight=None):
+        """Cached device atom; weighted atoms are keyed by the weight's identity+version."""
+        be = get_backend()
+        if self.mesh.geometry().dim() == 1 and kind == DUDV:
+            kind = STIFF
+        wkey = None if weight is None else (id(weight), weight.version)
+        key = (id(be), kind, da if kind in (DUDV, CONV) else 0, db if kind in (DUDV, CONVT) else 0, wkey)
+        a = self._atoms.get(key)
+        if a is None:
+            if weight is not None:   # drop stale versions of the same weight
+                for k in [k for k in self._atoms if k[0] == id(be) and k[1] == kind and k[4] and k[4][0] == id(weight)]:
+                    stale = self._atoms.pop(k)
+                    _purge_atom(stale)       # the library recycles handle numbers: forget everything keyed by it
+                    be.atom_free(stale)
+            a = be.atom(self.handle(), kind, key[2], key[3], weight.dev() if weight is not None else 0)
+            self._atoms[key] = a
+        return a
 
 
 def IntervalMesh(n, a, b):
@@ -331,19 +396,18 @@ class FunctionSpace:
     def __init__(self, mesh, family="CG", degree=1):
         if str(family) not in ("CG", "P", "Lagrange"):
             raise NotImplementedError("FunctionSpace family %r: only Lagrange ('CG'/'P')" % (family,))
-        if int(degree) != 1:
-            raise NotImplementedError("FunctionSpace degree %r: only P1 is built so far (P2: SURVEY 8(f4))" % (degree,))
         self._mesh = mesh
-        self._element = _Element(mesh.ufl_cell(), 1)
-        n = mesh.num_vertices()
-        # dof -> vertex; self-inverse reversal on intervals, identity otherwise
+        self._lay = mesh.layout(int(degree))       # raises for what is not built (P2 beyond intervals, ...)
+        self._element = _Element(mesh.ufl_cell(), int(degree))
+        n = self._lay.n
+        # dof -> node; self-inverse reversal on intervals (as serial dolfin orders P1 there), identity otherwise
         self._d2v = np.arange(n - 1, -1, -1) if mesh.topology().dim() == 1 else None
 
     def mesh(self):
         return self._mesh
 
     def dim(self):
-        return self._mesh.num_vertices()
+        return self._lay.n
 
     def ufl_element(self):
         return self._element
@@ -355,7 +419,7 @@ class FunctionSpace:
         return _DofMap(self)
 
     def tabulate_dof_coordinates(self):
-        return self.to_dof_order(self._mesh.coordinates())
+        return self.to_dof_order(self._lay.coords)
 
     def to_dof_order(self, a):
         return a if self._d2v is None else a[self._d2v]
@@ -539,7 +603,7 @@ class Vector:
         return self
 
     def inner(self, other):
-        lo, hi = self.V.mesh().owned_range()
+        lo, hi = self.V._lay.owned_range()
         if self._small() and self.V.mesh().part is None:
             return float(self.host() @ other.host())
         return _allreduce_sum(self.V.mesh(), get_backend().vec_dot(self.dev(), other.dev(), lo, hi))
@@ -855,7 +919,8 @@ class Function(Expr):
         return self._V.ufl_element()
 
     def compute_vertex_values(self, mesh=None):
-        return self._vec.host().copy()
+        vn = self._V._lay.vertex_nodes
+        return self._vec.host().copy() if vn is None else self._vec.host()[vn]
 
     def copy(self, deepcopy=False):
         return Function(self._V, self) if deepcopy else self
@@ -882,6 +947,15 @@ class Function(Expr):
 def _point_eval(f, x):
     mesh = f._V.mesh()
     X, cells, vals = mesh.coordinates(), mesh.cells(), f._vec.host()
+    if f._V._lay.degree == 2:
+        # quadratic on intervals: nodes 2 i (vertex i), 2 i + 1 (midpoint of cell i)
+        xs = X[:, 0]
+        if x[0] < xs[0] - 1e-12 or x[0] > xs[-1] + 1e-12:
+            raise RuntimeError("point %r outside the mesh" % (x,))
+        c = int(min(max(np.searchsorted(xs, x[0], side="right") - 1, 0), xs.size - 2))
+        s_ = (x[0] - xs[c]) / (xs[c + 1] - xs[c])
+        N = ((1 - s_) * (1 - 2 * s_), s_ * (2 * s_ - 1), 4 * s_ * (1 - s_))
+        return float(N[0] * vals[2 * c] + N[1] * vals[2 * c + 2] + N[2] * vals[2 * c + 1])
     if mesh.topology().dim() == 1:
         xs = X[:, 0]
         if x[0] < xs.min() - 1e-12 or x[0] > xs.max() + 1e-12:
@@ -1044,13 +1118,12 @@ class Expression(Expr):
             x = tuple(x[0])
         return float(self.eval_at(np.array([[float(v) for v in x]]))[0])
 
-    def as_function(self, mesh):
-        key = (id(mesh), tuple(sorted(self._param_values().items())))
+    def as_function(self, lay):
+        key = (id(lay), tuple(sorted(self._param_values().items())))
         f = self._cache.get(key)
         if f is None:
-            V = _p1_space(mesh)
-            f = Function(V)
-            f._vec._host = self.eval_at(mesh.coordinates())
+            f = Function(lay.space())
+            f._vec._host = self.eval_at(lay.coords)
             f._vec.touched_host()
             self._cache = {key: f}
         return f
@@ -1059,30 +1132,19 @@ class Expression(Expr):
         return [Term(1.0, (Factor(self),))]
 
 
-_P1_SPACES = {}
-
-
-def _p1_space(mesh):
-    V = _P1_SPACES.get(id(mesh))
-    if V is None or V.mesh() is not mesh:
-        V = FunctionSpace(mesh, "CG", 1)
-        _P1_SPACES[id(mesh)] = V
-    return V
-
-
 def interpolate(v, V):
     f = Function(V)
     if isinstance(v, Function):
-        if v._V.mesh() is V.mesh():
+        if v._V._lay is V._lay:
             f._vec.assign_from(v._vec)
         else:
-            f._vec._host = np.array([v(x) for x in V.mesh().coordinates()])
+            f._vec._host = np.array([v(x) for x in V._lay.coords])
             f._vec.touched_host()
     elif isinstance(v, Expression):
         if v.is_constant():
             f._vec.fill(v.eval_at(np.zeros((1, V.mesh().geometry().dim())))[0])
         else:
-            f._vec._host = v.eval_at(V.mesh().coordinates())
+            f._vec._host = v.eval_at(V._lay.coords)
             f._vec.touched_host()
     elif isinstance(v, (Constant, numbers.Real)):
         f._vec.fill(float(v))
@@ -1106,13 +1168,13 @@ class SubDomain:
         raise NotImplementedError("MeshFunction marking (SURVEY 8(f4))")
 
 
-def _eval_marker(marker, mesh):
+def _eval_marker(marker, lay):
     """Vertices selected by a dolfin-style marker ``f(x, on_boundary)``.
 
     First tried vectorised (x[k] are coordinate arrays), which numpy-friendly
     markers accept; otherwise vertex by vertex as dolfin does."""
     fn = marker.inside if isinstance(marker, SubDomain) else marker
-    X, onb = mesh.coordinates(), mesh.vertex_on_boundary()
+    X, onb = lay.coords, lay.on_boundary()
     try:
         res = fn([X[:, k] for k in range(X.shape[1])], onb)
         res = np.asarray(res)
@@ -1128,12 +1190,12 @@ class DirichletBC:
         if tag is not None:
             raise NotImplementedError("DirichletBC(V, g, meshfunction, tag) (SURVEY 8(f4))")
         self._V, self._value = V, value
-        mask = _eval_marker(marker, V.mesh())
+        mask = _eval_marker(marker, V._lay)
         self._vertices = np.where(mask)[0].astype(np.int32)
         self._vals = self._values_at(self._vertices)
 
     def _values_at(self, verts):
-        g, X = self._value, self._V.mesh().coordinates()
+        g, X = self._value, self._V._lay.coords
         if isinstance(g, (numbers.Real, Constant)):
             return np.full(verts.size, float(g))
         if isinstance(g, Expression):
@@ -1203,31 +1265,33 @@ class _AtomRef:
         self.coef, self.kind, self.da, self.db, self.weight = coef, kind, da, db, weight
 
 
-def _coef_vec(leaf, mesh):
-    """Device-resident P1 representation of a coefficient leaf on `mesh`."""
+def _coef_vec(leaf, lay):
+    """Device-resident nodal representation of a coefficient leaf in the layout of the integral."""
     if isinstance(leaf, Function):
-        if leaf._V.mesh() is not mesh:
-            raise ValueError("coefficient lives on a different mesh than the integral")
+        if leaf._V._lay is not lay:
+            if leaf._V.lay() is not lay.lay:
+                raise ValueError("coefficient lives on a different lay than the integral")
+            raise NotImplementedError("mixing Lagrange degrees in one integrand")
         return leaf._vec
     if isinstance(leaf, Expression):
-        return leaf.as_function(mesh)._vec
+        return leaf.as_function(lay)._vec
     raise TypeError("unsupported coefficient %r" % (type(leaf),))
 
 
-def _atom_for(test, trial, weights, mesh):
+def _atom_for(test, trial, weights, lay):
     """Map (test factor, trial factor, extra undifferentiated weights) to an atom."""
     if test.deriv == "grad" or trial.deriv == "grad":
         raise AssertionError("grad factors are handled by the caller")
     if len(weights) > 1:
         raise NotImplementedError("more than one weight function in one integrand")
-    w = _coef_vec(weights[0].leaf, mesh) if weights else None
+    w = _coef_vec(weights[0].leaf, lay) if weights else None
     if weights and weights[0].deriv is not None:
         raise NotImplementedError("differentiated weight function")
     dt, du = test.deriv, trial.deriv
     if dt is None and du is None:
         return (WMASS, 0, 0, w) if w is not None else (MASS, 0, 0, None)
     if w is not None:
-        if dt is not None and du is not None and mesh.topology().dim() == 1:
+        if dt is not None and du is not None and lay.mesh.topology().dim() == 1:
             return (WSTIFF, 0, 0, w)
         raise NotImplementedError("weighted derivative atoms beyond w u' v' in 1-D")
     if dt is not None and du is not None:
@@ -1237,7 +1301,15 @@ def _atom_for(test, trial, weights, mesh):
     return (CONVT, 0, dt, None)
 
 
-def _classify(term, mesh):
+def _weight_last(plain, lay):
+    """Order undifferentiated coefficients so that the one best suited as the atom's weight comes last:
+    an Expression (fixed data) before anything else, then the vector that changes least often."""
+    def key(c):
+        return (1 if isinstance(c.leaf, Expression) else 0, -_coef_vec(c.leaf, lay).version)
+    return sorted(plain, key=key)
+
+
+def _classify(term, lay):
     """Split a Term into (test factor, trial factor, coefficient factors, graddot factor)."""
     test = trial = gd = None
     coefs = []
@@ -1272,7 +1344,7 @@ def _purge_atom(atom):
         del _SCALAR_MEMO[k]
 
 
-def _matvec_cached(mesh, atom, g):
+def _matvec_cached(lay, atom, g):
     """A g as a Vector; cached while g is unchanged (stored modes and loads never change)."""
     key = (atom, id(g))
     hit = _MV_CACHE.get(key)
@@ -1280,8 +1352,8 @@ def _matvec_cached(mesh, atom, g):
         return hit[1]
     be = get_backend()
     out = Vector(g.V)
-    _halo(mesh, g)
-    lo, hi = mesh.owned_range()
+    _halo(lay, g)
+    lo, hi = lay.owned_range()
     be.spmv(atom, g.dev(), out.dev_for_write(), lo, hi)
     out.touched_dev()
     if len(_MV_CACHE) > 4096:
@@ -1290,9 +1362,9 @@ def _matvec_cached(mesh, atom, g):
     return out
 
 
-def _halo(mesh, vec):
-    if mesh.part is not None:
-        mesh.part.comm.halo_exchange(mesh, vec)
+def _halo(lay, vec):
+    if lay.part is not None:
+        lay.part.comm.halo_exchange(lay.mesh, vec)
 
 
 _SYMMETRIC_KINDS = (MASS, STIFF, WMASS, WSTIFF)
@@ -1305,7 +1377,7 @@ def _cached_product(atom, v):
     return None
 
 
-def _bilinear_scalar(mesh, atom, f, g, symmetric=False):
+def _bilinear_scalar(lay, atom, f, g, symmetric=False):
     """f^T A g with memoisation on (atom, vector identity, vector version).
 
     When A g (or, for a symmetric atom, A f) is already cached - stored modes and loads never
@@ -1316,33 +1388,33 @@ def _bilinear_scalar(mesh, atom, f, g, symmetric=False):
     if hit is not None and hit[1] is f and hit[2] is g:
         return hit[0]
     be = get_backend()
-    lo, hi = mesh.owned_range()
+    lo, hi = lay.owned_range()
     Ag = _cached_product(atom, g)
     other = f
     if Ag is None and symmetric and f is not g:
         Ag, other = _cached_product(atom, f), g
-    if Ag is not None and not (Ag._small() and mesh.part is None):
-        val = _allreduce_sum(mesh, be.vec_dot(other.dev(), Ag.dev(), lo, hi))
+    if Ag is not None and not (Ag._small() and lay.part is None):
+        val = _allreduce_sum(lay.mesh, be.vec_dot(other.dev(), Ag.dev(), lo, hi))
     elif Ag is not None:
         val = float(other.host() @ Ag.host())
     else:
-        _halo(mesh, g)
-        val = _allreduce_sum(mesh, be.bilinear(atom, f.dev(), g.dev(), lo, hi))
+        _halo(lay, g)
+        val = _allreduce_sum(lay.mesh, be.bilinear(atom, f.dev(), g.dev(), lo, hi))
     if len(_SCALAR_MEMO) > _SCALAR_MEMO_MAX:
         _SCALAR_MEMO.clear()
     _SCALAR_MEMO[key] = (val, f, g)
     return val
 
 
-def _ones(mesh):
-    if mesh._ones is None:
-        v = Vector(_p1_space(mesh), np.ones(mesh.num_vertices()))
-        mesh._ones = v
-    return mesh._ones
+def _ones(lay):
+    if lay._ones is None:
+        v = Vector(lay.space(), np.ones(lay.n))
+        lay._ones = v
+    return lay._ones
 
 
-def _term_scalar(term, mesh):
-    test, trial, coefs, gd = _classify(term, mesh)
+def _term_scalar(term, lay):
+    test, trial, coefs, gd = _classify(term, lay)
     if test is not None or trial is not None:
         raise ValueError("scalar assemble of a form with arguments")
     if gd is not None:
@@ -1350,34 +1422,36 @@ def _term_scalar(term, mesh):
             raise ValueError("scalar assemble of a form with arguments")
         if len(coefs) > 1:
             raise NotImplementedError("weighted inner(grad, grad) functional with several weights")
-        f, g = _coef_vec(gd.leaf, mesh), _coef_vec(gd.other, mesh)
+        f, g = _coef_vec(gd.leaf, lay), _coef_vec(gd.other, lay)
         if coefs:
-            atom = mesh.atom(WSTIFF, 0, 0, _coef_vec(coefs[0].leaf, mesh))
+            atom = lay.atom(WSTIFF, 0, 0, _coef_vec(coefs[0].leaf, lay))
         else:
-            atom = mesh.atom(STIFF)
-        return term.coef * _bilinear_scalar(mesh, atom, f, g, symmetric=True)
+            atom = lay.atom(STIFF)
+        return term.coef * _bilinear_scalar(lay, atom, f, g, symmetric=True)
     if len(coefs) == 0:
-        one = _ones(mesh)
-        return term.coef * _bilinear_scalar(mesh, mesh.atom(MASS), one, one)
+        one = _ones(lay)
+        return term.coef * _bilinear_scalar(lay, lay.atom(MASS), one, one)
     if len(coefs) == 1:
         c = coefs[0]
-        kind, da, db, w = _atom_for(Factor(None, None), Factor(None, c.deriv), [], mesh)
-        return term.coef * _bilinear_scalar(mesh, mesh.atom(kind, da, db, w), _ones(mesh), _coef_vec(c.leaf, mesh))
+        kind, da, db, w = _atom_for(Factor(None, None), Factor(None, c.deriv), [], lay)
+        return term.coef * _bilinear_scalar(lay, lay.atom(kind, da, db, w), _ones(lay), _coef_vec(c.leaf, lay))
     # f (test side) is the first factor, g (trial side) the second, further undifferentiated ones weight
     der = [c for c in coefs if c.deriv is not None]
     plain = [c for c in coefs if c.deriv is None]
     if len(der) > 2:
         raise NotImplementedError("more than two differentiated factors in a functional")
+    if len(der) + len(plain) > 2:
+        plain = _weight_last(plain, lay)
     ordered = der + plain
     f, g, rest = ordered[0], ordered[1], ordered[2:]
-    kind, da, db, w = _atom_for(Factor(None, f.deriv), Factor(None, g.deriv), rest, mesh)
-    return term.coef * _bilinear_scalar(mesh, mesh.atom(kind, da, db, w), _coef_vec(f.leaf, mesh), _coef_vec(g.leaf, mesh),
+    kind, da, db, w = _atom_for(Factor(None, f.deriv), Factor(None, g.deriv), rest, lay)
+    return term.coef * _bilinear_scalar(lay, lay.atom(kind, da, db, w), _coef_vec(f.leaf, lay), _coef_vec(g.leaf, lay),
                                         symmetric=kind in _SYMMETRIC_KINDS or (kind == DUDV and da == db))
 
 
-def _term_vector(term, mesh):
+def _term_vector(term, lay):
     """(coef, atom handle, coefficient Vector g) with  b += coef * A g."""
-    test, trial, coefs, gd = _classify(term, mesh)
+    test, trial, coefs, gd = _classify(term, lay)
     if trial is not None:
         raise ValueError("linear form with a trial function")
     if gd is not None:
@@ -1390,27 +1464,27 @@ def _term_vector(term, mesh):
             raise ValueError("two test functions in one integrand")
         if len(coefs) > 1:
             raise NotImplementedError("several weights on inner(grad, grad)")
-        atom = mesh.atom(WSTIFF, 0, 0, _coef_vec(coefs[0].leaf, mesh)) if coefs else mesh.atom(STIFF)
-        return term.coef, atom, _coef_vec(b, mesh)
+        atom = lay.atom(WSTIFF, 0, 0, _coef_vec(coefs[0].leaf, lay)) if coefs else lay.atom(STIFF)
+        return term.coef, atom, _coef_vec(b, lay)
     if test is None:
         raise ValueError("linear form without a test function")
     if not coefs:
-        return term.coef, mesh.atom(MASS), _ones(mesh)
+        return term.coef, lay.atom(MASS), _ones(lay)
     der = [c for c in coefs if c.deriv is not None]
     plain = [c for c in coefs if c.deriv is None]
     if len(der) > 1:
         raise NotImplementedError("two differentiated coefficients in a linear form")
-    if not der and len(plain) == 2:
-        # w g v is symmetric in (w, g): weight the atom with the coefficient that changes less often
-        plain.sort(key=lambda c: -_coef_vec(c.leaf, mesh).version)
+    if len(der) + len(plain) > 1:
+        # w g v is symmetric in (w, g): weight the atom with fixed data / the coefficient that changes less often
+        plain = _weight_last(plain, lay)
     ordered = der + plain
     g, rest = ordered[0], ordered[1:]
-    kind, da, db, w = _atom_for(test, Factor(None, g.deriv), rest, mesh)
-    return term.coef, mesh.atom(kind, da, db, w), _coef_vec(g.leaf, mesh)
+    kind, da, db, w = _atom_for(test, Factor(None, g.deriv), rest, lay)
+    return term.coef, lay.atom(kind, da, db, w), _coef_vec(g.leaf, lay)
 
 
-def _term_matrix(term, mesh):
-    test, trial, coefs, gd = _classify(term, mesh)
+def _term_matrix(term, lay):
+    test, trial, coefs, gd = _classify(term, lay)
     if gd is not None:
         a, b = gd.leaf, gd.other
         if not (isinstance(a, Argument) and isinstance(b, Argument) and {a.number, b.number} == {0, 1}):
@@ -1419,11 +1493,11 @@ def _term_matrix(term, mesh):
             raise ValueError("too many arguments in one integrand")
         if len(coefs) > 1 or (coefs and coefs[0].deriv is not None):
             raise NotImplementedError("several / differentiated weights on inner(grad, grad)")
-        w = _coef_vec(coefs[0].leaf, mesh) if coefs else None
+        w = _coef_vec(coefs[0].leaf, lay) if coefs else None
         return _AtomRef(term.coef, WSTIFF if w is not None else STIFF, 0, 0, w)
     if test is None or trial is None:
         raise ValueError("bilinear form needs a trial and a test function")
-    kind, da, db, w = _atom_for(test, trial, coefs, mesh)
+    kind, da, db, w = _atom_for(test, trial, coefs, lay)
     return _AtomRef(term.coef, kind, da, db, w)
 
 
@@ -1435,7 +1509,7 @@ class Matrix:
     """sum_t c_t A_t on one mesh, optionally with Dirichlet rows/columns eliminated."""
 
     def __init__(self, V, refs):
-        self.V, self.refs = V, refs
+        self.V, self.refs, self.lay = V, refs, V._lay
         self.bc_vertices = np.zeros(0, dtype=np.int32)
         self._op = 0
 
@@ -1451,29 +1525,40 @@ class Matrix:
 
     def merged(self):
         """Atoms with equal keys summed: (handles, coefs)."""
-        mesh, acc = self.mesh(), {}
+        acc = {}
         for r in self.refs:
-            h = mesh.atom(r.kind, r.da, r.db, r.weight)
+            h = self.lay.atom(r.kind, r.da, r.db, r.weight)
             acc[h] = acc.get(h, 0.0) + r.coef
         return list(acc), [acc[h] for h in acc]
 
     def op(self, reuse=0):
         handles, coefs = self.merged()
-        return get_backend().combine(self.mesh().handle(), handles, coefs, self.bc_vertices, reuse)
+        return get_backend().combine(self.lay.handle(), handles, coefs, self.bc_vertices, reuse)
 
     def array(self):
         """Dense copy in dof order (small systems / tests only)."""
-        be, mesh = get_backend(), self.mesh()
+        be = get_backend()
         op = self.op()
-        rp, cols = be.mesh_pattern(mesh.handle())
+        rp, cols = be.mesh_pattern(self.lay.handle())
         vals = be.atom_values(op, cols.size)
         be.atom_free(op)
-        n = mesh.num_vertices()
+        n = self.lay.n
         A = np.zeros((n, n))
         rows = np.repeat(np.arange(n), np.diff(rp))
         A[rows, cols] = vals
         p = vertex_to_dof_map(self.V)
         return A[np.ix_(p, p)]
+
+
+def _integral_layout(term, mesh):
+    """Layout (mesh + Lagrange degree) an integrand lives in: that of its functions / arguments on the
+    integration mesh; pure-Expression integrands are P1."""
+    for f in term.factors:
+        for leaf in (f.leaf, f.other):
+            V = getattr(leaf, "_V", None)
+            if V is not None and V.mesh() is mesh:
+                return V._lay
+    return mesh.layout(1)
 
 
 def assemble(form, tensor=None, **kw):
@@ -1485,15 +1570,15 @@ def assemble(form, tensor=None, **kw):
         total = 0.0
         for t, m in form.integrals:
             mesh = m.mesh if m.mesh is not None else Form([(t, m)]).mesh()
-            total += _term_scalar(t, mesh)
+            total += _term_scalar(t, _integral_layout(t, mesh))
         return total
     mesh = form.mesh()
     V = _argument_space(form, 0)
     if rank == 1:
         out = AssembledVector(V)
-        _assemble_vector_into(form, mesh, out)
+        _assemble_vector_into(form, V._lay, out)
         return out
-    return Matrix(V, [_term_matrix(t, m.mesh or mesh) for t, m in form.integrals])
+    return Matrix(V, [_term_matrix(t, V._lay) for t, m in form.integrals])
 
 
 def _argument_space(form, number):
@@ -1505,9 +1590,9 @@ def _argument_space(form, number):
     raise ValueError("form has no argument %d" % number)
 
 
-def _assemble_vector_into(form, mesh, out):
+def _assemble_vector_into(form, lay, out):
     """out = sum_s c_s A_s g_s.  Small systems on the host mirror, large ones by axpy on the device."""
-    pieces = [_term_vector(t, m.mesh or mesh) for t, m in form.integrals]
+    pieces = [_term_vector(t, lay) for t, m in form.integrals]
     merged = {}
     for c, atom, g in pieces:
         key = (atom, id(g))
@@ -1516,10 +1601,10 @@ def _assemble_vector_into(form, mesh, out):
         else:
             merged[key] = [c, atom, g]
     be = get_backend()
-    if out._small() and mesh.part is None:
+    if out._small() and lay.part is None:
         acc = np.zeros(out.n)
         for c, atom, g in merged.values():
-            acc += c * _matvec_cached(mesh, atom, g).host()
+            acc += c * _matvec_cached(lay, atom, g).host()
         out._host = acc
         out.touched_host()
         return
@@ -1527,7 +1612,7 @@ def _assemble_vector_into(form, mesh, out):
     out.touched_dev()
     for c, atom, g in merged.values():
         if c != 0.0:
-            be.vec_axpy(out.dev(), c, _matvec_cached(mesh, atom, g).dev())
+            be.vec_axpy(out.dev(), c, _matvec_cached(lay, atom, g).dev())
     out.touched_dev()
 
 
@@ -1536,7 +1621,7 @@ def norm(f, norm_type="L2", mesh=None):
     if isinstance(f, Vector):
         return f.norm("l2")
     kind = norm_type.lower()
-    m = f._V.mesh()
+    m = f._V._lay
     if kind == "l2":
         return math.sqrt(abs(_bilinear_scalar(m, m.atom(MASS), f._vec, f._vec)))
     if kind in ("h10", "h1"):
@@ -1596,7 +1681,7 @@ def _solve_linear(A, b, x, prm):
     use Jacobi-PCG with `relative_tolerance` (default 1e-10) from the settings."""
     be, mesh = get_backend(), A.mesh()
     method = str(prm.get("linear_solver", "default"))
-    n = mesh.num_vertices()
+    n = A.lay.n
     op = A.op()
     info = {}
     try:
@@ -1636,14 +1721,13 @@ def _apply_bcs_system(A, b, bcs):
     verts, vals = _bc_vertices(bcs)
     if verts.size == 0:
         return
-    mesh = A.mesh()
     if np.any(vals):
         g = Vector(A.V)
         g.host()[verts] = vals
         g.touched_host()
         handles, coefs = A.merged()
         for h, c in zip(handles, coefs):
-            b.axpy(-c, _matvec_cached(mesh, h, g))
+            b.axpy(-c, _matvec_cached(A.lay, h, g))
     for bc in _bc_list(bcs):
         A.apply_dirichlet(bc)
     tmp = DirichletBC.__new__(DirichletBC)

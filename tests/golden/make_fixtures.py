@@ -149,7 +149,42 @@ def heat1d_fixture():
     return out
 
 
+def elastic_fixture():
+    """The reference's tests/integration/test_elastic.py, loaded as is: P2 spaces, default Newton
+    solver, its analytic full-order model and its two PGDErrorComputation checks."""
+    import contextlib
+    import importlib.util
+    import io
+    import logging
+    from pgdrome.model import PGDErrorComputation as RefErr
+    spec = importlib.util.spec_from_file_location("ref_test_elastic", "/root/reference/tests/integration/test_elastic.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    logging.disable(logging.CRITICAL)
+    with contextlib.redirect_stdout(io.StringIO()):
+        meshes, vs = mod.create_meshes([113, 2, 100], [2, 2, 2], [[0, 1], [-1.0, 3.0], [0.2, 2.0]])
+        sol = mod.main(vs, writeFlag=False, name="fixture")
+    logging.disable(logging.NOTSET)
+    p = sol.problem
+    err = RefErr(fixed_dim=[0], n_samples=10, FOM_model=mod.FOM_solution(meshes=meshes, x=meshes[0].coordinates()),
+                 PGD_model=sol)
+    e, mean_e, max_e = err.evaluate_error()
+    err3 = RefErr(fixed_dim=[0], FOM_model=mod.FOM_solution(meshes=meshes, x=np.array([0.5])), PGD_model=sol,
+                  data_test=[[2.0, 1.5], [1.0, 1.0]], fixed_var=[0.5])
+    e3, mean3, max3 = err3.evaluate_error()
+    print("elastic ->", p.PGD_modes, "modes, fp", p.num_fp_it, "mean err", mean_e, "point err", mean3)
+    return {"PGD_modes": int(p.PGD_modes), "num_fp_it": [int(v) for v in p.num_fp_it],
+            "amplitude": [float(a) for a in p.amplitude], "alpha": [float(a) for a in p.alpha],
+            "dims": [V.dim() for V in vs], "errors": e.tolist(), "mean_error": float(mean_e), "max_error": float(max_e),
+            "point_errors": e3.tolist(), "mean_point_error": float(mean3),
+            "modes_vertex_values": [[f.compute_vertex_values().tolist() for f in p.PGD_func[d]] for d in range(3)]}
+
+
 def main():
+    with open(os.path.join(HERE, "reference_elastic.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_fixtures.py",
+                   "source": "reference tests/integration/test_elastic.py run unchanged (main + its error checks)",
+                   "arithmetic": "oracle numpy backend (FEniCS absent)", "run": elastic_fixture()}, f)
     with open(os.path.join(HERE, "reference_heat1d.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_fixtures.py",
                    "source": "reference tests/integration/test_heat1D.py run unchanged (create_PGD, heating case)",

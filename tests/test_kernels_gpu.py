@@ -229,6 +229,30 @@ def test_vector_ops(ctx):
         ctx.vec_free(yv)
 
 
+@pytest.mark.parametrize("kind", ["mass", "stiff", "conv", "convt", "wmass", "wstiff"])
+def test_p2_interval_atoms_match_oracle(ctx, kind):
+    """Quadratic elements on a non-uniform interval mesh: pattern bit-exact, values to rounding."""
+    rng = np.random.default_rng(4)
+    x = np.sort(np.concatenate([[0.0, 3.0], rng.uniform(0, 3, 37)]))
+    coords, cells = x.reshape(-1, 1), np.stack([np.arange(38), np.arange(1, 39)], axis=1).astype(np.int32)
+    nodes, tab = F.p2_interval_nodes(coords, cells)
+    h = ctx.mesh_upload(nodes, tab)
+    rp, cols = ctx.mesh_pattern(h)
+    rp_o, cols_o = F.csr_pattern(nodes.shape[0], tab)
+    assert np.array_equal(rp, rp_o) and np.array_equal(cols, cols_o)
+    assert ctx.mesh_info(h)["kl"] == 2 and ctx.mesh_info(h)["ku"] == 2
+    k = F.KIND_NAMES.index(kind)
+    w, wv = None, 0
+    if kind in ("wmass", "wstiff"):
+        w = 1.0 + nodes[:, 0] ** 2
+        wv = ctx.vec_from(w)
+    a = ctx.atom_assemble(h, k, 0, 0, wv)
+    ref = F.assemble_atom(nodes, tab, k, 0, 0, w)
+    vals = ctx.atom_download(a, ref.nnz)
+    assert np.abs(vals - ref.data).max() <= 1e-13 * np.abs(ref.data).max()
+    ctx.mesh_free(h)
+
+
 def test_lincomb(ctx):
     """y = sum_k c_k x_k (online reconstruction): exact against the same fma chain in numpy order."""
     rng = np.random.default_rng(17)

@@ -140,3 +140,22 @@ def test_online_evaluation_runs_on_the_device():
     ref = sum(c[k] * p.PGD_func[0][k].compute_vertex_values() for k in range(3))
     assert np.linalg.norm(u.compute_vertex_values() - ref) <= 1e-13 * np.linalg.norm(ref)
     assert sol.evaluate_max(0, [1], [4.2], 0) > 0
+
+
+def test_reference_elastic_integration_case_p2_on_gpu():
+    """tests/integration/test_elastic.py of the reference on the HIP engine (P2 interval kernel, Newton-type
+    solve, banded LU): exactly one mode, and the reference test's own ANALYTIC assertions."""
+    import json, os
+    from pgdrome_amd.model import PGDErrorComputation
+    from tests import elastic_problem
+    prob, sol, mean_e, max_e, mean_pt = elastic_problem.run_and_check(fem, PGDProblem, PGDErrorComputation)
+    assert prob.PGD_modes == 1
+    assert mean_e < 1e-4            # test_elastic.py:353
+    assert mean_pt < 1e-5           # test_elastic.py:380
+    with open(os.path.join(pgd_cases.GOLDEN, "reference_elastic.json")) as f:
+        ref = json.load(f)["run"]
+    assert [int(v) for v in prob.num_fp_it] == ref["num_fp_it"]
+    np.testing.assert_allclose(prob.alpha, ref["alpha"], rtol=1e-7)
+    for d in range(3):
+        r = np.array(ref["modes_vertex_values"][d][0])
+        assert np.linalg.norm(prob.PGD_func[d][0].compute_vertex_values() - r) <= 1e-6 * np.linalg.norm(r)

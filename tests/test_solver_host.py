@@ -80,8 +80,11 @@ def test_form_algebra_and_assemble_ranks():
     l += f * v * fem.dx(mesh)
     l += -(g * v * fem.dx(mesh))
     assert np.isclose(fem.assemble(l)[:].sum(), 2.0 - 1.0)
+    assert fem.FunctionSpace(mesh, "CG", 2).dim() == 21            # P2 on intervals is built
     with pytest.raises(NotImplementedError):
-        fem.FunctionSpace(mesh, "CG", 2)
+        fem.FunctionSpace(mesh, "CG", 3)
+    with pytest.raises(NotImplementedError):
+        fem.FunctionSpace(fem.UnitSquareMesh(2, 2), "CG", 2)
 
 
 def test_expression_dialect():
@@ -171,3 +174,41 @@ def test_reference_heat1d_integration_case(variant):
         for m in range(p.PGD_modes):
             r = np.array(ref["modes_vertex_values"][d][m])
             assert np.linalg.norm(p.PGD_func[d][m].compute_vertex_values() - r) <= 1e-6 * np.linalg.norm(r)
+
+
+def test_reference_elastic_integration_case_p2():
+    """tests/integration/test_elastic.py of the reference: quadratic elements, Newton-type solver,
+    'stiff' normalisation.  Pins: converges in exactly ONE mode (the reference's docstring, :15),
+    mean error against the ANALYTIC solution < 1e-4 and point error < 1e-5 (its assertions :353, :380),
+    and the numbers of the reference's own run of that test (fixture)."""
+    import json, os
+    from pgdrome_amd.model import PGDErrorComputation
+    from pgdrome_amd.solver import PGDProblem
+    from tests import elastic_problem
+    prob, sol, mean_e, max_e, mean_pt = elastic_problem.run_and_check(fem, PGDProblem, PGDErrorComputation)
+    assert prob.PGD_modes == 1 and mean_e < 1e-4 and mean_pt < 1e-5
+    with open(os.path.join(pgd_cases.GOLDEN, "reference_elastic.json")) as f:
+        ref = json.load(f)["run"]
+    assert [V.dim() for V in prob.V] == ref["dims"] == [227, 5, 201]
+    assert prob.PGD_modes == ref["PGD_modes"] and [int(v) for v in prob.num_fp_it] == ref["num_fp_it"]
+    np.testing.assert_allclose(prob.alpha, ref["alpha"], rtol=1e-7)
+    assert abs(mean_e - ref["mean_error"]) <= 1e-6 * ref["mean_error"] + 1e-12
+    for d in range(3):
+        r = np.array(ref["modes_vertex_values"][d][0])
+        assert np.linalg.norm(prob.PGD_func[d][0].compute_vertex_values() - r) <= 1e-6 * np.linalg.norm(r)
+
+
+def test_p2_interval_space_basics():
+    mesh = fem.IntervalMesh(4, 0.0, 2.0)
+    V = fem.FunctionSpace(mesh, "P", 2)
+    assert V.dim() == 9 and np.allclose(np.sort(V.tabulate_dof_coordinates().flatten()), np.linspace(0, 2, 9))
+    f = fem.interpolate(fem.Expression("x[0]*x[0]", degree=2), V)        # quadratics are reproduced exactly
+    assert np.isclose(f(0.3), 0.09) and np.isclose(f(1.9), 3.61) and np.allclose(f.compute_vertex_values(), [0, .25, 1, 2.25, 4])
+    assert np.isclose(fem.assemble(f * fem.dx(mesh)), 8.0 / 3.0)
+    assert np.isclose(fem.assemble(f.dx(0) * f.dx(0) * fem.dx(mesh)), 4.0 * 8.0 / 3.0)
+    assert np.isclose(fem.norm(f) ** 2, 32.0 / 5.0)
+    u, v = fem.TrialFunction(V), fem.TestFunction(V)
+    w = fem.Function(V)
+    fem.solve(u.dx(0) * v.dx(0) * fem.dx(mesh) == fem.Constant(2.0) * v * fem.dx(mesh), w,
+              fem.DirichletBC(V, 0.0, lambda x, on_boundary: on_boundary))
+    assert np.isclose(w(0.7), 0.7 * (2.0 - 0.7))                         # -u'' = 2: u = x (2 - x), exact in P2
