@@ -180,7 +180,41 @@ def elastic_fixture():
             "modes_vertex_values": [[f.compute_vertex_values().tolist() for f in p.PGD_func[d]] for d in range(3)]}
 
 
+def laplace_fixture():
+    """The reference's tests/integration/test_laplace.py, loaded as is: 4-way (x, y, q, u0) problem, all-FEM
+    and all-FD variants through its own create_PGD (setUp data: k 0.5, lx = ly = 3, elements 60/40/200/80)."""
+    import contextlib
+    import importlib.util
+    import io
+    import logging
+    import warnings
+    spec = importlib.util.spec_from_file_location("ref_test_laplace", "/root/reference/tests/integration/test_laplace.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = []
+    logging.disable(logging.CRITICAL)
+    warnings.filterwarnings("ignore")
+    with contextlib.redirect_stdout(io.StringIO()):
+        meshes, vs = mod.create_meshes([60, 40, 200, 80], [1, 1, 1, 1], [[0.0, 3.0], [0.0, 3.0], [0.0, 50.0], [10.0, 50.0]])
+    for typ in ("FEM", "FD"):
+        with contextlib.redirect_stdout(io.StringIO()):
+            sol, prm = mod.create_PGD(param={"k": 0.5, "lx": 3, "ly": 3}, vs=vs, _type=typ)
+        p = sol.problem
+        u = sol.evaluate(0, [1, 2, 3], [1.5, 50, 10], 0)
+        out.append({"variant": typ, "numModes": int(sol.numModes), "num_fp_it": [int(v) for v in p.num_fp_it],
+                    "alpha": [float(a) for a in p.alpha], "amplitude": [float(a) for a in p.amplitude],
+                    "evaluate_y1.5_q50_u10": u.compute_vertex_values().tolist(),
+                    "modes_vertex_values": [[f.compute_vertex_values().tolist() for f in p.PGD_func[d]] for d in range(4)]})
+        print("laplace", typ, "->", sol.numModes, "modes, fp", p.num_fp_it, "alpha", p.alpha)
+    logging.disable(logging.NOTSET)
+    return out
+
+
 def main():
+    with open(os.path.join(HERE, "reference_laplace.json"), "w") as f:
+        json.dump({"generator": "tests/golden/make_fixtures.py",
+                   "source": "reference tests/integration/test_laplace.py run unchanged (create_PGD, FEM and FD)",
+                   "arithmetic": "oracle numpy backend (FEniCS absent)", "runs": laplace_fixture()}, f)
     with open(os.path.join(HERE, "reference_elastic.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_fixtures.py",
                    "source": "reference tests/integration/test_elastic.py run unchanged (main + its error checks)",

@@ -1,0 +1,32 @@
+"""Checks shared by the CPU and GPU runs of the restated reference integration problems."""
+import json
+import os
+
+import numpy as np
+
+from tests import pgd_cases
+
+
+def load(name):
+    with open(os.path.join(pgd_cases.GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def check_laplace(fem, PGDProblem, FD_matrices, variant):
+    """test_laplace.py: exactly ONE mode (the reference's assertion :970-971) in both variants.  All-FEM:
+    iteration count, alpha and modes as in the reference's run.  All-FD: the stop test of the converged
+    iterate is a difference of O(1e6) products at rounding level, so its pass count is not reproducible
+    across summation orders - alpha, the modes and the evaluated field are."""
+    from tests import laplace_problem
+    ref = [r for r in load("reference_laplace.json")["runs"] if r["variant"] == variant][0]
+    p = laplace_problem.run(fem, PGDProblem, FD_matrices, fd=(variant == "FD"))
+    assert p.PGD_modes == ref["numModes"] == 1
+    np.testing.assert_allclose(p.alpha, ref["alpha"], rtol=1e-8)
+    if variant == "FEM":
+        assert [int(v) for v in p.num_fp_it] == ref["num_fp_it"]
+    # the separated mode: factors are fixed only up to scalings that cancel in the product -> compare the field
+    sol = p.return_PGD()
+    u = sol.evaluate(0, [1, 2, 3], [1.5, 50, 10], 0).compute_vertex_values()
+    r = np.array(ref["evaluate_y1.5_q50_u10"])
+    assert np.linalg.norm(u - r) <= 1e-6 * np.linalg.norm(r)
+    return p

@@ -159,3 +159,11 @@ def test_reference_elastic_integration_case_p2_on_gpu():
     for d in range(3):
         r = np.array(ref["modes_vertex_values"][d][0])
         assert np.linalg.norm(prob.PGD_func[d][0].compute_vertex_values() - r) <= 1e-6 * np.linalg.norm(r)
+
+
+@pytest.mark.parametrize("variant", ["FEM", "FD"])
+def test_reference_laplace_integration_case_on_gpu(variant):
+    """tests/integration/test_laplace.py of the reference (4-way, one mode) through the HIP engine."""
+    from pgdrome_amd.solver import FD_matrices
+    from tests import ref_cases
+    ref_cases.check_laplace(fem, PGDProblem, FD_matrices, variant)

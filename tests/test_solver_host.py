@@ -212,3 +212,10 @@ def test_p2_interval_space_basics():
     fem.solve(u.dx(0) * v.dx(0) * fem.dx(mesh) == fem.Constant(2.0) * v * fem.dx(mesh), w,
               fem.DirichletBC(V, 0.0, lambda x, on_boundary: on_boundary))
     assert np.isclose(w(0.7), 0.7 * (2.0 - 0.7))                         # -u'' = 2: u = x (2 - x), exact in P2
+
+
+@pytest.mark.parametrize("variant", ["FEM", "FD"])
+def test_reference_laplace_integration_case(variant):
+    from pgdrome_amd.solver import FD_matrices, PGDProblem
+    from tests import ref_cases
+    ref_cases.check_laplace(fem, PGDProblem, FD_matrices, variant)
