@@ -166,4 +166,4 @@ def test_reference_laplace_integration_case_on_gpu(variant):
     """tests/integration/test_laplace.py of the reference (4-way, one mode) through the HIP engine."""
     from pgdrome_amd.solver import FD_matrices
     from tests import ref_cases
-    ref_cases.check_laplace(fem, PGDProblem, FD_matrices, variant)
+    ref_cases.check_laplace(fem, PGDProblem, FD_matrices, variant, exact_counts=False)
