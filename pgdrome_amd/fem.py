@@ -674,7 +674,7 @@ class Expr:
             if len(t.factors) != 1 or t.factors[0].deriv is not None:
                 raise NotImplementedError(".dx() of a product / second derivative")
             f = t.factors[0]
-            out.append(Term(t.coef, (Factor(f.leaf, int(axes[0])),)))
+            out.append(t.with_factors((Factor(f.leaf, int(axes[0])),)))
         return Poly(out)
 
 
@@ -686,10 +686,25 @@ class Factor:
 
 
 class Term:
-    __slots__ = ("coef", "factors")
+    """coef * prod(factors).  The coefficient is a number times Constant objects that are read when the
+    term is USED, so a form built once follows later ``Constant.assign`` calls (time-stepping loops)."""
+    __slots__ = ("num", "factors", "consts")
 
-    def __init__(self, coef, factors):
-        self.coef, self.factors = float(coef), tuple(factors)
+    def __init__(self, num, factors, consts=()):
+        self.num, self.factors, self.consts = float(num), tuple(factors), tuple(consts)
+
+    @property
+    def coef(self):
+        v = self.num
+        for c in self.consts:
+            v *= c._v
+        return v
+
+    def scaled(self, c):
+        return Term(self.num * c, self.factors, self.consts)
+
+    def with_factors(self, factors):
+        return Term(self.num, factors, self.consts)
 
 
 class Poly(Expr):
@@ -727,11 +742,11 @@ def _as_poly(o):
 
 
 def _pmul(a, b):
-    return [Term(s.coef * t.coef, s.factors + t.factors) for s in a for t in b]
+    return [Term(s.num * t.num, s.factors + t.factors, s.consts + t.consts) for s in a for t in b]
 
 
 def _pscale(a, c):
-    return [Term(t.coef * c, t.factors) for t in a]
+    return [t.scaled(c) for t in a]
 
 
 class Constant(Expr):
@@ -750,7 +765,7 @@ class Constant(Expr):
         return self._v
 
     def _poly(self):
-        return [Term(self._v, ())]
+        return [Term(1.0, (), (self,))]
 
     def __call__(self, *a):
         return self._v
@@ -763,7 +778,7 @@ class Grad:
         p = _as_poly(f)
         if len(p) != 1 or len(p[0].factors) != 1 or p[0].factors[0].deriv is not None:
             raise NotImplementedError("grad() of anything but a plain function")
-        self.coef, self.leaf = p[0].coef, p[0].factors[0].leaf
+        self.num, self.consts, self.leaf = p[0].num, p[0].consts, p[0].factors[0].leaf
 
 
 def grad(f):
@@ -775,7 +790,7 @@ nabla_grad = grad
 
 def inner(a, b):
     if isinstance(a, Grad) and isinstance(b, Grad):
-        return Poly([Term(a.coef * b.coef, (Factor(a.leaf, "grad", b.leaf),))])
+        return Poly([Term(a.num * b.num, (Factor(a.leaf, "grad", b.leaf),), a.consts + b.consts)])
     if isinstance(a, Grad) or isinstance(b, Grad):
         raise NotImplementedError("inner(grad f, g) with a non-gradient g")
     return Poly(_pmul(_as_poly(a), _as_poly(b)))
@@ -822,7 +837,7 @@ class Form:
     __radd__ = __add__
 
     def __neg__(self):
-        return Form([(Term(-t.coef, t.factors), m) for t, m in self.integrals])
+        return Form([(t.scaled(-1.0), m) for t, m in self.integrals])
 
     def __sub__(self, o):
         if isinstance(o, numbers.Real) and o == 0:
@@ -834,7 +849,7 @@ class Form:
 
     def __mul__(self, c):
         c = _as_float(c)
-        return Form([(Term(t.coef * c, t.factors), m) for t, m in self.integrals])
+        return Form([(t.scaled(c), m) for t, m in self.integrals])
 
     __rmul__ = __mul__
 
@@ -1657,8 +1672,23 @@ def derivative(form, u, du=None):
         i = hits[0]
         f = t.factors[i]
         nf = Factor(trial if f.leaf is u else f.leaf, f.deriv, trial if f.other is u else f.other)
-        out.append((Term(t.coef, t.factors[:i] + (nf,) + t.factors[i + 1:]), m))
+        out.append((t.with_factors(t.factors[:i] + (nf,) + t.factors[i + 1:]), m))
     return Form(out)
+
+
+def _has_trial(term):
+    return any((isinstance(f.leaf, Argument) and f.leaf.number == 1) or
+               (isinstance(f.other, Argument) and f.other.number == 1) for f in term.factors)
+
+
+def lhs(form):
+    """Bilinear part of a residual form written with a TrialFunction (dolfin.lhs)."""
+    return Form([(t, m) for t, m in form.integrals if _has_trial(t)])
+
+
+def rhs(form):
+    """Right-hand side of a residual form: minus its linear part (dolfin.rhs)."""
+    return Form([(t.scaled(-1.0), m) for t, m in form.integrals if not _has_trial(t)])
 
 
 class _Params(dict):
