@@ -10,7 +10,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from oracle import fem_numpy as F          # mesh generator only (test infrastructure)
+from pgdrome_amd import fem, sizes
 from pgdrome_amd import _lib
 
 
@@ -19,7 +19,7 @@ def main():
     ctx = _lib.Context(0)
     for n in sizes:
         t0 = time.time()
-        coords, cells = F.box_mesh((0, 0, 0), (1, 1, 1), n - 1, n - 1, n - 1)
+        coords, cells = fem.box_mesh_arrays((0, 0, 0), (1, 1, 1), n - 1, n - 1, n - 1)
         t1 = time.time()
         mesh = ctx.mesh_upload(coords, cells)
         ctx.sync()
@@ -27,18 +27,18 @@ def main():
         info = ctx.mesh_info(mesh)
         nv, nnz = info["nv"], info["nnz"]
         del coords, cells
-        ak = ctx.atom_assemble(mesh, F.STIFF)
-        am = ctx.atom_assemble(mesh, F.MASS)
+        ak = ctx.atom_assemble(mesh, fem.STIFF)
+        am = ctx.atom_assemble(mesh, fem.MASS)
         ctx.sync()
         t3 = time.time()
         op = ctx.op_combine(mesh, [ak, am], [1.0, 1.0])
         ctx.sync()
         t4 = time.time()
-        print(f"n={n}^3 nv={nv} nnz={nnz} (formula {F.nnz_p1_box(n)}) host mesh {t1-t0:.2f}s upload+topology {t2-t1:.2f}s "
+        print(f"n={n}^3 nv={nv} nnz={nnz} (formula {sizes.nnz_p1_box(n)}) host mesh {t1-t0:.2f}s upload+topology {t2-t1:.2f}s "
               f"2 atoms {t3-t2:.3f}s combine {t4-t3:.3f}s", flush=True)
         x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, nv))
         y = ctx.vec_alloc(nv)
-        alg = F.spmv_bytes(nv, nnz)
+        alg = sizes.spmv_bytes(nv, nnz)
         variants = [(64, 0), (64, 1), (128, 1)]
         for rnd in range(3):                      # interleaved rounds in one process
             for var, grid in variants:

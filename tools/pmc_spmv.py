@@ -8,16 +8,16 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from oracle import fem_numpy as F          # mesh generator only
+from pgdrome_amd import fem
 from pgdrome_amd import _lib
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 use_dict = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 ctx = _lib.Context(0)
-coords, cells = F.box_mesh((0, 0, 0), (1, 1, 1), n - 1, n - 1, n - 1)
+coords, cells = fem.box_mesh_arrays((0, 0, 0), (1, 1, 1), n - 1, n - 1, n - 1)
 mesh = ctx.mesh_upload(coords, cells)
 del coords, cells
-ak, am = ctx.atom_assemble(mesh, F.STIFF), ctx.atom_assemble(mesh, F.MASS)
+ak, am = ctx.atom_assemble(mesh, fem.STIFF), ctx.atom_assemble(mesh, fem.MASS)
 op = ctx.op_combine(mesh, [ak, am], [1.0, 1.0])
 nv = ctx.mesh_info(mesh)["nv"]
 x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, nv))
