@@ -190,7 +190,8 @@ int pgd_cg_scalars_slot(pgd_handle ctx, int base, int init, double rtol, double 
 enum {
     PGD_TUNE_SPMV_ROWS = 1,  /* rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256 */
     PGD_TUNE_SPMV_DICT = 2   /* 1 (default): decode column ids from the mesh's relative-pattern
-                                dictionary when it has one (k_spmv_csr_dict); 0: always stream them */
+                                dictionary when it has one (k_spmv_csr_dict16 for rows <= 16 entries, else
+                                k_spmv_csr_dict); 2: dictionary, generic kernel only; 0: always stream them */
 };
 int pgd_tune(pgd_handle ctx, int knob, int64_t value);
 

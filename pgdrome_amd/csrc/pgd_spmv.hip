@@ -182,6 +182,59 @@ __global__ __launch_bounds__(R) void k_spmv_csr_dict(SpmvArgs A, const uint16_t 
     }
 }
 
+// Rows of at most 16 entries (every P1 mesh): the x gathers need only the pattern id, not the staged
+// values, so both memory phases are put in flight together - 8 value loads from HBM and 16 gathers
+// from L1/L2 per lane - and the wave waits once.  Segment bounds come from two uniform loads, so the
+// value stream starts without waiting for the per-lane row pointers.
+template <bool DOT, bool STORE>
+__global__ __launch_bounds__(64) void k_spmv_csr_dict16(SpmvArgs A, const uint16_t *__restrict__ pids,
+                                                        const int *__restrict__ dict_off) {
+    constexpr int R = 64, CAP = 16 * R;
+    if (A.flags && A.flags[0]) return;
+    __shared__ __align__(16) double s_vals[CAP + 2];
+    const int tid = threadIdx.x;
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int r0 = A.row_begin + b * R;
+    const int nr = min(R, A.row_end - r0);
+    const int s = A.row_ptr[r0], e = A.row_ptr[r0 + nr];          // uniform
+    const int sv = s & ~1, nvv = e - sv;
+    d2_t v[SPMV_VROUNDS];
+    const double *gv = A.vals + sv;
+#pragma unroll
+    for (int i = 0; i < SPMV_VROUNDS; ++i) {
+        const int k = (tid + i * R) * 2;
+        v[i] = *reinterpret_cast<const d2_t *>(gv + (k < nvv ? k : 0));
+    }
+    const int row = r0 + (tid < nr ? tid : 0);
+    const int a = A.row_ptr[row], len = (tid < nr) ? A.row_ptr[row + 1] - a : 0;
+    const int *off = dict_off + (int)pids[row] * DICT_DLEN;
+    int oo[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const i4_t o = *reinterpret_cast<const i4_t *>(off + 4 * q);
+        oo[4 * q] = o.x; oo[4 * q + 1] = o.y; oo[4 * q + 2] = o.z; oo[4 * q + 3] = o.w;
+    }
+    double xv[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) xv[k] = A.x[row + (k < len ? oo[k] : 0)];
+#pragma unroll
+    for (int i = 0; i < SPMV_VROUNDS; ++i) *reinterpret_cast<d2_t *>(s_vals + (tid + i * R) * 2) = v[i];
+    __syncthreads();
+    double acc = 0.0;
+    const int base = a - sv;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const double vk = s_vals[base + (k < len ? k : 0)];
+        acc = fma(k < len ? vk : 0.0, xv[k], acc);
+    }
+    if (STORE && tid < nr) A.y[r0 + tid] = acc;
+    if (DOT) {
+        const double t = (tid < nr) ? acc * A.w[r0 + tid] : 0.0;
+        const double sum = wave_sum(t);
+        if (tid == 0) A.partials[b] = sum;
+    }
+}
+
 // out partial[b*ny + m] = sum over the block's rows of x_i (A y_m)_i : one pass
 // over the matrix for up to MAXY stored modes (batched scalar functionals).
 struct SpmvMultiArgs {
@@ -260,7 +313,9 @@ int launch_spmv(Ctx *c, const Mesh *m, const double *vals, const double *x, doub
     const bool use_dict = c->spmv_dict && m->dict_count > 0;
 #define PGD_SPMV_LAUNCH(D, S)                                                                             \
     do {                                                                                                  \
-        if (use_dict) {                                                                                   \
+        if (use_dict && R == 64 && m->max_row <= 16 && c->spmv_dict == 1) {                               \
+            k_spmv_csr_dict16<D, S><<<nblk, 64, 0, c->stream>>>(A, m->pids, m->dict_off);                 \
+        } else if (use_dict) {                                                                            \
             if (R == 256) k_spmv_csr_dict<D, S, 256><<<nblk, 256, 0, c->stream>>>(A, m->pids, m->dict_off);      \
             else if (R == 128) k_spmv_csr_dict<D, S, 128><<<nblk, 128, 0, c->stream>>>(A, m->pids, m->dict_off); \
             else k_spmv_csr_dict<D, S, 64><<<nblk, 64, 0, c->stream>>>(A, m->pids, m->dict_off);                \
@@ -317,7 +372,7 @@ extern "C" {
 int pgd_tune(pgd_handle h, int knob, int64_t value) {
     PGD_CTX(c, h);
     if (knob == PGD_TUNE_SPMV_ROWS && (value == 64 || value == 128 || value == 256)) { c->spmv_rows = (int)value; return PGD_OK; }
-    if (knob == PGD_TUNE_SPMV_DICT && (value == 0 || value == 1)) { c->spmv_dict = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_DICT && value >= 0 && value <= 2) { c->spmv_dict = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }
 

@@ -182,12 +182,13 @@ def test_column_dictionary_is_lossless(ctx):
         out = {}
         for rows in (64, 128, 256):
             ctx.tune(1, rows)
-            for d in (1, 0):
+            for d in (1, 0, 2):
                 ctx.tune(2, d)
                 ctx.spmv(a, xv, y1)
                 out[(rows, d)] = (ctx.vec_download(y1), ctx.bilinear(a, xv, xv, 3, n - 2))
-            assert np.array_equal(out[(rows, 1)][0], out[(rows, 0)][0])
-            assert out[(rows, 1)][1] == out[(rows, 0)][1]
+            for d in (1, 2):
+                assert np.array_equal(out[(rows, d)][0], out[(rows, 0)][0])
+                assert out[(rows, d)][1] == out[(rows, 0)][1]
         ctx.tune(1, 64)
         ctx.tune(2, 1)
         assert np.all(np.abs(out[(64, 1)][0] - K @ x) <= 4e-15 * (np.abs(K) @ np.abs(x)))

@@ -10,7 +10,8 @@ import time
 import numpy as np
 
 sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
-from pgdrome_amd import fem, sizes
+from pgdrome_amd import fem
+from pgdrome_amd import sizes as psizes
 from pgdrome_amd import _lib
 
 
@@ -34,12 +35,12 @@ def main():
         op = ctx.op_combine(mesh, [ak, am], [1.0, 1.0])
         ctx.sync()
         t4 = time.time()
-        print(f"n={n}^3 nv={nv} nnz={nnz} (formula {sizes.nnz_p1_box(n)}) host mesh {t1-t0:.2f}s upload+topology {t2-t1:.2f}s "
+        print(f"n={n}^3 nv={nv} nnz={nnz} (formula {psizes.nnz_p1_box(n)}) host mesh {t1-t0:.2f}s upload+topology {t2-t1:.2f}s "
               f"2 atoms {t3-t2:.3f}s combine {t4-t3:.3f}s", flush=True)
         x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, nv))
         y = ctx.vec_alloc(nv)
-        alg = sizes.spmv_bytes(nv, nnz)
-        variants = [(64, 0), (64, 1), (128, 1)]
+        alg = psizes.spmv_bytes(nv, nnz)
+        variants = [(64, 0), (64, 2), (64, 1)]
         for rnd in range(3):                      # interleaved rounds in one process
             for var, grid in variants:
                 ctx.tune(1, var)
