@@ -151,8 +151,11 @@ def main():
     achieved = prof["bytes"] / prof["seconds"] / 1e9 if prof["seconds"] > 0 else 0.0
     # which form of the CSR product ran: column ids decoded from the mesh's pattern dictionary, or streamed
     patterns = be.ctx.mesh_dict_count(space.handle())
-    spmv_kernel = ("k_spmv_csr_dict<dot,store,64> (%d relative column patterns)" % patterns) if patterns \
-        else "k_spmv_csr<dot,store,64>"
+    max_row = be.ctx.mesh_info(space.handle())["max_row"]
+    spmv_kernel = "k_spmv_csr<dot,store,64>"
+    if patterns:
+        spmv_kernel = ("k_spmv_csr_dict16<dot,store>" if max_row <= 16 else "k_spmv_csr_dict<dot,store,64>") + \
+            " (%d relative column patterns)" % patterns
     out = {
         "metric": "PGD fixed-point iters/sec + SpMV HBM GB/s, 256^3 P1 space x 1D param",
         "value": K / elapsed, "unit": "fixed-point iterations/s", "n_gpus": world, "steps": K, "warmup": W,
