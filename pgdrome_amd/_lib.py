@@ -101,6 +101,7 @@ def load(path: Path | None = None):
         raise RuntimeError(
             f"{p} not found: build the HIP library first (python -m pgdrome_amd.build). "
             "pgdrome_amd has no CPU fallback.")
+    _preload_hip_runtime()
     lib = C.CDLL(str(p))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)      # AttributeError if the header and the library disagree
@@ -109,6 +110,26 @@ def load(path: Path | None = None):
     if path is None:
         _lib = lib
     return lib
+
+
+def _preload_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so; if libpgd_amd.so pulls in
+    the system copy first, a later `import torch` (needed for the RCCL path) finds the device taken and
+    reports "No HIP GPUs are available".  Loading torch's copy first (without importing torch) makes both
+    resolve to the same runtime whatever the import order."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = Path(list(spec.submodule_search_locations)[0]) / "lib" / "libamdhip64.so"
+    if cand.exists():
+        try:
+            C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def dptr(a: np.ndarray):

@@ -102,6 +102,9 @@ __global__ void k_pcg_check(double *__restrict__ slots, int *__restrict__ flags,
     else if (rr <= slots[slot_tol2]) flags[0] = 1;
 }
 
+// V2: two consecutive entries per lane (16-byte loads/stores); needs an even `lo`, the odd tail entry
+// is handled by one extra lane.
+template <bool V2>
 __global__ __launch_bounds__(TPB) void k_pcg_xr(double *__restrict__ x, double *__restrict__ r,
                                                 const double *__restrict__ p, const double *__restrict__ q,
                                                 const double *__restrict__ dinv, double *__restrict__ z, int64_t lo,
@@ -111,26 +114,65 @@ __global__ __launch_bounds__(TPB) void k_pcg_xr(double *__restrict__ x, double *
     __shared__ double s_red[4];
     const double alpha = slots[slot_rz] / slots[slot_pq];
     double rz = 0.0, rr = 0.0;
-    for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB) {
-        x[i] = fma(alpha, p[i], x[i]);
-        const double ri = fma(-alpha, q[i], r[i]), zi = dinv[i] * ri;
-        r[i] = ri; z[i] = zi;
-        rz = fma(ri, zi, rz); rr = fma(ri, ri, rr);
+    if (V2) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const int64_t npair = (hi - lo) >> 1;
+        for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < npair; k += (int64_t)gridDim.x * TPB) {
+            const int64_t i = lo + 2 * k;
+            const d2 pi = *reinterpret_cast<const d2 *>(p + i), qi = *reinterpret_cast<const d2 *>(q + i);
+            const d2 di = *reinterpret_cast<const d2 *>(dinv + i);
+            d2 xi = *reinterpret_cast<d2 *>(x + i), ri = *reinterpret_cast<d2 *>(r + i), zi;
+            xi.x = fma(alpha, pi.x, xi.x); xi.y = fma(alpha, pi.y, xi.y);
+            ri.x = fma(-alpha, qi.x, ri.x); ri.y = fma(-alpha, qi.y, ri.y);
+            zi.x = di.x * ri.x; zi.y = di.y * ri.y;
+            *reinterpret_cast<d2 *>(x + i) = xi;
+            *reinterpret_cast<d2 *>(r + i) = ri;
+            *reinterpret_cast<d2 *>(z + i) = zi;
+            rz = fma(ri.x, zi.x, rz); rz = fma(ri.y, zi.y, rz);
+            rr = fma(ri.x, ri.x, rr); rr = fma(ri.y, ri.y, rr);
+        }
+        if (((hi - lo) & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+            const int64_t i = hi - 1;
+            x[i] = fma(alpha, p[i], x[i]);
+            const double ri = fma(-alpha, q[i], r[i]), zi = dinv[i] * ri;
+            r[i] = ri; z[i] = zi;
+            rz = fma(ri, zi, rz); rr = fma(ri, ri, rr);
+        }
+    } else {
+        for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB) {
+            x[i] = fma(alpha, p[i], x[i]);
+            const double ri = fma(-alpha, q[i], r[i]), zi = dinv[i] * ri;
+            r[i] = ri; z[i] = zi;
+            rz = fma(ri, zi, rz); rr = fma(ri, ri, rr);
+        }
     }
     rz = block_sum(rz, s_red);
     rr = block_sum(rr, s_red);
     if (threadIdx.x == 0) { partials[2 * blockIdx.x] = rz; partials[2 * blockIdx.x + 1] = rr; }
 }
 
+template <bool V2>
 __global__ __launch_bounds__(TPB) void k_pcg_p(double *__restrict__ p, const double *__restrict__ z, int64_t lo,
                                                int64_t hi, const double *__restrict__ slots, int slot_num, int slot_den,
                                                const int *__restrict__ flags) {
     if (flags[0]) return;
     const double beta = slots[slot_num] / slots[slot_den];
-    for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB)
-        p[i] = fma(beta, p[i], z[i]);
+    if (V2) {
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const int64_t npair = (hi - lo) >> 1;
+        for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < npair; k += (int64_t)gridDim.x * TPB) {
+            const int64_t i = lo + 2 * k;
+            const d2 zi = *reinterpret_cast<const d2 *>(z + i);
+            d2 pi = *reinterpret_cast<d2 *>(p + i);
+            pi.x = fma(beta, pi.x, zi.x); pi.y = fma(beta, pi.y, zi.y);
+            *reinterpret_cast<d2 *>(p + i) = pi;
+        }
+        if (((hi - lo) & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[hi - 1] = fma(beta, p[hi - 1], z[hi - 1]);
+    } else {
+        for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB)
+            p[i] = fma(beta, p[i], z[i]);
+    }
 }
-
 
 // ---- single-reduction (Chronopoulos-Gear) form of the same Jacobi-PCG, used by the row-sharded
 // solve: ONE all-reduce per iteration instead of two.  Scalars: S[b+0..4] = (r.u, r.r, w.u interior,
@@ -299,7 +341,13 @@ static int pcg_xr(Ctx *c, double *x, double *r, const double *p, const double *q
                   int64_t lo, int64_t hi, int slot_rz, int slot_pq, int slot_out, int check_mode, int slot_tol2) {
     const int g = grid_for(hi - lo);
     PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS));
-    k_pcg_xr<<<g, TPB, 0, c->stream>>>(x, r, p, q, dinv, z, lo, hi, c->slots, slot_rz, slot_pq, c->partials, c->flags);
+    if ((lo & 1) == 0) {
+        const int g2 = grid_for((hi - lo + 1) / 2);
+        k_pcg_xr<true><<<g2, TPB, 0, c->stream>>>(x, r, p, q, dinv, z, lo, hi, c->slots, slot_rz, slot_pq, c->partials, c->flags);
+        PGD_LAUNCH_CHECK(c);
+        return reduce_partials(c, c->partials, g2, 2, slot_out, check_mode, slot_out + 1, slot_tol2);
+    }
+    k_pcg_xr<false><<<g, TPB, 0, c->stream>>>(x, r, p, q, dinv, z, lo, hi, c->slots, slot_rz, slot_pq, c->partials, c->flags);
     PGD_LAUNCH_CHECK(c);
     return reduce_partials(c, c->partials, g, 2, slot_out, check_mode, slot_out + 1, slot_tol2);
 }
@@ -409,7 +457,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
             PGD_TRY(reduce_partials(c, c->partials, nparts, 1, S_PQ, 0, 0, 0));
             // x, r, z update; the final reduction also runs the convergence test on r.r
             PGD_TRY(pcg_xr(c, x->d, r, p, q, o->dinv, z, 0, n, rz_old, S_PQ, out, 1, S_TOL2));
-            k_pcg_p<<<grid_for(n), TPB, 0, c->stream>>>(p, z, 0, n, c->slots, out, rz_old, c->flags);
+            k_pcg_p<true><<<grid_for((n + 1) / 2), TPB, 0, c->stream>>>(p, z, 0, n, c->slots, out, rz_old, c->flags);
         }
         return PGD_OK;
     };
@@ -536,7 +584,8 @@ int pgd_pcg_p_slot(pgd_handle h, pgd_handle ph, pgd_handle zh, int64_t lo, int64
     Vec *p = get_vec(c, ph), *z = get_vec(c, zh);
     if (!p || !z || p->n != z->n || !range_ok(p->n, lo, hi)) return fail(c, PGD_ERR_INVALID, "pcg_p_slot: invalid arguments");
     if (hi == lo) return PGD_OK;
-    k_pcg_p<<<grid_for(hi - lo), TPB, 0, c->stream>>>(p->d, z->d, lo, hi, c->slots, slot_num, slot_den, c->flags);
+    if ((lo & 1) == 0) k_pcg_p<true><<<grid_for((hi - lo + 1) / 2), TPB, 0, c->stream>>>(p->d, z->d, lo, hi, c->slots, slot_num, slot_den, c->flags);
+    else k_pcg_p<false><<<grid_for(hi - lo), TPB, 0, c->stream>>>(p->d, z->d, lo, hi, c->slots, slot_num, slot_den, c->flags);
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
 }
