@@ -66,8 +66,12 @@ int pgd_device_count(void);
 /* ------------------------------------------------------------------ meshes --- */
 /* Replaces dolfin's Mesh + DofMap + sparsity-pattern build behind
  * FunctionSpace(mesh,"CG",1) (callers: tests/integration/test_heat1D.py:26-40).
- * coords: nv x gdim row-major; cells: nc x nvpc.  P1: nvpc = gdim+1 simplex vertices.  P2 on
- * intervals: gdim = 1, nvpc = 3, nodes = vertices and cell midpoints, cell = (v0, v1, mid).
+ * coords: nv x gdim row-major; cells: nc x nvpc.  P1: nvpc = gdim+1 simplex vertices.  P2
+ * (FunctionSpace(mesh,"CG",2), tests/integration/test_elastic.py:33, test_laplace.py:880):
+ * nvpc = 3 / 6 / 10 for gdim = 1 / 2 / 3; "coords" are the NODES (vertices and edge midpoints),
+ * a cell record = its vertices followed by its edge nodes in the UFC local edge order
+ * (interval: (v0, v1, mid); triangle edges (1,2),(0,2),(0,1); tetrahedron (2,3),(1,3),(1,2),
+ * (0,3),(0,2),(0,1)); straight-sided geometry is taken from the vertices.
  * Builds on the device: vertex->cell adjacency (sorted) and the CSR pattern of
  * "vertices sharing a cell" with sorted columns.                                */
 int pgd_mesh_upload(pgd_handle ctx, const double *coords, int64_t nv, int gdim,

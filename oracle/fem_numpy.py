@@ -149,11 +149,123 @@ def element_matrices_p2_interval(coords, cells, kind, w=None):
     raise ValueError(f"unknown atom kind {kind}")
 
 
+# ---- quadratic Lagrange elements on triangles / tetrahedra: EXACT integration by polynomial algebra in
+# barycentric coordinates (no quadrature): int_K prod l_k^{a_k} = |K| D! prod a_k! / (sum a_k + D)!
+P2_EDGES = {2: ((1, 2), (0, 2), (0, 1)), 3: ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))}   # UFC local edges
+
+
+def _poly_mul(p, q):
+    out = {}
+    for ea, ca in p.items():
+        for eb, cb in q.items():
+            e = tuple(x + y for x, y in zip(ea, eb))
+            out[e] = out.get(e, 0.0) + ca * cb
+    return out
+
+
+def _poly_int(p, D):
+    """Integral over the simplex divided by its volume."""
+    tot = 0.0
+    for e, c in p.items():
+        num = math.factorial(D)
+        for a in e:
+            num *= math.factorial(a)
+        tot += c * num / math.factorial(sum(e) + D)
+    return tot
+
+
+def _p2_basis(D):
+    """P2 shape functions and their lambda-derivatives as polynomials {exponents: coef} in (l_0..l_D):
+    vertex i: l_i (2 l_i - 1); edge (a, b): 4 l_a l_b; node order = vertices, then P2_EDGES[D]."""
+    def mono(*idx):
+        e = [0] * (D + 1)
+        for i in idx:
+            e[i] += 1
+        return tuple(e)
+    N, dN = [], []
+    for i in range(D + 1):
+        N.append({mono(i, i): 2.0, mono(i): -1.0})
+        dN.append([({mono(i): 4.0, mono(): -1.0} if k == i else {}) for k in range(D + 1)])
+    for a, b in P2_EDGES[D]:
+        N.append({mono(a, b): 4.0})
+        dN.append([({mono(b): 4.0} if k == a else {mono(a): 4.0} if k == b else {}) for k in range(D + 1)])
+    return N, dN
+
+
+_P2_REF = {}
+
+
+def _p2_reference_tensors(D):
+    """Per-unit-volume integrals: mass[a,b], dd[a,b,k,l] = I(d_k N_a d_l N_b), nd[a,b,l] = I(N_a d_l N_b),
+    wmass[a,b,c] = I(N_a N_b N_c), wdd[a,b,c,k,l] = I(N_c d_k N_a d_l N_b)."""
+    if D not in _P2_REF:
+        N, dN = _p2_basis(D)
+        nn = len(N)
+        mass = np.zeros((nn, nn)); dd = np.zeros((nn, nn, D + 1, D + 1)); nd = np.zeros((nn, nn, D + 1))
+        wmass = np.zeros((nn, nn, nn)); wdd = np.zeros((nn, nn, nn, D + 1, D + 1))
+        for a in range(nn):
+            for b in range(nn):
+                ab = _poly_mul(N[a], N[b])
+                mass[a, b] = _poly_int(ab, D)
+                for c in range(nn):
+                    wmass[a, b, c] = _poly_int(_poly_mul(ab, N[c]), D)
+                for l in range(D + 1):
+                    if dN[b][l]:
+                        nd[a, b, l] = _poly_int(_poly_mul(N[a], dN[b][l]), D)
+                    for k in range(D + 1):
+                        if dN[a][k] and dN[b][l]:
+                            pk = _poly_mul(dN[a][k], dN[b][l])
+                            dd[a, b, k, l] = _poly_int(pk, D)
+                            for c in range(nn):
+                                wdd[a, b, c, k, l] = _poly_int(_poly_mul(pk, N[c]), D)
+        _P2_REF[D] = (mass, dd, nd, wmass, wdd)
+    return _P2_REF[D]
+
+
+def p2_simplex_nodes(coords, cells):
+    """Nodes of the P2 space on a triangle / tetrahedron mesh: the vertices, then one node per edge
+    (edges numbered by sorted vertex pair); cell record = (vertices..., edge nodes in UFC local order)."""
+    D = coords.shape[1]
+    nv = coords.shape[0]
+    pairs = np.concatenate([np.sort(cells[:, list(e)], axis=1) for e in P2_EDGES[D]], axis=0)
+    uniq, inv = np.unique(pairs, axis=0, return_inverse=True)
+    inv = inv.reshape(len(P2_EDGES[D]), cells.shape[0]).T
+    nodes = np.concatenate([coords, 0.5 * (coords[uniq[:, 0]] + coords[uniq[:, 1]])], axis=0)
+    tab = np.concatenate([cells, nv + inv], axis=1).astype(np.int32)
+    return nodes, tab
+
+
+def element_matrices_p2_simplex(coords, cells, kind, a=0, b=0, w=None):
+    """Local 6x6 / 10x10 matrices of P2 triangles / tetrahedra (row = test i, column = trial j)."""
+    D = coords.shape[1]
+    vol, g = _geometry(coords, cells[:, :D + 1])          # g[c, k, :] = grad lambda_k
+    mass, dd, nd, wmass, wdd = _p2_reference_tensors(D)
+    gg = np.einsum("ckd,cld->ckl", g, g)
+    if kind == MASS:
+        return vol[:, None, None] * mass[None]
+    if kind == STIFF:
+        return vol[:, None, None] * np.einsum("ijkl,ckl->cij", dd, gg)
+    if kind == DUDV:      # trial derivative along a, test derivative along b
+        return vol[:, None, None] * np.einsum("ijkl,ck,cl->cij", dd, g[:, :, b], g[:, :, a])
+    if kind == CONV:      # int u_{,a} v : N_i d_l N_j (grad l_l)_a
+        return vol[:, None, None] * np.einsum("ijl,cl->cij", nd, g[:, :, a])
+    if kind == CONVT:
+        return vol[:, None, None] * np.einsum("jil,cl->cij", nd, g[:, :, b])
+    wl = np.asarray(w, dtype=np.float64)[cells] if w is not None else None
+    if kind == WMASS:
+        return vol[:, None, None] * np.einsum("ijm,cm->cij", wmass, wl)
+    if kind == WSTIFF:
+        return vol[:, None, None] * np.einsum("ijmkl,cm,ckl->cij", wdd, wl, gg)
+    raise ValueError(f"unknown atom kind {kind}")
+
+
 def element_matrices(coords, cells, kind, a=0, b=0, w=None):
-    """Local matrices, row = test index i, column = trial index j (P1 simplices, or P2 intervals when
-    the cell records carry three nodes on a 1-D mesh)."""
+    """Local matrices, row = test index i, column = trial index j: P1 simplices; P2 intervals (three nodes
+    per cell on a 1-D mesh); P2 triangles / tetrahedra (6 / 10 nodes per cell)."""
     if coords.shape[1] == 1 and cells.shape[1] == 3:
         return element_matrices_p2_interval(coords, cells, kind, w)
+    if (coords.shape[1], cells.shape[1]) in ((2, 6), (3, 10)):
+        return element_matrices_p2_simplex(coords, cells, kind, a, b, w)
     vol, g = _geometry(coords, cells)
     nc, nv, D = g.shape
     if kind == MASS:

@@ -45,7 +45,8 @@ struct Mesh : Obj {
     int gdim = 0, nvpc = 0;
     int64_t nv = 0, nc = 0, nnz = 0;
     double *coords = nullptr;   // SoA: gdim arrays of nv doubles (coalesced per component)
-    int4 *cells = nullptr;      // one 16-byte record per cell, unused lanes = -1
+    int4 *cells = nullptr;      // one 16-byte record per cell, unused lanes = -1 (cells of <= 4 nodes)
+    int *cellsN = nullptr;      // flat records of nvpc nodes (P2 triangles: 6, P2 tetrahedra: 10)
     int *v2c_ptr = nullptr;     // nv+1
     int *v2c = nullptr;         // nc*nvpc, sorted per vertex
     int *row_ptr = nullptr;     // nv+1
@@ -58,7 +59,7 @@ struct Mesh : Obj {
     int *dict_off = nullptr;     // dict_count x DICT_DLEN relative offsets
     int dict_count = 0;          // 0: dictionary not available (irregular pattern) -> plain CSR kernel
     ~Mesh() override {
-        for (void *p : {(void *)coords, (void *)cells, (void *)v2c_ptr, (void *)v2c,
+        for (void *p : {(void *)coords, (void *)cells, (void *)cellsN, (void *)v2c_ptr, (void *)v2c,
                         (void *)row_ptr, (void *)cols, (void *)pids, (void *)dict_off})
             if (p) (void)hipFree(p);
     }

@@ -11,28 +11,49 @@
 
 namespace pgd {
 
-constexpr int MAX_ROW = 64;         // max P1 row length supported by the pattern builder
+constexpr int MAX_ROW = 64;         // max row length for int4 cell records (P1 simplices, P2 intervals)
+constexpr int MAX_ROW_P2 = 128;     // ... for P2 triangles / tetrahedra
 constexpr int ASM_CAP = 6144;       // CSR entries staged per 256-row workgroup (72 KiB LDS)
 
 // ------------------------------------------------------------------ adjacency
-__global__ __launch_bounds__(TPB) void k_v2c_count(const int4 *__restrict__ cells, int64_t nc, int nvpc,
-                                                   int *__restrict__ cnt) {
-    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < nc; e += (int64_t)gridDim.x * TPB) {
-        const int4 c = cells[e];
-        const int v[4] = {c.x, c.y, c.z, c.w};
-        for (int j = 0; j < nvpc; ++j) atomicAdd(&cnt[v[j]], 1);
+// Cell records: one int4 per cell for up to 4 nodes (P1 simplices, P2 intervals) - a single 16-byte load -
+// or flat records of nvpc ints for P2 triangles (6 nodes) / tetrahedra (10 nodes).
+template <int NVMAX>
+__device__ __forceinline__ void load_cell(const void *__restrict__ cells, int64_t e, int nvpc, int *u) {
+    if constexpr (NVMAX <= 4) {
+        const int4 c = ((const int4 *)cells)[e];
+        u[0] = c.x; u[1] = c.y; u[2] = c.z; u[3] = c.w;
+    } else {
+        const int *rec = (const int *)cells + e * nvpc;
+#pragma unroll
+        for (int j = 0; j < NVMAX; ++j) u[j] = j < nvpc ? rec[j] : -1;
     }
 }
 
-__global__ __launch_bounds__(TPB) void k_v2c_fill(const int4 *__restrict__ cells, int64_t nc, int nvpc,
+template <int NVMAX>
+__global__ __launch_bounds__(TPB) void k_v2c_count(const void *__restrict__ cells, int64_t nc, int nvpc,
+                                                   int *__restrict__ cnt) {
+    for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < nc; e += (int64_t)gridDim.x * TPB) {
+        int v[NVMAX];
+        load_cell<NVMAX>(cells, e, nvpc, v);
+#pragma unroll
+        for (int j = 0; j < NVMAX; ++j) if (j < nvpc) atomicAdd(&cnt[v[j]], 1);
+    }
+}
+
+template <int NVMAX>
+__global__ __launch_bounds__(TPB) void k_v2c_fill(const void *__restrict__ cells, int64_t nc, int nvpc,
                                                   const int *__restrict__ ptr, int *__restrict__ cursor,
                                                   int *__restrict__ v2c) {
     for (int64_t e = (int64_t)blockIdx.x * TPB + threadIdx.x; e < nc; e += (int64_t)gridDim.x * TPB) {
-        const int4 c = cells[e];
-        const int v[4] = {c.x, c.y, c.z, c.w};
-        for (int j = 0; j < nvpc; ++j) {
-            const int pos = atomicAdd(&cursor[v[j]], 1);
-            v2c[ptr[v[j]] + pos] = (int)e;
+        int v[NVMAX];
+        load_cell<NVMAX>(cells, e, nvpc, v);
+#pragma unroll
+        for (int j = 0; j < NVMAX; ++j) {
+            if (j < nvpc) {
+                const int pos = atomicAdd(&cursor[v[j]], 1);
+                v2c[ptr[v[j]] + pos] = (int)e;
+            }
         }
     }
 }
@@ -52,22 +73,25 @@ __global__ __launch_bounds__(TPB) void k_v2c_sort(const int *__restrict__ ptr, i
 }
 
 // --------------------------------------------------------------------- pattern
-// Sorted-unique neighbour list of one vertex into s_row (LDS, one row per thread,
-// stride MAX_ROW+1 to keep the banks apart).  Returns the length, or -1 on overflow.
-__device__ __forceinline__ int gather_row(int v, const int4 *__restrict__ cells, int nvpc,
+// Sorted-unique neighbour list of one node into s_row (LDS, one row per thread,
+// stride MAXR+1 to keep the banks apart).  Returns the length, or -1 on overflow.
+template <int NVMAX, int MAXR>
+__device__ __forceinline__ int gather_row(int v, const void *__restrict__ cells, int nvpc,
                                           const int *__restrict__ v2c_ptr, const int *__restrict__ v2c,
                                           int *s_row) {
     int len = 0;
     const int a = v2c_ptr[v], b = v2c_ptr[v + 1];
     for (int k = a; k < b; ++k) {
-        const int4 c = cells[v2c[k]];
-        const int u[4] = {c.x, c.y, c.z, c.w};
-        for (int j = 0; j < nvpc; ++j) {
+        int u[NVMAX];
+        load_cell<NVMAX>(cells, v2c[k], nvpc, u);
+#pragma unroll
+        for (int j = 0; j < NVMAX; ++j) {
+            if (j >= nvpc) continue;
             const int w = u[j];
             int pos = 0;
             while (pos < len && s_row[pos] < w) ++pos;
             if (pos < len && s_row[pos] == w) continue;
-            if (len >= MAX_ROW) return -1;
+            if (len >= MAXR) return -1;
             for (int t = len; t > pos; --t) s_row[t] = s_row[t - 1];
             s_row[pos] = w;
             ++len;
@@ -76,17 +100,19 @@ __device__ __forceinline__ int gather_row(int v, const int4 *__restrict__ cells,
     return len;
 }
 
-template <bool FILL>
-__global__ __launch_bounds__(TPB) void k_pattern(const int4 *__restrict__ cells, int nvpc,
-                                                 const int *__restrict__ v2c_ptr, const int *__restrict__ v2c,
-                                                 int64_t nv, int *__restrict__ row_len,
-                                                 const int *__restrict__ row_ptr, int *__restrict__ cols,
-                                                 int *__restrict__ stats /* [0] overflow, [1] max_row, [2] kl, [3] ku */) {
-    __shared__ int s_rows[TPB * (MAX_ROW + 1)];
-    const int64_t v = (int64_t)blockIdx.x * TPB + threadIdx.x;
+// NT threads per workgroup, each builds one row in its own LDS strip: <4, 64, 256> for int4 records,
+// <10, 128, 64> for P2 simplices (a P2 tetrahedron vertex on a structured box couples to 65 nodes).
+template <bool FILL, int NVMAX, int MAXR, int NT>
+__global__ __launch_bounds__(NT) void k_pattern(const void *__restrict__ cells, int nvpc,
+                                                const int *__restrict__ v2c_ptr, const int *__restrict__ v2c,
+                                                int64_t nv, int *__restrict__ row_len,
+                                                const int *__restrict__ row_ptr, int *__restrict__ cols,
+                                                int *__restrict__ stats /* [0] overflow, [1] max_row, [2] kl, [3] ku */) {
+    __shared__ int s_rows[NT * (MAXR + 1)];
+    const int64_t v = (int64_t)blockIdx.x * NT + threadIdx.x;
     if (v >= nv) return;
-    int *s_row = s_rows + threadIdx.x * (MAX_ROW + 1);
-    const int len = gather_row((int)v, cells, nvpc, v2c_ptr, v2c, s_row);
+    int *s_row = s_rows + threadIdx.x * (MAXR + 1);
+    const int len = gather_row<NVMAX, MAXR>((int)v, cells, nvpc, v2c_ptr, v2c, s_row);
     if (len < 0) { atomicExch(&stats[0], 1); if (!FILL) row_len[v] = 0; return; }
     if (!FILL) {
         row_len[v] = len;
@@ -275,6 +301,114 @@ __global__ __launch_bounds__(TPB) void k_assemble_p2_interval(AsmArgs A) {
     }
 }
 
+// Quadratic Lagrange elements on triangles / tetrahedra.  Cell record = (vertices, then one node per edge in
+// the UFC local edge order); shape functions in barycentric coordinates: vertex i: l_i (2 l_i - 1), edge
+// (a, b): 4 l_a l_b.  Local entries by a conical-product Gauss-Jacobi rule (4 points per direction, exact to
+// degree 7 - the highest integrand, weight * N_i * N_j, has degree 6).  One lane per row, accumulating
+// into its own CSR row in ascending cell order (no atomics, reproducible).
+__constant__ double GJ_X[3][4] = {
+    {0.06943184420297371, 0.33000947820757187, 0.6699905217924281, 0.9305681557970262},
+    {0.057104196114517725, 0.2768430136381238, 0.5835904323689168, 0.8602401356562195},
+    {0.048500549446997276, 0.23860073755186234, 0.5170472951043674, 0.7958514178967728}};
+__constant__ double GJ_W[3][4] = {   // weight (1 - t)^alpha on [0, 1], alpha = 0, 1, 2
+    {0.1739274225687269, 0.3260725774312731, 0.3260725774312731, 0.1739274225687269},
+    {0.13550691343148852, 0.2034645680102711, 0.12984754760823233, 0.031180970950008085},
+    {0.11088841561127774, 0.14345878979921445, 0.0686338871729231, 0.010352240749918081}};
+__constant__ int P2_EA[2][6] = {{1, 0, 0, 0, 0, 0}, {2, 1, 1, 0, 0, 0}};
+__constant__ int P2_EB[2][6] = {{2, 2, 1, 0, 0, 0}, {3, 3, 2, 3, 2, 1}};
+
+template <int D>
+__global__ __launch_bounds__(64) void k_assemble_p2_simplex(AsmArgs A, const int *__restrict__ cellsN) {
+    constexpr int NN = (D + 1) * (D + 2) / 2, NE = NN - (D + 1), NQ = (D == 2) ? 16 : 64;
+    const int64_t r = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (r >= A.nv) return;
+    const int ra = A.row_ptr[r], len = A.row_ptr[r + 1] - ra;
+    for (int k = 0; k < len; ++k) A.vals[ra + k] = 0.0;
+    const bool weighted = A.kind == PGD_ATOM_WMASS || A.kind == PGD_ATOM_WSTIFF;
+    for (int k = A.v2c_ptr[r]; k < A.v2c_ptr[r + 1]; ++k) {
+        const int *rec = cellsN + (int64_t)A.v2c[k] * NN;
+        int u[NN], i = 0;
+#pragma unroll
+        for (int t = 0; t < NN; ++t) { u[t] = rec[t]; if (u[t] == (int)r) i = t; }
+        double vol, g[D + 1][D], wl[NN], loc[NN];
+        p1_geometry<D>(A, u, vol, g);
+#pragma unroll
+        for (int t = 0; t < NN; ++t) { wl[t] = weighted ? A.w[u[t]] : 0.0; loc[t] = 0.0; }
+        for (int q = 0; q < NQ; ++q) {
+            double lam[D + 1], wq;
+            if constexpr (D == 2) {
+                const int qu = q >> 2, qv = q & 3;
+                const double a = GJ_X[1][qu], b = GJ_X[0][qv];
+                lam[1] = a; lam[2] = b * (1.0 - a); lam[0] = 1.0 - lam[1] - lam[2];
+                wq = 2.0 * GJ_W[1][qu] * GJ_W[0][qv];
+            } else {
+                const int qu = q >> 4, qv = (q >> 2) & 3, qw = q & 3;
+                const double a = GJ_X[2][qu], b = GJ_X[1][qv], cc = GJ_X[0][qw];
+                lam[1] = a; lam[2] = b * (1.0 - a); lam[3] = cc * (1.0 - a) * (1.0 - b);
+                lam[0] = 1.0 - lam[1] - lam[2] - lam[3];
+                wq = 6.0 * GJ_W[2][qu] * GJ_W[1][qv] * GJ_W[0][qw];
+            }
+            double N[NN], dN[NN][D];
+#pragma unroll
+            for (int t = 0; t < D + 1; ++t) {
+                N[t] = lam[t] * (2.0 * lam[t] - 1.0);
+#pragma unroll
+                for (int d = 0; d < D; ++d) dN[t][d] = (4.0 * lam[t] - 1.0) * g[t][d];
+            }
+#pragma unroll
+            for (int e = 0; e < NE; ++e) {
+                const int a = P2_EA[D - 2][e], b = P2_EB[D - 2][e];
+                N[D + 1 + e] = 4.0 * lam[a] * lam[b];
+#pragma unroll
+                for (int d = 0; d < D; ++d) dN[D + 1 + e][d] = 4.0 * (lam[b] * g[a][d] + lam[a] * g[b][d]);
+            }
+            double jac = vol * wq;
+            if (weighted) {
+                double wv = 0.0;
+#pragma unroll
+                for (int t = 0; t < NN; ++t) wv = fma(wl[t], N[t], wv);
+                jac *= wv;
+            }
+            // select row i without dynamic register indexing
+            double Ni = 0.0, dNi[D];
+#pragma unroll
+            for (int d = 0; d < D; ++d) dNi[d] = 0.0;
+#pragma unroll
+            for (int t = 0; t < NN; ++t) if (t == i) {
+                Ni = N[t];
+#pragma unroll
+                for (int d = 0; d < D; ++d) dNi[d] = dN[t][d];
+            }
+            double dNi_b = 0.0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) if (d == A.db) dNi_b = dNi[d];
+#pragma unroll
+            for (int j = 0; j < NN; ++j) {
+                double f = 0.0, dNj_a = 0.0;
+#pragma unroll
+                for (int d = 0; d < D; ++d) if (d == A.da) dNj_a = dN[j][d];
+                switch (A.kind) {
+                    case PGD_ATOM_MASS: case PGD_ATOM_WMASS: f = Ni * N[j]; break;
+                    case PGD_ATOM_CONV: f = Ni * dNj_a; break;
+                    case PGD_ATOM_CONVT: f = dNi_b * N[j]; break;
+                    case PGD_ATOM_DUDV: f = dNi_b * dNj_a; break;
+                    default:
+#pragma unroll
+                        for (int d = 0; d < D; ++d) f = fma(dNi[d], dN[j][d], f);
+                        break;
+                }
+                loc[j] = fma(jac, f, loc[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NN; ++j) {
+            int lo = 0, hi = len - 1;            // binary search: cols are sorted and contain u[j]
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (A.cols[ra + mid] < u[j]) lo = mid + 1; else hi = mid; }
+            A.vals[ra + lo] += loc[j];
+        }
+    }
+}
+
 // --------------------------------------------------------------------- host side
 static int build_topology(Ctx *c, Mesh *m) {
     void *p;
@@ -288,16 +422,21 @@ static int build_topology(Ctx *c, Mesh *m) {
     hipStream_t st = c->stream;
     PGD_HIP(c, hipMemsetAsync(cnt, 0, (size_t)(nv + 1) * sizeof(int), st));
     PGD_HIP(c, hipMemsetAsync(stats, 0, 8 * sizeof(int), st));
-    k_v2c_count<<<grid_for(nc), TPB, 0, st>>>(m->cells, nc, m->nvpc, cnt);
+    const bool flat = m->cellsN != nullptr;
+    const void *recs = flat ? (const void *)m->cellsN : (const void *)m->cells;
+    if (flat) k_v2c_count<10><<<grid_for(nc), TPB, 0, st>>>(recs, nc, m->nvpc, cnt);
+    else k_v2c_count<4><<<grid_for(nc), TPB, 0, st>>>(recs, nc, m->nvpc, cnt);
     int rc = scan_exclusive_i32(c, cnt, m->v2c_ptr, nv);
     if (rc != PGD_OK) { cleanup(); return rc; }
     PGD_HIP(c, hipMemsetAsync(cnt, 0, (size_t)(nv + 1) * sizeof(int), st));
-    k_v2c_fill<<<grid_for(nc), TPB, 0, st>>>(m->cells, nc, m->nvpc, m->v2c_ptr, cnt, m->v2c);
+    if (flat) k_v2c_fill<10><<<grid_for(nc), TPB, 0, st>>>(recs, nc, m->nvpc, m->v2c_ptr, cnt, m->v2c);
+    else k_v2c_fill<4><<<grid_for(nc), TPB, 0, st>>>(recs, nc, m->nvpc, m->v2c_ptr, cnt, m->v2c);
     k_v2c_sort<<<grid_for(nv), TPB, 0, st>>>(m->v2c_ptr, m->v2c, nv);
     // pattern: count, scan, fill
     PGD_TRY(dev_alloc(c, &p, (size_t)(nv + 1) * sizeof(int))); m->row_ptr = (int *)p;
-    const int gb = (int)((nv + TPB - 1) / TPB);
-    k_pattern<false><<<gb, TPB, 0, st>>>(m->cells, m->nvpc, m->v2c_ptr, m->v2c, nv, cnt, nullptr, nullptr, stats);
+    const int gb = flat ? (int)((nv + 63) / 64) : (int)((nv + TPB - 1) / TPB);
+    if (flat) k_pattern<false, 10, MAX_ROW_P2, 64><<<gb, 64, 0, st>>>(recs, m->nvpc, m->v2c_ptr, m->v2c, nv, cnt, nullptr, nullptr, stats);
+    else k_pattern<false, 4, MAX_ROW, TPB><<<gb, TPB, 0, st>>>(recs, m->nvpc, m->v2c_ptr, m->v2c, nv, cnt, nullptr, nullptr, stats);
     rc = scan_exclusive_i32(c, cnt, m->row_ptr, nv);
     if (rc != PGD_OK) { cleanup(); return rc; }
     int hstats[4] = {0, 0, 0, 0};
@@ -305,7 +444,7 @@ static int build_topology(Ctx *c, Mesh *m) {
     PGD_HIP(c, hipMemcpyAsync(hstats, stats, sizeof hstats, hipMemcpyDeviceToHost, st));
     PGD_HIP(c, hipMemcpyAsync(&total, m->row_ptr + nv, sizeof(int), hipMemcpyDeviceToHost, st));
     PGD_HIP(c, hipStreamSynchronize(st));
-    if (hstats[0]) { cleanup(); return fail(c, PGD_ERR_LIMIT, "mesh: a vertex has more than %d neighbours", MAX_ROW); }
+    if (hstats[0]) { cleanup(); return fail(c, PGD_ERR_LIMIT, "mesh: a node has more than %d neighbours", flat ? MAX_ROW_P2 : MAX_ROW); }
     if (total < 0) { cleanup(); return fail(c, PGD_ERR_LIMIT, "mesh: nnz overflows int32"); }
     m->nnz = total;
     m->max_row = hstats[1];
@@ -313,7 +452,8 @@ static int build_topology(Ctx *c, Mesh *m) {
     m->ku = hstats[3];
     PGD_TRY(dev_alloc(c, &p, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(int))); m->cols = (int *)p;
     PGD_HIP(c, hipMemsetAsync(m->cols, 0, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(int) + PAD_BYTES, st));
-    k_pattern<true><<<gb, TPB, 0, st>>>(m->cells, m->nvpc, m->v2c_ptr, m->v2c, nv, nullptr, m->row_ptr, m->cols, stats);
+    if (flat) k_pattern<true, 10, MAX_ROW_P2, 64><<<gb, 64, 0, st>>>(recs, m->nvpc, m->v2c_ptr, m->v2c, nv, nullptr, m->row_ptr, m->cols, stats);
+    else k_pattern<true, 4, MAX_ROW, TPB><<<gb, TPB, 0, st>>>(recs, m->nvpc, m->v2c_ptr, m->v2c, nv, nullptr, m->row_ptr, m->cols, stats);
     PGD_HIP(c, hipStreamSynchronize(st));
     cleanup();
     PGD_LAUNCH_CHECK(c);
@@ -455,9 +595,10 @@ extern "C" {
 int pgd_mesh_upload(pgd_handle h, const double *coords, int64_t nv, int gdim, const int32_t *cells,
                     int64_t nc, int nvpc, pgd_handle *out) {
     PGD_CTX(c, h);
-    const bool p2_interval = gdim == 1 && nvpc == 3;   // quadratic elements: cell record (v0, v1, midpoint)
-    if (!coords || !cells || !out || nv < 2 || nc < 1 || gdim < 1 || gdim > 3 || (nvpc != gdim + 1 && !p2_interval))
-        return fail(c, PGD_ERR_INVALID, "mesh_upload: need P1 simplices (nvpc == gdim + 1, gdim in 1..3) or P2 intervals (gdim 1, nvpc 3)");
+    // quadratic elements: cell record = (vertices, then edge nodes): 3 / 6 / 10 nodes in 1-D / 2-D / 3-D
+    const bool p2 = gdim >= 1 && gdim <= 3 && nvpc == (gdim + 1) * (gdim + 2) / 2;
+    if (!coords || !cells || !out || nv < 2 || nc < 1 || gdim < 1 || gdim > 3 || (nvpc != gdim + 1 && !p2))
+        return fail(c, PGD_ERR_INVALID, "mesh_upload: need P1 simplices (nvpc == gdim + 1, gdim in 1..3) or P2 simplices (nvpc 3 / 6 / 10)");
     if (nv >= (int64_t)1 << 31 || nc * nvpc >= (int64_t)1 << 31)
         return fail(c, PGD_ERR_LIMIT, "mesh_upload: index range exceeds int32");
     // validate connectivity on the host: an out-of-range vertex id would fault on the device
@@ -468,18 +609,25 @@ int pgd_mesh_upload(pgd_handle h, const double *coords, int64_t nv, int gdim, co
     m->gdim = gdim; m->nvpc = nvpc; m->nv = nv; m->nc = nc;
     void *p;
     PGD_TRY(dev_alloc(c, &p, (size_t)nv * 3 * sizeof(double))); m->coords = (double *)p;
-    PGD_TRY(dev_alloc(c, &p, (size_t)nc * sizeof(int4))); m->cells = (int4 *)p;
-    {   // host-side repack: AoS -> SoA coordinates, cells -> one int4 record each
+    {   // host-side repack: AoS -> SoA coordinates
         std::vector<double> soa((size_t)nv * 3, 0.0);
         for (int64_t v = 0; v < nv; ++v)
             for (int k = 0; k < gdim; ++k) soa[(size_t)k * nv + v] = coords[v * gdim + k];
+        PGD_HIP(c, hipMemcpyAsync(m->coords, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        PGD_HIP(c, hipStreamSynchronize(c->stream));
+    }
+    if (nvpc > 4) {   // P2 triangles / tetrahedra: flat records
+        PGD_TRY(dev_alloc(c, &p, (size_t)nc * nvpc * sizeof(int))); m->cellsN = (int *)p;
+        PGD_HIP(c, hipMemcpyAsync(m->cellsN, cells, (size_t)nc * nvpc * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        PGD_HIP(c, hipStreamSynchronize(c->stream));
+    } else {          // one int4 record per cell
+        PGD_TRY(dev_alloc(c, &p, (size_t)nc * sizeof(int4))); m->cells = (int4 *)p;
         std::vector<int4> rec((size_t)nc);
         for (int64_t e = 0; e < nc; ++e) {
             int u[4] = {-1, -1, -1, -1};
             for (int j = 0; j < nvpc; ++j) u[j] = cells[e * nvpc + j];
             rec[e] = make_int4(u[0], u[1], u[2], u[3]);
         }
-        PGD_HIP(c, hipMemcpyAsync(m->coords, soa.data(), soa.size() * sizeof(double), hipMemcpyHostToDevice, c->stream));
         PGD_HIP(c, hipMemcpyAsync(m->cells, rec.data(), rec.size() * sizeof(int4), hipMemcpyHostToDevice, c->stream));
         PGD_HIP(c, hipStreamSynchronize(c->stream));
     }
@@ -559,7 +707,9 @@ int pgd_atom_assemble(pgd_handle h, pgd_handle mh, int kind, int da, int db, pgd
     A.cells = m->cells; A.v2c_ptr = m->v2c_ptr; A.v2c = m->v2c; A.row_ptr = m->row_ptr; A.cols = m->cols;
     A.w = w; A.vals = a->vals; A.nv = m->nv; A.kind = kind; A.da = da; A.db = db;
     const int gb = (int)((m->nv + TPB - 1) / TPB);
-    if (m->gdim == 1 && m->nvpc == 3) k_assemble_p2_interval<<<gb, TPB, 0, c->stream>>>(A);
+    if (m->cellsN && m->gdim == 2) k_assemble_p2_simplex<2><<<(int)((m->nv + 63) / 64), 64, 0, c->stream>>>(A, m->cellsN);
+    else if (m->cellsN) k_assemble_p2_simplex<3><<<(int)((m->nv + 63) / 64), 64, 0, c->stream>>>(A, m->cellsN);
+    else if (m->gdim == 1 && m->nvpc == 3) k_assemble_p2_interval<<<gb, TPB, 0, c->stream>>>(A);
     else if (m->gdim == 1) k_assemble_p1<1><<<gb, TPB, 0, c->stream>>>(A);
     else if (m->gdim == 2) k_assemble_p1<2><<<gb, TPB, 0, c->stream>>>(A);
     else k_assemble_p1<3><<<gb, TPB, 0, c->stream>>>(A);

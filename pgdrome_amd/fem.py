@@ -209,8 +209,12 @@ class DofLayout:
     """The degrees of freedom of a Lagrange space as the device sees them: node coordinates, cell -> node
     connectivity (uploaded as a "dof mesh"), and the cache of assembled atoms.
 
-    degree 1: nodes = mesh vertices.  degree 2 (intervals only so far): nodes ordered along the interval,
-    vertex i -> node 2 i, midpoint of cell i -> node 2 i + 1, cell record (v0, v1, mid)."""
+    degree 1: nodes = mesh vertices.  degree 2 on intervals: nodes ordered along the interval, vertex i ->
+    node 2 i, midpoint of cell i -> node 2 i + 1, cell record (v0, v1, mid).  degree 2 on triangles /
+    tetrahedra: the vertices keep their numbers, one node per edge follows (edges numbered by sorted vertex
+    pair), cell record (vertices, edge nodes in the UFC local edge order)."""
+
+    P2_EDGES = {2: ((1, 2), (0, 2), (0, 1)), 3: ((2, 3), (1, 3), (1, 2), (0, 3), (0, 2), (0, 1))}
 
     def __init__(self, mesh, degree):
         self.mesh, self.degree = mesh, int(degree)
@@ -230,9 +234,24 @@ class DofLayout:
             self.coords = nodes.reshape(-1, 1)
             self.cells = np.stack([2 * C[:, 0], 2 * C[:, 1], 2 * C[:, 0] + 1], axis=1).astype(np.int32)
             self.vertex_nodes = np.arange(0, 2 * nv - 1, 2)
+            self.edge_nodes = np.arange(1, 2 * nv - 1, 2)
+            self.edge_vertices = np.stack([self.vertex_nodes[:-1], self.vertex_nodes[1:]], axis=1)
+        elif self.degree == 2 and mesh.topology().dim() in (2, 3):
+            if mesh.part is not None:
+                raise NotImplementedError("P2 on a sharded mesh")
+            X, C = mesh.coordinates(), mesh.cells()
+            nv, loc = X.shape[0], self.P2_EDGES[mesh.topology().dim()]
+            pairs = np.concatenate([np.sort(C[:, list(e)], axis=1) for e in loc], axis=0).astype(np.int64)
+            keys, inv = np.unique(pairs[:, 0] * nv + pairs[:, 1], return_inverse=True)
+            ev = np.stack([keys // nv, keys % nv], axis=1)
+            self.coords = np.concatenate([X, 0.5 * (X[ev[:, 0]] + X[ev[:, 1]])], axis=0)
+            self.cells = np.concatenate([C, nv + inv.reshape(len(loc), C.shape[0]).T], axis=1).astype(np.int32)
+            self.vertex_nodes = np.arange(nv)
+            self.edge_nodes = nv + np.arange(ev.shape[0])
+            self.edge_vertices = ev
         else:
             raise NotImplementedError("Lagrange degree %d on %s cells: P1 everywhere, P2 on intervals "
-                                      "(SURVEY 8(f4))" % (self.degree, mesh.ufl_cell()))
+                                      "/ triangles / tetrahedra (SURVEY 8(f4))" % (self.degree, mesh.ufl_cell()))
         self.n = self.coords.shape[0]
         self._handles, self._atoms = {}, {}
         self._ones = self._space = None
@@ -250,7 +269,44 @@ class DofLayout:
             return onb
         flags = np.zeros(self.n, dtype=bool)
         flags[self.vertex_nodes] = onb
+        tdim = self.mesh.topology().dim()
+        if tdim > 1:
+            # an edge node lies on the boundary when its edge belongs to a boundary facet (a facet of one cell)
+            C = self.mesh.cells().astype(np.int64)
+            nv = C.max() + 1
+            if tdim == 2:
+                fe = np.concatenate([np.sort(C[:, list(e)], axis=1) for e in self.P2_EDGES[2]], axis=0)
+                keys, cnt = np.unique(fe[:, 0] * nv + fe[:, 1], return_counts=True)
+                bkeys = keys[cnt == 1]
+            else:
+                faces = np.concatenate([np.sort(C[:, [a, b, c]], axis=1)
+                                        for a, b, c in ((1, 2, 3), (0, 2, 3), (0, 1, 3), (0, 1, 2))], axis=0)
+                fk, idx, cnt = np.unique((faces[:, 0] * nv + faces[:, 1]) * nv + faces[:, 2],
+                                         return_index=True, return_counts=True)
+                bf = faces[idx[cnt == 1]]
+                be = np.concatenate([bf[:, [0, 1]], bf[:, [0, 2]], bf[:, [1, 2]]], axis=0)
+                bkeys = np.unique(be[:, 0] * nv + be[:, 1])
+            ek = self.edge_vertices[:, 0].astype(np.int64) * nv + self.edge_vertices[:, 1]
+            flags[self.edge_nodes] = np.isin(ek, bkeys)
         return flags
+
+    def embed_p1(self, vertex_values):
+        """Nodal values of the piecewise-LINEAR interpolant of per-vertex data in this layout (edge nodes
+        take the mean of their end points) - how a degree-1 coefficient enters a P2 integrand."""
+        if self.vertex_nodes is None:
+            return np.asarray(vertex_values, dtype=np.float64)
+        out = np.empty(self.n)
+        out[self.vertex_nodes] = vertex_values
+        vn_of = np.full(self.n, -1, dtype=np.int64)
+        vn_of[self.vertex_nodes] = np.arange(len(self.vertex_nodes))
+        ev = self.edge_vertices
+        if self.mesh.topology().dim() == 1:
+            a, b = vn_of[ev[:, 0]], vn_of[ev[:, 1]]
+        else:
+            a, b = ev[:, 0], ev[:, 1]
+        vv = np.asarray(vertex_values, dtype=np.float64)
+        out[self.edge_nodes] = 0.5 * (vv[a] + vv[b])
+        return out
 
     def space(self):
         if self._space is None:
@@ -967,6 +1023,19 @@ class Function(Expr):
 def _point_eval(f, x):
     mesh = f._V.mesh()
     X, cells, vals = mesh.coordinates(), mesh.cells(), f._vec.host()
+    if f._V._lay.degree == 2 and mesh.topology().dim() > 1:
+        lay = f._V._lay
+        D = mesh.topology().dim()
+        P = X[cells]
+        T = np.transpose(P[:, 1:, :] - P[:, :1, :], (0, 2, 1))
+        lam = np.linalg.solve(T, (x[None, :] - P[:, 0, :])[:, :, None])[:, :, 0]
+        L = np.concatenate([(1.0 - lam.sum(axis=1))[:, None], lam], axis=1)
+        k = int(np.argmax(L.min(axis=1)))
+        if L[k].min() < -1e-10:
+            raise RuntimeError("point %r outside the mesh" % (x,))
+        l = L[k]
+        N = [l[i] * (2.0 * l[i] - 1.0) for i in range(D + 1)] + [4.0 * l[a] * l[b] for a, b in lay.P2_EDGES[D]]
+        return float(np.dot(N, vals[lay.cells[k]]))
     if f._V._lay.degree == 2:
         # quadratic on intervals: nodes 2 i (vertex i), 2 i + 1 (midpoint of cell i)
         xs = X[:, 0]
@@ -1143,7 +1212,11 @@ class Expression(Expr):
         f = self._cache.get(key)
         if f is None:
             f = Function(lay.space())
-            f._vec._host = self.eval_at(lay.coords)
+            if lay.degree == 2 and getattr(self, "_degree", 2) == 1:
+                # a degree-1 Expression is interpolated into P1 cell by cell (as the form compiler does)
+                f._vec._host = lay.embed_p1(self.eval_at(lay.coords[lay.vertex_nodes]))
+            else:
+                f._vec._host = self.eval_at(lay.coords)
             f._vec.touched_host()
             self._cache = {key: f}
         return f

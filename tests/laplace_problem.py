@@ -114,3 +114,30 @@ def run(fem, PGDProblem, FD_matrices, fd=False):
         setattr(p, k, v)
     p.solve_PGD(_problem="linear", solve_modes=solve_modes)
     return p
+
+
+def full_order_profile(fem, y, q, u0, elems=(60, 40), degree=2):
+    """The 2-D full-order model the reference's test compares the PGD solution with
+    (test_laplace.py:867-929): quadratic triangles on [0, 3]^2, T = u0 (1 - x/3) on the left / right edge,
+    source q on the left half; returns T(x_i, y) on the 61 vertices of the PGD x-mesh."""
+    k, lx, ly = 0.5, 3.0, 3.0
+    mesh = fem.RectangleMesh(fem.Point(0, 0), fem.Point(lx, ly), elems[0], elems[1])
+    V = fem.FunctionSpace(mesh, "CG", degree)
+    v, T = fem.TestFunction(V), fem.TrialFunction(V)
+    source = fem.Expression("x[0]<L/2 ? q00 : 0", degree=1, L=lx, q00=q)
+    a = k * fem.inner(fem.grad(v), fem.grad(T)) * fem.dx()
+    l = v * source * fem.dx()
+    bc = fem.DirichletBC(V, fem.Expression("u00*(1. - 1./3.*x[0])", degree=1, u00=u0),
+                         lambda x, on_boundary: on_boundary and fem.near(x[0], 0.0, 1e-6) or fem.near(x[0], lx, 1e-6))
+    sol = fem.Function(V)
+    fem.solve(a == l, sol, bcs=bc)
+    xs = np.linspace(0, lx, elems[0] + 1)
+    return np.array([sol((x, y)) for x in xs])
+
+
+def pgd_profile(p, y, q, u0):
+    """PGD field on the x-mesh for (y, q, u0), boundary lifting added as the reference's test does (:1043-1080)."""
+    sol = p.return_PGD()
+    lift = p.param["lift"]
+    return sol.evaluate(0, [1, 2, 3], [y, q, u0], 0).compute_vertex_values() + \
+        lift[0].compute_vertex_values() * lift[1](y) * lift[2](q) * lift[3](u0)

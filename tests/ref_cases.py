@@ -31,4 +31,11 @@ def check_laplace(fem, PGDProblem, FD_matrices, variant, exact_counts=True):
     u = sol.evaluate(0, [1, 2, 3], [1.5, 50, 10], 0).compute_vertex_values()
     r = np.array(ref["evaluate_y1.5_q50_u10"])
     assert np.linalg.norm(u - r) <= 1e-6 * np.linalg.norm(r)
+    # against the 2-D full-order model on QUADRATIC triangles, with the reference's own bars
+    # (test_laplace.py:1091-1092: mean relative error < 1e-6 all-FEM, < 2e-4 all-FD)
+    errs = []
+    for y, q, u0 in ((1.5, 50.0, 10.0), (0.37, 12.5, 41.0), (2.9, 33.0, 17.5)):
+        fom = laplace_problem.full_order_profile(fem, y, q, u0)
+        errs.append(np.linalg.norm(laplace_problem.pgd_profile(p, y, q, u0) - fom) / np.linalg.norm(fom))
+    assert np.mean(errs) < (1e-6 if variant == "FEM" else 2e-4), errs
     return p

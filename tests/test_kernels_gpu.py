@@ -20,6 +20,10 @@ MESHES = {
     "rect64": lambda: F.rectangle_mesh((0, 0), (1, 1), 63, 63),
     "box6x5x4": lambda: F.box_mesh((0, 0, 0), (1, 2, 3), 5, 4, 3),
     "box20": lambda: F.box_mesh((0, 0, 0), (1, 1, 1), 19, 19, 19),
+    # quadratic elements on triangles / tetrahedra (6 / 10 nodes per cell); geometry jittered below
+    "p2tri9x7": lambda: F.rectangle_mesh((0, 0), (2, 1), 9, 7),
+    "p2tet4x3x3": lambda: F.box_mesh((0, 0, 0), (1, 2, 1), 4, 3, 3),
+    "p2tet9": lambda: F.box_mesh((0, 0, 0), (1, 1, 1), 9, 9, 9),
 }
 
 
@@ -37,8 +41,10 @@ def jitter(coords, cells, seed=7):
 @pytest.fixture(scope="module", params=sorted(MESHES))
 def mesh(request, ctx):
     coords, cells = MESHES[request.param]()
-    if request.param in ("rect17x9", "box6x5x4"):
+    if request.param in ("rect17x9", "box6x5x4", "p2tri9x7", "p2tet4x3x3"):
         coords = jitter(coords, cells)
+    if request.param.startswith("p2"):
+        coords, cells = F.p2_simplex_nodes(coords, cells)     # straight-sided: edge nodes at the midpoints
     h = ctx.mesh_upload(coords, cells)
     yield request.param, coords, cells, h
     ctx.mesh_free(h)

@@ -105,3 +105,23 @@ def test_fd_matrices_match_reference_fixture():
     M, D2, D1 = FD_matrices(np.linspace(0, 1, 5))
     assert np.allclose(M.diagonal(), [.125, .25, .25, .25, .125])
     assert np.allclose(D2.toarray()[1, :3], [4, -8, 4]) and np.allclose(D1.toarray()[1, :2], [-1, 1])
+
+
+@pytest.mark.parametrize("gdim", [2, 3])
+def test_p2_simplex_matrices_integrate_polynomials_exactly(gdim):
+    """Quadratic triangles / tetrahedra (exact barycentric integration): known integrals over [0,2]x[0,1](x[0,1])."""
+    c, e = F.rectangle_mesh((0, 0), (2, 1), 5, 4) if gdim == 2 else F.box_mesh((0, 0, 0), (2, 1, 1), 3, 2, 2)
+    nodes, tab = F.p2_simplex_nodes(c, e)
+    assert tab.shape[1] == (6 if gdim == 2 else 10) and np.array_equal(tab[:, :gdim + 1], e)
+    assert nodes.shape[0] == (11 * 9 if gdim == 2 else 7 * 5 * 5)
+    x, y = nodes[:, 0], nodes[:, 1]
+    one, f = np.ones(nodes.shape[0]), x * x + x * y
+    M, K = F.assemble_atom(nodes, tab, F.MASS), F.assemble_atom(nodes, tab, F.STIFF)
+    assert np.isclose(one @ (M @ one), 2.0) and np.isclose(one @ (M @ f), 8 / 3 + 1.0)
+    assert np.isclose(f @ (K @ f), 18.0) and np.abs(K @ one).max() < 1e-13
+    assert np.isclose(one @ (F.assemble_atom(nodes, tab, F.CONV, a=0) @ f), 5.0)            # int f_x
+    assert np.isclose(f @ (F.assemble_atom(nodes, tab, F.CONVT, b=1) @ one), 2.0)           # int f_y = int x
+    assert np.isclose(f @ (F.assemble_atom(nodes, tab, F.DUDV, a=0, b=1) @ f), 19 / 3)      # int f_x f_y
+    assert np.isclose(one @ (F.assemble_atom(nodes, tab, F.WMASS, w=x * x) @ f), 8.4)       # int x^2 f
+    assert np.isclose(f @ (F.assemble_atom(nodes, tab, F.WSTIFF, w=x) @ f), 26.0)           # int x |grad f|^2
+    assert abs(M - M.T).max() < 1e-15 and abs(K - K.T).max() < 1e-13

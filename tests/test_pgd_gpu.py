@@ -167,3 +167,35 @@ def test_reference_laplace_integration_case_on_gpu(variant):
     from pgdrome_amd.solver import FD_matrices
     from tests import ref_cases
     ref_cases.check_laplace(fem, PGDProblem, FD_matrices, variant, exact_counts=False)
+
+
+@pytest.mark.parametrize("shape", ["triangle", "tetrahedron"])
+def test_p2_full_order_poisson_on_gpu_equals_oracle(hip_backend, shape):
+    """Quadratic elements on triangles / tetrahedra (the full-order model of the reference's test_laplace):
+    HIP assembly (quadrature) + PCG vs the oracle (exact integration) + direct solve, same frontend code."""
+    from oracle.backend_numpy import NumpyBackend
+
+    def run(backend):
+        fem.set_backend(backend)
+        fem.clear_caches()
+        mesh = fem.RectangleMesh(fem.Point(0, 0), fem.Point(3, 2), 24, 16) if shape == "triangle" else \
+            fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 2, 1), 6, 8, 5)
+        V = fem.FunctionSpace(mesh, "CG", 2)
+        u, v = fem.TrialFunction(V), fem.TestFunction(V)
+        q = fem.Expression("x[0] < 1.5 ? 3.0 + x[1] : 0.0", degree=1)
+        a = fem.Constant(1.5) * fem.inner(fem.grad(u), fem.grad(v)) * fem.dx + u * v * fem.dx
+        l = q * v * fem.dx
+        bc = fem.DirichletBC(V, fem.Expression("1.0 + x[0]", degree=1), lambda x, on: on and (x[0] < 1e-8 or x[1] > 2 - 1e-8))
+        T = fem.Function(V)
+        fem.solve(a == l, T, bcs=bc, solver_parameters={"linear_solver": "cg", "preconditioner": "jacobi"})
+        pt = (1.3, 0.7) if shape == "triangle" else (0.4, 0.7, 0.3)
+        return T.vector().host().copy(), T(pt), fem.norm(T), V.dim()
+    try:
+        xg, pg, ng, n = run(hip_backend)
+        xo, po, no, _ = run(NumpyBackend())
+    finally:
+        fem.set_backend(hip_backend)
+        fem.clear_caches()
+    assert n == xg.size and n > 1000
+    assert np.linalg.norm(xg - xo) <= 1e-8 * np.linalg.norm(xo)      # PCG rtol 1e-10 on both sides
+    assert abs(pg - po) <= 1e-8 * abs(po) and abs(ng - no) <= 1e-9 * no

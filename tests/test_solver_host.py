@@ -83,8 +83,9 @@ def test_form_algebra_and_assemble_ranks():
     assert fem.FunctionSpace(mesh, "CG", 2).dim() == 21            # P2 on intervals is built
     with pytest.raises(NotImplementedError):
         fem.FunctionSpace(mesh, "CG", 3)
+    assert fem.FunctionSpace(fem.UnitSquareMesh(2, 2), "CG", 2).dim() == 25     # ... and on triangles / tetrahedra
     with pytest.raises(NotImplementedError):
-        fem.FunctionSpace(fem.UnitSquareMesh(2, 2), "CG", 2)
+        fem.FunctionSpace(fem.UnitSquareMesh(2, 2), "DG", 1)
 
 
 def test_expression_dialect():
@@ -212,6 +213,36 @@ def test_p2_interval_space_basics():
     fem.solve(u.dx(0) * v.dx(0) * fem.dx(mesh) == fem.Constant(2.0) * v * fem.dx(mesh), w,
               fem.DirichletBC(V, 0.0, lambda x, on_boundary: on_boundary))
     assert np.isclose(w(0.7), 0.7 * (2.0 - 0.7))                         # -u'' = 2: u = x (2 - x), exact in P2
+
+
+def test_p2_triangle_and_tetrahedron_space_basics():
+    mesh = fem.RectangleMesh(fem.Point(0, 0), fem.Point(2, 1), 6, 4)
+    V = fem.FunctionSpace(mesh, "CG", 2)
+    assert V.dim() == 13 * 9                                             # vertices + edges = the (2n+1) grid
+    lay = V._lay
+    assert lay.on_boundary().sum() == 2 * (12 + 8) and lay.on_boundary()[lay.vertex_nodes].sum() == 2 * (6 + 4)
+    f = fem.interpolate(fem.Expression("x[0]*x[0] + x[0]*x[1]", degree=2), V)   # quadratics are reproduced
+    assert np.isclose(f((0.37, 0.81)), 0.37 * 0.37 + 0.37 * 0.81)
+    assert np.isclose(fem.assemble(f * fem.dx(mesh)), 8.0 / 3.0 + 1.0)
+    assert np.isclose(fem.assemble(fem.inner(fem.grad(f), fem.grad(f)) * fem.dx(mesh)), 18.0)
+    assert f.compute_vertex_values().size == mesh.num_vertices()
+    # a degree-1 Expression enters a P2 integrand as its piecewise-linear interpolant
+    g = fem.Expression("x[0]*x[0]", degree=1)
+    assert np.isclose(fem.assemble(g * fem.TestFunction(V) * fem.dx(mesh)).host().sum(),
+                      fem.assemble(fem.interpolate(g, fem.FunctionSpace(mesh, "CG", 1)) * fem.dx(mesh)))
+    u, v = fem.TrialFunction(V), fem.TestFunction(V)
+    w = fem.Function(V)
+    fem.solve(fem.inner(fem.grad(u), fem.grad(v)) * fem.dx == fem.Constant(2.0) * v * fem.dx, w,
+              fem.DirichletBC(V, 0.0, lambda x, on_boundary: on_boundary and (fem.near(x[0], 0) or fem.near(x[0], 2))))
+    assert np.isclose(w((0.7, 0.3)), 0.7 * (2.0 - 0.7))                 # -u_xx = 2, natural top/bottom: exact in P2
+    box = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 2), 2, 3, 2)
+    V3 = fem.FunctionSpace(box, "CG", 2)
+    assert V3.dim() == 5 * 7 * 5
+    onb = V3._lay.on_boundary()
+    assert onb.sum() == 5 * 7 * 5 - 3 * 5 * 3                            # all nodes of the (2n+1) grid but the interior
+    h = fem.interpolate(fem.Expression("x[2]*x[2] + x[0]*x[1]", degree=2), V3)
+    assert np.isclose(h((0.2, 0.9, 1.3)), 1.69 + 0.18)
+    assert np.isclose(fem.assemble(h * fem.dx(box)), 8.0 / 3.0 + 0.5)
 
 
 @pytest.mark.parametrize("variant", ["FEM", "FD"])
