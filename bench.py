@@ -47,6 +47,9 @@ def parse():
                     help="with --dist-driver: force the Chronopoulos-Gear recurrence that N > 1 uses")
     ap.add_argument("--dist-driver", action="store_true",
                     help="N=1 only: run the row-sharded (host-driven, RCCL) solver path with one rank")
+    ap.add_argument("--python-driver", action="store_true",
+                    help="sharded runs: drive the PCG recurrence from Python over torch.distributed instead of "
+                         "the in-library loop (pgd_pcg_solve_sharded over RCCL)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     return ap.parse_args()
 
@@ -89,7 +92,7 @@ def main():
     P = fem.Point
     if sharded:
         from pgdrome_amd import dist as pdist
-        comm = pdist.TorchComm(dist, be, True if args.single_reduction else None)
+        comm = pdist.TorchComm(dist, be, True if args.single_reduction else None, in_library=not args.python_driver)
         space = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), n - 1, n - 1, n - 1)
     else:
         space = fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), n - 1, n - 1, n - 1)
@@ -164,6 +167,8 @@ def main():
         "config": {"workload": "cfg4: 3D-space %d^3 P1 (BoxMesh, 6 tets/cube) x 1D-parameter %d P1, "
                                "-Laplace(u)+mu*u=1, Jacobi-PCG rtol %g" % (n, args.n_mu, args.rtol),
                    "spatial_dofs": n_sp, "nnz": nnz, "parallelism": "z-slab row sharding x%d" % world if sharded else "single GPU",
+                   "sharded_pcg_driver": (("in-library loop, RCCL" if comm.in_library == "rccl" else
+                                           "python loop, torch.distributed") if sharded else None),
                    "pcg_iterations_per_step": pcg_its / K, "modes_completed": len(prob.num_fp_it),
                    "setup_seconds_untimed": t_setup},
         "roofline": {"bound": "hbm", "kernel": spmv_kernel, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

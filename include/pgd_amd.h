@@ -188,6 +188,38 @@ int pgd_cg_update_slot(pgd_handle ctx, pgd_handle x, pgd_handle r, pgd_handle u,
 /* after the all-reduce: next alpha/beta, iteration count, done <- r.r <= tol2 (init: also sets tol2) */
 int pgd_cg_scalars_slot(pgd_handle ctx, int base, int init, double rtol, double atol);
 
+/* ----------------------------------------------- sharded solve, in-library --- */
+/* The same single-reduction recurrence with the ITERATION LOOP AND THE COMMUNICATION inside the
+ * library (no host language between two iterations): per iteration one halo exchange of the
+ * boundary planes with the z-neighbours (rank-1, rank+1) and one all-reduce of 5 slots, issued on
+ * the context's stream.  A context is bound to its communication once:
+ *   - RCCL (one process per GPU, xGMI): rank 0 calls pgd_comm_unique_id, the 128 bytes travel to
+ *     the other ranks by any means (torch.distributed broadcast), every rank calls
+ *     pgd_comm_bind_rccl; the binding is checked on the spot (ring shift + all-reduce of rank ids).
+ *     librccl is resolved at run time from the copy already loaded in the process.
+ *   - callbacks: the library calls back for the two steps (several ranks sharing one GPU in tests:
+ *     host-staged gloo).  A callback returns 0 on success.
+ * Local numbering of a rank's vectors: [0, lo_ghost) ghost plane below, [own0, own1) owned rows,
+ * [own1, own1 + hi_ghost) ghost plane above; own0 == lo_ghost.                                     */
+typedef int (*pgd_halo_fn)(void *user, pgd_handle vec, int64_t own0, int64_t own1, int64_t lo_ghost,
+                           int64_t hi_ghost);
+typedef int (*pgd_allreduce_fn)(void *user, int first_slot, int count);
+int pgd_comm_bind_callbacks(pgd_handle ctx, pgd_halo_fn halo, pgd_allreduce_fn allreduce, void *user,
+                            int rank, int world);
+int pgd_comm_unique_id(pgd_handle ctx, uint8_t *out128);
+int pgd_comm_bind_rccl(pgd_handle ctx, const uint8_t *id128, int rank, int world);
+int pgd_comm_unbind(pgd_handle ctx);
+int pgd_comm_info(pgd_handle ctx, int *kind /* 0 none, 1 callbacks, 2 rccl */, int *rank, int *world);
+int pgd_comm_halo(pgd_handle ctx, pgd_handle vec, int64_t own0, int64_t own1, int64_t lo_ghost,
+                  int64_t hi_ghost);
+int pgd_comm_allreduce_slots(pgd_handle ctx, int first_slot, int count);
+/* Jacobi-PCG on the rows [own0, own1) of this rank's slab of A (replaces the KSP solve of
+ * solver.py:636,716 for the row-partitioned spatial dimension); b, x are local slab vectors, x holds
+ * the start value and returns with current ghost planes.  iters / rel_res are global.            */
+int pgd_pcg_solve_sharded(pgd_handle ctx, pgd_handle A, pgd_handle b, pgd_handle x, int64_t own0,
+                          int64_t own1, int64_t lo_ghost, int64_t hi_ghost, double rtol, double atol,
+                          int maxit, int *iters, double *rel_res);
+
 /* ------------------------------------------------------------------ tuning --- */
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed.                                        */

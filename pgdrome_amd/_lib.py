@@ -23,6 +23,10 @@ PI64 = C.POINTER(C.c_int64)
 PH = C.POINTER(C.c_int64)
 VP = C.c_void_p
 
+PU8 = C.POINTER(C.c_uint8)
+HALO_FN = C.CFUNCTYPE(C.c_int, VP, H, I64, I64, I64, I64)      # pgd_halo_fn
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, VP, C.c_int, C.c_int)      # pgd_allreduce_fn
+
 # name -> (restype, argtypes); mirrors include/pgd_amd.h declaration by declaration
 SIGNATURES = {
     "pgd_ctx_create": (C.c_int, [C.c_int, VP, PH]),
@@ -74,6 +78,14 @@ SIGNATURES = {
     "pgd_cg_init_slot": (C.c_int, [H, H, H, H, H, H, H, H, I64, I64, C.c_int]),
     "pgd_cg_update_slot": (C.c_int, [H, H, H, H, H, H, H, H, I64, I64, C.c_int]),
     "pgd_cg_scalars_slot": (C.c_int, [H, C.c_int, C.c_int, F64, F64]),
+    "pgd_comm_bind_callbacks": (C.c_int, [H, HALO_FN, ALLREDUCE_FN, VP, C.c_int, C.c_int]),
+    "pgd_comm_unique_id": (C.c_int, [H, PU8]),
+    "pgd_comm_bind_rccl": (C.c_int, [H, PU8, C.c_int, C.c_int]),
+    "pgd_comm_unbind": (C.c_int, [H]),
+    "pgd_comm_info": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "pgd_comm_halo": (C.c_int, [H, H, I64, I64, I64, I64]),
+    "pgd_comm_allreduce_slots": (C.c_int, [H, C.c_int, C.c_int]),
+    "pgd_pcg_solve_sharded": (C.c_int, [H, H, H, H, I64, I64, I64, I64, F64, F64, C.c_int, C.POINTER(C.c_int), PD]),
     "pgd_tune": (C.c_int, [H, C.c_int, I64]),
     "pgd_prof_enable": (C.c_int, [H, C.c_int]),
     "pgd_prof_read": (C.c_int, [H, PI64, PD, PD]),
@@ -379,6 +391,69 @@ class Context:
 
     def cg_scalars_slot(self, base, init, rtol, atol):
         self._ck(self.lib.pgd_cg_scalars_slot(self.h, int(base), int(init), float(rtol), float(atol)))
+
+    # ---- in-library sharded solve
+    def comm_bind_callbacks(self, halo, allreduce, rank, world):
+        """halo(vec, own0, own1, lo_ghost, hi_ghost), allreduce(first_slot, count): Python callables.  An
+        exception inside a callback is kept and re-raised by the library call that triggered it."""
+        self._cb_error = None
+
+        def _halo(user, vec, own0, own1, lo_g, hi_g):
+            try:
+                halo(vec, own0, own1, lo_g, hi_g)
+                return 0
+            except BaseException as e:      # noqa: BLE001 - must not propagate through the C frame
+                self._cb_error = e
+                return -1
+
+        def _allreduce(user, first, count):
+            try:
+                allreduce(first, count)
+                return 0
+            except BaseException as e:      # noqa: BLE001
+                self._cb_error = e
+                return -1
+        self._cbs = (HALO_FN(_halo), ALLREDUCE_FN(_allreduce))      # keep the thunks alive
+        self._ck(self.lib.pgd_comm_bind_callbacks(self.h, self._cbs[0], self._cbs[1], None, int(rank), int(world)))
+
+    def comm_unique_id(self):
+        buf = (C.c_uint8 * 128)()
+        self._ck(self.lib.pgd_comm_unique_id(self.h, buf))
+        return bytes(buf)
+
+    def comm_bind_rccl(self, unique_id, rank, world):
+        if len(unique_id) != 128:
+            raise ValueError("RCCL unique id must be 128 bytes")
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._ck(self.lib.pgd_comm_bind_rccl(self.h, buf, int(rank), int(world)))
+
+    def comm_unbind(self):
+        self._ck(self.lib.pgd_comm_unbind(self.h))
+        self._cbs = None
+
+    def comm_info(self):
+        k, r, w = C.c_int(), C.c_int(), C.c_int()
+        self._ck(self.lib.pgd_comm_info(self.h, C.byref(k), C.byref(r), C.byref(w)))
+        return {"kind": ("none", "callbacks", "rccl")[k.value], "rank": r.value, "world": w.value}
+
+    def _ck_cb(self, rc):
+        err = getattr(self, "_cb_error", None)
+        if err is not None:
+            self._cb_error = None
+            raise err
+        self._ck(rc)
+
+    def comm_halo(self, vec, own0, own1, lo_g, hi_g):
+        self._ck_cb(self.lib.pgd_comm_halo(self.h, vec, int(own0), int(own1), int(lo_g), int(hi_g)))
+
+    def comm_allreduce_slots(self, first, count):
+        self._ck_cb(self.lib.pgd_comm_allreduce_slots(self.h, int(first), int(count)))
+
+    def pcg_solve_sharded(self, op, b, x, own0, own1, lo_g, hi_g, rtol, atol, maxit):
+        it, rel = C.c_int(), F64()
+        self._ck_cb(self.lib.pgd_pcg_solve_sharded(self.h, op, b, x, int(own0), int(own1), int(lo_g), int(hi_g),
+                                                   float(rtol), float(atol), int(maxit), C.byref(it), C.byref(rel)))
+        return it.value, rel.value
 
     def tune(self, knob, value):
         self._ck(self.lib.pgd_tune(self.h, int(knob), int(value)))

@@ -175,6 +175,7 @@ int pgd_ctx_destroy(pgd_handle h) {
     if (!c) return PGD_ERR_INVALID;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    comm_release(c);
     c->objs.clear();
     for (auto &kv : c->pool) (void)hipFree(kv.second);
     c->pool.clear();

@@ -77,6 +77,18 @@ struct Csr : Obj {
     }
 };
 
+// Communication binding of a context for the row-sharded solve (pgd_comm.hip)
+struct Comm {
+    int kind = 0;                 // 0 none, 1 host callbacks, 2 RCCL
+    int rank = 0, world = 1;
+    pgd_halo_fn halo_cb = nullptr;
+    pgd_allreduce_fn allreduce_cb = nullptr;
+    void *user = nullptr;
+    void *nccl = nullptr;         // ncclComm_t
+    pgd_handle work[7] = {0, 0, 0, 0, 0, 0, 0};   // r, u, w, p, s, q, dinv of the sharded PCG
+    int64_t work_n = 0;
+};
+
 struct Ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -103,6 +115,8 @@ struct Ctx {
     int *ibuf = nullptr;          // small int32 scratch (bc dofs, index lists)
     int64_t ibuf_cap = 0;
 
+    Comm comm;
+
     int num_cu = 256;
     int spmv_dict = 1;            // use the column dictionary when the mesh has one
     int spmv_rows = 64;           // rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256
@@ -128,6 +142,7 @@ int ensure_work(Ctx *c, int i, int64_t n);
 int ensure_mask(Ctx *c, int64_t n);
 int ensure_ibuf(Ctx *c, int64_t n);
 void prof_flush(Ctx *c);
+void comm_release(Ctx *c);          // pgd_comm.hip
 
 inline Vec *get_vec(Ctx *c, pgd_handle h) { return static_cast<Vec *>(get_obj(c, h, Obj::VEC)); }
 inline Mesh *get_mesh(Ctx *c, pgd_handle h) { return static_cast<Mesh *>(get_obj(c, h, Obj::MESH)); }

@@ -21,9 +21,12 @@ the CPU tests), on torch's current stream, which is also the stream the HIP
 library enqueues on - so kernels and collectives are ordered without host
 synchronisation.  The small time/parameter dimensions are replicated.
 
-The PCG recurrence is driven from here with the same kernels as the single-GPU
-``pgd_pcg_solve`` (device-resident scalars, a done flag, a host look at the
-flag every CHECK_EVERY iterations).
+The PCG recurrence of a sharded solve runs INSIDE the HIP library when the backend is the HIP one
+(``pgd_pcg_solve_sharded``, csrc/pgd_comm.hip: iteration loop, halo ncclSend/ncclRecv and the all-reduce
+issued from C++ on the context's stream; the library binds to RCCL with a unique id broadcast from rank 0
+here, and checks the binding with a ring shift).  The loops in this file are the same recurrence driven
+from Python with the same kernels: they serve the numpy oracle backend in the CPU tests, and remain the
+fallback transport (torch.distributed) if the in-library binding cannot be established.
 """
 from __future__ import annotations
 
@@ -39,11 +42,12 @@ S_PQ, S_TOL2, S_FINAL_RR, S_INIT, S_PAIR = 2, 5, 6, 20, 16
 class TorchComm:
     """Communication + sharded-solve driver on top of torch.distributed."""
 
-    def __init__(self, dist, backend, single_reduction=None):
+    def __init__(self, dist, backend, single_reduction=None, in_library=True):
         import torch
         self.torch, self.dist, self.be = torch, dist, backend
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self._check_stream()
+        self.in_library = None        # "rccl" / "callbacks" once the library owns the sharded PCG loop
         # more than one rank: the single-reduction recurrence (one all-reduce per iteration, halo
         # overlapped with the interior rows); one rank: the textbook two-reduction form
         self.single_reduction = (dist.get_world_size() > 1) if single_reduction is None else single_reduction
@@ -51,6 +55,53 @@ class TorchComm:
         self._work = {}
         self._views = {}
         self.stats = {"halo": 0, "allreduce": 0}
+        if in_library and getattr(backend, "name", "") == "hip":
+            self.bind_library()
+
+    def bind_library(self):
+        """Hand the sharded PCG loop and its two communication steps to the HIP library.
+
+        RCCL process group: the library opens its own communicator on the context's stream (unique id
+        from rank 0, broadcast here); every rank reports whether its binding and the library's ring-shift
+        check succeeded, and only if ALL did is the in-library path used - otherwise all ranks keep the
+        torch.distributed transport of this class.  gloo with device memory (tests: ranks sharing one
+        GPU): the library calls back into this class for the two steps."""
+        import warnings
+        be, dist = self.be, self.dist
+        if dist.get_backend() != "nccl":
+            be.comm_bind_callbacks(self._cb_halo, self._cb_allreduce, self.rank, self.world)
+            self.in_library = "callbacks"
+            return
+        box, why = [None], ""
+        if self.rank == 0:
+            try:
+                box[0] = be.comm_unique_id()
+            except Exception as e:          # noqa: BLE001 - reported below, every rank must learn of it
+                why = str(e)
+        if self.world > 1:
+            dist.broadcast_object_list(box, src=0)
+        ok = 0.0
+        if box[0] is not None:
+            try:
+                be.comm_bind_rccl(box[0], self.rank, self.world)
+                ok = 1.0
+            except Exception as e:          # noqa: BLE001
+                why = str(e)
+        flag = self.torch.tensor([ok], dtype=self.torch.float64, device=self._scalar_device())
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) == 1.0:
+            self.in_library = "rccl"
+        else:
+            be.comm_unbind()
+            warnings.warn("in-library RCCL binding not available on every rank (%s): the sharded PCG is driven "
+                          "through torch.distributed instead" % (why or "another rank failed"))
+
+    def _cb_halo(self, vec, own0, own1, lo_g, hi_g):
+        from types import SimpleNamespace
+        self.halo_exchange_raw(SimpleNamespace(part=SimpleNamespace(own0=own0, own1=own1, lo_ghost=lo_g, hi_ghost=hi_g)), vec)
+
+    def _cb_allreduce(self, first, count):
+        self.allreduce_slots(first, count)
 
     def _check_stream(self):
         """Collectives are ordered against torch's current stream: the HIP library must enqueue on it too."""
@@ -214,6 +265,15 @@ class TorchComm:
         return iters, (np.sqrt(rr / bb) if bb > 0 else 0.0)
 
     def pcg(self, mesh, op, b, x, rtol, atol, maxit):
+        if self.in_library:
+            part = mesh.part
+            self._check_stream()
+            iters, rel = self.be.pcg_solve_sharded(op, b.dev(), x.dev(), part.own0, part.own1, part.lo_ghost,
+                                                   part.hi_ghost, rtol, atol, maxit)
+            x.touched_dev()
+            x._host_ok = False
+            x._halo_version = x.version      # the library returned x with current ghost planes
+            return iters, rel
         if self.single_reduction:
             return self.pcg_single_reduction(mesh, op, b, x, rtol, atol, maxit)
         be, part = self.be, mesh.part

@@ -146,6 +146,31 @@ class HipBackend:
     def slots_set(self, vals, first=0):
         self.ctx.slots_upload(vals, first)
 
+    # ---- the sharded solve with loop and communication inside the library (csrc/pgd_comm.hip)
+    def comm_bind_callbacks(self, halo, allreduce, rank, world):
+        self.ctx.comm_bind_callbacks(halo, allreduce, rank, world)
+
+    def comm_unique_id(self):
+        return self.ctx.comm_unique_id()
+
+    def comm_bind_rccl(self, unique_id, rank, world):
+        self.ctx.comm_bind_rccl(unique_id, rank, world)
+
+    def comm_unbind(self):
+        self.ctx.comm_unbind()
+
+    def comm_info(self):
+        return self.ctx.comm_info()
+
+    def comm_halo(self, vec, own0, own1, lo_g, hi_g):
+        self.ctx.comm_halo(vec, own0, own1, lo_g, hi_g)
+
+    def comm_allreduce_slots(self, first, count):
+        self.ctx.comm_allreduce_slots(first, count)
+
+    def pcg_solve_sharded(self, op, b, x, own0, own1, lo_g, hi_g, rtol, atol, maxit):
+        return self.ctx.pcg_solve_sharded(op, b, x, own0, own1, lo_g, hi_g, rtol, atol, maxit)
+
     def sync(self):
         self.ctx.sync()
 

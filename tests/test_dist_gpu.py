@@ -1,7 +1,13 @@
-"""The host-driven (sharded) PCG recurrence on the GPU with world_size 1 over RCCL:
-exercises the *_slot kernels, the zero-copy torch views of library-owned device
-memory, the shared HIP stream and an in-stream all-reduce.  (Two ranks cannot
-share one GPU under RCCL; the N > 1 exchange logic is covered by tests/test_dist_cpu.py.)"""
+"""The sharded PCG on the GPU.
+
+* world_size 1 over RCCL: the in-library loop (pgd_pcg_solve_sharded) bound to a real RCCL communicator
+  (unique id, ncclCommInitRank, the library's ring-shift self-test = ncclSend/ncclRecv to itself, in-stream
+  ncclAllReduce on the slot bank), and the Python-driven loop over torch.distributed (zero-copy torch views
+  of library-owned memory, shared HIP stream).
+* 2 and 3 processes sharing GPU 0 with REAL halo exchanges (two ranks cannot share one GPU under RCCL, so
+  the transport is gloo staged through the host): the same in-library C++ loop with the two communication
+  steps bound to callbacks, and the Python-driven loop.
+The N > 1 exchange logic is also covered on the CPU by tests/test_dist_cpu.py."""
 import os
 import socket
 
@@ -46,18 +52,28 @@ def test_sharded_driver_world1_matches_library_pcg():
         torch.cuda.set_stream(tstream)
         be2 = fem.set_backend(HipBackend(0, tstream.cuda_stream))
         fem.clear_caches()
-        comm = pdist.TorchComm(dist, be2)
-        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
-        assert mesh.part.lo_ghost == 0 and mesh.part.hi_ghost == 0
-        p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=3))
-        fem.STATS["pcg_iterations"] = 0
-        p.solve_PGD(_problem="linear")
-        assert p.num_fp_it == ref.num_fp_it
-        np.testing.assert_allclose(p.amplitude, ref.amplitude, rtol=1e-9)
-        for m in range(ref.PGD_modes):
-            got = p.PGD_func[0][m].compute_vertex_values()
-            assert np.linalg.norm(got - ref_x[m]) <= 1e-8 * np.linalg.norm(ref_x[m])
-        assert comm.stats["allreduce"] > 100
+        for in_library in (True, False):
+            fem.clear_caches()
+            comm = pdist.TorchComm(dist, be2, in_library=in_library)
+            if in_library:     # the library opened its own RCCL communicator and passed its ring-shift check
+                assert comm.in_library == "rccl" and be2.comm_info() == {"kind": "rccl", "rank": 0, "world": 1}
+            else:
+                assert comm.in_library is None
+            mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+            assert mesh.part.lo_ghost == 0 and mesh.part.hi_ghost == 0
+            p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=3))
+            fem.STATS["pcg_iterations"] = 0
+            p.solve_PGD(_problem="linear")
+            assert p.num_fp_it == ref.num_fp_it
+            np.testing.assert_allclose(p.amplitude, ref.amplitude, rtol=1e-9)
+            for m in range(ref.PGD_modes):
+                got = p.PGD_func[0][m].compute_vertex_values()
+                assert np.linalg.norm(got - ref_x[m]) <= 1e-8 * np.linalg.norm(ref_x[m])
+            assert fem.STATS["pcg_iterations"] > 100
+            if not in_library:
+                assert comm.stats["allreduce"] > 100
+        be2.comm_unbind()
+        assert be2.comm_info()["kind"] == "none"
         # zero-copy view really aliases the library's memory
         v = be2.vec_from(np.arange(5.0))
         t = be2.vec_tensor(v)
@@ -71,7 +87,7 @@ def test_sharded_driver_world1_matches_library_pcg():
         dist.destroy_process_group()
 
 
-def _shared_gpu_worker(rank, world, port, shape, q):
+def _shared_gpu_worker(rank, world, port, shape, q, in_library):
     """One of several ranks that all use GPU 0: HIP kernels for the local arithmetic, gloo (staged
     through the host) for the exchange steps."""
     import torch
@@ -87,7 +103,8 @@ def _shared_gpu_worker(rank, world, port, shape, q):
         tstream = torch.cuda.Stream(device=0)
         torch.cuda.set_stream(tstream)
         be = fem.set_backend(HipBackend(0, tstream.cuda_stream))
-        comm = pdist.TorchComm(dist, be)
+        comm = pdist.TorchComm(dist, be, in_library=in_library)
+        assert comm.in_library == ("callbacks" if in_library else None)
         P = fem.Point
         mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
         p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=3))
@@ -100,10 +117,11 @@ def _shared_gpu_worker(rank, world, port, shape, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_solve_with_real_halos_on_one_gpu(world):
+@pytest.mark.parametrize("world,in_library", [(2, True), (3, True), (2, False)])
+def test_sharded_solve_with_real_halos_on_one_gpu(world, in_library):
     """Row-sharded solve with the HIP kernels and REAL halo exchanges: `world` processes share GPU 0
-    and exchange through gloo.  Must reproduce the unsharded GPU run (same modes, same iteration counts)."""
+    and exchange through gloo - with the iteration loop inside the library (communication by callbacks)
+    or driven from Python.  Must reproduce the unsharded GPU run (same modes, same iteration counts)."""
     import torch.multiprocessing as mp
     from pgdrome_amd import fem, problems
     from pgdrome_amd.hip_backend import HipBackend
@@ -123,7 +141,7 @@ def test_sharded_solve_with_real_halos_on_one_gpu(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, shape, q, in_library)) for r in range(world)]
     for pr in procs:
         pr.start()
     out = q.get(timeout=300)
