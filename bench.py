@@ -56,6 +56,12 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries exactly ONE line, the JSON result: RCCL prints its version banner to stdout when a
+    # communicator is created, so everything else this process (and the libraries it loads) writes to
+    # file descriptor 1 is sent to stderr, and the saved descriptor is used for the result line only
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
 
@@ -185,7 +191,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(prob, spec, be, pcg_its / K, args)
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
