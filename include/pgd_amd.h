@@ -76,6 +76,12 @@ int pgd_device_count(void);
  * "vertices sharing a cell" with sorted columns.                                */
 int pgd_mesh_upload(pgd_handle ctx, const double *coords, int64_t nv, int gdim,
                     const int32_t *cells, int64_t nc, int nvpc, pgd_handle *mesh);
+/* Vector-valued Lagrange space on a scalar layout (VectorFunctionSpace(mesh,"P",k),
+ * tests/integration/test_solver_problem.py:74): dof (node i, component c) = ncomp*i + c; the CSR
+ * pattern couples all components of neighbouring nodes.  The result is a layout like any other
+ * (vectors of ncomp*nv entries; pgd_op_combine, pgd_spmv, pgd_pcg_solve, ... apply unchanged); its atoms
+ * are built from atoms of the scalar layout with pgd_atom_embed.                                 */
+int pgd_mesh_blocked(pgd_handle ctx, pgd_handle scalar_mesh, int ncomp, pgd_handle *mesh);
 int pgd_mesh_info(pgd_handle ctx, pgd_handle mesh, int64_t *nv, int64_t *nc, int64_t *nnz,
                   int32_t *max_row_len, int32_t *kl, int32_t *ku);
 int pgd_mesh_pattern_download(pgd_handle ctx, pgd_handle mesh, int32_t *row_ptr, int32_t *cols);
@@ -111,6 +117,12 @@ int pgd_vec_dot(pgd_handle ctx, pgd_handle x, pgd_handle y, int64_t lo, int64_t 
  * weighted kinds, 0 otherwise.  Deterministic (owner-computes, no atomics).     */
 int pgd_atom_assemble(pgd_handle ctx, pgd_handle mesh, int kind, int da, int db,
                       pgd_handle wvec, pgd_handle *atom);
+/* dst[(ncomp*i + cv), (ncomp*j + cu)] += coef * src[i, j]: the scalar atom `src` (e.g. DUDV(a,b)) placed
+ * in the (test component cv, trial component cu) block of an atom of the blocked layout.  dst = 0
+ * creates a zero atom first; *out is the destination.  One term of inner(C*eps(u), eps(v))*dx
+ * (test_solver_problem.py:127-150) is one call.                                                  */
+int pgd_atom_embed(pgd_handle ctx, pgd_handle blocked_mesh, pgd_handle src, int cv, int cu, double coef,
+                   pgd_handle dst, pgd_handle *out);
 int pgd_atom_upload(pgd_handle ctx, pgd_handle mesh, const double *vals, pgd_handle *atom);
 int pgd_atom_download(pgd_handle ctx, pgd_handle atom, double *vals);
 int pgd_atom_free(pgd_handle ctx, pgd_handle atom);

@@ -26,10 +26,28 @@ class _Mesh:
         self.ku = int((self.cols - rows).max())
 
 
+class _BlockedMesh:
+    """Vector-valued layout: dof (node i, component c) = ncomp i + c (pgd_mesh_blocked)."""
+
+    def __init__(self, base, base_handle, ncomp):
+        self.base, self.base_handle, self.ncomp = base, base_handle, ncomp
+        self.coords, self.cells = base.coords, base.cells
+        self.n = base.n * ncomp
+        P = sps.kron(sps.csr_matrix((np.ones(base.cols.size), base.cols, base.rp), shape=(base.n, base.n)),
+                     np.ones((ncomp, ncomp))).tocsr()
+        P.sort_indices()
+        self.rp, self.cols = P.indptr.astype(np.int32), P.indices.astype(np.int32)
+        self.kl, self.ku = base.kl * ncomp + ncomp - 1, base.ku * ncomp + ncomp - 1
+
+
 class NumpyBackend:
     name = "oracle-numpy"
 
-    def __init__(self):
+    def __init__(self, direct_above=None):
+        # systems larger than `direct_above` rows are solved by a sparse direct factorisation instead of
+        # the Jacobi-PCG loop in numpy (ill-conditioned elasticity systems of the reference's
+        # test_solver_problem need > 10^4 iterations); None: always the PCG restatement
+        self.direct_above = direct_above
         self._obj = {}
         self._next = 1
         self.slots = np.zeros(NSLOTS)
@@ -45,6 +63,21 @@ class NumpyBackend:
     # ---- meshes
     def mesh(self, coords, cells):
         return self._put(_Mesh(np.asarray(coords, dtype=np.float64), np.asarray(cells, dtype=np.int32)))
+
+    def mesh_blocked(self, mh, ncomp):
+        return self._put(_BlockedMesh(self._obj[mh], mh, int(ncomp)))
+
+    def atom_embed(self, bmh, src, cv, cu, coef=1.0, dst=0):
+        b = self._obj[bmh]
+        smh, A = self._obj[src]
+        assert smh == b.base_handle, "atom_embed: atom of another layout"
+        E = np.zeros((b.ncomp, b.ncomp))
+        E[cv, cu] = coef
+        blk = sps.kron(A, E).tocsr()
+        if dst:
+            self._obj[dst] = (bmh, (self._obj[dst][1] + blk).tocsr())
+            return dst
+        return self._put((bmh, blk))
 
     def mesh_info(self, mh):
         m = self._obj[mh]
@@ -157,6 +190,12 @@ class NumpyBackend:
 
     # ---- solvers
     def pcg(self, op, b, x, rtol, atol, maxit):
+        A = self._obj[op][1]
+        if self.direct_above is not None and A.shape[0] > self.direct_above:
+            self._obj[x][:] = F.direct_solve(A, self._obj[b])
+            r = self._obj[b] - A @ self._obj[x]
+            bn = np.linalg.norm(self._obj[b])
+            return 1, float(np.linalg.norm(r) / bn) if bn > 0 else 0.0
         sol, it, rel = F.pcg_jacobi(self._obj[op][1], self._obj[b], self._obj[x], rtol, atol, maxit)
         self._obj[x][:] = sol
         return it, rel

@@ -36,6 +36,8 @@ SIGNATURES = {
     "pgd_version": (C.c_int, []),
     "pgd_device_count": (C.c_int, []),
     "pgd_mesh_upload": (C.c_int, [H, PD, I64, C.c_int, PI32, I64, C.c_int, PH]),
+    "pgd_mesh_blocked": (C.c_int, [H, H, C.c_int, PH]),
+    "pgd_atom_embed": (C.c_int, [H, H, H, C.c_int, C.c_int, F64, H, PH]),
     "pgd_mesh_info": (C.c_int, [H, H, PI64, PI64, PI64, PI32, PI32, PI32]),
     "pgd_mesh_pattern_download": (C.c_int, [H, H, PI32, PI32]),
     "pgd_mesh_dict_count": (C.c_int, [H, H, PI32]),
@@ -196,6 +198,16 @@ class Context:
         self._ck(self.lib.pgd_mesh_upload(self.h, dptr(coords), coords.shape[0], coords.shape[1],
                                           iptr(cells), cells.shape[0], cells.shape[1], C.byref(m)))
         return m.value
+
+    def mesh_blocked(self, mesh, ncomp):
+        m = H(0)
+        self._ck(self.lib.pgd_mesh_blocked(self.h, mesh, int(ncomp), C.byref(m)))
+        return m.value
+
+    def atom_embed(self, bmesh, src, cv, cu, coef=1.0, dst=0):
+        out = H(0)
+        self._ck(self.lib.pgd_atom_embed(self.h, bmesh, src, int(cv), int(cu), float(coef), int(dst), C.byref(out)))
+        return out.value
 
     def mesh_info(self, mesh):
         nv, nc, nnz = I64(), I64(), I64()

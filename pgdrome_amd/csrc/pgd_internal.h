@@ -43,6 +43,8 @@ struct Vec : Obj {
 
 struct Mesh : Obj {
     int gdim = 0, nvpc = 0;
+    int ncomp = 1;              // > 1: blocked (vector-valued) layout over the scalar layout `base`: pattern only
+    pgd_handle base = 0;
     int64_t nv = 0, nc = 0, nnz = 0;
     double *coords = nullptr;   // SoA: gdim arrays of nv doubles (coalesced per component)
     int4 *cells = nullptr;      // one 16-byte record per cell, unused lanes = -1 (cells of <= 4 nodes)

@@ -586,6 +586,40 @@ static int build_dictionary(Ctx *c, Mesh *m) {
     return PGD_OK;
 }
 
+
+// ---------------------------------------------------------------- blocked (vector-valued) layouts
+// A vector-valued Lagrange space with NC components on a scalar layout: dof (node i, component c) has the
+// number NC i + c, and dof row NC i + c couples to BOTH components of every node j of scalar row i - the
+// scalar pattern with each entry widened to NC columns.  Entry k of scalar row i therefore sits at
+// position NC k + cu of every dof row NC i + cv: embedding a scalar atom into a block needs no search.
+__global__ __launch_bounds__(TPB) void k_block_rowptr(const int *__restrict__ rp, int64_t n, int nc, int *__restrict__ brp) {
+    const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;     // dof row
+    if (r > n * nc) return;
+    if (r == n * nc) { brp[r] = rp[n] * nc * nc; return; }
+    const int64_t i = r / nc, c = r % nc;
+    brp[r] = (rp[i] * nc + (int)c * (rp[i + 1] - rp[i])) * nc;
+}
+
+__global__ __launch_bounds__(TPB) void k_block_cols(const int *__restrict__ rp, const int *__restrict__ cols, int64_t n,
+                                                    int nc, const int *__restrict__ brp, int *__restrict__ bcols) {
+    const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (r >= n * nc) return;
+    const int64_t i = r / nc;
+    const int a = rp[i], len = rp[i + 1] - a, base = brp[r];
+    for (int k = 0; k < len; ++k)
+        for (int c = 0; c < nc; ++c) bcols[base + k * nc + c] = cols[a + k] * nc + c;
+}
+
+// dst[(row NC i + cv), (col NC j + cu)] += coef * src[i, j]
+__global__ __launch_bounds__(TPB) void k_block_embed(const int *__restrict__ rp, const double *__restrict__ src, int64_t n,
+                                                     int nc, int cv, int cu, double coef, const int *__restrict__ brp,
+                                                     double *__restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int a = rp[i], len = rp[i + 1] - a, base = brp[i * nc + cv];
+    for (int k = 0; k < len; ++k) dst[base + k * nc + cu] += coef * src[a + k];
+}
+
 }  // namespace pgd
 
 using namespace pgd;
@@ -692,6 +726,7 @@ int pgd_atom_assemble(pgd_handle h, pgd_handle mh, int kind, int da, int db, pgd
     PGD_CTX(c, h);
     Mesh *m = get_mesh(c, mh);
     if (!m || !out) return fail(c, PGD_ERR_INVALID, "atom_assemble: invalid mesh handle");
+    if (m->ncomp != 1) return fail(c, PGD_ERR_INVALID, "atom_assemble: blocked layouts take their atoms from pgd_atom_embed");
     if (kind < PGD_ATOM_MASS || kind > PGD_ATOM_WSTIFF) return fail(c, PGD_ERR_INVALID, "atom_assemble: unknown kind %d", kind);
     if (da < 0 || da >= m->gdim || db < 0 || db >= m->gdim) return fail(c, PGD_ERR_INVALID, "atom_assemble: derivative axis out of range");
     const double *w = nullptr;
@@ -713,6 +748,52 @@ int pgd_atom_assemble(pgd_handle h, pgd_handle mh, int kind, int da, int db, pgd
     else if (m->gdim == 1) k_assemble_p1<1><<<gb, TPB, 0, c->stream>>>(A);
     else if (m->gdim == 2) k_assemble_p1<2><<<gb, TPB, 0, c->stream>>>(A);
     else k_assemble_p1<3><<<gb, TPB, 0, c->stream>>>(A);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pgd_mesh_blocked(pgd_handle h, pgd_handle mh, int ncomp, pgd_handle *out) {
+    PGD_CTX(c, h);
+    Mesh *m = get_mesh(c, mh);
+    if (!m || !out || ncomp < 2 || ncomp > 3) return fail(c, PGD_ERR_INVALID, "mesh_blocked: need a scalar layout and 2 or 3 components");
+    if (m->ncomp != 1) return fail(c, PGD_ERR_INVALID, "mesh_blocked: the base layout must be scalar");
+    if ((int64_t)m->nnz * ncomp * ncomp >= (int64_t)1 << 31 || m->nv * ncomp >= (int64_t)1 << 31)
+        return fail(c, PGD_ERR_LIMIT, "mesh_blocked: index range exceeds int32");
+    std::unique_ptr<Mesh> b(new Mesh);
+    b->kind = Obj::MESH;
+    b->gdim = m->gdim; b->nvpc = m->nvpc; b->ncomp = ncomp; b->base = mh;
+    b->nv = m->nv * ncomp; b->nc = m->nc; b->nnz = m->nnz * ncomp * ncomp;
+    b->max_row = m->max_row * ncomp;
+    b->kl = m->kl * ncomp + ncomp - 1; b->ku = m->ku * ncomp + ncomp - 1;
+    void *p;
+    PGD_TRY(dev_alloc(c, &p, (size_t)(b->nv + 1) * sizeof(int))); b->row_ptr = (int *)p;
+    PGD_TRY(dev_alloc(c, &p, (size_t)(b->nnz > 0 ? b->nnz : 1) * sizeof(int))); b->cols = (int *)p;
+    PGD_HIP(c, hipMemsetAsync(b->cols, 0, (size_t)(b->nnz > 0 ? b->nnz : 1) * sizeof(int) + PAD_BYTES, c->stream));
+    k_block_rowptr<<<(int)((b->nv + TPB) / TPB), TPB, 0, c->stream>>>(m->row_ptr, m->nv, ncomp, b->row_ptr);
+    k_block_cols<<<(int)((b->nv + TPB - 1) / TPB), TPB, 0, c->stream>>>(m->row_ptr, m->cols, m->nv, ncomp, b->row_ptr, b->cols);
+    PGD_LAUNCH_CHECK(c);
+    PGD_TRY(build_dictionary(c, b.get()));
+    *out = put_obj(c, b.release());
+    return PGD_OK;
+}
+
+int pgd_atom_embed(pgd_handle h, pgd_handle bmh, pgd_handle src, int cv, int cu, double coef, pgd_handle dst, pgd_handle *out) {
+    PGD_CTX(c, h);
+    Mesh *b = get_mesh(c, bmh);
+    Csr *a = get_csr(c, src);
+    Mesh *m = a ? get_mesh(c, a->mesh) : nullptr;
+    if (!b || !a || !m || !out || b->ncomp < 2 || b->base != a->mesh)
+        return fail(c, PGD_ERR_INVALID, "atom_embed: need a blocked layout and an atom of its scalar base layout");
+    if (cv < 0 || cv >= b->ncomp || cu < 0 || cu >= b->ncomp) return fail(c, PGD_ERR_INVALID, "atom_embed: component out of range");
+    Csr *d = nullptr;
+    if (dst) {
+        d = get_csr(c, dst);
+        if (!d || d->mesh != bmh) return fail(c, PGD_ERR_INVALID, "atom_embed: destination is not an atom of the blocked layout");
+        *out = dst;
+    } else {
+        PGD_TRY(new_csr(c, bmh, b, out, &d));      // zero-filled
+    }
+    k_block_embed<<<(int)((m->nv + TPB - 1) / TPB), TPB, 0, c->stream>>>(m->row_ptr, a->vals, m->nv, b->ncomp, cv, cu, coef, b->row_ptr, d->vals);
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
 }

@@ -184,6 +184,27 @@ class Mesh:
     def atom(self, kind, da=0, db=0, weight=None):
         return self.layout(1).atom(kind, da, db, weight)
 
+    def facets(self):
+        """(facet -> sorted vertices, exterior flag): the codimension-1 entities, numbered by sorted vertex
+        tuple (in 2-D the same numbering as the edge nodes of the P2 layout)."""
+        if getattr(self, "_facets", None) is None:
+            c = self._cells.astype(np.int64)
+            nv, k = self.num_vertices(), c.shape[1]
+            if self._gdim == 1:
+                cnt = np.bincount(c.ravel(), minlength=nv)
+                self._facets = (np.arange(nv, dtype=np.int64).reshape(-1, 1), cnt == 1)
+            else:
+                loc = np.concatenate([np.sort(np.delete(c, j, axis=1), axis=1) for j in range(k)], axis=0)
+                key = loc[:, 0]
+                for j in range(1, k - 1):
+                    key = key * nv + loc[:, j]
+                uk, idx, cnt = np.unique(key, return_index=True, return_counts=True)
+                self._facets = (loc[idx], cnt == 1)
+        return self._facets
+
+    def num_facets(self):
+        return self.facets()[0].shape[0]
+
     def vertex_on_boundary(self):
         """Vertices on exterior facets (facets that belong to exactly one cell)."""
         if self._on_boundary is None:
@@ -367,8 +388,18 @@ def RectangleMesh(p0, p1, nx, ny, diagonal="right"):
         tris = ((v0, v1, v3), (v0, v2, v3))
     elif diagonal == "left":
         tris = ((v0, v1, v2), (v1, v2, v3))
+    elif diagonal == "crossed":
+        # four triangles per cell around its midpoint; the midpoints follow the grid vertices
+        xm, ym = 0.5 * (xs[:-1] + xs[1:]), 0.5 * (ys[:-1] + ys[1:])
+        XM, YM = np.meshgrid(xm, ym, indexing="xy")
+        coords = np.concatenate([coords, np.stack([XM.ravel(), YM.ravel()], axis=1)], axis=0)
+        vm = (nx + 1) * (ny + 1) + (iy * nx + ix).ravel()
+        cells = np.empty((4 * nx * ny, 3), dtype=np.int32)
+        for k, t in enumerate(((v0, v1, vm), (v0, v2, vm), (v1, v3, vm), (v2, v3, vm))):
+            cells[k::4] = np.sort(np.stack(t, axis=1), axis=1)
+        return Mesh(coords, cells)
     else:
-        raise NotImplementedError("RectangleMesh diagonal=%r (only 'right'/'left')" % (diagonal,))
+        raise NotImplementedError("RectangleMesh diagonal=%r ('right', 'left', 'crossed')" % (diagonal,))
     cells = np.empty((2 * nx * ny, 3), dtype=np.int32)
     for k, t in enumerate(tris):
         cells[k::2] = np.stack(t, axis=1)
@@ -449,6 +480,8 @@ class _DofMap:
 
 
 class FunctionSpace:
+    _ncomp = 1
+
     def __init__(self, mesh, family="CG", degree=1):
         if str(family) not in ("CG", "P", "Lagrange"):
             raise NotImplementedError("FunctionSpace family %r: only Lagrange ('CG'/'P')" % (family,))
@@ -491,6 +524,110 @@ class FunctionSpace:
 
     def __hash__(self):
         return id(self)
+
+
+class BlockLayout:
+    """Degrees of freedom of a VECTOR-valued Lagrange space: dof (node i, component c) = ncomp i + c over a
+    scalar DofLayout.  The device sees it as a layout of its own (pgd_mesh_blocked); its atoms are scalar
+    atoms of the base layout embedded in a (test component, trial component) block (pgd_atom_embed)."""
+
+    def __init__(self, base, ncomp):
+        if base.part is not None:
+            raise NotImplementedError("vector-valued space on a sharded mesh")
+        self.base, self.ncomp = base, int(ncomp)
+        self.mesh, self.degree = base.mesh, base.degree
+        self.n = base.n * self.ncomp
+        self.coords = np.repeat(base.coords, self.ncomp, axis=0)       # dof coordinates
+        self.vertex_nodes = base.vertex_nodes
+        self._handles, self._atoms = {}, {}
+        self._ones = self._space = None
+
+    part = None
+
+    def owned_range(self):
+        return (0, self.n)
+
+    def on_boundary(self):
+        return np.repeat(self.base.on_boundary(), self.ncomp)
+
+    def space(self):
+        if self._space is None:
+            self._space = VectorFunctionSpace(self.mesh, "CG", self.degree, dim=self.ncomp)
+        return self._space
+
+    def handle(self):
+        be = get_backend()
+        h = self._handles.get(id(be))
+        if h is None:
+            h = be.mesh_blocked(self.base.handle(), self.ncomp)
+            self._handles[id(be)] = h
+        return h
+
+    def atom(self, kind, da=0, db=0, weight=None, cv=None, cu=None):
+        """Scalar atom (kind, da, db) in block (cv, cu); cv = cu = None: in every diagonal block (norms)."""
+        if weight is not None:
+            raise NotImplementedError("weighted atoms on vector-valued spaces")
+        be = get_backend()
+        src = self.base.atom(kind, da, db)
+        key = (id(be), src, cv, cu)
+        a = self._atoms.get(key)
+        if a is None:
+            if cv is None:
+                a = be.atom_embed(self.handle(), src, 0, 0, 1.0, 0)
+                for c in range(1, self.ncomp):
+                    be.atom_embed(self.handle(), src, c, c, 1.0, a)
+            else:
+                a = be.atom_embed(self.handle(), src, int(cv), int(cu), 1.0, 0)
+            self._atoms[key] = a
+        return a
+
+
+def _block_layout(mesh, degree, ncomp):
+    key = ("vector", int(degree), int(ncomp))
+    lay = mesh._layouts.get(key)
+    if lay is None:
+        lay = BlockLayout(mesh.layout(int(degree)), ncomp)
+        mesh._layouts[key] = lay
+    return lay
+
+
+class _VectorElement(_Element):
+    def __init__(self, cell, degree, ncomp):
+        _Element.__init__(self, cell, degree)
+        self._ncomp = ncomp
+
+    def __str__(self):
+        return "<vector element with %d components of FiniteElement('Lagrange', %s, %d)>" % (
+            self._ncomp, self._cell, self._degree)
+
+    __repr__ = __str__
+
+    def value_shape(self):
+        return (self._ncomp,)
+
+
+class VectorFunctionSpace(FunctionSpace):
+    """Vector-valued Lagrange space, dofs interleaved by component (node-major)."""
+
+    def __init__(self, mesh, family="CG", degree=1, dim=None):
+        if str(family) not in ("CG", "P", "Lagrange"):
+            raise NotImplementedError("VectorFunctionSpace family %r: only Lagrange ('CG'/'P')" % (family,))
+        self._mesh = mesh
+        self._ncomp = int(dim) if dim is not None else mesh.geometry().dim()
+        if self._ncomp < 2 or self._ncomp > 3:
+            raise NotImplementedError("vector-valued spaces with %d components" % self._ncomp)
+        self._lay = _block_layout(mesh, int(degree), self._ncomp)
+        self._element = _VectorElement(mesh.ufl_cell(), int(degree), self._ncomp)
+        self._d2v = None
+        self._scalar = None
+
+    def num_sub_spaces(self):
+        return self._ncomp
+
+    def scalar_space(self):
+        if self._scalar is None:
+            self._scalar = self._lay.base.space()
+        return self._scalar
 
 
 def vertex_to_dof_map(V):
@@ -651,6 +788,29 @@ class Vector:
         self.scale(a)
         return self
 
+    # GenericVector arithmetic (new vectors)
+    def __add__(self, x):
+        out = self.copy()
+        out.axpy(1.0, x)
+        return out
+
+    def __sub__(self, x):
+        out = self.copy()
+        out.axpy(-1.0, x)
+        return out
+
+    def __neg__(self):
+        out = self.copy()
+        out.scale(-1.0)
+        return out
+
+    def __mul__(self, a):
+        out = self.copy()
+        out.scale(float(a))
+        return out
+
+    __rmul__ = __mul__
+
     def __itruediv__(self, a):
         self.scale(1.0 / a)
         return self
@@ -735,15 +895,16 @@ class Expr:
             if len(t.factors) != 1 or t.factors[0].deriv is not None:
                 raise NotImplementedError(".dx() of a product / second derivative")
             f = t.factors[0]
-            out.append(t.with_factors((Factor(f.leaf, int(axes[0])),)))
+            out.append(t.with_factors((Factor(f.leaf, int(axes[0]), None, f.comp),)))
         return Poly(out)
 
 
 class Factor:
-    __slots__ = ("leaf", "deriv", "other")
+    __slots__ = ("leaf", "deriv", "other", "comp")
 
-    def __init__(self, leaf, deriv=None, other=None):
-        self.leaf, self.deriv, self.other = leaf, deriv, other   # deriv: None | axis | "grad" (dot with `other`)
+    def __init__(self, leaf, deriv=None, other=None, comp=None):
+        # deriv: None | axis | "grad" (dot with `other`); comp: component of a vector-valued leaf
+        self.leaf, self.deriv, self.other, self.comp = leaf, deriv, other, comp
 
 
 class Term:
@@ -812,20 +973,45 @@ def _pscale(a, c):
 
 class Constant(Expr):
     def __init__(self, value, cell=None, name=None):
+        self._vals = None
         if isinstance(value, (tuple, list, np.ndarray)) and np.ndim(value) > 0:
-            raise NotImplementedError("vector/tensor Constant (vector-valued spaces: SURVEY 8(f4))")
+            if np.ndim(value) != 1:
+                raise NotImplementedError("tensor-valued Constant")
+            self._vals = np.array(value, dtype=np.float64)     # vector valued: used through dot() / [i]
+            self._v = float("nan")
+            return
         self._v = float(value)
 
     def assign(self, v):
-        self._v = float(v)
+        if self._vals is not None:
+            self._vals[:] = np.asarray(v.values() if isinstance(v, Constant) else v, dtype=np.float64)
+        else:
+            self._v = float(v)
 
     def values(self):
-        return np.array([self._v])
+        return self._vals.copy() if self._vals is not None else np.array([self._v])
+
+    def ufl_shape(self):
+        return () if self._vals is None else (self._vals.size,)
+
+    def __getitem__(self, i):
+        if self._vals is None:
+            raise TypeError("scalar Constant is not subscriptable")
+        return float(self._vals[i])
+
+    def __len__(self):
+        if self._vals is None:
+            raise TypeError("scalar Constant has no len()")
+        return self._vals.size
 
     def __float__(self):
+        if self._vals is not None:
+            raise TypeError("vector-valued Constant used as a scalar")
         return self._v
 
     def _poly(self):
+        if self._vals is not None:
+            raise TypeError("vector-valued Constant in a scalar expression: use dot() or index it")
         return [Term(1.0, (), (self,))]
 
     def __call__(self, *a):
@@ -849,7 +1035,143 @@ def grad(f):
 nabla_grad = grad
 
 
+class Indexed(Expr):
+    """Component i of a vector-valued Function / Argument."""
+
+    def __init__(self, leaf, i):
+        n = leaf._V._ncomp
+        if not 0 <= int(i) < n:
+            raise IndexError("component %r of a %d-vector" % (i, n))
+        self.leaf, self.i = leaf, int(i)
+
+    def _poly(self):
+        return [Term(1.0, (Factor(self.leaf, None, None, self.i),))]
+
+
+class ListTensor:
+    """as_vector([...]) / as_matrix([[...]]): a rank-1 or rank-2 array of scalar expressions.  Only the
+    algebra the elasticity forms of the reference use: M * v, scalar * T, T + T, inner / dot, indexing."""
+
+    def __init__(self, entries):
+        a = np.empty(np.shape(entries), dtype=object)
+        if a.ndim not in (1, 2):
+            raise NotImplementedError("tensors of rank %d" % a.ndim)
+        for idx in np.ndindex(a.shape):
+            e = entries[idx[0]] if a.ndim == 1 else entries[idx[0]][idx[1]]
+            a[idx] = e if isinstance(e, Expr) else float(e)
+        self.a = a
+
+    def ufl_shape(self):
+        return self.a.shape
+
+    def __getitem__(self, i):
+        r = self.a[i]
+        return ListTensor(r) if isinstance(r, np.ndarray) else r
+
+    def __len__(self):
+        return self.a.shape[0]
+
+    @staticmethod
+    def _mul(x, y):
+        if isinstance(x, float) and isinstance(y, float):
+            return x * y
+        if isinstance(x, float):
+            return 0.0 if x == 0.0 else (y if x == 1.0 else x * y)
+        if isinstance(y, float):
+            return 0.0 if y == 0.0 else (x if y == 1.0 else x * y)
+        return x * y
+
+    @staticmethod
+    def _add(x, y):
+        if isinstance(x, float) and x == 0.0:
+            return y
+        if isinstance(y, float) and y == 0.0:
+            return x
+        return x + y
+
+    def __mul__(self, o):
+        if isinstance(o, Measure):
+            raise TypeError("a tensor-valued integrand: contract it with inner() / dot() first")
+        comps = _vector_components(o)
+        if comps is not None:
+            if self.a.ndim != 2 or self.a.shape[1] != len(comps):
+                raise ValueError("shape mismatch in matrix * vector")
+            out = []
+            for i in range(self.a.shape[0]):
+                acc = 0.0
+                for k in range(self.a.shape[1]):
+                    acc = self._add(acc, self._mul(self.a[i, k], comps[k]))
+                out.append(acc)
+            return ListTensor(out)
+        c = o if isinstance(o, Expr) else float(o)
+        out = np.empty(self.a.shape, dtype=object)
+        for idx in np.ndindex(self.a.shape):
+            out[idx] = self._mul(self.a[idx], c)
+        return ListTensor(out.tolist())
+
+    def __rmul__(self, o):
+        c = o if isinstance(o, Expr) else float(o)
+        out = np.empty(self.a.shape, dtype=object)
+        for idx in np.ndindex(self.a.shape):
+            out[idx] = self._mul(c, self.a[idx])
+        return ListTensor(out.tolist())
+
+    def __add__(self, o):
+        b = o.a if isinstance(o, ListTensor) else np.array(_vector_components(o), dtype=object)
+        if b.shape != self.a.shape:
+            raise ValueError("shape mismatch in tensor sum")
+        out = np.empty(self.a.shape, dtype=object)
+        for idx in np.ndindex(self.a.shape):
+            out[idx] = self._add(self.a[idx], b[idx])
+        return ListTensor(out.tolist())
+
+    def __neg__(self):
+        return self.__rmul__(-1.0)
+
+    def __sub__(self, o):
+        return self + (-1.0) * (o if isinstance(o, ListTensor) else ListTensor(_vector_components(o)))
+
+
+def as_vector(entries):
+    return ListTensor(list(entries))
+
+
+def as_matrix(entries):
+    return ListTensor(np.asarray(entries, dtype=object).tolist())
+
+
+as_tensor = as_matrix
+
+
+def _vector_components(o):
+    """Components of a vector-valued operand (ListTensor of rank 1, vector Constant, vector-valued
+    Function / Argument) or None for scalars."""
+    if isinstance(o, ListTensor):
+        return list(o.a) if o.a.ndim == 1 else None
+    if isinstance(o, Constant) and o._vals is not None:
+        return [float(v) for v in o._vals]
+    V = getattr(o, "_V", None)
+    if V is not None and getattr(V, "_ncomp", 1) > 1 and isinstance(o, (Function, Argument)):
+        return [Indexed(o, i) for i in range(V._ncomp)]
+    if isinstance(o, (tuple, list, np.ndarray)) and np.ndim(o) == 1:
+        return [e if isinstance(e, Expr) else float(e) for e in o]
+    return None
+
+
 def inner(a, b):
+    ca, cb = _vector_components(a), _vector_components(b)
+    if ca is not None or cb is not None:
+        if ca is None or cb is None or len(ca) != len(cb):
+            raise ValueError("inner / dot of operands of different shape")
+        acc = 0.0
+        for x, y in zip(ca, cb):
+            acc = ListTensor._add(acc, ListTensor._mul(x, y))
+        return acc if isinstance(acc, Expr) else Poly([Term(float(acc), ())])
+    if isinstance(a, ListTensor) and isinstance(b, ListTensor):      # rank 2: full contraction
+        acc = 0.0
+        for idx in np.ndindex(a.a.shape):
+            acc = ListTensor._add(acc, ListTensor._mul(a.a[idx], b.a[idx]))
+        return acc if isinstance(acc, Expr) else Poly([Term(float(acc), ())])
     if isinstance(a, Grad) and isinstance(b, Grad):
         return Poly([Term(a.num * b.num, (Factor(a.leaf, "grad", b.leaf),), a.consts + b.consts)])
     if isinstance(a, Grad) or isinstance(b, Grad):
@@ -861,27 +1183,37 @@ dot = inner
 
 
 class Measure:
+    """dx: cell integrals over a whole mesh.  ds: exterior-facet integrals, optionally restricted to the
+    facets a MeshFunction marks with ``subdomain_id`` (``ds(2)``)."""
+
     def __init__(self, kind="dx", domain=None, subdomain_data=None, subdomain_id=None):
-        if kind != "dx":
-            raise NotImplementedError("Measure %r: only cell integrals dx (ds: SURVEY 8(f4))" % (kind,))
+        if kind not in ("dx", "ds"):
+            raise NotImplementedError("Measure %r: cell integrals dx and exterior-facet integrals ds" % (kind,))
+        if kind == "dx" and (subdomain_id is not None or subdomain_data is not None):
+            raise NotImplementedError("cell-subdomain integrals dx(id)")
         self.kind, self.mesh = kind, domain
-        if subdomain_id is not None or subdomain_data is not None:
-            raise NotImplementedError("subdomain integrals (SURVEY 8(f4))")
+        self.subdomain_data, self.subdomain_id = subdomain_data, subdomain_id
+        if self.mesh is None and subdomain_data is not None:
+            self.mesh = subdomain_data.mesh()
 
     def __call__(self, *args, **kw):
-        mesh = kw.get("domain")
+        mesh, sid = kw.get("domain", self.mesh), kw.get("subdomain_id", self.subdomain_id)
+        data = kw.get("subdomain_data", self.subdomain_data)
         for a in args:
             if isinstance(a, Mesh):
                 mesh = a
+            elif isinstance(a, numbers.Integral) and self.kind == "ds":
+                sid = int(a)
             elif a is not None:
-                raise NotImplementedError("dx(subdomain id) (SURVEY 8(f4))")
-        return Measure(self.kind, mesh)
+                raise NotImplementedError("dx(subdomain id)")
+        return Measure(self.kind, mesh, data, sid)
 
     def __rmul__(self, o):
         return Form([(t, self) for t in _as_poly(o)])
 
 
 dx = Measure("dx")
+ds = Measure("ds")
 
 
 class Form:
@@ -955,7 +1287,22 @@ class Argument(Expr):
         return self._V
 
     def _poly(self):
+        if self._V._ncomp > 1:
+            raise TypeError("vector-valued argument in a scalar expression: index it (v[i]) or use dot()")
         return [Term(1.0, (Factor(self),))]
+
+    def __getitem__(self, i):
+        if self._V._ncomp == 1:
+            raise TypeError("scalar argument is not subscriptable")
+        return Indexed(self, i)
+
+    def __len__(self):
+        if self._V._ncomp == 1:
+            raise TypeError("scalar argument has no len()")
+        return self._V._ncomp
+
+    def ufl_shape(self):
+        return () if self._V._ncomp == 1 else (self._V._ncomp,)
 
 
 def TestFunction(V):
@@ -996,7 +1343,24 @@ class Function(Expr):
 
     def compute_vertex_values(self, mesh=None):
         vn = self._V._lay.vertex_nodes
+        nc = self._V._ncomp
+        if nc > 1:     # dolfin: all vertex values of component 0, then component 1, ...
+            a = self._vec.host().reshape(-1, nc)
+            return (a if vn is None else a[vn]).T.reshape(-1).copy()
         return self._vec.host().copy() if vn is None else self._vec.host()[vn]
+
+    def __getitem__(self, i):
+        if self._V._ncomp == 1:
+            raise TypeError("scalar Function is not subscriptable")
+        return Indexed(self, i)
+
+    def __len__(self):
+        if self._V._ncomp == 1:
+            raise TypeError("scalar Function has no len()")
+        return self._V._ncomp
+
+    def ufl_shape(self):
+        return () if self._V._ncomp == 1 else (self._V._ncomp,)
 
     def copy(self, deepcopy=False):
         return Function(self._V, self) if deepcopy else self
@@ -1012,6 +1376,8 @@ class Function(Expr):
         self.assign(other)
 
     def _poly(self):
+        if self._V._ncomp > 1:
+            raise TypeError("vector-valued Function in a scalar expression: index it (u[i]) or use dot()")
         return [Term(1.0, (Factor(self),))]
 
     def __call__(self, *x):
@@ -1021,6 +1387,14 @@ class Function(Expr):
 
 
 def _point_eval(f, x):
+    if f._V._ncomp > 1:
+        # evaluate every component with the scalar machinery on a strided view of the dof vector
+        nc, base = f._V._ncomp, f._V._lay.base
+        full = f._vec.host()
+        out = np.empty(nc)
+        for c in range(nc):
+            out[c] = _point_eval(_ScalarView(base, full[c::nc]), x)
+        return out
     mesh = f._V.mesh()
     X, cells, vals = mesh.coordinates(), mesh.cells(), f._vec.host()
     if f._V._lay.degree == 2 and mesh.topology().dim() > 1:
@@ -1061,6 +1435,21 @@ def _point_eval(f, x):
     if L[k].min() < -1e-10:
         raise RuntimeError("point %r outside the mesh" % (x,))
     return float(L[k] @ vals[cells[k]])
+
+
+class _ScalarView:
+    """One component of a vector-valued Function, seen as a scalar function for point evaluation."""
+
+    class _Vec:
+        def __init__(self, a):
+            self._a = a
+
+        def host(self):
+            return self._a
+
+    def __init__(self, lay, values):
+        self._V = lay.space()
+        self._vec = _ScalarView._Vec(np.ascontiguousarray(values))
 
 
 _EXPR_FUNCS = {
@@ -1159,9 +1548,13 @@ class Expression(Expr):
     documented deviation)."""
 
     def __init__(self, code=None, degree=None, element=None, cell=None, domain=None, name=None, **params):
-        if isinstance(code, (tuple, list)):
-            raise NotImplementedError("vector-valued Expression (SURVEY 8(f4))")
         object.__setattr__(self, "_params", dict(params))
+        self._components = None
+        if isinstance(code, (tuple, list)):
+            # vector valued: one scalar Expression per component; usable with interpolate() / DirichletBC
+            self._components = [Expression(c, degree=degree, **params) for c in code]
+            self._code, self._py, self._degree, self._cache = None, None, degree, {}
+            return
         self._code = code
         self._py = compile(_c_to_py(code), "<Expression %r>" % (code,), "eval") if code is not None else None
         self._degree = degree
@@ -1189,6 +1582,8 @@ class Expression(Expr):
         return out
 
     def is_constant(self):
+        if self._components is not None:
+            return all(c.is_constant() for c in self._components)
         return "x[" not in self._code
 
     def eval_at(self, coords):
@@ -1222,10 +1617,42 @@ class Expression(Expr):
         return f
 
     def _poly(self):
+        if self._components is not None:
+            raise TypeError("vector-valued Expression in a scalar expression")
         return [Term(1.0, (Factor(self),))]
 
 
+def _interpolate_vector(v, V):
+    """Nodal interpolation into a vector-valued space (dofs interleaved by component)."""
+    f = Function(V)
+    nc, base = V._ncomp, V._lay.base
+    vals = np.empty((base.n, nc))
+    if isinstance(v, Function) and v._V._ncomp == nc:
+        if v._V._lay is V._lay:
+            f._vec.assign_from(v._vec)
+            return f
+        vals[:] = np.array([v(x) for x in base.coords])
+    elif isinstance(v, Expression) and v._components is not None and len(v._components) == nc:
+        for c, e in enumerate(v._components):
+            vals[:, c] = e.eval_at(base.coords)
+    elif isinstance(v, Expression) and v._components is None:
+        vals[:] = v.eval_at(base.coords)[:, None]          # the same scalar in every component
+    elif isinstance(v, Constant) and v._vals is not None and v._vals.size == nc:
+        vals[:] = v._vals[None, :]
+    elif isinstance(v, (Constant, numbers.Real)):
+        vals[:] = float(v)
+    elif isinstance(v, (tuple, list, np.ndarray)) and len(v) == nc:
+        vals[:] = np.asarray(v, dtype=np.float64)[None, :]
+    else:
+        raise TypeError("cannot interpolate %r into a %d-vector space" % (type(v), nc))
+    f._vec._host = vals.reshape(-1)
+    f._vec.touched_host()
+    return f
+
+
 def interpolate(v, V):
+    if V._ncomp > 1:
+        return _interpolate_vector(v, V)
     f = Function(V)
     if isinstance(v, Function):
         if v._V._lay is V._lay:
@@ -1253,42 +1680,161 @@ def project(v, V, bcs=None, **kw):
 
 
 # ----------------------------------------------------------------- boundary conditions
+class MeshFunction:
+    """dolfin.MeshFunction("size_t", mesh, dim[, value]): one value per mesh entity of dimension `dim`
+    (cells, facets or vertices)."""
+
+    def __init__(self, value_type, mesh, dim, value=0):
+        tdim = mesh.topology().dim()
+        self._mesh, self._dim = mesh, int(dim)
+        if self._dim == tdim:
+            n = mesh.num_cells()
+        elif self._dim == tdim - 1:
+            n = mesh.num_facets()
+        elif self._dim == 0:
+            n = mesh.num_vertices()
+        else:
+            raise NotImplementedError("MeshFunction over entities of dimension %d of a %d-D mesh" % (self._dim, tdim))
+        dt = {"size_t": np.int64, "int": np.int64, "bool": bool, "double": np.float64}[str(value_type)]
+        self._a = np.full(n, value, dtype=dt)
+
+    def mesh(self):
+        return self._mesh
+
+    def dim(self):
+        return self._dim
+
+    def set_all(self, v):
+        self._a[:] = v
+
+    def array(self):
+        return self._a
+
+    def size(self):
+        return self._a.size
+
+    def __getitem__(self, i):
+        return self._a[i]
+
+    def __setitem__(self, i, v):
+        self._a[i] = v
+
+    def entity_vertices(self):
+        """(entity -> vertices, on-boundary flag per entity)."""
+        tdim = self._mesh.topology().dim()
+        if self._dim == tdim:
+            return self._mesh.cells().astype(np.int64), np.zeros(self._mesh.num_cells(), dtype=bool)
+        if self._dim == tdim - 1:
+            return self._mesh.facets()
+        return np.arange(self._mesh.num_vertices()).reshape(-1, 1), self._mesh.vertex_on_boundary()
+
+
+def _eval_inside(fn, P, onb):
+    """inside(x, on_boundary) at the points P (m x gdim): vectorised when the marker allows it, point by
+    point (as dolfin calls it) otherwise."""
+    try:
+        res = np.asarray(fn([P[:, k] for k in range(P.shape[1])], onb))
+        if res.shape == (P.shape[0],) and res.dtype == bool:
+            return res
+    except (ValueError, TypeError):
+        pass
+    return np.array([bool(fn(P[i], bool(onb[i]))) for i in range(P.shape[0])], dtype=bool)
+
+
 class SubDomain:
     def inside(self, x, on_boundary):
         raise NotImplementedError
 
-    def mark(self, meshfunction, value):
-        raise NotImplementedError("MeshFunction marking (SURVEY 8(f4))")
+    def mark(self, meshfunction, value, check_midpoint=True):
+        """Entities all of whose vertices (and whose midpoint) lie inside get `value` (dolfin's rule;
+        ``on_boundary`` is the entity's flag).  Every vertex is evaluated at most once per flag value, and
+        midpoints only for the entities whose vertices passed."""
+        ent, onb = meshfunction.entity_vertices()
+        X = meshfunction.mesh().coordinates()
+        ok = np.ones(ent.shape[0], dtype=bool)
+        for flag in (True, False):
+            sel = np.where(onb == flag)[0]
+            if sel.size == 0:
+                continue
+            verts = np.unique(ent[sel])
+            inside_v = np.zeros(X.shape[0], dtype=bool)
+            inside_v[verts] = _eval_inside(self.inside, X[verts], np.full(verts.size, flag))
+            ok[sel] = inside_v[ent[sel]].all(axis=1)
+        if check_midpoint and ent.shape[1] > 1:
+            cand = np.where(ok)[0]
+            if cand.size:
+                ok[cand] = _eval_inside(self.inside, X[ent[cand]].mean(axis=1), onb[cand])
+        meshfunction._a[ok] = value
 
 
 def _eval_marker(marker, lay):
-    """Vertices selected by a dolfin-style marker ``f(x, on_boundary)``.
-
-    First tried vectorised (x[k] are coordinate arrays), which numpy-friendly
-    markers accept; otherwise vertex by vertex as dolfin does."""
+    """Nodes selected by a dolfin-style marker ``f(x, on_boundary)``: vectorised when the marker accepts
+    coordinate arrays, otherwise node by node as dolfin does."""
     fn = marker.inside if isinstance(marker, SubDomain) else marker
-    X, onb = lay.coords, lay.on_boundary()
-    try:
-        res = fn([X[:, k] for k in range(X.shape[1])], onb)
-        res = np.asarray(res)
-        if res.shape == (X.shape[0],) and res.dtype == bool:
-            return res
-    except (ValueError, TypeError):
-        pass
-    return np.array([bool(fn(X[i], bool(onb[i]))) for i in range(X.shape[0])], dtype=bool)
+    return _eval_inside(fn, lay.coords, lay.on_boundary())
+
+
+def _facet_nodes(lay, facet_ids):
+    """Nodes of a scalar layout on the given facets of its mesh: their vertices and, for P2, the nodes of
+    their edges."""
+    mesh = lay.mesh
+    fv = mesh.facets()[0][facet_ids]
+    vn = lay.vertex_nodes
+    nodes = [fv.ravel() if vn is None else np.asarray(vn)[fv.ravel()]]
+    if lay.degree == 2 and fv.shape[1] >= 2:
+        nv = mesh.num_vertices()
+        ekeys = lay.edge_vertices[:, 0].astype(np.int64) * nv + lay.edge_vertices[:, 1]
+        order = np.argsort(ekeys)
+        for a in range(fv.shape[1]):
+            for b in range(a + 1, fv.shape[1]):
+                lo, hi = np.minimum(fv[:, a], fv[:, b]), np.maximum(fv[:, a], fv[:, b])
+                if mesh.topology().dim() == 1:
+                    continue
+                pos = order[np.searchsorted(ekeys[order], lo * nv + hi)]
+                nodes.append(np.asarray(lay.edge_nodes)[pos])
+    return np.unique(np.concatenate(nodes))
 
 
 class DirichletBC:
     def __init__(self, V, value, marker, tag=None, method="topological"):
-        if tag is not None:
-            raise NotImplementedError("DirichletBC(V, g, meshfunction, tag) (SURVEY 8(f4))")
         self._V, self._value = V, value
-        mask = _eval_marker(marker, V._lay)
-        self._vertices = np.where(mask)[0].astype(np.int32)
+        lay = V._lay
+        if isinstance(marker, MeshFunction):
+            if tag is None:
+                raise TypeError("DirichletBC(V, g, meshfunction, tag): the tag is missing")
+            if marker.mesh() is not V.mesh() or marker.dim() != V.mesh().topology().dim() - 1:
+                raise ValueError("DirichletBC needs a facet MeshFunction of the space's mesh")
+            scalar = lay.base if V._ncomp > 1 else lay
+            nodes = _facet_nodes(scalar, np.where(marker.array() == tag)[0])
+            if V._ncomp > 1:
+                nodes = (nodes[:, None] * V._ncomp + np.arange(V._ncomp)[None, :]).ravel()
+            self._vertices = nodes.astype(np.int32)
+        else:
+            if tag is not None:
+                raise TypeError("DirichletBC(V, g, marker): a tag needs a MeshFunction")
+            mask = _eval_marker(marker, lay)
+            self._vertices = np.where(mask)[0].astype(np.int32)
         self._vals = self._values_at(self._vertices)
 
     def _values_at(self, verts):
         g, X = self._value, self._V._lay.coords
+        nc = self._V._ncomp
+        if nc > 1:
+            comp = verts % nc
+            if isinstance(g, Constant) and g._vals is not None:
+                return g._vals[comp].astype(np.float64)
+            if isinstance(g, (tuple, list, np.ndarray)):
+                return np.asarray(g, dtype=np.float64)[comp]
+            if isinstance(g, Expression) and g._components is not None:
+                out = np.empty(verts.size)
+                for c, e in enumerate(g._components):
+                    out[comp == c] = e.eval_at(X[verts[comp == c]])
+                return out
+            if isinstance(g, Function) and g._V._ncomp == nc:
+                return g._vec.host()[verts]
+            if isinstance(g, (numbers.Real, Constant)):
+                return np.full(verts.size, float(g))
+            raise TypeError("unsupported Dirichlet value %r on a vector-valued space" % (type(g),))
         if isinstance(g, (numbers.Real, Constant)):
             return np.full(verts.size, float(g))
         if isinstance(g, Expression):
@@ -1351,11 +1897,31 @@ def _bc_vertices(bcs):
 
 # ---------------------------------------------------------------------------- assembly
 class _AtomRef:
-    """One atom of one mesh with a scalar coefficient."""
-    __slots__ = ("coef", "kind", "da", "db", "weight")
+    """One atom of one mesh with a scalar coefficient; on a vector-valued space the atom sits in the block
+    (test component cv, trial component cu)."""
+    __slots__ = ("coef", "kind", "da", "db", "weight", "cv", "cu")
 
-    def __init__(self, coef, kind, da=0, db=0, weight=None):
-        self.coef, self.kind, self.da, self.db, self.weight = coef, kind, da, db, weight
+    def __init__(self, coef, kind, da=0, db=0, weight=None, cv=None, cu=None):
+        self.coef, self.kind, self.da, self.db, self.weight, self.cv, self.cu = coef, kind, da, db, weight, cv, cu
+
+    def key(self):
+        return (self.kind, self.da if self.kind in (DUDV, CONV) else 0, self.db if self.kind in (DUDV, CONVT) else 0,
+                id(self.weight) if self.weight is not None else None, self.cv or 0, self.cu or 0)
+
+    def transposed_key(self):
+        kind = {CONV: CONVT, CONVT: CONV}.get(self.kind, self.kind)
+        da, db = self.key()[1], self.key()[2]
+        return (kind, db, da, id(self.weight) if self.weight is not None else None, self.cu or 0, self.cv or 0)
+
+
+def _lay_atom(lay, kind, da, db, w, cv=None, cu=None):
+    """Atom of a layout; on a vector-valued layout in block (cv, cu), a side without a vector-valued factor
+    (the all-ones function of a functional) using component 0."""
+    if isinstance(lay, BlockLayout):
+        return lay.atom(kind, da, db, w, cv or 0, cu or 0)
+    if cv is not None or cu is not None:
+        raise ValueError("component of a vector-valued function in an integrand over a scalar space")
+    return lay.atom(kind, da, db, w)
 
 
 def _coef_vec(leaf, lay):
@@ -1523,11 +2089,12 @@ def _term_scalar(term, lay):
         return term.coef * _bilinear_scalar(lay, atom, f, g, symmetric=True)
     if len(coefs) == 0:
         one = _ones(lay)
-        return term.coef * _bilinear_scalar(lay, lay.atom(MASS), one, one)
+        return term.coef * _bilinear_scalar(lay, _lay_atom(lay, MASS, 0, 0, None), one, one)
     if len(coefs) == 1:
         c = coefs[0]
         kind, da, db, w = _atom_for(Factor(None, None), Factor(None, c.deriv), [], lay)
-        return term.coef * _bilinear_scalar(lay, lay.atom(kind, da, db, w), _ones(lay), _coef_vec(c.leaf, lay))
+        return term.coef * _bilinear_scalar(lay, _lay_atom(lay, kind, da, db, w, None, c.comp), _ones(lay),
+                                            _coef_vec(c.leaf, lay))
     # f (test side) is the first factor, g (trial side) the second, further undifferentiated ones weight
     der = [c for c in coefs if c.deriv is not None]
     plain = [c for c in coefs if c.deriv is None]
@@ -1538,8 +2105,9 @@ def _term_scalar(term, lay):
     ordered = der + plain
     f, g, rest = ordered[0], ordered[1], ordered[2:]
     kind, da, db, w = _atom_for(Factor(None, f.deriv), Factor(None, g.deriv), rest, lay)
-    return term.coef * _bilinear_scalar(lay, lay.atom(kind, da, db, w), _coef_vec(f.leaf, lay), _coef_vec(g.leaf, lay),
-                                        symmetric=kind in _SYMMETRIC_KINDS or (kind == DUDV and da == db))
+    return term.coef * _bilinear_scalar(lay, _lay_atom(lay, kind, da, db, w, f.comp, g.comp), _coef_vec(f.leaf, lay),
+                                        _coef_vec(g.leaf, lay),
+                                        symmetric=(kind in _SYMMETRIC_KINDS or (kind == DUDV and da == db)) and f.comp == g.comp)
 
 
 def _term_vector(term, lay):
@@ -1562,7 +2130,7 @@ def _term_vector(term, lay):
     if test is None:
         raise ValueError("linear form without a test function")
     if not coefs:
-        return term.coef, lay.atom(MASS), _ones(lay)
+        return term.coef, _lay_atom(lay, MASS, 0, 0, None, test.comp, None), _ones(lay)
     der = [c for c in coefs if c.deriv is not None]
     plain = [c for c in coefs if c.deriv is None]
     if len(der) > 1:
@@ -1573,7 +2141,7 @@ def _term_vector(term, lay):
     ordered = der + plain
     g, rest = ordered[0], ordered[1:]
     kind, da, db, w = _atom_for(test, Factor(None, g.deriv), rest, lay)
-    return term.coef, lay.atom(kind, da, db, w), _coef_vec(g.leaf, lay)
+    return term.coef, _lay_atom(lay, kind, da, db, w, test.comp, g.comp), _coef_vec(g.leaf, lay)
 
 
 def _term_matrix(term, lay):
@@ -1591,7 +2159,7 @@ def _term_matrix(term, lay):
     if test is None or trial is None:
         raise ValueError("bilinear form needs a trial and a test function")
     kind, da, db, w = _atom_for(test, trial, coefs, lay)
-    return _AtomRef(term.coef, kind, da, db, w)
+    return _AtomRef(term.coef, kind, da, db, w, test.comp, trial.comp)
 
 
 class AssembledVector(Vector):
@@ -1610,7 +2178,16 @@ class Matrix:
         return self.V.mesh()
 
     def is_symmetric(self):
-        return all(r.kind in (MASS, STIFF, WMASS, WSTIFF) or (r.kind == DUDV and r.da == r.db) for r in self.refs)
+        """The SUM is symmetric when every atom's coefficient equals that of its transposed partner
+        (DUDV(a,b) in block (cv,cu) <-> DUDV(b,a) in block (cu,cv); CONV <-> CONVT)."""
+        acc = {}
+        for r in self.refs:
+            acc[r.key()] = acc.get(r.key(), 0.0) + r.coef
+        scale = max((abs(v) for v in acc.values()), default=0.0)
+        for r in self.refs:
+            if abs(acc[r.key()] - acc.get(r.transposed_key(), 0.0)) > 1e-14 * scale:
+                return False
+        return True
 
     def apply_dirichlet(self, bc):
         self.bc_vertices = np.union1d(self.bc_vertices, bc.vertices()).astype(np.int32)
@@ -1620,7 +2197,7 @@ class Matrix:
         """Atoms with equal keys summed: (handles, coefs)."""
         acc = {}
         for r in self.refs:
-            h = self.lay.atom(r.kind, r.da, r.db, r.weight)
+            h = _lay_atom(self.lay, r.kind, r.da, r.db, r.weight, r.cv, r.cu)
             acc[h] = acc.get(h, 0.0) + r.coef
         return list(acc), [acc[h] for h in acc]
 
@@ -1663,7 +2240,10 @@ def assemble(form, tensor=None, **kw):
         total = 0.0
         for t, m in form.integrals:
             mesh = m.mesh if m.mesh is not None else Form([(t, m)]).mesh()
-            total += _term_scalar(t, _integral_layout(t, mesh))
+            if m.kind == "ds":
+                total += _ds_scalar(t, _integral_layout(t, mesh), m)
+            else:
+                total += _term_scalar(t, _integral_layout(t, mesh))
         return total
     mesh = form.mesh()
     V = _argument_space(form, 0)
@@ -1671,7 +2251,152 @@ def assemble(form, tensor=None, **kw):
         out = AssembledVector(V)
         _assemble_vector_into(form, V._lay, out)
         return out
+    if any(m.kind == "ds" for t, m in form.integrals):
+        raise NotImplementedError("bilinear forms over ds (Robin terms)")
     return Matrix(V, [_term_matrix(t, V._lay) for t, m in form.integrals])
+
+
+# exterior-facet integrals: only the load-type integrands the reference uses - a constant times one
+# (component of a) test function or Function:  int_Gamma N_i ds  is computed ON THE DEVICE by treating the
+# marked facets as a mesh of their own (one disconnected interval / triangle per facet, same polynomial
+# degree), assembling its mass atom and multiplying by ones; the boundary-sized result is scattered into a
+# vector of the space once and cached.
+_DS_CACHE = {}
+
+
+def _boundary_load(scalar_lay, measure):
+    mesh = scalar_lay.mesh
+    fv, ext = mesh.facets()
+    if measure.subdomain_data is not None and measure.subdomain_id is not None:
+        mf = measure.subdomain_data
+        if mf.mesh() is not mesh or mf.dim() != mesh.topology().dim() - 1:
+            raise ValueError("ds: subdomain_data must be a facet MeshFunction of the integration mesh")
+        ids = np.where((mf.array() == measure.subdomain_id) & ext)[0]
+    elif measure.subdomain_id is None:
+        ids = np.where(ext)[0]
+    else:
+        raise ValueError("ds(%r) without subdomain_data" % (measure.subdomain_id,))
+    key = (id(get_backend()), id(scalar_lay), ids.tobytes())
+    hit = _DS_CACHE.get(key)
+    if hit is not None:
+        return hit
+    out = np.zeros(scalar_lay.n)
+    tdim, deg = mesh.topology().dim(), scalar_lay.degree
+    if ids.size and tdim == 1:
+        out[_facet_nodes(scalar_lay, ids)] = 1.0                    # point evaluation at boundary vertices
+    elif ids.size:
+        X = mesh.coordinates()
+        f = fv[ids]
+        m = f.shape[0]
+        if tdim == 2:      # facets = edges -> intervals laid end to end
+            length = np.linalg.norm(X[f[:, 1]] - X[f[:, 0]], axis=1)
+            start = np.concatenate([[0.0], np.cumsum(length)[:-1]])
+            per = 2 if deg == 1 else 3
+            co = np.empty((m, per))
+            co[:, 0], co[:, 1] = start, start + length
+            if deg == 2:
+                co[:, 2] = start + 0.5 * length
+            bcoords = co.reshape(-1, 1)
+            bcells = np.arange(m * per, dtype=np.int32).reshape(m, per)
+            nodes = [f[:, 0], f[:, 1]]
+            if deg == 2:
+                nodes.append(None)     # edge node, filled below
+        else:              # facets = triangles -> congruent triangles in the plane, side by side
+            a = X[f[:, 1]] - X[f[:, 0]]
+            b = X[f[:, 2]] - X[f[:, 0]]
+            la = np.linalg.norm(a, axis=1)
+            bx = np.einsum("ij,ij->i", a, b) / la
+            by = np.sqrt(np.maximum(np.einsum("ij,ij->i", b, b) - bx * bx, 0.0))
+            off = np.concatenate([[0.0], np.cumsum(la + np.abs(bx) + 1.0)[:-1]]) + np.abs(np.minimum(bx, 0.0))
+            P0 = np.stack([off, np.zeros(m)], axis=1)
+            P1 = np.stack([off + la, np.zeros(m)], axis=1)
+            P2_ = np.stack([off + bx, by], axis=1)
+            pts = [P0, P1, P2_]
+            if deg == 2:
+                pts += [0.5 * (P1 + P2_), 0.5 * (P0 + P2_), 0.5 * (P0 + P1)]      # UFC edge order (1,2),(0,2),(0,1)
+            per = len(pts)
+            bcoords = np.stack(pts, axis=1).reshape(-1, 2)
+            bcells = np.arange(m * per, dtype=np.int32).reshape(m, per)
+            nodes = [f[:, 0], f[:, 1], f[:, 2]] + ([None] * 3 if deg == 2 else [])
+        be = get_backend()
+        bm = be.mesh(bcoords, bcells)
+        at = be.atom(bm, MASS, 0, 0, 0)
+        one, res = be.vec_from(np.ones(bcells.size)), be.vec_zeros(bcells.size)
+        be.spmv(at, one, res)
+        loads = be.vec_to_host(res).reshape(m, per)
+        for h in (one, res):
+            be.vec_free(h)
+        be.atom_free(at)
+        be.mesh_free(bm)
+        # global node of every local boundary node
+        vn = scalar_lay.vertex_nodes
+        gl = np.empty((m, per), dtype=np.int64)
+        nvert = f.shape[1]
+        for j in range(nvert):
+            gl[:, j] = f[:, j] if vn is None else np.asarray(vn)[f[:, j]]
+        if deg == 2:
+            nv = mesh.num_vertices()
+            ekeys = scalar_lay.edge_vertices[:, 0].astype(np.int64) * nv + scalar_lay.edge_vertices[:, 1]
+            order = np.argsort(ekeys)
+            pairs = [(0, 1)] if tdim == 2 else [(1, 2), (0, 2), (0, 1)]
+            for k, (a_, b_) in enumerate(pairs):
+                lo, hi = np.minimum(f[:, a_], f[:, b_]), np.maximum(f[:, a_], f[:, b_])
+                gl[:, nvert + k] = np.asarray(scalar_lay.edge_nodes)[order[np.searchsorted(ekeys[order], lo * nv + hi)]]
+        np.add.at(out, gl.ravel(), loads.ravel())
+    if len(_DS_CACHE) > 64:
+        _DS_CACHE.clear()
+    _DS_CACHE[key] = out
+    return out
+
+
+def _ds_load_vector(lay, measure, comp):
+    """int_Gamma N_i ds as a Vector of the space of `lay` (in component `comp` of a vector-valued space)."""
+    scalar = lay.base if isinstance(lay, BlockLayout) else lay
+    L = _boundary_load(scalar, measure)
+    key = ("vec", id(get_backend()), id(lay), id(L), comp)
+    v = _DS_CACHE.get(key)
+    if v is None:
+        full = np.zeros(lay.n)
+        if isinstance(lay, BlockLayout):
+            full[(comp or 0)::lay.ncomp] = L
+        else:
+            full[:] = L
+        v = Vector(lay.space(), full)
+        v._keep = L
+        _DS_CACHE[key] = v
+    return v
+
+
+def _ds_split(term, lay):
+    test, trial, coefs, gd = _classify(term, lay)
+    if gd is not None or trial is not None or any(c.deriv is not None for c in coefs):
+        raise NotImplementedError("ds integrands beyond  constant * (test function | function)")
+    return test, coefs
+
+
+def _ds_scalar(term, lay, measure):
+    test, coefs = _ds_split(term, lay)
+    if test is not None:
+        raise ValueError("scalar assemble of a form with arguments")
+    if len(coefs) == 0:
+        return term.coef * float(_boundary_load(lay.base if isinstance(lay, BlockLayout) else lay, measure).sum())
+    if len(coefs) != 1:
+        raise NotImplementedError("ds functional of a product of functions")
+    c = coefs[0]
+    f, L = _coef_vec(c.leaf, lay), _ds_load_vector(lay, measure, c.comp)
+    if f._small():
+        return term.coef * float(f.host() @ L.host())
+    return term.coef * get_backend().vec_dot(f.dev(), L.dev())
+
+
+def _ds_vector(term, lay, measure):
+    """(coef, None, load Vector): b += coef * load."""
+    test, coefs = _ds_split(term, lay)
+    if test is None:
+        raise ValueError("linear form without a test function")
+    if coefs:
+        raise NotImplementedError("ds linear form with a non-constant coefficient")
+    return term.coef, None, _ds_load_vector(lay, measure, test.comp)
 
 
 def _argument_space(form, number):
@@ -1685,7 +2410,7 @@ def _argument_space(form, number):
 
 def _assemble_vector_into(form, lay, out):
     """out = sum_s c_s A_s g_s.  Small systems on the host mirror, large ones by axpy on the device."""
-    pieces = [_term_vector(t, lay) for t, m in form.integrals]
+    pieces = [_ds_vector(t, lay, m) if m.kind == "ds" else _term_vector(t, lay) for t, m in form.integrals]
     merged = {}
     for c, atom, g in pieces:
         key = (atom, id(g))
@@ -1697,7 +2422,7 @@ def _assemble_vector_into(form, lay, out):
     if out._small() and lay.part is None:
         acc = np.zeros(out.n)
         for c, atom, g in merged.values():
-            acc += c * _matvec_cached(lay, atom, g).host()
+            acc += c * (g if atom is None else _matvec_cached(lay, atom, g)).host()
         out._host = acc
         out.touched_host()
         return
@@ -1705,7 +2430,7 @@ def _assemble_vector_into(form, lay, out):
     out.touched_dev()
     for c, atom, g in merged.values():
         if c != 0.0:
-            be.vec_axpy(out.dev(), c, _matvec_cached(lay, atom, g).dev())
+            be.vec_axpy(out.dev(), c, (g if atom is None else _matvec_cached(lay, atom, g)).dev())
     out.touched_dev()
 
 
@@ -1749,7 +2474,7 @@ def derivative(form, u, du=None):
             raise NotImplementedError("form is nonlinear in the unknown (u appears twice in an integrand)")
         i = hits[0]
         f = t.factors[i]
-        nf = Factor(trial if f.leaf is u else f.leaf, f.deriv, trial if f.other is u else f.other)
+        nf = Factor(trial if f.leaf is u else f.leaf, f.deriv, trial if f.other is u else f.other, f.comp)
         out.append((t.with_factors(t.factors[:i] + (nf,) + t.factors[i + 1:]), m))
     return Form(out)
 
@@ -1942,3 +2667,4 @@ def solve(eq, u, bcs=None, solver_parameters=None, **kw):
 def clear_caches():
     _SCALAR_MEMO.clear()
     _MV_CACHE.clear()
+    _DS_CACHE.clear()

@@ -21,6 +21,12 @@ class HipBackend:
     def mesh(self, coords, cells):
         return self.ctx.mesh_upload(coords, cells)
 
+    def mesh_blocked(self, mh, ncomp):
+        return self.ctx.mesh_blocked(mh, ncomp)
+
+    def atom_embed(self, bmh, src, cv, cu, coef=1.0, dst=0):
+        return self.ctx.atom_embed(bmh, src, cv, cu, coef, dst)
+
     def mesh_info(self, mh):
         return self.ctx.mesh_info(mh)
 

@@ -210,7 +210,56 @@ def laplace_fixture():
     return out
 
 
+def solver_problem_fixture():
+    """The reference's tests/integration/test_solver_problem.py, loaded as is, on a COARSER discretisation
+    (its own functions take the element counts: 40 x 4 "crossed" cells with vector P2 in space instead of
+    200 x 20; 2 / 10 / 10 elements for load factor, Young's-modulus factor and Poisson ratio): 2-D plane-strain
+    cantilever, PGD variables (x, p, E, nu), "linear" and "nonlinear" solve_PGD, its FEM_reference."""
+    import contextlib
+    import importlib.util
+    import io
+    import logging
+    import warnings
+    spec = importlib.util.spec_from_file_location("ref_test_solver_problem",
+                                                  "/root/reference/tests/integration/test_solver_problem.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    logging.disable(logging.CRITICAL)
+    warnings.filterwarnings("ignore")
+    ranges = [[0.0, 2.0], [0.5, 1.5], [0.1, 0.4]]
+    sample, point = [1.5, 0.75, 0.2], (500.0, 50.0)
+    out = {"elements_x": [40, 4], "elements_extra": [2, 10, 10], "sample": sample, "point": list(point), "runs": []}
+    with contextlib.redirect_stdout(io.StringIO()):
+        _, v_x = mod.create_meshX([40, 4], 2)
+        _, v_e = mod.create_meshesExtra([2, 10, 10], [1, 1, 1], ranges)
+        for problem, settings in (("linear", {"linear_solver": "mumps"}),
+                                  ("nonlinear", {"relative_tolerance": 1e-8, "linear_solver": "mumps"})):
+            params = {"E_0": 30000, "g1": fem.Constant((0.0, -0.5)), "g2": fem.Constant((0.0, -1.5))}
+            p, sol = mod.main_PGD([v_x] + v_e, params, problem=problem, settings=settings)
+            u = sol.evaluate(0, [1, 2, 3], sample, 0)
+            out["runs"].append({"problem": problem, "numModes": int(sol.numModes),
+                                "num_fp_it": [int(v) for v in p.num_fp_it],
+                                "amplitude": [float(a) for a in p.amplitude], "alpha": [float(a) for a in p.alpha],
+                                "evaluate_vertex_values": u.compute_vertex_values().tolist(),
+                                "evaluate_point": [float(v) for v in u(point)]})
+            print("solver_problem", problem, "->", sol.numModes, "modes, fp", p.num_fp_it, "amp", p.amplitude, file=sys.stderr)
+        ref = mod.FEM_reference(v_x, params)(sample)
+    out["fem_vertex_values"] = ref.compute_vertex_values().tolist()
+    out["fem_point"] = [float(v) for v in ref(point)]
+    logging.disable(logging.NOTSET)
+    return out
+
+
 def main():
+    only = set(sys.argv[1:])
+    if not only or "solver_problem" in only:
+        with open(os.path.join(HERE, "reference_solver_problem.json"), "w") as f:
+            json.dump({"generator": "tests/golden/make_fixtures.py",
+                       "source": "reference tests/integration/test_solver_problem.py functions run unchanged on a "
+                                 "coarser discretisation (main_PGD linear + nonlinear, FEM_reference)",
+                       "arithmetic": "oracle numpy backend (FEniCS absent)", "run": solver_problem_fixture()}, f)
+    if only and only != {"all"}:
+        return
     with open(os.path.join(HERE, "reference_laplace.json"), "w") as f:
         json.dump({"generator": "tests/golden/make_fixtures.py",
                    "source": "reference tests/integration/test_laplace.py run unchanged (create_PGD, FEM and FD)",

@@ -214,6 +214,67 @@ def test_column_dictionary_is_lossless(ctx):
     ctx.mesh_free(h)
 
 
+@pytest.mark.parametrize("ncomp", [2, 3])
+def test_blocked_layout_and_embedded_atoms(ctx, ncomp):
+    """pgd_mesh_blocked / pgd_atom_embed against scipy's Kronecker product (dof = ncomp * node + component)."""
+    coords, cells = F.rectangle_mesh((0, 0), (2, 1), 7, 5)
+    coords = jitter(coords, cells)
+    nodes, tab = F.p2_simplex_nodes(coords, cells)
+    h = ctx.mesh_upload(nodes, tab)
+    bh = ctx.mesh_blocked(h, ncomp)
+    n = nodes.shape[0]
+    rp, cols = ctx.mesh_pattern(bh)
+    rp_s, cols_s = F.csr_pattern(n, tab)
+    P = sps.kron(sps.csr_matrix((np.ones(cols_s.size), cols_s, rp_s), shape=(n, n)), np.ones((ncomp, ncomp))).tocsr()
+    P.sort_indices()
+    assert np.array_equal(rp, P.indptr) and np.array_equal(cols, P.indices)          # index data: bit-exact
+    info = ctx.mesh_info(bh)
+    rows = np.repeat(np.arange(n * ncomp), np.diff(rp))
+    assert info["nv"] == n * ncomp and info["nnz"] == P.nnz
+    assert info["kl"] >= (rows - cols).max() and info["ku"] >= (cols - rows).max()
+    # an elasticity-like sum of embedded atoms
+    terms = [(F.DUDV, 0, 0, 0, 0, 2.0), (F.DUDV, 1, 1, 0, 0, 0.5), (F.DUDV, 1, 1, 1, 1, 2.0), (F.DUDV, 0, 0, 1, 1, 0.5),
+             (F.DUDV, 1, 0, 0, 1, 1.0), (F.DUDV, 0, 1, 1, 0, 1.0), (F.MASS, 0, 0, ncomp - 1, ncomp - 1, 0.3)]
+    ref = sps.csr_matrix((n * ncomp, n * ncomp))
+    dst = 0
+    for kind, da, db, cv, cu, coef in terms:
+        a = ctx.atom_assemble(h, kind, da, db, 0)
+        dst = ctx.atom_embed(bh, a, cv, cu, coef, dst)
+        E = np.zeros((ncomp, ncomp))
+        E[cv, cu] = coef
+        ref = ref + sps.kron(F.assemble_atom(nodes, tab, kind, da, db), E)
+        ctx.atom_free(a)
+    full = ref.tocsr()
+    dense = full.toarray()
+    vals = ctx.atom_download(dst, P.nnz)
+    assert np.abs(vals - dense[rows, cols]).max() <= 1e-13 * np.abs(dense).max()
+    # the blocked layout is a layout like any other: SpMV and PCG apply
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, n * ncomp)
+    xv, yv = ctx.vec_from(x), ctx.vec_alloc(n * ncomp)
+    ctx.spmv(dst, xv, yv)
+    assert np.abs(ctx.vec_download(yv) - full @ x).max() <= 1e-12 * np.abs(full @ x).max()
+    assert abs(full - full.T).max() < 1e-12 * np.abs(full.data).max()
+    bc = np.where(np.repeat(nodes[:, 0] < 1e-9, ncomp))[0].astype(np.int32)
+    op = ctx.op_combine(bh, [dst], [1.0], bc)
+    A, b = F.apply_dirichlet((full + 0.7 * sps.identity(n * ncomp)).tocsr(), rng.uniform(-1, 1, n * ncomp), bc)
+    ctx.atom_free(op)
+    ident = ctx.atom_upload(bh, (rows == cols).astype(np.float64))
+    op = ctx.op_combine(bh, [dst, ident], [1.0, 0.7], bc)
+    bv, sv = ctx.vec_from(b), ctx.vec_alloc(n * ncomp)
+    its, rel = ctx.pcg_solve(op, bv, sv, 1e-12, 0.0, 5000)
+    sol = F.direct_solve(A, b)
+    assert rel <= 1e-12 and np.linalg.norm(ctx.vec_download(sv) - sol) <= 1e-9 * np.linalg.norm(sol)
+    with pytest.raises(RuntimeError):
+        ctx.atom_assemble(bh, F.MASS)                      # blocked layouts have no geometry of their own
+    for v in (xv, yv, bv, sv):
+        ctx.vec_free(v)
+    for a in (op, ident, dst):
+        ctx.atom_free(a)
+    ctx.mesh_free(bh)
+    ctx.mesh_free(h)
+
+
 def test_vector_ops(ctx):
     rng = np.random.default_rng(5)
     for n in (1, 63, 64, 257, 100_003):

@@ -199,3 +199,10 @@ def test_p2_full_order_poisson_on_gpu_equals_oracle(hip_backend, shape):
     assert n == xg.size and n > 1000
     assert np.linalg.norm(xg - xo) <= 1e-8 * np.linalg.norm(xo)      # PCG rtol 1e-10 on both sides
     assert abs(pg - po) <= 1e-8 * abs(po) and abs(ng - no) <= 1e-9 * no
+
+
+def test_reference_solver_problem_integration_case_vector_p2_on_gpu():
+    """tests/integration/test_solver_problem.py of the reference (plane-strain cantilever, vector P2 on a crossed
+    mesh, ds loads) through the HIP engine: blocked layout, embedded atoms, Jacobi-PCG on the elasticity systems."""
+    from tests import ref_cases
+    ref_cases.check_solver_problem(fem, PGDProblem, "linear", exact_counts=False)

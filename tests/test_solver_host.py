@@ -250,3 +250,49 @@ def test_reference_laplace_integration_case(variant):
     from pgdrome_amd.solver import FD_matrices, PGDProblem
     from tests import ref_cases
     ref_cases.check_laplace(fem, PGDProblem, FD_matrices, variant)
+
+
+@pytest.mark.parametrize("problem", ["linear", "nonlinear"])
+def test_reference_solver_problem_integration_case_vector_p2(problem):
+    """2-D plane-strain cantilever: VECTOR P2 on a "crossed" mesh, facet MeshFunction, ds loads, 4 PGD variables."""
+    from pgdrome_amd.solver import PGDProblem
+    from tests import ref_cases
+    ref_cases.check_solver_problem(fem, PGDProblem, problem, exact_counts=(problem == "linear"))
+
+
+def test_vector_space_basics():
+    mesh = fem.RectangleMesh(fem.Point(0, 0), fem.Point(2, 1), 4, 2, "crossed")
+    assert mesh.num_vertices() == 5 * 3 + 4 * 2 and mesh.num_cells() == 4 * 4 * 2
+    V = fem.VectorFunctionSpace(mesh, "P", 2)
+    S = fem.FunctionSpace(mesh, "P", 2)
+    assert V.dim() == 2 * S.dim() and str(V.ufl_element()).split(" ")[0] == "<vector"
+    w = fem.interpolate(fem.Expression(("x[0]*x[1]", "1.0 + x[0]*x[0]"), degree=2), V)
+    assert np.allclose(w((0.7, 0.4)), [0.28, 1.49])
+    vv = w.compute_vertex_values()
+    X = mesh.coordinates()
+    assert np.allclose(vv[:X.shape[0]], X[:, 0] * X[:, 1]) and np.allclose(vv[X.shape[0]:], 1 + X[:, 0] ** 2)
+    # component-wise forms against the scalar space
+    a0 = fem.interpolate(fem.Expression("x[0]*x[1]", degree=2), S)
+    assert np.isclose(fem.assemble(w[0] * w[0] * fem.dx(mesh)), fem.assemble(a0 * a0 * fem.dx(mesh)))
+    assert np.isclose(fem.assemble(w[0].dx(1) * w[1].dx(0) * fem.dx(mesh)), 2 * 8 / 3)         # int x * 2x
+    assert np.isclose(fem.assemble(fem.inner(w, w) * fem.dx(mesh)), fem.norm(w) ** 2)
+    eps = fem.as_vector([w[0].dx(0), w[1].dx(1), w[0].dx(1) + w[1].dx(0)])                       # (y, 0, 3x)
+    C = fem.as_matrix([[2.0, 1.0, 0.0], [1.0, 2.0, 0.0], [0.0, 0.0, 0.5]])
+    assert np.isclose(fem.assemble(fem.inner(C * eps, eps) * fem.dx(mesh)), 2 * 2 / 3 + 0.5 * 9 * 8 / 3)
+    # facets, marking, ds
+    mf = fem.MeshFunction("size_t", mesh, 1)
+    mf.set_all(0)
+
+    class Top(fem.SubDomain):
+        def inside(self, x, on_boundary):
+            return fem.near(x[1], 1.0) and x[0] > 0.99
+
+    Top().mark(mf, 7)
+    assert (mf.array() == 7).sum() == 2
+    ds = fem.Measure("ds", domain=mesh, subdomain_data=mf)
+    assert np.isclose(fem.assemble(fem.dot(fem.Constant((0.0, 1.0)), w) * ds(7)), 1.0 + (8 - 1) / 3)   # int_1^2 1 + x^2
+    b = fem.assemble(fem.dot(fem.Constant((3.0, -2.0)), fem.TestFunction(V)) * ds(7))
+    assert np.isclose(b.host()[0::2].sum(), 3.0) and np.isclose(b.host()[1::2].sum(), -2.0)
+    assert np.isclose(fem.assemble(fem.Constant(1.0) * a0 * fem.ds(mesh)), 0.5 * 4 / 2 + 1.0 + 2 * 0.5)   # int xy over the boundary
+    bc = fem.DirichletBC(V, fem.Constant((0.5, -0.5)), mf, 7)
+    assert bc.vertices().size == 2 * 5 and set(np.unique(bc.vertex_values())) == {0.5, -0.5}

@@ -37,7 +37,7 @@ def main():
     from pgdrome_amd import fem
     if args.backend == "oracle":
         from oracle.backend_numpy import NumpyBackend
-        fem.set_backend(NumpyBackend())
+        fem.set_backend(NumpyBackend(direct_above=20000))     # test_solver_problem: 131 k-dof elasticity systems
     else:
         from pgdrome_amd.hip_backend import HipBackend
         fem.set_backend(HipBackend(0))
