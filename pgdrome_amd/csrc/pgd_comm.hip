@@ -248,15 +248,11 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     }
     const pgd_handle r = k.work[0], u = k.work[1], w = k.work[2], p = k.work[3], s = k.work[4], q = k.work[5], dinv = k.work[6];
     constexpr int B = 24, CHECK = 16;       // slot base of the recurrence (pgdrome_amd/dist.py uses the same)
-    // interior rows first would overlap the exchange; here the exchange is stream-ordered before the product
-    int64_t glo = lo_g, ghi = hi_g;
-    if (own1 - own0 < glo + ghi) { glo = own1 - own0; ghi = 0; }
+    // The exchange is stream-ordered before the product, so the owned rows go in ONE launch; the slots of the
+    // two boundary-row partials (kept for the overlapped host-driven variant) stay zero.
     auto spmv_dot3 = [&](pgd_handle uu, pgd_handle ww) -> int {
         PGD_TRY(comm_halo(c, uu, get_vec(c, uu)->d, own0, own1, lo_g, hi_g));
-        PGD_TRY(pgd_spmv_dot_slot(h, oh, uu, ww, uu, own0 + glo, own1 - ghi, B + 2));
-        PGD_TRY(pgd_spmv_dot_slot(h, oh, uu, ww, uu, own0, own0 + glo, B + 3));
-        PGD_TRY(pgd_spmv_dot_slot(h, oh, uu, ww, uu, own1 - ghi, own1, B + 4));
-        return PGD_OK;
+        return pgd_spmv_dot_slot(h, oh, uu, ww, uu, own0, own1, B + 2);
     };
     PGD_TRY(pgd_flags_reset(h));
     const double zeros[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
