@@ -14,12 +14,21 @@ after the hot path:
 * ``PGDErrorComputation`` (model.py:1666-1825): Latin-hypercube sampling (seed 3452) of the free
   coordinates and relative l2 errors against a full-order model callable.
 
-Not built (out of scope so far): pxdmf / hdf5 / xdmf I/O, sensor responses through
-``fenicstools.Probes``, derivatives.
+* result files (model.py:162-575, 1414-1453): ``write_pxdmf`` / ``_write_xdmf`` / ``write_hdf5`` /
+  ``load_pxdmf`` / ``save_modes_latex``.  The reference stores the heavy data in HDF5 through
+  ``dolfin.HDF5File`` / ``XDMFFile`` and reads it back with h5py; neither exists in this image, so the
+  same XML layout (Grid / Information / Topology / Geometry / Attribute per PGD coordinate, the layout the
+  ParaView PGD plugin reads) is written with XDMF ``Format="Binary"`` data items (raw little-endian files
+  next to the .pxdmf, ``Seek`` offsets) and the mode functions go to ``<grid>_data.npz``.  ``load_pxdmf``
+  reads the XML, Binary and - when h5py is importable - HDF items, i.e. also reference-written files.
+
+Not built: sensor responses through ``fenicstools.Probes``, derivatives.
 """
 from __future__ import annotations
 
 import logging
+import os
+import xml.etree.ElementTree as et
 
 import numpy as np
 from scipy import interpolate
@@ -33,15 +42,28 @@ DEVICE_EVAL_MIN_DOFS = 1 << 16   # fixed dimensions at least this large are reco
 
 
 class PGDAttribute:
-    def __init__(self, name="", n_modes=0, field="Node", _type="Scalar"):
-        self.name, self.n_modes, self.field, self._type = name, n_modes, field, _type
+    def __init__(self, name="", n_modes=0, _type="Node", field="Scalar"):
+        # _type: "Node" | "Cell" (where the values live); field: "Scalar" | "Vector" (model.py:1469-1474)
+        self.name, self.n_modes, self._type, self.field = name, n_modes, _type, field
         self.data = []                # vertex values per mode, shape (n, 1)
         self.interpolationfct = []    # callables per mode (Functions or interp1d objects)
         self.interpolationInfo = {"name": 1, "family": "P", "degree": 1, "_type": "scalar"}
 
     def fill_data(self, modes):
         self.interpolationfct = list(modes)
-        self.data = [np.asarray(f.compute_vertex_values()).reshape(-1, 1) for f in modes]
+        self.data = []
+        for f in modes:
+            nc = f.function_space()._ncomp
+            v = np.asarray(f.compute_vertex_values())
+            self.data.append(v.reshape(nc, -1).T.copy() if nc > 1 else v.reshape(-1, 1))
+        if modes and modes[0].function_space()._ncomp > 1:
+            self.interpolationInfo = dict(self.interpolationInfo, _type="vector")
+        if modes:
+            self.interpolationInfo = dict(self.interpolationInfo, degree=modes[0].function_space().ufl_element().degree())
+
+    def print_info(self):
+        print("PGDAttribute %s: type %s, field %s, %d modes, interpolation %s" % (
+            self.name, self._type, self.field, len(self.data), self.interpolationInfo))
 
 
 class PGDMesh:
@@ -50,7 +72,11 @@ class PGDMesh:
         self.info = info or []
         self.attributes = []
         self.fenics_mesh = fmesh
+        self.numNodes, self.numElements, self.meshdim = 0, None, 0
+        self.dataX = self.dataY = self.dataZ = np.zeros(0)
+        self.topology, self.typElements, self.typGeometry = None, None, "XYZ"
         if fmesh is not None:
+            self.meshdim = fmesh.topology().dim()
             X = fmesh.coordinates()
             n = fmesh.num_vertices()
             self.numNodes, self.numElements = n, fmesh.num_cells()
@@ -69,23 +95,260 @@ class PGD:
         self.name = name
         self.numModes = n_modes
         self.used_numModes = n_modes
-        self.num_pgd_var = len(fmeshes)
         self.problem = None
+        self.folder = ""
         self.mesh = []
         info = list(modes_info) + ["u", "Node", "Scalar"][len(modes_info):]
         for d, fm in enumerate(fmeshes):
             pm = PGDMesh("PGD%d" % (d + 1), fm, [name_coord[d]] if d < len(name_coord) else [])
             att = PGDAttribute(info[0], n_modes, info[1], info[2])
-            att.fill_data(pgd_modes[d] if d < len(pgd_modes) else [])
+            att.fill_data(list(pgd_modes[d])[:n_modes] if d < len(pgd_modes) else [])   # the first n_modes (model.py:1483-1487)
             pm.attributes.append(att)
             self.mesh.append(pm)
         if verbose:
             self.print_info()
 
+    @property
+    def num_pgd_var(self):
+        return len(self.mesh)
+
     def print_info(self):
         print("PGD solution %r: %d modes, %d coordinates" % (self.name, self.numModes, self.num_pgd_var))
         for m in self.mesh:
             print("  %s %s: %d nodes, %d elements" % (m.name, m.info, m.numNodes, m.numElements))
+
+    @property
+    def fenics_meshes(self):
+        return [m.fenics_mesh for m in self.mesh]
+
+    # ------------------------------------------------------------------------ result files
+    def _grid_info(self, d):
+        """[dimension, coordinate name, unit] of a PGD coordinate, the three <Information> items of a grid."""
+        m = self.mesh[d]
+        if len(m.info) >= 3:
+            return [int(m.info[0]), str(m.info[1]), str(m.info[2])]
+        return [int(m.meshdim), str(m.info[0]) if m.info else "C%d" % d, "-?-"]
+
+    @staticmethod
+    def _visual(att, k, pad):
+        """Node data of mode k as the reference's XDMF writer lays it out: (N, 1) for a scalar field,
+        (N, 3) zero-padded for a vector field."""
+        a = np.asarray(att.data[k], dtype=np.float64)
+        if a.ndim == 1:
+            a = a.reshape(-1, 1)
+        if a.shape[1] > 1 or pad:
+            out = np.zeros((a.shape[0], 3))
+            out[:, :a.shape[1]] = a
+            return out
+        return a
+
+    def write_hdf5(self, folder):
+        """The mode FUNCTIONS of every coordinate (mesh + dof vectors), what the reference keeps in
+        ``<grid>_data.h5`` (model.py:162-181) - here ``<grid>_data.npz``."""
+        for pm in self.mesh:
+            arrays = {"coordinates": pm.fenics_mesh.coordinates(), "cells": pm.fenics_mesh.cells()}
+            for a, att in enumerate(pm.attributes):
+                for k in range(self.numModes):
+                    f = att.interpolationfct[k]
+                    V = f.function_space()
+                    arrays["ATT%d_MODE_%d" % (a, k)] = f.vector().host()
+                    arrays["ATT%d_META" % a] = np.array([V.ufl_element().degree(), V._ncomp])
+            np.savez(os.path.join(folder, pm.name + "_data.npz"), **arrays)
+        self.logger.info("Wrote %i data files for Mode data", self.num_pgd_var)
+
+    def _write_xdmf(self, folder):
+        """Per coordinate: ``<grid>.bin`` (raw little-endian: topology int32, geometry and one block per mode
+        float64) and a ``<grid>.xdmf`` that references it (model.py:183-196 writes .xdmf + .h5)."""
+        self._layout = {}
+        for pm in self.mesh:
+            topo = np.ascontiguousarray(pm.topology, dtype="<i4")
+            geom = np.ascontiguousarray(pm.fenics_mesh.coordinates(), dtype="<f8")
+            if geom.shape[1] == 1:                         # XDMF has no 1-D geometry: pad like dolfin does
+                geom = np.concatenate([geom, np.zeros_like(geom)], axis=1)
+            items, pos = {}, 0
+            with open(os.path.join(folder, pm.name + ".bin"), "wb") as fb:
+                for key, arr in [("topology", topo), ("geometry", geom)] + [
+                        ("%d/%d" % (a, k), np.ascontiguousarray(self._visual(att, k, False), dtype="<f8"))
+                        for a, att in enumerate(pm.attributes) for k in range(len(att.data))]:
+                    fb.write(arr.tobytes())
+                    items[key] = (pos, arr.shape)
+                    pos += arr.nbytes
+            self._layout[pm.name] = items
+            with open(os.path.join(folder, pm.name + ".xdmf"), "w") as fx:
+                fx.write('<?xml version="1.0"?>\n<Xdmf Version="3.0"><Domain>\n')
+                fx.write(self._grid_xml(pm, items, False, "  "))
+                fx.write("</Domain></Xdmf>\n")
+
+    @staticmethod
+    def _binary_item(name, entry, number_type, precision):
+        pos, shape = entry
+        return ('<DataItem Dimensions="%s" NumberType="%s" Precision="%d" Format="Binary" Endian="Little" Seek="%d">'
+                '%s.bin</DataItem>' % (" ".join(str(v) for v in shape), number_type, precision, pos, name))
+
+    def _grid_xml(self, pm, items, pad_vectors, ind):
+        d = self.mesh.index(pm)
+        dims, cname, unit = self._grid_info(d)
+        out = [ind + '<Grid Name="%s">' % pm.name,
+               ind + '  <Information Name="Dims" Value="%s" />' % dims,
+               ind + '  <Information Name="Dim0" Value="%s" />' % cname,
+               ind + '  <Information Name="Unit0" Value="%s" />' % unit]
+        tshape = items["topology"][1]
+        out.append(ind + '    <Topology NumberOfElements = "%d" TopologyType = "%s" NodesPerElement = "%d" >' % (
+            pm.numElements, pm.typElements, tshape[1]))
+        out.append(ind + "      " + self._binary_item(pm.name, items["topology"], "Int", 4))
+        out.append(ind + "    </Topology>")
+        gshape = items["geometry"][1]
+        out.append(ind + '    <Geometry GeometryType = "%s">' % ("XY" if gshape[1] == 2 else "XYZ"))
+        out.append(ind + "      " + self._binary_item(pm.name, items["geometry"], "Float", 8))
+        out.append(ind + "    </Geometry>")
+        for a, att in enumerate(pm.attributes):
+            for k in range(len(att.data)):
+                out.append(ind + '    <Attribute Name="%s_%d" AttributeType="%s" Center="Node">' % (att.name, k, att.field))
+                if att.field.lower() == "vector" and pad_vectors:
+                    # grids of different dimension in one file: vector attributes carry three components on
+                    # every grid, a 1-D coordinate repeating its values (model.py:321-368), written inline
+                    v = self._visual(att, k, True)
+                    if dims == 1:
+                        v = np.repeat(v[:, :1], 3, axis=1)
+                    out.append(ind + '      <DataItem Dimensions="%d 3" Format="XML" NumberType="float" >' % v.shape[0])
+                    out.extend("%.8e %.8e %.8e" % tuple(r) for r in v)
+                    out.append(ind + "      </DataItem>")
+                else:
+                    out.append(ind + "      " + self._binary_item(pm.name, items["%d/%d" % (a, k)], "Float", 8))
+                out.append(ind + "    </Attribute>")
+        out.append(ind + "</Grid>")
+        return "\n".join(out) + "\n"
+
+    def write_pxdmf(self, folder, xdmf_exist=False):
+        """One ``<name>.pxdmf`` with a grid per PGD coordinate and its modes as attributes - the file the
+        ParaView PGD plugin opens (model.py:198-416)."""
+        if xdmf_exist is False or not getattr(self, "_layout", None):
+            self._write_xdmf(folder)
+        dims = [self._grid_info(d)[0] for d in range(self.num_pgd_var)]
+        pad = max(dims) != min(dims)
+        path = os.path.join(folder, self.name + ".pxdmf")
+        with open(path, "w") as f:
+            f.write('<?xml version="1.0"?><!--pxdmf written by pgdrome_amd.model.PGD.write_pxdmf-->\n')
+            f.write('<!DOCTYPE Xdmf SYSTEM "Xdmf.dtd" []>\n')
+            f.write('<Xdmf Version="3.0" xmlns:xi="http://www.w3.org/2001/XInclude">\n')
+            f.write('  <Domain Name="%s.pxdmf">\n' % self.name)
+            for pm in self.mesh:
+                f.write(self._grid_xml(pm, self._layout[pm.name], pad, "    "))
+            f.write("  </Domain>\n</Xdmf>")
+        self.logger.info("Wrote %s ", path)
+
+    @staticmethod
+    def _read_item(item, folder):
+        """numpy array of a <DataItem>: inline XML, raw Binary, or HDF (needs h5py)."""
+        fmt = item.get("Format", "XML")
+        dims = tuple(int(v) for v in item.get("Dimensions").split())
+        if fmt == "XML":
+            return np.array(item.text.split(), dtype=np.float64).reshape(dims)
+        if fmt == "Binary":
+            kind = item.get("NumberType", "Float").lower()
+            dt = np.dtype(("<" if item.get("Endian", "Little") == "Little" else ">") +
+                          ("f" if kind == "float" else "u" if kind == "uint" else "i") + item.get("Precision", "8"))
+            with open(os.path.join(folder, item.text.strip()), "rb") as fb:
+                fb.seek(int(item.get("Seek", "0")))
+                return np.frombuffer(fb.read(int(np.prod(dims)) * dt.itemsize), dtype=dt).reshape(dims).copy()
+        if fmt == "HDF":
+            try:
+                import h5py
+            except ImportError as e:
+                raise RuntimeError("this pxdmf file keeps its data in HDF5 (%s): h5py is needed to read it"
+                                   % item.text.strip()) from e
+            fname, key = item.text.strip().split(":")
+            with h5py.File(os.path.join(folder, fname), "r") as hf:
+                return np.array(hf.get(key))
+        raise ValueError("unknown DataItem format %r" % fmt)
+
+    def load_pxdmf(self, filepath, verbose=False):
+        """Read a pxdmf file into this instance: ``sol = PGD().load_pxdmf(path)`` (model.py:418-572).  The mode
+        functions (``<grid>_data.npz``) are attached by ``create_interpolation_fcts``."""
+        folder = os.path.dirname(os.path.abspath(filepath))
+        root = et.parse(filepath).getroot()
+        self.folder = folder
+        self.name = root.findall("Domain")[0].attrib.get("Name")
+        self.mesh = []
+        for g in root.iter("Grid"):
+            pm = PGDMesh(g.get("Name"))
+            data = os.path.join(folder, pm.name + "_data.npz")
+            if os.path.exists(data):
+                with np.load(data) as z:
+                    pm.fenics_mesh = fem.Mesh(z["coordinates"], z["cells"])
+            info = [[e.attrib.get("Name"), e.attrib.get("Value")] for e in g.iter("Information")]
+            pm.info = [int(info[0][1]), info[1][1], info[2][1]] if len(info) >= 3 else [v for _, v in info]
+            pm.meshdim = int(info[0][1])
+            for e in g.iter("Topology"):
+                pm.numElements = int(e.attrib.get("NumberOfElements"))
+                pm.typElements = e.attrib.get("TopologyType")
+                pm.topology = self._read_item(e[0], folder).astype(np.int64)
+            for e in g.iter("Geometry"):
+                pm.typGeometry = e.attrib.get("GeometryType")
+                geom = self._read_item(e[0], folder)
+                pm.numNodes = geom.shape[0]
+                pm.dataX = geom[:, 0].copy()
+                pm.dataY = geom[:, 1].copy() if geom.shape[1] > 1 else np.zeros(pm.numNodes)
+                pm.dataZ = geom[:, 2].copy() if geom.shape[1] > 2 else np.zeros(pm.numNodes)
+            for e in g.iter("Attribute"):
+                name = "_".join(e.attrib.get("Name").split("_")[:-1])
+                att = next((a for a in pm.attributes if a.name == name), None)
+                if att is None:
+                    att = PGDAttribute(name, 0, e.attrib.get("Center"), e.attrib.get("AttributeType"))
+                    pm.attributes.append(att)
+                att.data.append(self._read_item(e[0], folder))
+                att.n_modes = len(att.data)
+            self.mesh.append(pm)
+        self.numModes = self.used_numModes = len(self.mesh[0].attributes[0].data)
+        if verbose:
+            self.print_info()
+            for pm in self.mesh:
+                for att in pm.attributes:
+                    att.print_info()
+        return self
+
+    def _load_mode_functions(self, d, attri):
+        """Mode functions of coordinate d from ``<grid>_data.npz`` in the space interpolationInfo names."""
+        pm = self.mesh[d]
+        att = pm.attributes[attri]
+        path = os.path.join(self.folder, pm.name + "_data.npz")
+        if not os.path.exists(path):
+            raise ValueError("mode functions of dimension %d are missing: %s not found (write_hdf5 creates it)" % (d, path))
+        info = att.interpolationInfo
+        with np.load(path) as z:
+            mesh = fem.Mesh(z["coordinates"], z["cells"])
+            pm.fenics_mesh = mesh
+            kind = str(info.get("_type", "scalar")).lower()
+            if kind == "scalar":
+                V = fem.FunctionSpace(mesh, info.get("family", "P"), int(info.get("degree", 1)))
+            elif kind == "vector":
+                V = fem.VectorFunctionSpace(mesh, info.get("family", "P"), int(info.get("degree", 1)))
+            else:
+                raise ValueError("function space type not defined or wrong defined %s" % (kind,))
+            out = []
+            for k in range(self.numModes):
+                vals = z["ATT%d_MODE_%d" % (attri, k)]
+                if vals.size != V.dim():
+                    raise ValueError("stored mode has %d dofs, the space named in interpolationInfo %d" % (vals.size, V.dim()))
+                f = fem.Function(V)
+                f.vector()._host = vals.astype(np.float64)
+                f.vector().touched_host()
+                out.append(f)
+        att.interpolationfct = out
+
+    def save_modes_latex(self, folder, attri, prefix="_"):
+        """1-D modes as text tables [dof coordinate, mode 1, mode 2, ...] sorted by coordinate (model.py:1414-1453)."""
+        for d, pm in enumerate(self.mesh):
+            if str(pm.typElements).lower() != "polyline":
+                continue
+            fcts = pm.attributes[attri].interpolationfct
+            x = fcts[0].function_space().tabulate_dof_coordinates().reshape((-1, 1))[:, 0]
+            order = np.argsort(x, kind="stable")
+            table = np.zeros((x.size, self.numModes + 1))
+            table[:, 0] = x[order]
+            for m in range(self.numModes):
+                table[:, m + 1] = fcts[m].vector()[:][order]
+            np.savetxt(os.path.join(folder, "modes_%s_%i_%s.out" % (prefix, attri, self._grid_info(d)[1])), table, delimiter=",")
 
     # ------------------------------------------------------------------ interpolation
     def create_interpolation_fcts(self, free_dim, attri, verbose=True):
@@ -104,8 +367,7 @@ class PGD:
                                         for k in range(self.numModes)]
             elif kind == 1:
                 if len(att.interpolationfct) != self.numModes:
-                    raise ValueError("mode functions of dimension %d are missing (loading them from "
-                                     "_data.h5 files is not built)" % d)
+                    self._load_mode_functions(d, attri)
             else:
                 self.logger.error("interpolation name not defined: %s", kind)
         self.logger.info("Attribute interpolation functions saved")
@@ -127,6 +389,9 @@ class PGD:
             if len(self.mesh[d].attributes[attri].interpolationfct) == 0:
                 self.create_interpolation_fcts(free_dim, attri)
                 break
+        fixed = self.mesh[fixed_dim].attributes[attri]
+        if len(fixed.interpolationfct) == 0 and fixed.interpolationInfo.get("name") == 1:
+            self.create_interpolation_fcts([fixed_dim], attri)     # a loaded solution: read the mode functions
 
     def mode_factors(self, free_dim, coord, attri):
         """c_k = prod_i F_i^k(coord_i) for every used mode."""

@@ -83,3 +83,124 @@ def test_interp1d_path_matches_reference(solution):
     assert isinstance(u, np.ndarray) and np.linalg.norm(u.reshape(-1) - r) <= 1e-6 * np.linalg.norm(r)
     with pytest.raises(ValueError):
         sol.evaluate(0, [1, 2], [3.0, 0.81], 0)        # interp1d refuses to extrapolate
+
+
+# ------------------------------------------------------------------ result files
+@pytest.fixture()
+def oracle_backend():
+    old = fem._backend
+    fem.set_backend(NumpyBackend())
+    fem.clear_caches()
+    yield
+    fem.set_backend(old)
+    fem.clear_caches()
+
+
+def test_pxdmf_round_trip_like_the_reference_unit_test(oracle_backend, tmp_path):
+    """u(x, p, E) = x^2 p / E with P1 / P1 / P2 modes, written and read back: the scenario and the assertions of
+    the reference's tests/unit/test_pgdclass_dolfin.py (there through dolfin.HDF5File / XDMFFile / h5py, absent
+    here; the heavy data go to raw binary XDMF items and .npz instead)."""
+    mx, mp_, me = fem.IntervalMesh(50, 0.0, 1.0), fem.IntervalMesh(10, 0.0, 2.0), fem.IntervalMesh(10, 0.5, 1.0)
+    Vs = [fem.FunctionSpace(mx, "CG", 1), fem.FunctionSpace(mp_, "CG", 1), fem.FunctionSpace(me, "CG", 2)]
+    codes = ["x[0]*x[0]", "x[0]", "1.0/x[0]"]
+    modes = [[fem.project(fem.Expression(c, degree=10), V) for _ in range(2)] for c, V in zip(codes, Vs)]
+    pgd = PGD(name="Test", n_modes=1, fmeshes=[mx, mp_, me], pgd_modes=modes, name_coord=["X", "P", "E"],
+              modes_info=["U_x", "Node", "Scalar"])
+    folder = str(tmp_path)
+    pgd.write_pxdmf(folder, False)
+    pgd.write_hdf5(folder)
+    assert {"Test.pxdmf", "PGD1.xdmf", "PGD1.bin", "PGD1_data.npz", "PGD3_data.npz"} <= set(os.listdir(folder))
+    sol = PGD().load_pxdmf(os.path.join(folder, "Test.pxdmf"))
+    assert sol.name == "Test.pxdmf" and sol.num_pgd_var == 3 and sol.numModes == 1
+    assert [m.numNodes for m in sol.mesh] == [51, 11, 11] and [m.numElements for m in sol.mesh] == [50, 10, 10]
+    assert [m.info for m in sol.mesh] == [[1, "X", "-?-"], [1, "P", "-?-"], [1, "E", "-?-"]]
+    assert sol.mesh[0].typElements == "Polyline" and np.array_equal(sol.mesh[0].topology, mx.cells())
+    assert np.array_equal(sol.mesh[2].dataX, me.coordinates()[:, 0]) and not sol.mesh[2].dataY.any()
+    att = sol.mesh[0].attributes[0]
+    assert (att.name, att._type, att.field) == ("U_x", "Node", "Scalar")
+    assert np.array_equal(att.data[0], modes[0][0].compute_vertex_values().reshape(-1, 1))      # bit-exact
+    for d, deg in enumerate((1, 1, 2)):
+        sol.mesh[d].attributes[0].interpolationInfo = {"name": 1, "family": "CG", "degree": deg, "_type": "scalar"}
+    sol.create_interpolation_fcts([0, 1, 2], 0)
+    f = [sol.mesh[d].attributes[0].interpolationfct[0] for d in range(3)]
+    assert abs(f[0](0.8) - 0.64) < 1e-3 and abs(f[1](0.8) - 0.8) < 1e-3 and abs(f[2](0.8) - 1.25) < 1e-3
+    assert np.array_equal(f[2].vector().host(), modes[2][0].vector().host())                     # P2 dofs bit-exact
+    u = sol.evaluate(0, [1, 2], [0.75, 0.75], 0)
+    assert abs(u(0.5) - 0.5 ** 2 * 0.75 / 0.75) < 0.05
+    assert abs(sol.evaluate_max(0, [1, 2], [0.75, 0.75], 0) - 1.0) < 1e-2
+    # a wrong space for the stored dofs is reported, not mis-read
+    sol.mesh[2].attributes[0].interpolationInfo["degree"] = 1
+    sol.mesh[2].attributes[0].interpolationfct = []
+    with pytest.raises(ValueError):
+        sol.create_interpolation_fcts([2], 0)
+    sol.mesh[2].attributes[0].interpolationInfo["degree"] = 2
+    sol.create_interpolation_fcts([2], 0)
+    sol.save_modes_latex(folder, 0)
+    tab = np.loadtxt(os.path.join(folder, "modes___0_X.out"), delimiter=",")
+    assert tab.shape == (51, 2) and np.all(np.diff(tab[:, 0]) > 0) and np.allclose(tab[:, 1], tab[:, 0] ** 2)
+
+
+def test_pxdmf_vector_field_on_grids_of_different_dimension(oracle_backend, tmp_path):
+    """A 2-D vector-valued coordinate next to a 1-D one: vector attributes carry three components on every grid
+    (the 1-D grid repeating its values), written inline as the reference does (model.py:321-368)."""
+    mesh = fem.RectangleMesh(fem.Point(0, 0), fem.Point(2, 1), 4, 2)
+    V = fem.VectorFunctionSpace(mesh, "P", 1)
+    mp_ = fem.IntervalMesh(4, 0.0, 1.0)
+    U = fem.interpolate(fem.Expression(("x[0]", "x[0]*x[1]"), degree=2), V)
+    P = fem.interpolate(fem.Expression("1.0 + x[0]", degree=1), fem.FunctionSpace(mp_, "P", 1))
+    pgd = PGD(name="vec", n_modes=1, fmeshes=[mesh, mp_], pgd_modes=[[U], [P]], name_coord=["X", "p"],
+              modes_info=["U", "Node", "Vector"])
+    pgd.write_pxdmf(str(tmp_path))
+    pgd.write_hdf5(str(tmp_path))
+    text = open(os.path.join(str(tmp_path), "vec.pxdmf")).read()
+    assert text.count('Format="XML"') == 2 and 'TopologyType = "Triangle"' in text and 'GeometryType = "XY"' in text
+    sol = PGD().load_pxdmf(os.path.join(str(tmp_path), "vec.pxdmf"))
+    X = mesh.coordinates()
+    a = sol.mesh[0].attributes[0].data[0]
+    assert a.shape == (X.shape[0], 3) and np.allclose(a[:, 0], X[:, 0], atol=1e-8) and np.allclose(a[:, 1], X[:, 0] * X[:, 1], atol=1e-8)
+    assert not a[:, 2].any()
+    b = sol.mesh[1].attributes[0].data[0]
+    assert b.shape == (5, 3) and np.allclose(b, np.repeat((1 + mp_.coordinates()), 3, axis=1), atol=1e-8)
+    sol.mesh[0].attributes[0].interpolationInfo = {"name": 1, "family": "P", "degree": 1, "_type": "vector"}
+    sol.mesh[1].attributes[0].interpolationInfo = {"name": 1, "family": "P", "degree": 1, "_type": "scalar"}
+    u = sol.evaluate(0, [1], [0.5], 0)
+    assert np.allclose(u((1.5, 0.5)), 1.5 * np.array([1.5, 0.75]))
+
+
+def test_load_pxdmf_reads_inline_items_and_names_the_missing_hdf5_reader(oracle_backend, tmp_path):
+    doc = """<?xml version="1.0"?><Xdmf Version="3.0"><Domain Name="hand.pxdmf"><Grid Name="PGD1">
+<Information Name="Dims" Value="1" /><Information Name="Dim0" Value="t" /><Information Name="Unit0" Value="s" />
+<Topology NumberOfElements = "2" TopologyType = "Polyline" NodesPerElement = "2" ><DataItem Dimensions = "2 2" NumberType = "UInt" Format = "XML">
+0 1
+1 2
+</DataItem></Topology>
+<Geometry GeometryType = "XY"><DataItem Dimensions = "3 2" Format = "XML">
+0.0 0.0
+0.5 0.0
+1.0 0.0
+</DataItem></Geometry>
+<Attribute Name="T_0" AttributeType="Scalar" Center="Node"><DataItem Dimensions="3 1" Format="XML" NumberType="float" >
+1.0
+2.0
+4.0
+</DataItem></Attribute>
+%s
+</Grid></Domain></Xdmf>"""
+    path = os.path.join(str(tmp_path), "hand.pxdmf")
+    with open(path, "w") as f:
+        f.write(doc % "")
+    sol = PGD().load_pxdmf(path)
+    pm = sol.mesh[0]
+    assert sol.numModes == 1 and pm.info == [1, "t", "s"] and pm.numNodes == 3 and pm.topology.tolist() == [[0, 1], [1, 2]]
+    assert pm.attributes[0].name == "T" and pm.attributes[0].data[0][:, 0].tolist() == [1.0, 2.0, 4.0]
+    pm.attributes[0].interpolationInfo = {"name": 0, "kind": "linear"}
+    sol.create_interpolation_fcts([0], 0)
+    assert np.isclose(pm.attributes[0].interpolationfct[0](0.75), 3.0)
+    with open(path, "w") as f:
+        f.write(doc % '<Attribute Name="T_1" AttributeType="Scalar" Center="Node"><DataItem Dimensions="3 1" Format="HDF">'
+                      'PGD1.h5:/VisualisationVector/1</DataItem></Attribute>')
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        with pytest.raises(RuntimeError, match="h5py"):
+            PGD().load_pxdmf(path)
