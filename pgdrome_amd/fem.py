@@ -1386,70 +1386,73 @@ class Function(Expr):
         return _point_eval(self, np.array([float(v) for v in x]))
 
 
-def _point_eval(f, x):
-    if f._V._ncomp > 1:
-        # evaluate every component with the scalar machinery on a strided view of the dof vector
-        nc, base = f._V._ncomp, f._V._lay.base
-        full = f._vec.host()
-        out = np.empty(nc)
-        for c in range(nc):
-            out[c] = _point_eval(_ScalarView(base, full[c::nc]), x)
-        return out
-    mesh = f._V.mesh()
-    X, cells, vals = mesh.coordinates(), mesh.cells(), f._vec.host()
-    if f._V._lay.degree == 2 and mesh.topology().dim() > 1:
-        lay = f._V._lay
-        D = mesh.topology().dim()
+def point_basis(lay, x, grad=False):
+    """Nodes of the scalar layout `lay` whose shape functions are non-zero at the point x, their values
+    and (grad=True) their gradients there: the cell containing x is found from the barycentric
+    coordinates of x in every cell (the mesh's inverse affine maps are cached on the mesh)."""
+    mesh = lay.mesh
+    x = np.atleast_1d(np.asarray(x, dtype=np.float64))
+    X, cells = mesh.coordinates(), mesh.cells()
+    D = mesh.topology().dim()
+    inv = getattr(mesh, "_affine_inv", None)
+    if inv is None:
         P = X[cells]
         T = np.transpose(P[:, 1:, :] - P[:, :1, :], (0, 2, 1))
-        lam = np.linalg.solve(T, (x[None, :] - P[:, 0, :])[:, :, None])[:, :, 0]
-        L = np.concatenate([(1.0 - lam.sum(axis=1))[:, None], lam], axis=1)
-        k = int(np.argmax(L.min(axis=1)))
-        if L[k].min() < -1e-10:
-            raise RuntimeError("point %r outside the mesh" % (x,))
-        l = L[k]
-        N = [l[i] * (2.0 * l[i] - 1.0) for i in range(D + 1)] + [4.0 * l[a] * l[b] for a, b in lay.P2_EDGES[D]]
-        return float(np.dot(N, vals[lay.cells[k]]))
-    if f._V._lay.degree == 2:
-        # quadratic on intervals: nodes 2 i (vertex i), 2 i + 1 (midpoint of cell i)
-        xs = X[:, 0]
-        if x[0] < xs[0] - 1e-12 or x[0] > xs[-1] + 1e-12:
-            raise RuntimeError("point %r outside the mesh" % (x,))
-        c = int(min(max(np.searchsorted(xs, x[0], side="right") - 1, 0), xs.size - 2))
-        s_ = (x[0] - xs[c]) / (xs[c + 1] - xs[c])
-        N = ((1 - s_) * (1 - 2 * s_), s_ * (2 * s_ - 1), 4 * s_ * (1 - s_))
-        return float(N[0] * vals[2 * c] + N[1] * vals[2 * c + 2] + N[2] * vals[2 * c + 1])
-    if mesh.topology().dim() == 1:
-        xs = X[:, 0]
-        if x[0] < xs.min() - 1e-12 or x[0] > xs.max() + 1e-12:
-            raise RuntimeError("point %r outside the mesh" % (x,))
-        order = np.argsort(xs)
-        return float(np.interp(x[0], xs[order], vals[order]))
-    # simplices: barycentric coordinates of x in every cell, take the one containing it
-    P = X[cells]
-    T = np.transpose(P[:, 1:, :] - P[:, :1, :], (0, 2, 1))
-    lam = np.linalg.solve(T, (x[None, :] - P[:, 0, :])[:, :, None])[:, :, 0]
-    lam0 = 1.0 - lam.sum(axis=1)
-    L = np.concatenate([lam0[:, None], lam], axis=1)
+        inv = (np.linalg.inv(T), P[:, 0, :].copy())
+        mesh._affine_inv = inv
+    Tinv, P0 = inv
+    lam = np.einsum("cij,cj->ci", Tinv, x[None, :] - P0)
+    L = np.concatenate([(1.0 - lam.sum(axis=1))[:, None], lam], axis=1)
     k = int(np.argmax(L.min(axis=1)))
     if L[k].min() < -1e-10:
         raise RuntimeError("point %r outside the mesh" % (x,))
-    return float(L[k] @ vals[cells[k]])
+    l = L[k]
+    g = np.concatenate([-Tinv[k].sum(axis=0)[None, :], Tinv[k]], axis=0)       # grad lambda_i, (D+1) x D
+    if lay.degree == 1:
+        nodes, N, dN = cells[k], l, g
+    else:
+        edges = ((0, 1),) if D == 1 else lay.P2_EDGES[D]
+        N = np.array([l[i] * (2.0 * l[i] - 1.0) for i in range(D + 1)] + [4.0 * l[a_] * l[b_] for a_, b_ in edges])
+        dN = np.array([(4.0 * l[i] - 1.0) * g[i] for i in range(D + 1)] +
+                      [4.0 * (l[b_] * g[a_] + l[a_] * g[b_]) for a_, b_ in edges])
+        nodes = lay.cells[k]
+    return (nodes, N, dN) if grad else (nodes, N)
 
 
-class _ScalarView:
-    """One component of a vector-valued Function, seen as a scalar function for point evaluation."""
+def _point_eval(f, x):
+    V = f._V
+    nc = V._ncomp
+    base = V._lay.base if nc > 1 else V._lay
+    nodes, N = point_basis(base, x)
+    vals = f._vec.host()
+    if nc > 1:
+        return np.array([float(N @ vals[nodes * nc + c]) for c in range(nc)])
+    return float(N @ vals[nodes])
 
-    class _Vec:
-        def __init__(self, a):
-            self._a = a
 
-        def host(self):
-            return self._a
+def point_gradient(f, x):
+    """Gradient of a scalar Function at a point, taken in the cell that contains it (a cell-wise polynomial:
+    what projecting the derivative onto DG(degree - 1) gives, model.py:1088-1205)."""
+    V = f._V
+    if V._ncomp > 1:
+        raise NotImplementedError("gradient of a vector-valued function")
+    nodes, N, dN = point_basis(V._lay, x, grad=True)
+    return dN.T @ f._vec.host()[nodes]
 
-    def __init__(self, lay, values):
-        self._V = lay.space()
-        self._vec = _ScalarView._Vec(np.ascontiguousarray(values))
+
+class DerivativeFunction:
+    """d f / d x_axis of a scalar Function as a callable of the point."""
+
+    def __init__(self, f, axis=0):
+        self.f, self.axis = f, int(axis)
+
+    def function_space(self):
+        return self.f.function_space()
+
+    def __call__(self, *x):
+        if len(x) == 1 and hasattr(x[0], "__len__"):
+            x = tuple(x[0])
+        return float(point_gradient(self.f, np.array([float(v) for v in x]))[self.axis])
 
 
 _EXPR_FUNCS = {

@@ -22,7 +22,12 @@ after the hot path:
   next to the .pxdmf, ``Seek`` offsets) and the mode functions go to ``<grid>_data.npz``.  ``load_pxdmf``
   reads the XML, Binary and - when h5py is importable - HDF items, i.e. also reference-written files.
 
-Not built: sensor responses through ``fenicstools.Probes``, derivatives.
+* sensor responses and parameter derivatives (model.py:107-131, 862-953, 1088-1412): ``eval_fixed_modes``
+  (the reference evaluates the fixed-dimension modes at the sensor points with ``fenicstools.Probes``; here by
+  point location + shape functions, cached the same way), ``evaluate_sensor_response``,
+  ``create_derivation_fct`` (cell-wise derivative of the 1-D modes = the reference's DG(degree - 1)
+  projection), ``evaluate_derivative``, ``evaluate_derivative_sensor_response``, and the
+  ``evaluate_min_abs / max_abs / max_norm / abs_value`` reductions.
 """
 from __future__ import annotations
 
@@ -47,6 +52,7 @@ class PGDAttribute:
         self.name, self.n_modes, self._type, self.field = name, n_modes, _type, field
         self.data = []                # vertex values per mode, shape (n, 1)
         self.interpolationfct = []    # callables per mode (Functions or interp1d objects)
+        self.derivationfct = []       # d mode / d coordinate, callables (create_derivation_fct)
         self.interpolationInfo = {"name": 1, "family": "P", "degree": 1, "_type": "scalar"}
 
     def fill_data(self, modes):
@@ -97,6 +103,9 @@ class PGD:
         self.used_numModes = n_modes
         self.problem = None
         self.folder = ""
+        self.pos = 0                  # point used by evaluate_abs_value
+        self._eval_fixed_modes = {}
+        self.name_coord, self.modes_info = name_coord, modes_info
         self.mesh = []
         info = list(modes_info) + ["u", "Node", "Scalar"][len(modes_info):]
         for d, fm in enumerate(fmeshes):
@@ -111,6 +120,25 @@ class PGD:
     @property
     def num_pgd_var(self):
         return len(self.mesh)
+
+    def __str__(self):
+        return "PGD(name: %s)(meshes: %s)(modes: %s)" % (self.name, len(self.mesh), self.numModes)
+
+    __repr__ = __str__
+
+    def _info_str(self):
+        return ("summary of PGDModel class\n-------------------------------\n"
+                "name:                          %s\nnumber of PGD variables:       %s\n"
+                "number of modes for each mesh -- max: %s -- used: %s\nnumber of saved meshes:        %s\n"
+                "number of elements per mesh:    %s\nfolder:                        %s" % (
+                    self.name, self.num_pgd_var, self.numModes, self.used_numModes, len(self.mesh),
+                    "".join(" %s, " % m.numElements for m in self.mesh), self.folder))
+
+    def create_from_problem(self, problem=None):
+        self.problem = problem
+        self.name = problem.name
+        self.logger.info("PGDModel created from PGDProblem %s", self.name)
+        return self
 
     def print_info(self):
         print("PGD solution %r: %d modes, %d coordinates" % (self.name, self.numModes, self.num_pgd_var))
@@ -427,13 +455,136 @@ class PGD:
             out.vector().touched_host()
         return out
 
-    def evaluate_min(self, fixed_dim, free_dim, coord, attri):
+    def _evaluated_values(self, fixed_dim, free_dim, coord, attri):
+        """All values of the evaluated field: the array itself (interp1d mode) or the dof vector."""
         u = self.evaluate(fixed_dim, free_dim, coord, attri)
-        return float(np.min(u if isinstance(u, np.ndarray) else u.compute_vertex_values()))
+        return u if isinstance(u, np.ndarray) else u.vector()[:]
 
-    def evaluate_max(self, fixed_dim, free_dim, coord, attri):
+    def evaluate_min(self, fixed_dim, free_dim, coord, attri, *args, **kwargs):
+        return float(np.min(self._evaluated_values(fixed_dim, free_dim, coord, attri)))
+
+    def evaluate_min_abs(self, fixed_dim, free_dim, coord, attri, *args, **kwargs):
+        return float(np.min(np.abs(self._evaluated_values(fixed_dim, free_dim, coord, attri))))
+
+    def evaluate_max(self, fixed_dim, free_dim, coord, attri, *args, **kwargs):
+        return float(np.max(self._evaluated_values(fixed_dim, free_dim, coord, attri)))
+
+    def evaluate_max_abs(self, fixed_dim, free_dim, coord, attri, *args, **kwargs):
+        return float(np.max(np.abs(self._evaluated_values(fixed_dim, free_dim, coord, attri))))
+
+    def evaluate_max_norm(self, fixed_dim, free_dim, coord, attri, *args, **kwargs):
+        """Largest Euclidean norm of the field over the nodes (vector-valued fields; model.py:1033-1069)."""
         u = self.evaluate(fixed_dim, free_dim, coord, attri)
-        return float(np.max(u if isinstance(u, np.ndarray) else u.compute_vertex_values()))
+        if isinstance(u, np.ndarray):
+            return float(np.max(np.linalg.norm(u.reshape(u.shape[0], -1), axis=1)))
+        V = u.function_space()
+        if V.mesh().geometry().dim() == 1:
+            raise ValueError("Function is 1D use evaluate_max instead!!")
+        return float(np.max(np.linalg.norm(u.vector()[:].reshape(-1, V._ncomp), axis=1)))
+
+    def evaluate_abs_value(self, fixed_dim, free_dim, coord, attri, *args, **kwargs):
+        """max |u(self.pos)| - the field at the point stored in ``pos`` (model.py:1071-1086)."""
+        return float(np.max(np.abs(self.evaluate(fixed_dim, free_dim, coord, attri)(self.pos))))
+
+    # ------------------------------------------------------ sensor responses and derivatives
+    def _check_free(self, free_dim, coord, attri, fixed_dim):
+        if len(coord) != self.num_pgd_var - 1:
+            raise ValueError("given variables are missing or to much, coord=%s <-> num_pgd_var=%s",
+                             coord, self.num_pgd_var - 1)
+        for d in free_dim:
+            if np.sum(self.mesh[d].dataY) != 0 and np.sum(self.mesh[d].dataZ) != 0:
+                raise ValueError("free Dimensions are not 1D, interpolation not possible")
+        if attri >= len(self.mesh[fixed_dim].attributes):
+            raise ValueError("attribute number not possible")
+        for d in free_dim:
+            if len(self.mesh[d].attributes[attri].interpolationfct) == 0:
+                self.create_interpolation_fcts(free_dim, attri)
+                break
+
+    def eval_fixed_modes(self, sensor_points, fixed_dim, attri):
+        """ALL modes of the fixed dimension at the sensor points, cached per point set: shape (points, modes) for
+        a scalar field, (points, components, modes) for a vector field; a single mode drops the mode axis."""
+        pts = np.asarray(sensor_points, dtype=np.float64)
+        key = (float(np.sum(pts)), pts.shape, fixed_dim, attri)
+        hit = self._eval_fixed_modes.get(key)
+        if hit is not None:
+            return hit
+        modes = self.mesh[fixed_dim].attributes[attri].interpolationfct
+        V = modes[0].function_space()
+        gdim = V.mesh().geometry().dim()
+        pts = pts.reshape(-1, gdim)
+        nc = V._ncomp
+        base = V._lay.base if nc > 1 else V._lay
+        out = np.zeros((pts.shape[0], nc, self.numModes))
+        vecs = [modes[k].vector().host() for k in range(self.numModes)]
+        for i, x in enumerate(pts):
+            nodes, N = fem.point_basis(base, x)
+            for k in range(self.numModes):
+                for c in range(nc):
+                    out[i, c, k] = N @ vecs[k][nodes * nc + c]
+        if nc == 1:
+            out = out[:, 0, :]
+        if self.numModes == 1:
+            out = out[..., 0]
+        self._eval_fixed_modes[key] = out
+        return out
+
+    def _contract_modes(self, eval_fixedmode, factors):
+        if self.numModes == 1:
+            return eval_fixedmode * factors[0]
+        return np.sum(eval_fixedmode[..., 0:self.used_numModes] * factors, axis=-1)
+
+    def evaluate_sensor_response(self, fixed_dim, free_dim, coord, attri, sensor_points):
+        """The evaluated field at given points of the fixed dimension, as an array (model.py:862-953)."""
+        self._check_free(free_dim, coord, attri, fixed_dim)
+        fixed = self.eval_fixed_modes(sensor_points, fixed_dim, attri)
+        return self._contract_modes(fixed, self.mode_factors(free_dim, coord, attri))
+
+    def create_derivation_fct(self, free_dim, attri):
+        """d mode / d coordinate for the given (1-D, scalar) coordinates as callables (model.py:1088-1205)."""
+        if len(free_dim) > self.num_pgd_var:
+            raise ValueError("given number of Dimensions larger then existing Meshes in PGD solution")
+        if attri > len(self.mesh[free_dim[0]].attributes):
+            raise ValueError("attribute number not possible")
+        for d in free_dim:
+            att = self.mesh[d].attributes[attri]
+            if att.interpolationInfo["name"] == 0:
+                raise ValueError("derivation for interp1 functions not implemented (only fencis functions)")
+            if att.interpolationInfo["name"] != 1:
+                self.logger.error("interpolation name not defined: %s", att.interpolationInfo["name"])
+                continue
+            if att.interpolationfct[0].function_space()._ncomp > 1:
+                raise NotImplementedError("derivative of vector-valued modes (tensor DG space)")
+            att.derivationfct = [fem.DerivativeFunction(att.interpolationfct[k], 0) for k in range(self.numModes)]
+        self.logger.info("derivations for dimensions %s are saved in PGD instance" % (free_dim,))
+
+    def _derivative_factors(self, free_dim, coord, attri, d_dim, fixed_dim):
+        self._check_free(free_dim, coord, attri, fixed_dim)
+        if fixed_dim == d_dim:
+            raise ValueError("derivation against fixed dim not possible in the moment")
+        if self.mesh[free_dim[0]].attributes[attri].interpolationInfo["name"] == 0:
+            self.logger.error("derivation for interp1 functions not implemented (only fencis functions)")
+            raise ValueError("derivation for interp1 functions not implemented (only fencis functions)")
+        c = np.ones(self.used_numModes)
+        for k in range(self.used_numModes):
+            for i, d in enumerate(free_dim):
+                att = self.mesh[d].attributes[attri]
+                fct = att.derivationfct[k] if d == d_dim else att.interpolationfct[k]
+                c[k] *= float(fct(coord[i]))
+        return c
+
+    def evaluate_derivative(self, fixed_dim, free_dim, coord, attri, d_dim):
+        """d u / d coordinate(d_dim) on the fixed dimension, a Function (model.py:1208-1303)."""
+        c = self._derivative_factors(free_dim, coord, attri, d_dim, fixed_dim)
+        modes = self.mesh[fixed_dim].attributes[attri].interpolationfct
+        out = fem.Function(modes[0].function_space())
+        for k in range(self.used_numModes):
+            out.vector().axpy(c[k], modes[k].vector())
+        return out
+
+    def evaluate_derivative_sensor_response(self, fixed_dim, free_dim, coord, attri, d_dim, sensor_points):
+        c = self._derivative_factors(free_dim, coord, attri, d_dim, fixed_dim)
+        return self._contract_modes(self.eval_fixed_modes(sensor_points, fixed_dim, attri), c)
 
 
 class PGDErrorComputation(object):

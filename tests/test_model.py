@@ -204,3 +204,56 @@ def test_load_pxdmf_reads_inline_items_and_names_the_missing_hdf5_reader(oracle_
     except ImportError:
         with pytest.raises(RuntimeError, match="h5py"):
             PGD().load_pxdmf(path)
+
+
+def test_sensor_responses_derivatives_and_reductions(oracle_backend):
+    """u(x, p, E) = sum_k X_k(x) P_k(p) W_k(E) with known factors: sensor responses, d/dp, d/dE and the
+    min / max reductions against closed forms (model.py:862-1412)."""
+    mx, mp_, me = fem.IntervalMesh(20, 0.0, 1.0), fem.IntervalMesh(10, 0.0, 2.0), fem.IntervalMesh(40, 0.5, 1.0)
+    Vs = [fem.FunctionSpace(mx, "CG", 2), fem.FunctionSpace(mp_, "CG", 1), fem.FunctionSpace(me, "CG", 2)]
+    codes = [["x[0]*x[0]", "1.0 - x[0]"], ["x[0]", "1.0"], ["x[0]*x[0]", "2.0*x[0]"]]
+    modes = [[fem.interpolate(fem.Expression(c, degree=2), V) for c in cs] for cs, V in zip(codes, Vs)]
+    sol = PGD(name="known", n_modes=2, fmeshes=[mx, mp_, me], pgd_modes=modes, name_coord=["X", "P", "E"],
+              modes_info=["U", "Node", "Scalar"])
+    p, e = 1.3, 0.8
+
+    def u(x):
+        return x * x * p * e * e + (1 - x) * 2 * e
+    pts = [[0.15], [0.5], [0.93]]
+    r = sol.evaluate_sensor_response(0, [1, 2], [p, e], 0, pts)
+    assert r.shape == (3,) and np.allclose(r, [u(0.15), u(0.5), u(0.93)], rtol=1e-12)
+    assert sol.eval_fixed_modes(pts, 0, 0).shape == (3, 2) and len(sol._eval_fixed_modes) == 1
+    sol.used_numModes = 1
+    assert np.allclose(sol.evaluate_sensor_response(0, [1, 2], [p, e], 0, pts), [x[0] ** 2 * p * e * e for x in pts])
+    sol.used_numModes = 2
+    sol.create_derivation_fct([1, 2], 0)
+    du_dp = sol.evaluate_derivative(0, [1, 2], [p, e], 0, 1)          # x^2 e^2 (+ 0)
+    assert np.isclose(du_dp(0.5), 0.25 * e * e)
+    du_de = sol.evaluate_derivative_sensor_response(0, [1, 2], [p, e], 0, 2, pts)
+    assert np.allclose(du_de, [x[0] ** 2 * p * 2 * e + (1 - x[0]) * 2 for x in pts], rtol=1e-10)
+    with pytest.raises(ValueError):
+        sol.evaluate_derivative(0, [1, 2], [p, e], 0, 0)
+    full = sol.evaluate(0, [1, 2], [p, e], 0).vector()[:]
+    assert np.isclose(sol.evaluate_max(0, [1, 2], [p, e], 0), full.max()) and np.isclose(sol.evaluate_min(0, [1, 2], [p, e], 0), full.min())
+    assert np.isclose(sol.evaluate_max_abs(0, [1, 2], [p, e], 0), np.abs(full).max())
+    assert sol.evaluate_min_abs(0, [1, 2], [p, e], 0) >= 0
+    sol.pos = 0.5
+    assert np.isclose(sol.evaluate_abs_value(0, [1, 2], [p, e], 0), abs(u(0.5)))
+    with pytest.raises(ValueError):
+        sol.evaluate_max_norm(0, [1, 2], [p, e], 0)
+    assert str(sol) == "PGD(name: known)(meshes: 3)(modes: 2)" and "number of PGD variables:       3" in sol._info_str()
+
+
+def test_vector_field_sensor_response_and_max_norm(oracle_backend):
+    mesh = fem.RectangleMesh(fem.Point(0, 0), fem.Point(2, 1), 4, 2)
+    V = fem.VectorFunctionSpace(mesh, "P", 2)
+    mp_ = fem.IntervalMesh(4, 0.0, 1.0)
+    U = [fem.interpolate(fem.Expression(("x[0]*x[1]", "x[1]"), degree=2), V), fem.interpolate(fem.Expression(("1.0", "x[0]"), degree=2), V)]
+    P = [fem.interpolate(fem.Expression(c, degree=1), fem.FunctionSpace(mp_, "P", 1)) for c in ("x[0]", "1.0")]
+    sol = PGD(name="v", n_modes=2, fmeshes=[mesh, mp_], pgd_modes=[U, P], name_coord=["X", "p"], modes_info=["U", "Node", "Vector"])
+    r = sol.evaluate_sensor_response(0, [1], [0.5], 0, [[1.5, 0.5], [0.2, 0.9]])
+    assert r.shape == (2, 2)
+    assert np.allclose(r, [[0.5 * 0.75 + 1.0, 0.5 * 0.5 + 1.5], [0.5 * 0.18 + 1.0, 0.5 * 0.9 + 0.2]])
+    nodes = V._lay.base.coords
+    expect = np.max(np.hypot(0.5 * nodes[:, 0] * nodes[:, 1] + 1.0, 0.5 * nodes[:, 1] + nodes[:, 0]))
+    assert np.isclose(sol.evaluate_max_norm(0, [1], [0.5], 0), expect)
