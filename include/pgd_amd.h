@@ -169,6 +169,10 @@ int pgd_slots_upload(pgd_handle ctx, const double *in, int first, int count);
 int pgd_flags_reset(pgd_handle ctx);
 int pgd_flags_download(pgd_handle ctx, int32_t *done, int32_t *iters, int32_t *status);
 int pgd_op_diag_inv(pgd_handle ctx, pgd_handle op, pgd_handle dinv);
+/* Build the symmetric half storage of an SPD operator for the products of a host-driven solve
+ * (the library solves do this themselves): *used = 1 if the mesh's patterns qualify and
+ * a_ij == a_ji held to rounding, else 0 and the CSR kernels stay in use.          */
+int pgd_op_symmetrize(pgd_handle ctx, pgd_handle op, int *used);
 /* y = A x on [r0,r1), slot <- sum w_i y_i (local part)                          */
 int pgd_spmv_dot_slot(pgd_handle ctx, pgd_handle A, pgd_handle x, pgd_handle y, pgd_handle w,
                       int64_t r0, int64_t r1, int slot);
@@ -237,6 +241,16 @@ int pgd_pcg_solve_sharded(pgd_handle ctx, pgd_handle A, pgd_handle b, pgd_handle
  * sums), never which result is computed.                                        */
 enum {
     PGD_TUNE_SPMV_ROWS = 1,  /* rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256 */
+    PGD_TUNE_SPMV_GRID_MIN_BYTES = 8, /* ... used when a grid plane of values exceeds this many bytes (default 1.5 MiB) */
+    PGD_TUNE_SPMV_GRID_PAIRS = 9, /* 1 (default): the march keeps its x planes in LDS (k_spmv_sym_grid3) */
+    PGD_TUNE_SPMV_ZCHUNK = 6,   /* k_spmv_sym_grid (structured vertex grids): planes per workgroup march; 0 = off */
+    PGD_TUNE_SPMV_WG_PER_CU = 7, /* ... workgroups resident per CU (0: uncapped) */
+    PGD_TUNE_SPMV_SYM_PAD = 5, /* doubles of padding between the slot arrays of the symmetric storage */
+    PGD_TUNE_SPMV_STRIP = 4, /* k_spmv_sym on meshes whose grid planes exceed the L2: 64-row blocks per strip of the
+                                strip-by-strip, plane-after-plane walk (default 128; 0: plain row order) */
+    PGD_TUNE_SPMV_SYM = 3,   /* 1 (default): the products of the SPD solves (pgd_pcg_solve, pgd_pcg_solve_sharded,
+                                pgd_spmv_dot_slot after pgd_op_symmetrize) read the operator from its symmetric
+                                half storage when the mesh qualifies (k_spmv_sym); 0: always the CSR kernels */
     PGD_TUNE_SPMV_DICT = 2   /* 1 (default): decode column ids from the mesh's relative-pattern
                                 dictionary when it has one (k_spmv_csr_dict16 for rows <= 16 entries, else
                                 k_spmv_csr_dict); 2: dictionary, generic kernel only; 0: always stream them */

@@ -88,6 +88,7 @@ SIGNATURES = {
     "pgd_comm_halo": (C.c_int, [H, H, I64, I64, I64, I64]),
     "pgd_comm_allreduce_slots": (C.c_int, [H, C.c_int, C.c_int]),
     "pgd_pcg_solve_sharded": (C.c_int, [H, H, H, H, I64, I64, I64, I64, F64, F64, C.c_int, C.POINTER(C.c_int), PD]),
+    "pgd_op_symmetrize": (C.c_int, [H, H, C.POINTER(C.c_int)]),
     "pgd_tune": (C.c_int, [H, C.c_int, I64]),
     "pgd_prof_enable": (C.c_int, [H, C.c_int]),
     "pgd_prof_read": (C.c_int, [H, PI64, PD, PD]),
@@ -466,6 +467,11 @@ class Context:
         self._ck_cb(self.lib.pgd_pcg_solve_sharded(self.h, op, b, x, int(own0), int(own1), int(lo_g), int(hi_g),
                                                    float(rtol), float(atol), int(maxit), C.byref(it), C.byref(rel)))
         return it.value, rel.value
+
+    def op_symmetrize(self, op):
+        used = C.c_int(0)
+        self._ck(self.lib.pgd_op_symmetrize(self.h, op, C.byref(used)))
+        return bool(used.value)
 
     def tune(self, knob, value):
         self._ck(self.lib.pgd_tune(self.h, int(knob), int(value)))

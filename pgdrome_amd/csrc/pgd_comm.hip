@@ -254,6 +254,11 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         PGD_TRY(comm_halo(c, uu, get_vec(c, uu)->d, own0, own1, lo_g, hi_g));
         return pgd_spmv_dot_slot(h, oh, uu, ww, uu, own0, own1, B + 2);
     };
+    {
+        Mesh *m = get_mesh(c, op->mesh);
+        bool sym = false;
+        if (m) PGD_TRY(ensure_sym(c, m, op, &sym));
+    }
     PGD_TRY(pgd_flags_reset(h));
     const double zeros[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     PGD_TRY(pgd_slots_upload(h, zeros, B, 9));

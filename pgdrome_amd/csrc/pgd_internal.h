@@ -57,12 +57,21 @@ struct Mesh : Obj {
     // Column-index dictionary (lossless): FEM rows repeat a handful of RELATIVE column patterns
     // (cols[k] - row); when a mesh has <= DICT_MAXP of them every row stores a 2-byte pattern id
     // and k_spmv_csr_dict rebuilds its column ids from the table instead of streaming 4 B/entry.
+    // Symmetric half storage (pgd_spmv.hip, k_spmv_sym): per relative pattern a 16-int record
+    // [packed(ulen, llen, 8 x 3-bit lower slots), 7 upper offsets, 8 lower distances]; sym_w = 4 or 8 upper
+    // slots (diagonal first) per row, 0 = the mesh does not qualify (rows longer than 8 + 7, or the slot of a
+    // row in its lower neighbours' rows is not a function of its own pattern)
+    int *sym_tab = nullptr;
+    int *sym_ld = nullptr;      // LDS deltas of the pattern slots for k_spmv_sym_grid3 (structured grids only)
+    int sym_w = 0;
+    int sym_plane = 0;          // rows per grid plane (0: none recognised)
+    int sym_nx = 0, sym_ny = 0; // full structured vertex grid: row = x + nx y + nx ny z (0: not one)
     uint16_t *pids = nullptr;    // nv
     int *dict_off = nullptr;     // dict_count x DICT_DLEN relative offsets
     int dict_count = 0;          // 0: dictionary not available (irregular pattern) -> plain CSR kernel
     ~Mesh() override {
         for (void *p : {(void *)coords, (void *)cells, (void *)cellsN, (void *)v2c_ptr, (void *)v2c,
-                        (void *)row_ptr, (void *)cols, (void *)pids, (void *)dict_off})
+                        (void *)row_ptr, (void *)cols, (void *)pids, (void *)dict_off, (void *)sym_tab, (void *)sym_ld})
             if (p) (void)hipFree(p);
     }
 };
@@ -72,10 +81,16 @@ struct Csr : Obj {
     double *vals = nullptr;
     double *dinv = nullptr;    // lazily built inverse diagonal
     bool dinv_valid = false;
-    size_t vals_bytes = 0, dinv_bytes = 0;
+    // symmetric half storage of the same operator: sym_w arrays of nv doubles, slot s of row i at
+    // uvals[s * nv + i] (slot 0 = diagonal, then the entries right of it; zero padded)
+    double *uvals = nullptr;
+    bool uvals_valid = false;
+    int64_t uvals_stride = 0;  // doubles between two slot arrays (rows + padding)
+    size_t vals_bytes = 0, dinv_bytes = 0, uvals_bytes = 0;
     ~Csr() override {
         if (vals) dev_release(ctx, vals, vals_bytes);
         if (dinv) dev_release(ctx, dinv, dinv_bytes);
+        if (uvals) dev_release(ctx, uvals, uvals_bytes);
     }
 };
 
@@ -122,6 +137,13 @@ struct Ctx {
     int num_cu = 256;
     int spmv_dict = 1;            // use the column dictionary when the mesh has one
     int spmv_rows = 64;           // rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256
+    int64_t spmv_grid_min_plane_bytes = (int64_t)3 << 19;   // planes of values above this size take k_spmv_sym_grid
+    int spmv_grid_pairs = 1;      // k_spmv_sym_grid3 (x from LDS) instead of k_spmv_sym_grid
+    int spmv_zchunk = 32;         // k_spmv_sym_grid: planes a workgroup marches through (0: never use that kernel)
+    int spmv_wg_per_cu = 3;       // ... workgroups resident per CU (LDS reservation; 0: no cap)
+    int spmv_strip = 128;         // k_spmv_sym: 64-row blocks per strip of the plane-by-plane walk (0: plain order)
+    int64_t spmv_sym_pad = 0;     // padding (doubles) between the slot arrays of the symmetric storage
+    int spmv_sym = 1;             // PCG products from the symmetric half storage when the mesh qualifies
 
     // SpMV launch timing (HIP events on `stream`)
     bool prof = false;
@@ -145,6 +167,12 @@ int ensure_mask(Ctx *c, int64_t n);
 int ensure_ibuf(Ctx *c, int64_t n);
 void prof_flush(Ctx *c);
 void comm_release(Ctx *c);          // pgd_comm.hip
+struct Mesh;
+struct Csr;
+int build_sym_tables(Ctx *c, Mesh *m);                       // pgd_spmv.hip
+int ensure_sym(Ctx *c, const Mesh *m, Csr *a, bool *usable);  // pgd_spmv.hip: convert (once per operator)
+int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0,
+                   int64_t r1, bool dot, bool store, const int *flags, int *nparts_out);
 
 inline Vec *get_vec(Ctx *c, pgd_handle h) { return static_cast<Vec *>(get_obj(c, h, Obj::VEC)); }
 inline Mesh *get_mesh(Ctx *c, pgd_handle h) { return static_cast<Mesh *>(get_obj(c, h, Obj::MESH)); }

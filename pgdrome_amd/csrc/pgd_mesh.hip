@@ -667,6 +667,7 @@ int pgd_mesh_upload(pgd_handle h, const double *coords, int64_t nv, int gdim, co
     }
     PGD_TRY(build_topology(c, m.get()));
     PGD_TRY(build_dictionary(c, m.get()));
+    PGD_TRY(build_sym_tables(c, m.get()));
     *out = put_obj(c, m.release());
     return PGD_OK;
 }
@@ -773,6 +774,7 @@ int pgd_mesh_blocked(pgd_handle h, pgd_handle mh, int ncomp, pgd_handle *out) {
     k_block_cols<<<(int)((b->nv + TPB - 1) / TPB), TPB, 0, c->stream>>>(m->row_ptr, m->cols, m->nv, ncomp, b->row_ptr, b->cols);
     PGD_LAUNCH_CHECK(c);
     PGD_TRY(build_dictionary(c, b.get()));
+    PGD_TRY(build_sym_tables(c, b.get()));
     *out = put_obj(c, b.release());
     return PGD_OK;
 }

@@ -390,6 +390,7 @@ int pgd_op_combine(pgd_handle h, pgd_handle mh, const pgd_handle *atoms, const d
         *op = put_obj(c, a.release());
     }
     o->dinv_valid = false;
+    o->uvals_valid = false;      // new values: the symmetric copy is rebuilt by the next solve
     const uint8_t *mask = nullptr;
     if (nbc > 0) {
         PGD_TRY(ensure_mask(c, m->nv));
@@ -437,6 +438,8 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         return fail(c, PGD_ERR_INVALID, "pcg_solve: invalid handles or size mismatch");
     const int64_t n = m->nv;
     PGD_TRY(csr_diag_inv(c, m, o));
+    bool sym = false;
+    PGD_TRY(ensure_sym(c, m, o, &sym));       // SPD solve: read every off-diagonal value once per product
     for (int i = 0; i < 4; ++i) PGD_TRY(ensure_work(c, i, n));
     double *r = c->work[0], *z = c->work[1], *p = c->work[2], *q = c->work[3];
     PGD_HIP(c, hipMemsetAsync(c->flags, 0, 8 * sizeof(int), c->stream));
@@ -444,7 +447,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     // 16 + 2 (k & 1), +1, so iteration 0 finds "the previous r.z" in slot 18 like every even iteration:
     // all 16-iteration chunks are identical and can be replayed as one hipGraph.
     constexpr int S_INIT = 18, S_PAIR = 16;
-    PGD_TRY(launch_spmv(c, m, o->vals, x->d, q, nullptr, 0, n, false, true, nullptr, nullptr));
+    PGD_TRY(launch_spmv_op(c, m, o, x->d, q, nullptr, 0, n, false, true, nullptr, nullptr));
     PGD_TRY(pcg_init(c, b->d, q, o->dinv, r, z, p, 0, n, S_INIT));
     k_pcg_tol<<<1, 64, 0, c->stream>>>(c->slots, c->flags, rtol, atol, S_INIT + 1, S_INIT + 2, S_TOL2);
     PGD_LAUNCH_CHECK(c);
@@ -453,7 +456,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         for (int k = 0; k < count; ++k) {
             const int out = S_PAIR + 2 * ((start + k) & 1), rz_old = S_PAIR + 2 * ((start + k + 1) & 1);
             int nparts = 0;
-            PGD_TRY(launch_spmv(c, m, o->vals, p, q, p, 0, n, true, true, c->flags, &nparts));
+            PGD_TRY(launch_spmv_op(c, m, o, p, q, p, 0, n, true, true, c->flags, &nparts));
             PGD_TRY(reduce_partials(c, c->partials, nparts, 1, S_PQ, 0, 0, 0));
             // x, r, z update; the final reduction also runs the convergence test on r.r
             PGD_TRY(pcg_xr(c, x->d, r, p, q, o->dinv, z, 0, n, rz_old, S_PQ, out, 1, S_TOL2));

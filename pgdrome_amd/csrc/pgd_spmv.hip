@@ -25,6 +25,7 @@ constexpr int SPMV_CAP = 4096;                       // staged entries per 256-r
 constexpr int SPMV_VROUNDS = 8;                      // double2 loads per lane: 16 entries per row
 constexpr int SPMV_CROUNDS = 4;                      // int4 loads per lane
 constexpr int MAXY = 8;                              // vectors per pass of k_spmv_multi
+constexpr int64_t SYM_PLANE_L2_BYTES = (int64_t)3 << 19;   // 1.5 MiB: above this a plane of values is walked in strips
 
 struct SpmvArgs {
     const int *row_ptr, *cols;
@@ -290,6 +291,27 @@ __global__ __launch_bounds__(TPB) void k_spmv_multi(SpmvMultiArgs A) {
     }
 }
 
+// HIP-event timing of one launch in four (the events perturb the stream by ~5 us each side); the byte count is
+// the CSR formula of SURVEY 8d for the rows covered, whatever internal form of the operator the kernel reads
+static int prof_begin(Ctx *c, bool dot, bool store, bool *timed) {
+    const bool candidate = c->prof && (!c->prof_pcg_only || (dot && store));
+    *timed = candidate && ((c->prof_seen++ & 3) == 0);
+    if (*timed) {
+        if (c->ev_used + 2 > c->ev.size()) prof_flush(c);
+        PGD_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+    }
+    return PGD_OK;
+}
+
+static int prof_end(Ctx *c, const Mesh *m, int64_t nrows) {
+    PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+    c->ev_used += 2;
+    c->prof_launches += 1;
+    const double frac = m->nv > 0 ? (double)nrows / (double)m->nv : 0.0;
+    c->prof_bytes += 12.0 * (double)m->nnz * frac + 20.0 * (double)nrows;
+    return PGD_OK;
+}
+
 int launch_spmv(Ctx *c, const Mesh *m, const double *vals, const double *x, double *y, const double *w,
                 int64_t r0, int64_t r1, bool dot, bool store, const int *flags, int *nparts_out) {
     if (r1 < 0) r1 = m->nv;
@@ -303,13 +325,8 @@ int launch_spmv(Ctx *c, const Mesh *m, const double *vals, const double *x, doub
     SpmvArgs A;
     A.row_ptr = m->row_ptr; A.cols = m->cols; A.vals = vals; A.x = x; A.w = w; A.y = y;
     A.partials = c->partials; A.flags = flags; A.row_begin = (int)r0; A.row_end = (int)r1;
-    // events perturb the stream (~5 us each side): time one launch in four
-    const bool candidate = c->prof && (!c->prof_pcg_only || (dot && store));
-    const bool timed = candidate && ((c->prof_seen++ & 3) == 0);
-    if (timed) {
-        if (c->ev_used + 2 > c->ev.size()) prof_flush(c);
-        PGD_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
-    }
+    bool timed = false;
+    PGD_TRY(prof_begin(c, dot, store, &timed));
     const bool use_dict = c->spmv_dict && m->dict_count > 0;
 #define PGD_SPMV_LAUNCH(D, S)                                                                             \
     do {                                                                                                  \
@@ -329,14 +346,528 @@ int launch_spmv(Ctx *c, const Mesh *m, const double *vals, const double *x, doub
     else if (dot) PGD_SPMV_LAUNCH(true, false);
     else PGD_SPMV_LAUNCH(false, true);
 #undef PGD_SPMV_LAUNCH
-    if (timed) {
-        PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
-        c->ev_used += 2;
-        c->prof_launches += 1;
-        // algorithmic bytes of the rows this launch covers: 12 B per entry + 20 B per row
-        const double frac = m->nv > 0 ? (double)nrows / (double)m->nv : 0.0;
-        c->prof_bytes += 12.0 * (double)m->nnz * frac + 20.0 * (double)nrows;
+    if (timed) PGD_TRY(prof_end(c, m, nrows));
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+// ------------------------------------------------------------------ symmetric half storage
+// An SPD finite-element operator is stored ONCE per unordered pair: per row the diagonal and the entries
+// right of it, slot by slot in sym_w arrays of n doubles (ELL, structure of arrays).  Row i needs a_ij for
+// its lower neighbours j < i too: those sit in row j's slots, and for a mesh whose rows repeat a few relative
+// patterns the slot is a function of row i's pattern - so lane i READS uvals[slot * n + (i - d)], a shifted,
+// perfectly coalesced stream like every other access of this kernel (own slots, x at i + offset).  No scatter,
+// no atomics, fixed summation order.  Every value leaves HBM once (8 (nnz + n) / 2 bytes instead of 12 nnz); the
+// second use, at most one grid plane (~4 MB of values) later, is served by the Infinity Cache.
+struct SymArgs {
+    const double *uvals, *x, *w;
+    double *y, *partials;
+    const int *flags, *tab;
+    const uint16_t *pids;
+    int64_t n;              // slot stride in doubles (rows + padding)
+    int row_begin, row_end;
+    // Traversal order of the 64-row blocks.  The lower neighbours of a row lie up to one grid plane back; when a
+    // plane of values (plane rows x 8 W bytes) does not fit an XCD's 4 MiB L2, the blocks are walked strip by
+    // strip: `strip` consecutive blocks of a plane, then the same blocks of the next plane, ... so the slots a
+    // strip reads from the plane below were loaded by the same XCD a few hundred KB of traffic earlier.
+    // plane_blocks = 0: plain order.
+    int nblk, plane_blocks, strip, nz;
+};
+
+struct SymRec { int v[16]; };
+
+__device__ __forceinline__ SymRec sym_load(const int *tab, int pid) {
+    SymRec r;
+    const i4_t *q = reinterpret_cast<const i4_t *>(tab + pid * 16);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const i4_t o = q[k];
+        r.v[4 * k] = o.x; r.v[4 * k + 1] = o.y; r.v[4 * k + 2] = o.z; r.v[4 * k + 3] = o.w;
     }
+    return r;
+}
+
+// (ulen incl. diagonal, llen, upper offsets, lower distances and slots) of one CSR row; false when the row
+// does not fit the record (no diagonal, more than 7 + 8 off-diagonal entries, a slot beyond 7)
+__device__ bool sym_describe(const int *__restrict__ row_ptr, const int *__restrict__ cols, int r, int *rec) {
+    for (int k = 0; k < 16; ++k) rec[k] = 0;
+    const int a = row_ptr[r], b = row_ptr[r + 1];
+    int nl = 0, nu = 0, slots = 0;
+    bool diag = false;
+    for (int k = a; k < b; ++k) {
+        const int col = cols[k];
+        if (col < r) {
+            int posd = -1, posr = -1;
+            for (int t = row_ptr[col]; t < row_ptr[col + 1]; ++t) {
+                if (cols[t] == col) posd = t;
+                if (cols[t] == r) posr = t;
+            }
+            const int slot = posr - posd;
+            if (posd < 0 || posr < 0 || slot < 1 || slot > 7 || nl >= 8) return false;
+            rec[8 + nl] = r - col;
+            slots |= slot << (3 * nl);
+            ++nl;
+        } else if (col == r) {
+            diag = true;
+        } else {
+            if (nu >= 7) return false;
+            ++nu;
+            rec[nu] = col - r;
+        }
+    }
+    if (!diag) return false;
+    rec[0] = (nu + 1) | (nl << 4) | (slots << 8);
+    return true;
+}
+
+__global__ __launch_bounds__(TPB) void k_sym_rep(const uint16_t *__restrict__ pids, int64_t n, int *__restrict__ rep) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) atomicMin(&rep[pids[i]], (int)i);
+}
+
+__global__ void k_sym_build(const int *__restrict__ row_ptr, const int *__restrict__ cols, const int *__restrict__ rep,
+                            int npat, int64_t nv, int *__restrict__ tab, int *__restrict__ flags) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npat) return;
+    int rec[16];
+    if (rep[p] < 0 || rep[p] >= nv || !sym_describe(row_ptr, cols, rep[p], rec)) { flags[0] = 1; return; }
+    for (int k = 0; k < 16; ++k) tab[p * 16 + k] = rec[k];
+}
+
+__global__ __launch_bounds__(TPB) void k_sym_verify(const int *__restrict__ row_ptr, const int *__restrict__ cols,
+                                                    const uint16_t *__restrict__ pids, const int *__restrict__ tab,
+                                                    int64_t n, int *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    int rec[16];
+    bool ok = sym_describe(row_ptr, cols, (int)i, rec);
+    const int *t = tab + (int)pids[i] * 16;
+    for (int k = 0; ok && k < 16; ++k) ok = rec[k] == t[k];
+    if (!ok) flags[0] = 1;
+}
+
+// CSR values -> the slot arrays; also checks a_ij == a_ji to rounding (flags[1] counts violations)
+template <int W>
+__global__ __launch_bounds__(TPB) void k_csr_to_sym(const int *__restrict__ row_ptr, const double *__restrict__ vals,
+                                                    const uint16_t *__restrict__ pids, const int *__restrict__ tab,
+                                                    int64_t n, int64_t stride, double *__restrict__ uvals,
+                                                    int *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int *t = tab + (int)pids[i] * 16;
+    const int hdr = t[0], ulen = hdr & 15, llen = (hdr >> 4) & 15;
+    const int a = row_ptr[i];
+#pragma unroll
+    for (int s = 0; s < W; ++s) uvals[(int64_t)s * stride + i] = s < ulen ? vals[a + llen + s] : 0.0;
+    bool asym = false;
+    for (int m = 0; m < llen; ++m) {
+        const int64_t src = i - t[8 + m];
+        const int slot = (hdr >> (8 + 3 * m)) & 7;
+        const int ls = (tab[(int)pids[src] * 16] >> 4) & 15;
+        const double aij = vals[a + m], aji = vals[row_ptr[src] + ls + slot];
+        if (fabs(aij - aji) > 1e-12 * (fabs(aij) + fabs(aji))) asym = true;
+    }
+    if (asym) atomicAdd(&flags[1], 1);
+}
+
+// One row of the product from the slot arrays: 2 W value loads, 2 W x loads, all issued before the first use.
+template <int W>
+__device__ __forceinline__ double sym_row_rec(const SymArgs &A, int64_t row, const SymRec &t) {
+    const int hdr = t.v[0], ulen = hdr & 15, llen = (hdr >> 4) & 15;
+    double uv[W], ux[W], lv[W], lx[W];
+#pragma unroll
+    for (int s = 0; s < W; ++s) {
+        uv[s] = A.uvals[(int64_t)s * A.n + row];                      // zero beyond ulen
+        ux[s] = A.x[row + ((s > 0 && s < ulen) ? t.v[s] : 0)];
+    }
+#pragma unroll
+    for (int m = 0; m < W; ++m) {
+        const bool on = m < llen;
+        const int64_t src = row - (on ? t.v[8 + m] : 0);
+        const int slot = on ? (hdr >> (8 + 3 * m)) & 7 : 0;
+        lv[m] = A.uvals[(int64_t)slot * A.n + src];
+        lx[m] = A.x[src];
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int m = 0; m < W; ++m) acc = fma(m < llen ? lv[m] : 0.0, lx[m], acc);     // ascending columns: lower first
+#pragma unroll
+    for (int s = 0; s < W; ++s) acc = fma(uv[s], ux[s], acc);
+    return acc;
+}
+
+template <int W>
+__device__ __forceinline__ double sym_row(const SymArgs &A, int64_t row) {
+    return sym_row_rec<W>(A, row, sym_load(A.tab, (int)A.pids[row]));
+}
+
+template <bool DOT, bool STORE, int W>
+__global__ __launch_bounds__(64) void k_spmv_sym(SymArgs A) {
+    if (A.flags && A.flags[0]) return;
+    const int tid = threadIdx.x;
+    int b = xcd_remap(blockIdx.x, gridDim.x);
+    if (A.plane_blocks > 0) {
+        const int per = A.nz * A.strip;                   // blocks of one strip through all planes
+        const int s = b / per, rem = b - s * per;
+        const int z = rem / A.strip, within = s * A.strip + (rem - z * A.strip);
+        b = z * A.plane_blocks + within;
+        if (within >= A.plane_blocks || b >= A.nblk) return;       // padding of the last strip / plane (uniform)
+    }
+    const int r0 = A.row_begin + b * 64;
+    const int nr = min(64, A.row_end - r0);
+    const int64_t row = r0 + (tid < nr ? tid : 0);
+    const double acc = sym_row<W>(A, row);
+    if (STORE && tid < nr) A.y[r0 + tid] = acc;
+    if (DOT) {
+        const double v = (tid < nr) ? acc * A.w[r0 + tid] : 0.0;
+        const double sum = wave_sum(v);
+        if (tid == 0) A.partials[b] = sum;
+    }
+}
+
+// Structured vertex grids (row = x + nx y + nx ny z): a workgroup owns a 64 x 4 patch of (x, y) and MARCHES along z
+// through its chunk of planes.  The slots it reads for the plane below were loaded by the same workgroup one step
+// earlier; with only a few workgroups resident per CU (the launch reserves LDS it does not use to cap them) the
+// bytes an XCD moves between the two uses stay well inside its 4 MiB L2, so each off-diagonal value crosses the
+// fabric once.  (In row order the 1 024 waves an XCD keeps in flight span a whole plane of 256^2 rows: the second
+// use of every value then misses L2 and costs as much as the first.)
+struct SymGridArgs {
+    SymArgs a;
+    int nx, ny, z0, z1, zchunk, tiles_x, tiles_y, npat;
+};
+
+template <bool DOT, bool STORE, int W>
+__global__ __launch_bounds__(256) void k_spmv_sym_grid(SymGridArgs G) {
+    extern __shared__ double s_dyn[];          // occupancy cap only; the first 4 doubles carry the dot partials
+    const SymArgs &A = G.a;
+    if (A.flags && A.flags[0]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_chunk = G.tiles_x * G.tiles_y;
+    const int chunk = b / per_chunk, tile = b - chunk * per_chunk;
+    const int ty = tile / G.tiles_x, tx = tile - ty * G.tiles_x;
+    const int x = tx * 64 + lane, y = ty * 4 + wv;
+    const bool live = x < G.nx && y < G.ny;
+    const int64_t plane = (int64_t)G.nx * G.ny;
+    const int64_t base = (live ? x : 0) + (int64_t)G.nx * (live ? y : 0);
+    const int za = G.z0 + chunk * G.zchunk, zb = min(G.z1, za + G.zchunk);
+    double dot = 0.0;
+    if (za >= zb) { if (DOT && tid == 0) A.partials[b] = 0.0; return; }
+    // the pattern record of the NEXT plane is fetched while this plane's 32 loads are in flight: with few waves per
+    // CU the id -> record -> values chain of dependent loads would otherwise set the pace
+    SymRec t = sym_load(A.tab, (int)A.pids[base + plane * za]);
+    for (int z = za; z < zb; ++z) {
+        const int64_t row = base + plane * z;
+        const int64_t nrow = base + plane * (z + 1 < zb ? z + 1 : z);
+        const SymRec tn = sym_load(A.tab, (int)A.pids[nrow]);
+        const double acc = sym_row_rec<W>(A, row, t);
+        if (STORE && live) A.y[row] = acc;
+        if (DOT && live) dot = fma(acc, A.w[row], dot);
+        t = tn;
+    }
+    if (DOT) {
+        const double sum = wave_sum(dot);
+        if (lane == 0) s_dyn[wv] = sum;
+        __syncthreads();
+        if (tid == 0) A.partials[b] = (s_dyn[0] + s_dyn[1]) + (s_dyn[2] + s_dyn[3]);
+    }
+}
+
+// The march with x served from LDS.  PMC showed the L1 address/data path (TA busy 82-84 %), not HBM, pacing all the
+// forms above: per row they pull 2 W + 15 eight-byte loads = ~256 B through the L1 although only ~90-150 B cross the
+// fabric.  Here the workgroup keeps the three planes of x its patch touches (patch + one halo cell each way) in LDS -
+// each x value enters the L1 once per patch and plane - and every neighbour read is a ds_read_b64 at
+// centre + delta, delta looked up per pattern slot (sym_ld: dx + 66 dy and the plane dz).  The pattern records are
+// read from an LDS copy too.  Only the slot values and y still use the vector-memory path.
+constexpr int G3_HX = 66, G3_HY = 6, G3_SLICE = G3_HX * G3_HY;      // 64 x 4 patch + halo = 396 doubles per plane
+constexpr int G3_MAXP = 64;                                        // pattern records copied to LDS
+
+struct SymGrid3Args {
+    SymGridArgs g;
+    const int *ld;          // per pattern 16 ints: [k] = ((dz + 1) << 12) | (dx + 66 dy + 2048) for slot k (1..7 upper, 8.. lower)
+    int nzgrid;             // planes of the whole (local) grid
+};
+
+template <bool DOT, bool STORE>
+__global__ __launch_bounds__(256) void k_spmv_sym_grid3(SymGrid3Args H) {
+    __shared__ double s_x[3 * G3_SLICE];
+    __shared__ __align__(16) int s_tab[G3_MAXP * 16];
+    __shared__ __align__(16) int s_ld[G3_MAXP * 16];
+    __shared__ double s_red[4];
+    const SymGridArgs &G = H.g;
+    const SymArgs &A = G.a;
+    if (A.flags && A.flags[0]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    for (int k = tid; k < G.npat * 16; k += 256) { s_tab[k] = A.tab[k]; s_ld[k] = H.ld[k]; }
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_chunk = G.tiles_x * G.tiles_y;
+    const int chunk = b / per_chunk, tile = b - chunk * per_chunk;
+    const int ty = tile / G.tiles_x, tx = tile - ty * G.tiles_x;
+    const int x0 = tx * 64, y0 = ty * 4;
+    const int x = x0 + lane, y = y0 + wv;
+    const bool live = x < G.nx && y < G.ny;
+    const int64_t plane = (int64_t)G.nx * G.ny;
+    const int64_t base = (live ? x : 0) + (int64_t)G.nx * (live ? y : 0);
+    const int centre = (wv + 1) * G3_HX + lane + 1;
+    const int za = G.z0 + chunk * G.zchunk, zb = min(G.z1, za + G.zchunk);
+    // the two halo-patch cells this thread stages per plane (396 cells, 256 threads)
+    int64_t goff[2];
+    bool gok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + q * 256;
+        const int ly = i / G3_HX, lx = i - ly * G3_HX;
+        const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+        gok[q] = i < G3_SLICE && gx >= 0 && gx < G.nx && gy >= 0 && gy < G.ny;
+        goff[q] = gok[q] ? gx + (int64_t)G.nx * gy : 0;
+    }
+    auto fetch = [&](int z, double v[2]) {
+        const bool zok = z >= 0 && z < H.nzgrid;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) v[q] = (zok && gok[q]) ? A.x[goff[q] + plane * z] : 0.0;
+    };
+    auto put = [&](int z, const double v[2]) {
+        const int sl = ((z % 3) + 3) % 3;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (tid + q * 256 < G3_SLICE) s_x[sl * G3_SLICE + tid + q * 256] = v[q];
+    };
+    double dot = 0.0;
+    if (za < zb) {
+        double v[2];
+        for (int z = za - 1; z <= za + 1; ++z) { fetch(z, v); put(z, v); }
+    }
+    __syncthreads();
+    for (int z = za; z < zb; ++z) {
+        double vn[2];
+        fetch(z + 2, vn);                                   // in flight while this plane is computed
+        const int64_t row = base + plane * z;
+        const int pid = A.pids[row];
+        const int *t = s_tab + pid * 16, *ld = s_ld + pid * 16;
+        const int hdr = t[0], ulen = hdr & 15, llen = (hdr >> 4) & 15;
+        const int sl0 = ((z - 1) % 3 + 3) % 3;             // slice of plane z - 1; planes z, z + 1 follow cyclically
+        int sb[3];
+        sb[0] = sl0 * G3_SLICE; sb[1] = ((sl0 + 1) % 3) * G3_SLICE; sb[2] = ((sl0 + 2) % 3) * G3_SLICE;
+        double uv[8], lv[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) uv[s] = A.uvals[(int64_t)s * A.n + row];                  // zero beyond ulen
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const bool on = m < llen;
+            const int64_t src = row - (on ? t[8 + m] : 0);
+            const int slot = on ? (hdr >> (8 + 3 * m)) & 7 : 0;
+            lv[m] = A.uvals[(int64_t)slot * A.n + src];
+        }
+        const double xc = s_x[sb[1] + centre];
+        double acc = 0.0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {                      // ascending columns: lower entries first
+            const bool on = m < llen;
+            const int code = on ? ld[8 + m] : ((1 << 12) | 2048);
+            const double xv = s_x[sb[code >> 12] + centre + (code & 4095) - 2048];
+            acc = fma(on ? lv[m] : 0.0, xv, acc);
+        }
+        acc = fma(uv[0], xc, acc);
+#pragma unroll
+        for (int s = 1; s < 8; ++s) {
+            const bool on = s < ulen;
+            const int code = on ? ld[s] : ((1 << 12) | 2048);
+            const double xv = s_x[sb[code >> 12] + centre + (code & 4095) - 2048];
+            acc = fma(uv[s], xv, acc);
+        }
+        if (STORE && live) A.y[row] = acc;
+        if (DOT && live) dot = fma(acc, xc, dot);           // the PCG product: w is x itself (checked by the launcher)
+        __syncthreads();                                    // everyone is done with plane z - 1
+        put(z + 2, vn);                                     // ... whose slice receives plane z + 2
+        __syncthreads();
+    }
+    if (DOT) {
+        const double sum = wave_sum(dot);
+        if (lane == 0) s_red[wv] = sum;
+        __syncthreads();
+        if (tid == 0) A.partials[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+}
+
+int build_sym_tables(Ctx *c, Mesh *m) {
+    m->sym_w = 0;
+    if (m->dict_count <= 0 || m->max_row > 15 || m->nnz == 0) return PGD_OK;
+    void *p;
+    int *ibuf = nullptr;       // rep[DICT_MAXP], flags[8]
+    PGD_TRY(dev_alloc(c, &p, (DICT_MAXP + 8) * sizeof(int))); ibuf = (int *)p;
+    int *rep = ibuf, *flags = ibuf + DICT_MAXP;
+    PGD_TRY(dev_alloc(c, &p, (size_t)DICT_MAXP * 16 * sizeof(int))); m->sym_tab = (int *)p;
+    hipStream_t st = c->stream;
+    PGD_HIP(c, hipMemsetAsync(rep, 0x7f, DICT_MAXP * sizeof(int), st));
+    PGD_HIP(c, hipMemsetAsync(flags, 0, 8 * sizeof(int), st));
+    PGD_HIP(c, hipMemsetAsync(m->sym_tab, 0, (size_t)DICT_MAXP * 16 * sizeof(int), st));
+    k_sym_rep<<<(int)((m->nv + TPB - 1) / TPB), TPB, 0, st>>>(m->pids, m->nv, rep);      // one thread per row, no grid cap
+    k_sym_build<<<1, DICT_MAXP, 0, st>>>(m->row_ptr, m->cols, rep, m->dict_count, m->nv, m->sym_tab, flags);
+    k_sym_verify<<<(int)((m->nv + TPB - 1) / TPB), TPB, 0, st>>>(m->row_ptr, m->cols, m->pids, m->sym_tab, m->nv, flags);
+    std::vector<int> tab((size_t)m->dict_count * 16);
+    int f = 1;
+    PGD_HIP(c, hipMemcpyAsync(&f, flags, sizeof f, hipMemcpyDeviceToHost, st));
+    PGD_HIP(c, hipMemcpyAsync(tab.data(), m->sym_tab, tab.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+    PGD_HIP(c, hipStreamSynchronize(st));
+    (void)hipFree(ibuf);
+    PGD_LAUNCH_CHECK(c);
+    if (f != 0) { (void)hipFree(m->sym_tab); m->sym_tab = nullptr; return PGD_OK; }
+    int maxu = 0;
+    for (int q = 0; q < m->dict_count; ++q) maxu = std::max(maxu, tab[(size_t)q * 16] & 15);
+    int maxl = 0;
+    for (int q = 0; q < m->dict_count; ++q) maxl = std::max(maxl, (tab[(size_t)q * 16] >> 4) & 15);
+    m->sym_w = (maxu <= 4 && maxl <= 4) ? 4 : 8;
+    // rows per grid plane, read off the richest pattern: its largest lower distance after the last jump by a
+    // factor >= 4 in the sorted distances (1, nx, nx+1 | nx ny, ...); 0 when there is no such structure
+    int best = 0;
+    for (int q = 1; q < m->dict_count; ++q)
+        if (((tab[(size_t)q * 16] >> 4) & 15) > ((tab[(size_t)best * 16] >> 4) & 15)) best = q;
+    std::vector<int> d;
+    for (int k = 0; k < ((tab[(size_t)best * 16] >> 4) & 15); ++k) d.push_back(tab[(size_t)best * 16 + 8 + k]);
+    std::sort(d.begin(), d.end());
+    m->sym_plane = 0;
+    for (size_t k = 1; k < d.size(); ++k)
+        if (d[k] >= 4 * (int64_t)d[k - 1]) m->sym_plane = d[k];
+    // a full structured vertex grid (row = x + nx y + nx ny z, the 15-point pattern of the 6-tetrahedra-per-cube mesh):
+    // lower distances 1, nx, nx + 1, P, P + 1, P + nx, P + nx + 1 with P = nx ny dividing the row count
+    m->sym_nx = m->sym_ny = 0;
+    if (d.size() == 7 && d[0] == 1 && d[2] == d[1] + 1 && d[4] == d[3] + 1 && d[5] == d[3] + d[1] && d[6] == d[5] + 1 &&
+        d[3] % d[1] == 0 && m->nv % d[3] == 0 && d[1] >= 2) {
+        m->sym_nx = d[1];
+        m->sym_ny = d[3] / d[1];
+    }
+    if (m->sym_nx > 0) {
+        // LDS deltas of every slot of every pattern for k_spmv_sym_grid3: offset = dx + nx dy + nx ny dz, each in -1..1
+        const int64_t nx = m->sym_nx, P = (int64_t)m->sym_nx * m->sym_ny;
+        std::vector<int> ld((size_t)DICT_MAXP * 16, (1 << 12) | 2048);
+        bool ok = true;
+        auto code = [&](int64_t off) -> int {
+            const int64_t dz = (off >= 0 ? (off + P / 2) / P : -((-off + P / 2) / P));
+            const int64_t rem = off - dz * P;
+            const int64_t dy = (rem >= 0 ? (rem + nx / 2) / nx : -((-rem + nx / 2) / nx));
+            const int64_t dx = rem - dy * nx;
+            if (dz < -1 || dz > 1 || dy < -1 || dy > 1 || dx < -1 || dx > 1) { ok = false; return (1 << 12) | 2048; }
+            return (int)(((dz + 1) << 12) | (dx + G3_HX * dy + 2048));
+        };
+        for (int q = 0; q < m->dict_count; ++q) {
+            const int hdr = tab[(size_t)q * 16], ulen = hdr & 15, llen = (hdr >> 4) & 15;
+            for (int sidx = 1; sidx < ulen; ++sidx) ld[(size_t)q * 16 + sidx] = code(tab[(size_t)q * 16 + sidx]);
+            for (int k = 0; k < llen; ++k) ld[(size_t)q * 16 + 8 + k] = code(-(int64_t)tab[(size_t)q * 16 + 8 + k]);
+        }
+        if (ok) {
+            PGD_TRY(dev_alloc(c, &p, ld.size() * sizeof(int))); m->sym_ld = (int *)p;
+            PGD_HIP(c, hipMemcpyAsync(m->sym_ld, ld.data(), ld.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            PGD_HIP(c, hipStreamSynchronize(st));
+        }
+    }
+    return PGD_OK;
+}
+
+int ensure_sym(Ctx *c, const Mesh *m, Csr *a, bool *usable) {
+    *usable = false;
+    if (!c->spmv_sym || m->sym_w == 0) return PGD_OK;
+    if (a->uvals_valid) { *usable = a->uvals != nullptr; return PGD_OK; }
+    a->uvals_valid = true;                       // decided for this set of values, whatever the outcome
+    // slot arrays are padded apart: with a power-of-two row count (256^3) they would sit exactly 2^27 bytes from each
+    // other and every lane's 8 + 7 streams would walk the same HBM channels in step
+    const int64_t stride = m->nv + c->spmv_sym_pad;
+    if (a->uvals && a->uvals_stride != stride) { dev_release(c, a->uvals, a->uvals_bytes); a->uvals = nullptr; }
+    if (!a->uvals) {
+        void *p;
+        a->uvals_bytes = (size_t)m->sym_w * (size_t)stride * sizeof(double);
+        PGD_TRY(dev_alloc(c, &p, a->uvals_bytes));
+        a->uvals = (double *)p;
+        a->uvals_stride = stride;
+    }
+    PGD_HIP(c, hipMemsetAsync(c->flags + 4, 0, 4 * sizeof(int), c->stream));
+    const int g = (int)((m->nv + TPB - 1) / TPB);
+    if (m->sym_w == 4) k_csr_to_sym<4><<<g, TPB, 0, c->stream>>>(m->row_ptr, a->vals, m->pids, m->sym_tab, m->nv, stride, a->uvals, c->flags + 4);
+    else k_csr_to_sym<8><<<g, TPB, 0, c->stream>>>(m->row_ptr, a->vals, m->pids, m->sym_tab, m->nv, stride, a->uvals, c->flags + 4);
+    int f[2] = {0, 0};
+    PGD_HIP(c, hipMemcpyAsync(f, c->flags + 4, sizeof f, hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    PGD_LAUNCH_CHECK(c);
+    if (f[1] != 0) {      // not symmetric: keep the general kernel for this operator
+        dev_release(c, a->uvals, a->uvals_bytes);
+        a->uvals = nullptr;
+        return PGD_OK;
+    }
+    *usable = true;
+    return PGD_OK;
+}
+
+int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0,
+                   int64_t r1, bool dot, bool store, const int *flags, int *nparts_out) {
+    if (!(c->spmv_sym && m->sym_w && a->uvals_valid && a->uvals))
+        return launch_spmv(c, m, a->vals, x, y, w, r0, r1, dot, store, flags, nparts_out);
+    if (r1 < 0) r1 = m->nv;
+    if (r0 < 0 || r0 > r1 || r1 > m->nv) return fail(c, PGD_ERR_INVALID, "spmv: bad row range");
+    const int64_t nrows = r1 - r0;
+    const int nblk = (int)((nrows + 63) / 64);
+    if (nparts_out) *nparts_out = nblk;
+    if (nblk == 0) return PGD_OK;
+    if (dot) PGD_TRY(ensure_partials(c, (int64_t)nblk > 4 * MAX_VEC_BLOCKS ? nblk : 4 * MAX_VEC_BLOCKS));
+    SymArgs A;
+    A.uvals = a->uvals; A.x = x; A.w = w; A.y = y; A.partials = c->partials; A.flags = flags;
+    A.tab = m->sym_tab; A.pids = m->pids; A.n = a->uvals_stride; A.row_begin = (int)r0; A.row_end = (int)r1;
+    A.nblk = nblk; A.plane_blocks = 0; A.strip = 0; A.nz = 0;
+    int grid = nblk;
+    const int64_t plane_bytes = (int64_t)m->sym_plane * 8 * m->sym_w;
+    if (c->spmv_strip > 0 && plane_bytes > SYM_PLANE_L2_BYTES && nblk > 0) {
+        A.plane_blocks = (int)((m->sym_plane + 32) / 64);
+        A.strip = std::min(c->spmv_strip, A.plane_blocks);
+        A.nz = (nblk + A.plane_blocks - 1) / A.plane_blocks;
+        const int nstrips = (A.plane_blocks + A.strip - 1) / A.strip;
+        const int64_t g = (int64_t)nstrips * A.nz * A.strip;
+        if (g >= (int64_t)1 << 30) { A.plane_blocks = 0; } else grid = (int)g;
+    }
+    const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
+    if (c->spmv_zchunk > 0 && m->sym_w == 8 && plane > 0 && r0 % plane == 0 && r1 % plane == 0 &&
+        plane * 8 * m->sym_w > c->spmv_grid_min_plane_bytes) {
+        SymGridArgs G;
+        G.a = A;
+        G.nx = m->sym_nx; G.ny = m->sym_ny; G.z0 = (int)(r0 / plane); G.z1 = (int)(r1 / plane);
+        G.zchunk = c->spmv_zchunk;
+        G.npat = m->dict_count;
+        const bool ldsx = c->spmv_grid_pairs != 0 && m->sym_ld && m->dict_count <= G3_MAXP && (!dot || w == x);
+        G.tiles_x = (G.nx + 63) / 64; G.tiles_y = (G.ny + 3) / 4;
+        const int chunks = (G.z1 - G.z0 + G.zchunk - 1) / G.zchunk;
+        const int64_t gg = (int64_t)chunks * G.tiles_x * G.tiles_y;
+        if (gg < ((int64_t)1 << 30)) {
+            const int wgs = (int)gg;
+            if (nparts_out) *nparts_out = wgs;
+            if (dot) PGD_TRY(ensure_partials(c, (int64_t)wgs > 4 * MAX_VEC_BLOCKS ? wgs : 4 * MAX_VEC_BLOCKS));
+            G.a.partials = c->partials;
+            // reserve LDS to cap the workgroups resident per CU (160 KiB per CU)
+            const size_t lds = c->spmv_wg_per_cu > 0 ? (size_t)(160 * 1024 / c->spmv_wg_per_cu - 512) : 64;
+            bool timed2 = false;
+            PGD_TRY(prof_begin(c, dot, store, &timed2));
+            if (ldsx) {
+                SymGrid3Args H;
+                H.g = G; H.ld = m->sym_ld; H.nzgrid = (int)(m->nv / plane);
+                if (dot && store) k_spmv_sym_grid3<true, true><<<wgs, 256, 0, c->stream>>>(H);
+                else if (dot) k_spmv_sym_grid3<true, false><<<wgs, 256, 0, c->stream>>>(H);
+                else k_spmv_sym_grid3<false, true><<<wgs, 256, 0, c->stream>>>(H);
+            } else if (dot && store) k_spmv_sym_grid<true, true, 8><<<wgs, 256, lds, c->stream>>>(G);
+            else if (dot) k_spmv_sym_grid<true, false, 8><<<wgs, 256, lds, c->stream>>>(G);
+            else k_spmv_sym_grid<false, true, 8><<<wgs, 256, lds, c->stream>>>(G);
+            if (timed2) PGD_TRY(prof_end(c, m, nrows));
+            PGD_LAUNCH_CHECK(c);
+            return PGD_OK;
+        }
+    }
+    bool timed = false;
+    PGD_TRY(prof_begin(c, dot, store, &timed));
+#define PGD_SYM_LAUNCH(D, S)                                                          \
+    do {                                                                              \
+        if (m->sym_w == 4) k_spmv_sym<D, S, 4><<<grid, 64, 0, c->stream>>>(A);        \
+        else k_spmv_sym<D, S, 8><<<grid, 64, 0, c->stream>>>(A);                      \
+    } while (0)
+    if (dot && store) PGD_SYM_LAUNCH(true, true);
+    else if (dot) PGD_SYM_LAUNCH(true, false);
+    else PGD_SYM_LAUNCH(false, true);
+#undef PGD_SYM_LAUNCH
+    if (timed) PGD_TRY(prof_end(c, m, nrows));
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
 }
@@ -373,6 +904,13 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     PGD_CTX(c, h);
     if (knob == PGD_TUNE_SPMV_ROWS && (value == 64 || value == 128 || value == 256)) { c->spmv_rows = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_DICT && value >= 0 && value <= 2) { c->spmv_dict = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_SYM && value >= 0 && value <= 1) { c->spmv_sym = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_SYM_PAD && value >= 0 && value <= (1 << 24)) { c->spmv_sym_pad = value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_GRID_MIN_BYTES && value >= 0) { c->spmv_grid_min_plane_bytes = value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_GRID_PAIRS && value >= 0 && value <= 1) { c->spmv_grid_pairs = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_ZCHUNK && value >= 0 && value <= 65536) { c->spmv_zchunk = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_WG_PER_CU && value >= 0 && value <= 32) { c->spmv_wg_per_cu = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_STRIP && value >= 0 && value <= 65536) { c->spmv_strip = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }
 
@@ -420,6 +958,17 @@ int pgd_bilinear_many(pgd_handle h, pgd_handle ah, pgd_handle xh, const pgd_hand
     return launch_spmv_multi(c, m, a->vals, x->d, ys.data(), ny, r0, r1, out);
 }
 
+int pgd_op_symmetrize(pgd_handle h, pgd_handle ah, int *used) {
+    PGD_CTX(c, h);
+    Csr *a = get_csr(c, ah);
+    Mesh *m = a ? get_mesh(c, a->mesh) : nullptr;
+    if (!a || !m) return fail(c, PGD_ERR_INVALID, "op_symmetrize: invalid handle");
+    bool usable = false;
+    PGD_TRY(ensure_sym(c, m, a, &usable));
+    if (used) *used = usable ? 1 : 0;
+    return PGD_OK;
+}
+
 int pgd_spmv_dot_slot(pgd_handle h, pgd_handle ah, pgd_handle xh, pgd_handle yh, pgd_handle wh, int64_t r0,
                       int64_t r1, int slot) {
     PGD_CTX(c, h);
@@ -430,7 +979,7 @@ int pgd_spmv_dot_slot(pgd_handle h, pgd_handle ah, pgd_handle xh, pgd_handle yh,
         slot < 0 || slot >= PGD_NSLOTS)
         return fail(c, PGD_ERR_INVALID, "spmv_dot_slot: invalid handles, sizes or slot");
     int nparts = 0;
-    PGD_TRY(launch_spmv(c, m, a->vals, x->d, y->d, w->d, r0, r1, true, true, c->flags, &nparts));
+    PGD_TRY(launch_spmv_op(c, m, a, x->d, y->d, w->d, r0, r1, true, true, c->flags, &nparts));
     if (nparts == 0) {   // empty row range: its partial is 0 (callers all-reduce the slot unconditionally)
         PGD_HIP(c, hipMemsetAsync(c->slots + slot, 0, sizeof(double), c->stream));
         return PGD_OK;

@@ -275,6 +275,96 @@ def test_blocked_layout_and_embedded_atoms(ctx, ncomp):
     ctx.mesh_free(h)
 
 
+@pytest.mark.parametrize("name", ["interval33", "rect17x9", "box6x5x4", "box20"])
+def test_symmetric_half_storage_products(ctx, name):
+    """k_spmv_sym (every off-diagonal value stored once, lower entries read from the neighbours' slots) against the
+    oracle product, on full and partial row ranges, with Dirichlet rows eliminated; a non-symmetric operator is
+    refused and keeps the CSR kernel."""
+    coords, cells = MESHES[name]()
+    if name in ("rect17x9", "box6x5x4"):
+        coords = jitter(coords, cells)
+    h = ctx.mesh_upload(coords, cells)
+    n = coords.shape[0]
+    K, M = F.assemble_atom(coords, cells, F.STIFF), F.assemble_atom(coords, cells, F.MASS)
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bc = boundary_dofs(coords)[::2].astype(np.int32)
+    op = ctx.op_combine(h, [ak, am], [1.0, 0.37], bc)
+    A, _ = F.apply_dirichlet((K + 0.37 * M).tocsr(), np.zeros(n), bc)
+    rng = np.random.default_rng(99)
+    x, w = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
+    xv, wv, yv = ctx.vec_from(x), ctx.vec_from(w), ctx.vec_alloc(n)
+    ctx.flags_reset()
+    ctx.spmv_dot_slot(op, xv, yv, wv, 0, n, 30)
+    y_csr, d_csr = ctx.vec_download(yv), ctx.slots_download(30, 1)[0]
+    assert ctx.op_symmetrize(op) is True
+    ctx.vec_fill(yv, -3.0)
+    ctx.spmv_dot_slot(op, xv, yv, wv, 0, n, 31)
+    y_sym, d_sym = ctx.vec_download(yv), ctx.slots_download(31, 1)[0]
+    ref = A @ x
+    rowabs = np.abs(A) @ np.abs(x)
+    assert np.all(np.abs(y_sym - ref) <= 4e-15 * rowabs + 1e-300) and np.all(np.abs(y_csr - ref) <= 4e-15 * rowabs + 1e-300)
+    assert abs(d_sym - w @ ref) <= 1e-13 * (np.abs(w) @ rowabs) and abs(d_sym - d_csr) <= 1e-13 * (np.abs(w) @ rowabs)
+    r0, r1 = n // 3, 2 * n // 3 + 1
+    ctx.vec_fill(yv, -7.0)
+    ctx.spmv_dot_slot(op, xv, yv, wv, r0, r1, 32)
+    y2 = ctx.vec_download(yv)
+    assert np.array_equal(y2[r0:r1], y_sym[r0:r1]) and np.all(y2[:r0] == -7.0) and np.all(y2[r1:] == -7.0)
+    assert abs(ctx.slots_download(32, 1)[0] - w[r0:r1] @ ref[r0:r1]) <= 1e-13 * (np.abs(w) @ rowabs)
+    if name.startswith("box"):
+        # structured vertex grids: the z-marching kernel (forced here; it is chosen by plane size otherwise), whole
+        # grid and a slab of planes as a row-sharded rank would call it
+        nxy = {"box6x5x4": 6 * 5, "box20": 20 * 20}[name]
+        ctx.tune(8, 0)
+        for ldsx in (0, 1):          # 1: x planes in LDS (needs w = x, the PCG product x . A x), 0: x through the L1
+            ctx.tune(9, ldsx)
+            wh, wa = (xv, x) if ldsx else (wv, w)
+            for zc in (1, 3, 32):
+                ctx.tune(6, zc)
+                ctx.vec_fill(yv, -5.0)
+                ctx.spmv_dot_slot(op, xv, yv, wh, 0, n, 35)
+                assert np.array_equal(ctx.vec_download(yv), y_sym)          # same per-row arithmetic, bit for bit
+                assert abs(ctx.slots_download(35, 1)[0] - wa @ ref) <= 1e-13 * (np.abs(wa) @ rowabs)
+            ctx.vec_fill(yv, -5.0)
+            ctx.spmv_dot_slot(op, xv, yv, wh, nxy, 3 * nxy, 36)
+            y3 = ctx.vec_download(yv)
+            assert np.array_equal(y3[nxy:3 * nxy], y_sym[nxy:3 * nxy]) and np.all(y3[:nxy] == -5.0) and np.all(y3[3 * nxy:] == -5.0)
+            assert abs(ctx.slots_download(36, 1)[0] - wa[nxy:3 * nxy] @ ref[nxy:3 * nxy]) <= 1e-13 * (np.abs(wa) @ rowabs)
+        ctx.tune(8, 3 << 19)
+        ctx.tune(6, 32)
+    # the solve: same solution with and without the symmetric storage
+    b = A @ rng.uniform(-1, 1, n)
+    sols = []
+    for sym in (1, 0):
+        ctx.tune(3, sym)
+        bv, sv = ctx.vec_from(b), ctx.vec_alloc(n)
+        its, rel = ctx.pcg_solve(op, bv, sv, 1e-12, 0.0, 5000)
+        sols.append((ctx.vec_download(sv), its))
+        assert rel <= 1e-12
+        ctx.vec_free(bv)
+        ctx.vec_free(sv)
+    ctx.tune(3, 1)
+    assert np.linalg.norm(sols[0][0] - sols[1][0]) <= 1e-9 * np.linalg.norm(sols[1][0]) and abs(sols[0][1] - sols[1][1]) <= 2
+    # new values through the same handle: the copy is rebuilt
+    op = ctx.op_combine(h, [ak, am], [2.0, 0.1], bc, op=op)
+    assert ctx.op_symmetrize(op) is True
+    ctx.flags_reset()                      # the solves above left the done flag set: later launches would be no-ops
+    ctx.spmv_dot_slot(op, xv, yv, wv, 0, n, 33)
+    A2, _ = F.apply_dirichlet((2.0 * K + 0.1 * M).tocsr(), np.zeros(n), bc)
+    assert np.all(np.abs(ctx.vec_download(yv) - A2 @ x) <= 4e-15 * (np.abs(A2) @ np.abs(x)) + 1e-300)
+    # not symmetric -> refused, CSR kernel keeps the result right
+    ac = ctx.atom_assemble(h, F.CONV, 0, 0, 0)
+    opn = ctx.op_combine(h, [ak, ac], [1.0, 0.5], np.zeros(0, dtype=np.int32))
+    assert ctx.op_symmetrize(opn) is False
+    ctx.spmv_dot_slot(opn, xv, yv, wv, 0, n, 34)
+    An = (K + 0.5 * F.assemble_atom(coords, cells, F.CONV, 0, 0)).tocsr()
+    assert np.all(np.abs(ctx.vec_download(yv) - An @ x) <= 4e-15 * (np.abs(An) @ np.abs(x)) + 1e-300)
+    for v in (xv, wv, yv):
+        ctx.vec_free(v)
+    for a in (op, opn, ak, am, ac):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
 def test_vector_ops(ctx):
     rng = np.random.default_rng(5)
     for n in (1, 63, 64, 257, 100_003):
