@@ -241,13 +241,9 @@ int pgd_pcg_solve_sharded(pgd_handle ctx, pgd_handle A, pgd_handle b, pgd_handle
  * sums), never which result is computed.                                        */
 enum {
     PGD_TUNE_SPMV_ROWS = 1,  /* rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256 */
-    PGD_TUNE_SPMV_GRID_MIN_BYTES = 8, /* ... used when a grid plane of values exceeds this many bytes (default 1.5 MiB) */
-    PGD_TUNE_SPMV_GRID_PAIRS = 9, /* 1 (default): the march keeps its x planes in LDS (k_spmv_sym_grid3) */
-    PGD_TUNE_SPMV_ZCHUNK = 6,   /* k_spmv_sym_grid (structured vertex grids): planes per workgroup march; 0 = off */
-    PGD_TUNE_SPMV_WG_PER_CU = 7, /* ... workgroups resident per CU (0: uncapped) */
-    PGD_TUNE_SPMV_SYM_PAD = 5, /* doubles of padding between the slot arrays of the symmetric storage */
-    PGD_TUNE_SPMV_STRIP = 4, /* k_spmv_sym on meshes whose grid planes exceed the L2: 64-row blocks per strip of the
-                                strip-by-strip, plane-after-plane walk (default 128; 0: plain row order) */
+    PGD_TUNE_SPMV_GRID_MIN_BYTES = 8, /* ... used when a grid plane of values has at least this many bytes (default 0) */
+    PGD_TUNE_SPMV_ZCHUNK = 6,   /* k_spmv_sym_grid3 (structured vertex grids, x planes in LDS): planes per workgroup
+                                   march (default 16); 0 = off (k_spmv_sym in row order) */
     PGD_TUNE_SPMV_SYM = 3,   /* 1 (default): the products of the SPD solves (pgd_pcg_solve, pgd_pcg_solve_sharded,
                                 pgd_spmv_dot_slot after pgd_op_symmetrize) read the operator from its symmetric
                                 half storage when the mesh qualifies (k_spmv_sym); 0: always the CSR kernels */

@@ -64,7 +64,6 @@ struct Mesh : Obj {
     int *sym_tab = nullptr;
     int *sym_ld = nullptr;      // LDS deltas of the pattern slots for k_spmv_sym_grid3 (structured grids only)
     int sym_w = 0;
-    int sym_plane = 0;          // rows per grid plane (0: none recognised)
     int sym_nx = 0, sym_ny = 0; // full structured vertex grid: row = x + nx y + nx ny z (0: not one)
     uint16_t *pids = nullptr;    // nv
     int *dict_off = nullptr;     // dict_count x DICT_DLEN relative offsets
@@ -137,12 +136,8 @@ struct Ctx {
     int num_cu = 256;
     int spmv_dict = 1;            // use the column dictionary when the mesh has one
     int spmv_rows = 64;           // rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256
-    int64_t spmv_grid_min_plane_bytes = (int64_t)3 << 19;   // planes of values above this size take k_spmv_sym_grid
-    int spmv_grid_pairs = 1;      // k_spmv_sym_grid3 (x from LDS) instead of k_spmv_sym_grid
-    int spmv_zchunk = 32;         // k_spmv_sym_grid: planes a workgroup marches through (0: never use that kernel)
-    int spmv_wg_per_cu = 3;       // ... workgroups resident per CU (LDS reservation; 0: no cap)
-    int spmv_strip = 128;         // k_spmv_sym: 64-row blocks per strip of the plane-by-plane walk (0: plain order)
-    int64_t spmv_sym_pad = 0;     // padding (doubles) between the slot arrays of the symmetric storage
+    int64_t spmv_grid_min_plane_bytes = 0;   // structured grids whose planes of values are at least this large take k_spmv_sym_grid3
+    int spmv_zchunk = 16;         // k_spmv_sym_grid3: planes a workgroup marches through (0: never use that kernel)
     int spmv_sym = 1;             // PCG products from the symmetric half storage when the mesh qualifies
 
     // SpMV launch timing (HIP events on `stream`)

@@ -25,7 +25,6 @@ constexpr int SPMV_CAP = 4096;                       // staged entries per 256-r
 constexpr int SPMV_VROUNDS = 8;                      // double2 loads per lane: 16 entries per row
 constexpr int SPMV_CROUNDS = 4;                      // int4 loads per lane
 constexpr int MAXY = 8;                              // vectors per pass of k_spmv_multi
-constexpr int64_t SYM_PLANE_L2_BYTES = (int64_t)3 << 19;   // 1.5 MiB: above this a plane of values is walked in strips
 
 struct SpmvArgs {
     const int *row_ptr, *cols;
@@ -366,12 +365,6 @@ struct SymArgs {
     const uint16_t *pids;
     int64_t n;              // slot stride in doubles (rows + padding)
     int row_begin, row_end;
-    // Traversal order of the 64-row blocks.  The lower neighbours of a row lie up to one grid plane back; when a
-    // plane of values (plane rows x 8 W bytes) does not fit an XCD's 4 MiB L2, the blocks are walked strip by
-    // strip: `strip` consecutive blocks of a plane, then the same blocks of the next plane, ... so the slots a
-    // strip reads from the plane below were loaded by the same XCD a few hundred KB of traffic earlier.
-    // plane_blocks = 0: plain order.
-    int nblk, plane_blocks, strip, nz;
 };
 
 struct SymRec { int v[16]; };
@@ -505,14 +498,7 @@ template <bool DOT, bool STORE, int W>
 __global__ __launch_bounds__(64) void k_spmv_sym(SymArgs A) {
     if (A.flags && A.flags[0]) return;
     const int tid = threadIdx.x;
-    int b = xcd_remap(blockIdx.x, gridDim.x);
-    if (A.plane_blocks > 0) {
-        const int per = A.nz * A.strip;                   // blocks of one strip through all planes
-        const int s = b / per, rem = b - s * per;
-        const int z = rem / A.strip, within = s * A.strip + (rem - z * A.strip);
-        b = z * A.plane_blocks + within;
-        if (within >= A.plane_blocks || b >= A.nblk) return;       // padding of the last strip / plane (uniform)
-    }
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
     const int r0 = A.row_begin + b * 64;
     const int nr = min(64, A.row_end - r0);
     const int64_t row = r0 + (tid < nr ? tid : 0);
@@ -526,56 +512,17 @@ __global__ __launch_bounds__(64) void k_spmv_sym(SymArgs A) {
 }
 
 // Structured vertex grids (row = x + nx y + nx ny z): a workgroup owns a 64 x 4 patch of (x, y) and MARCHES along z
-// through its chunk of planes.  The slots it reads for the plane below were loaded by the same workgroup one step
-// earlier; with only a few workgroups resident per CU (the launch reserves LDS it does not use to cap them) the
-// bytes an XCD moves between the two uses stay well inside its 4 MiB L2, so each off-diagonal value crosses the
-// fabric once.  (In row order the 1 024 waves an XCD keeps in flight span a whole plane of 256^2 rows: the second
-// use of every value then misses L2 and costs as much as the first.)
+// through its chunk of planes.
 struct SymGridArgs {
     SymArgs a;
     int nx, ny, z0, z1, zchunk, tiles_x, tiles_y, npat;
 };
 
-template <bool DOT, bool STORE, int W>
-__global__ __launch_bounds__(256) void k_spmv_sym_grid(SymGridArgs G) {
-    extern __shared__ double s_dyn[];          // occupancy cap only; the first 4 doubles carry the dot partials
-    const SymArgs &A = G.a;
-    if (A.flags && A.flags[0]) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int b = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_chunk = G.tiles_x * G.tiles_y;
-    const int chunk = b / per_chunk, tile = b - chunk * per_chunk;
-    const int ty = tile / G.tiles_x, tx = tile - ty * G.tiles_x;
-    const int x = tx * 64 + lane, y = ty * 4 + wv;
-    const bool live = x < G.nx && y < G.ny;
-    const int64_t plane = (int64_t)G.nx * G.ny;
-    const int64_t base = (live ? x : 0) + (int64_t)G.nx * (live ? y : 0);
-    const int za = G.z0 + chunk * G.zchunk, zb = min(G.z1, za + G.zchunk);
-    double dot = 0.0;
-    if (za >= zb) { if (DOT && tid == 0) A.partials[b] = 0.0; return; }
-    // the pattern record of the NEXT plane is fetched while this plane's 32 loads are in flight: with few waves per
-    // CU the id -> record -> values chain of dependent loads would otherwise set the pace
-    SymRec t = sym_load(A.tab, (int)A.pids[base + plane * za]);
-    for (int z = za; z < zb; ++z) {
-        const int64_t row = base + plane * z;
-        const int64_t nrow = base + plane * (z + 1 < zb ? z + 1 : z);
-        const SymRec tn = sym_load(A.tab, (int)A.pids[nrow]);
-        const double acc = sym_row_rec<W>(A, row, t);
-        if (STORE && live) A.y[row] = acc;
-        if (DOT && live) dot = fma(acc, A.w[row], dot);
-        t = tn;
-    }
-    if (DOT) {
-        const double sum = wave_sum(dot);
-        if (lane == 0) s_dyn[wv] = sum;
-        __syncthreads();
-        if (tid == 0) A.partials[b] = (s_dyn[0] + s_dyn[1]) + (s_dyn[2] + s_dyn[3]);
-    }
-}
-
-// The march with x served from LDS.  PMC showed the L1 address/data path (TA busy 82-84 %), not HBM, pacing all the
-// forms above: per row they pull 2 W + 15 eight-byte loads = ~256 B through the L1 although only ~90-150 B cross the
-// fabric.  Here the workgroup keeps the three planes of x its patch touches (patch + one halo cell each way) in LDS -
+// x is served from LDS.  rocprofv3 --pmc showed the L1 address/data path (TA_BUSY 82-84 % of the launch), not HBM,
+// pacing both the CSR kernels and k_spmv_sym: per row they pull ~256 B through the L1 (values + 15 eight-byte x
+// gathers) although only 90-150 B cross the fabric; every re-ordering of the same loads (strips of planes, a march
+// with x through the L1, two rows per lane with 16-byte loads) ran at the same 430-450 us or slower on 256^3.
+// Here the workgroup keeps the three planes of x its patch touches (patch + one halo cell each way) in LDS -
 // each x value enters the L1 once per patch and plane - and every neighbour read is a ds_read_b64 at
 // centre + delta, delta looked up per pattern slot (sym_ld: dx + 66 dy and the plane dz).  The pattern records are
 // read from an LDS copy too.  Only the slot values and y still use the vector-memory path.
@@ -689,6 +636,27 @@ __global__ __launch_bounds__(256) void k_spmv_sym_grid3(SymGrid3Args H) {
     }
 }
 
+// every neighbour a pattern names must be a grid neighbour of the row (x + dx, y + dy, z + dz inside the grid): only
+// then is "x at row + offset" the LDS cell centre + delta of k_spmv_sym_grid3
+__global__ __launch_bounds__(TPB) void k_grid_verify(const uint16_t *__restrict__ pids, const int *__restrict__ tab,
+                                                     const int *__restrict__ ld, int64_t n, int nx, int ny, int nz,
+                                                     int *__restrict__ flags) {
+    const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (r >= n) return;
+    const int64_t P = (int64_t)nx * ny;
+    const int z = (int)(r / P), y = (int)((r - z * P) / nx), x = (int)(r - z * P - (int64_t)y * nx);
+    const int *t = tab + (int)pids[r] * 16, *l = ld + (int)pids[r] * 16;
+    const int hdr = t[0], ulen = hdr & 15, llen = (hdr >> 4) & 15;
+    bool ok = true;
+    for (int k = 1; k < 16; ++k) {
+        if ((k < 8 && k >= ulen) || (k >= 8 && k - 8 >= llen)) continue;
+        const int code = l[k], dz = (code >> 12) - 1, in = (code & 4095) - 2048;
+        const int dy = (in + G3_HX + G3_HX / 2) / G3_HX - 1, dx = in - dy * G3_HX;      // in = dx + 66 dy
+        if (x + dx < 0 || x + dx >= nx || y + dy < 0 || y + dy >= ny || z + dz < 0 || z + dz >= nz) ok = false;
+    }
+    if (!ok) flags[0] = 1;
+}
+
 int build_sym_tables(Ctx *c, Mesh *m) {
     m->sym_w = 0;
     if (m->dict_count <= 0 || m->max_row > 15 || m->nnz == 0) return PGD_OK;
@@ -717,17 +685,13 @@ int build_sym_tables(Ctx *c, Mesh *m) {
     int maxl = 0;
     for (int q = 0; q < m->dict_count; ++q) maxl = std::max(maxl, (tab[(size_t)q * 16] >> 4) & 15);
     m->sym_w = (maxu <= 4 && maxl <= 4) ? 4 : 8;
-    // rows per grid plane, read off the richest pattern: its largest lower distance after the last jump by a
-    // factor >= 4 in the sorted distances (1, nx, nx+1 | nx ny, ...); 0 when there is no such structure
+    // sorted lower distances of the richest pattern
     int best = 0;
     for (int q = 1; q < m->dict_count; ++q)
         if (((tab[(size_t)q * 16] >> 4) & 15) > ((tab[(size_t)best * 16] >> 4) & 15)) best = q;
     std::vector<int> d;
     for (int k = 0; k < ((tab[(size_t)best * 16] >> 4) & 15); ++k) d.push_back(tab[(size_t)best * 16 + 8 + k]);
     std::sort(d.begin(), d.end());
-    m->sym_plane = 0;
-    for (size_t k = 1; k < d.size(); ++k)
-        if (d[k] >= 4 * (int64_t)d[k - 1]) m->sym_plane = d[k];
     // a full structured vertex grid (row = x + nx y + nx ny z, the 15-point pattern of the 6-tetrahedra-per-cube mesh):
     // lower distances 1, nx, nx + 1, P, P + 1, P + nx, P + nx + 1 with P = nx ny dividing the row count
     m->sym_nx = m->sym_ny = 0;
@@ -756,9 +720,20 @@ int build_sym_tables(Ctx *c, Mesh *m) {
         }
         if (ok) {
             PGD_TRY(dev_alloc(c, &p, ld.size() * sizeof(int))); m->sym_ld = (int *)p;
+            int *vf = nullptr;
+            PGD_TRY(dev_alloc(c, &p, 8 * sizeof(int))); vf = (int *)p;
+            PGD_HIP(c, hipMemsetAsync(vf, 0, 8 * sizeof(int), st));
             PGD_HIP(c, hipMemcpyAsync(m->sym_ld, ld.data(), ld.size() * sizeof(int), hipMemcpyHostToDevice, st));
+            k_grid_verify<<<(int)((m->nv + TPB - 1) / TPB), TPB, 0, st>>>(m->pids, m->sym_tab, m->sym_ld, m->nv, m->sym_nx,
+                                                                        m->sym_ny, (int)(m->nv / P), vf);
+            int bad = 1;
+            PGD_HIP(c, hipMemcpyAsync(&bad, vf, sizeof bad, hipMemcpyDeviceToHost, st));
             PGD_HIP(c, hipStreamSynchronize(st));
+            (void)hipFree(vf);
+            PGD_LAUNCH_CHECK(c);
+            if (bad) { (void)hipFree(m->sym_ld); m->sym_ld = nullptr; }
         }
+        if (!m->sym_ld) m->sym_nx = m->sym_ny = 0;
     }
     return PGD_OK;
 }
@@ -768,9 +743,7 @@ int ensure_sym(Ctx *c, const Mesh *m, Csr *a, bool *usable) {
     if (!c->spmv_sym || m->sym_w == 0) return PGD_OK;
     if (a->uvals_valid) { *usable = a->uvals != nullptr; return PGD_OK; }
     a->uvals_valid = true;                       // decided for this set of values, whatever the outcome
-    // slot arrays are padded apart: with a power-of-two row count (256^3) they would sit exactly 2^27 bytes from each
-    // other and every lane's 8 + 7 streams would walk the same HBM channels in step
-    const int64_t stride = m->nv + c->spmv_sym_pad;
+    const int64_t stride = m->nv;      // (padding the arrays apart - 2^27-byte strides at 256^3 - measured no difference)
     if (a->uvals && a->uvals_stride != stride) { dev_release(c, a->uvals, a->uvals_bytes); a->uvals = nullptr; }
     if (!a->uvals) {
         void *p;
@@ -810,27 +783,18 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
     SymArgs A;
     A.uvals = a->uvals; A.x = x; A.w = w; A.y = y; A.partials = c->partials; A.flags = flags;
     A.tab = m->sym_tab; A.pids = m->pids; A.n = a->uvals_stride; A.row_begin = (int)r0; A.row_end = (int)r1;
-    A.nblk = nblk; A.plane_blocks = 0; A.strip = 0; A.nz = 0;
-    int grid = nblk;
-    const int64_t plane_bytes = (int64_t)m->sym_plane * 8 * m->sym_w;
-    if (c->spmv_strip > 0 && plane_bytes > SYM_PLANE_L2_BYTES && nblk > 0) {
-        A.plane_blocks = (int)((m->sym_plane + 32) / 64);
-        A.strip = std::min(c->spmv_strip, A.plane_blocks);
-        A.nz = (nblk + A.plane_blocks - 1) / A.plane_blocks;
-        const int nstrips = (A.plane_blocks + A.strip - 1) / A.strip;
-        const int64_t g = (int64_t)nstrips * A.nz * A.strip;
-        if (g >= (int64_t)1 << 30) { A.plane_blocks = 0; } else grid = (int)g;
-    }
+    // structured grid, plane-aligned row range, PCG product (w = x) or plain product: the LDS march
     const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
-    if (c->spmv_zchunk > 0 && m->sym_w == 8 && plane > 0 && r0 % plane == 0 && r1 % plane == 0 &&
-        plane * 8 * m->sym_w > c->spmv_grid_min_plane_bytes) {
-        SymGridArgs G;
+    if (c->spmv_zchunk > 0 && m->sym_w == 8 && plane > 0 && m->sym_ld && m->dict_count <= G3_MAXP && (!dot || w == x) &&
+        r0 % plane == 0 && r1 % plane == 0 && plane * 8 * m->sym_w >= c->spmv_grid_min_plane_bytes) {
+        SymGrid3Args H;
+        SymGridArgs &G = H.g;
         G.a = A;
         G.nx = m->sym_nx; G.ny = m->sym_ny; G.z0 = (int)(r0 / plane); G.z1 = (int)(r1 / plane);
         G.zchunk = c->spmv_zchunk;
         G.npat = m->dict_count;
-        const bool ldsx = c->spmv_grid_pairs != 0 && m->sym_ld && m->dict_count <= G3_MAXP && (!dot || w == x);
         G.tiles_x = (G.nx + 63) / 64; G.tiles_y = (G.ny + 3) / 4;
+        H.ld = m->sym_ld; H.nzgrid = (int)(m->nv / plane);
         const int chunks = (G.z1 - G.z0 + G.zchunk - 1) / G.zchunk;
         const int64_t gg = (int64_t)chunks * G.tiles_x * G.tiles_y;
         if (gg < ((int64_t)1 << 30)) {
@@ -838,24 +802,17 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
             if (nparts_out) *nparts_out = wgs;
             if (dot) PGD_TRY(ensure_partials(c, (int64_t)wgs > 4 * MAX_VEC_BLOCKS ? wgs : 4 * MAX_VEC_BLOCKS));
             G.a.partials = c->partials;
-            // reserve LDS to cap the workgroups resident per CU (160 KiB per CU)
-            const size_t lds = c->spmv_wg_per_cu > 0 ? (size_t)(160 * 1024 / c->spmv_wg_per_cu - 512) : 64;
             bool timed2 = false;
             PGD_TRY(prof_begin(c, dot, store, &timed2));
-            if (ldsx) {
-                SymGrid3Args H;
-                H.g = G; H.ld = m->sym_ld; H.nzgrid = (int)(m->nv / plane);
-                if (dot && store) k_spmv_sym_grid3<true, true><<<wgs, 256, 0, c->stream>>>(H);
-                else if (dot) k_spmv_sym_grid3<true, false><<<wgs, 256, 0, c->stream>>>(H);
-                else k_spmv_sym_grid3<false, true><<<wgs, 256, 0, c->stream>>>(H);
-            } else if (dot && store) k_spmv_sym_grid<true, true, 8><<<wgs, 256, lds, c->stream>>>(G);
-            else if (dot) k_spmv_sym_grid<true, false, 8><<<wgs, 256, lds, c->stream>>>(G);
-            else k_spmv_sym_grid<false, true, 8><<<wgs, 256, lds, c->stream>>>(G);
+            if (dot && store) k_spmv_sym_grid3<true, true><<<wgs, 256, 0, c->stream>>>(H);
+            else if (dot) k_spmv_sym_grid3<true, false><<<wgs, 256, 0, c->stream>>>(H);
+            else k_spmv_sym_grid3<false, true><<<wgs, 256, 0, c->stream>>>(H);
             if (timed2) PGD_TRY(prof_end(c, m, nrows));
             PGD_LAUNCH_CHECK(c);
             return PGD_OK;
         }
     }
+    const int grid = nblk;
     bool timed = false;
     PGD_TRY(prof_begin(c, dot, store, &timed));
 #define PGD_SYM_LAUNCH(D, S)                                                          \
@@ -905,12 +862,8 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_SPMV_ROWS && (value == 64 || value == 128 || value == 256)) { c->spmv_rows = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_DICT && value >= 0 && value <= 2) { c->spmv_dict = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_SYM && value >= 0 && value <= 1) { c->spmv_sym = (int)value; return PGD_OK; }
-    if (knob == PGD_TUNE_SPMV_SYM_PAD && value >= 0 && value <= (1 << 24)) { c->spmv_sym_pad = value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_GRID_MIN_BYTES && value >= 0) { c->spmv_grid_min_plane_bytes = value; return PGD_OK; }
-    if (knob == PGD_TUNE_SPMV_GRID_PAIRS && value >= 0 && value <= 1) { c->spmv_grid_pairs = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK && value >= 0 && value <= 65536) { c->spmv_zchunk = (int)value; return PGD_OK; }
-    if (knob == PGD_TUNE_SPMV_WG_PER_CU && value >= 0 && value <= 32) { c->spmv_wg_per_cu = (int)value; return PGD_OK; }
-    if (knob == PGD_TUNE_SPMV_STRIP && value >= 0 && value <= 65536) { c->spmv_strip = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }
 

@@ -311,26 +311,25 @@ def test_symmetric_half_storage_products(ctx, name):
     assert np.array_equal(y2[r0:r1], y_sym[r0:r1]) and np.all(y2[:r0] == -7.0) and np.all(y2[r1:] == -7.0)
     assert abs(ctx.slots_download(32, 1)[0] - w[r0:r1] @ ref[r0:r1]) <= 1e-13 * (np.abs(w) @ rowabs)
     if name.startswith("box"):
-        # structured vertex grids: the z-marching kernel (forced here; it is chosen by plane size otherwise), whole
-        # grid and a slab of planes as a row-sharded rank would call it
+        # structured vertex grids: the z-marching kernel with x planes in LDS, on the whole grid and on a slab of
+        # planes as a row-sharded rank calls it
         nxy = {"box6x5x4": 6 * 5, "box20": 20 * 20}[name]
-        ctx.tune(8, 0)
-        for ldsx in (0, 1):          # 1: x planes in LDS (needs w = x, the PCG product x . A x), 0: x through the L1
-            ctx.tune(9, ldsx)
-            wh, wa = (xv, x) if ldsx else (wv, w)
-            for zc in (1, 3, 32):
-                ctx.tune(6, zc)
-                ctx.vec_fill(yv, -5.0)
-                ctx.spmv_dot_slot(op, xv, yv, wh, 0, n, 35)
-                assert np.array_equal(ctx.vec_download(yv), y_sym)          # same per-row arithmetic, bit for bit
-                assert abs(ctx.slots_download(35, 1)[0] - wa @ ref) <= 1e-13 * (np.abs(wa) @ rowabs)
+        for zc in (1, 3, 16):        # planes per workgroup march; w = x: the PCG product x . A x
+            ctx.tune(6, zc)
             ctx.vec_fill(yv, -5.0)
-            ctx.spmv_dot_slot(op, xv, yv, wh, nxy, 3 * nxy, 36)
-            y3 = ctx.vec_download(yv)
-            assert np.array_equal(y3[nxy:3 * nxy], y_sym[nxy:3 * nxy]) and np.all(y3[:nxy] == -5.0) and np.all(y3[3 * nxy:] == -5.0)
-            assert abs(ctx.slots_download(36, 1)[0] - wa[nxy:3 * nxy] @ ref[nxy:3 * nxy]) <= 1e-13 * (np.abs(wa) @ rowabs)
-        ctx.tune(8, 3 << 19)
-        ctx.tune(6, 32)
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 35)
+            assert np.array_equal(ctx.vec_download(yv), y_sym)              # same per-row arithmetic, bit for bit
+            assert abs(ctx.slots_download(35, 1)[0] - x @ ref) <= 1e-13 * (np.abs(x) @ rowabs)
+        ctx.vec_fill(yv, -5.0)
+        ctx.spmv_dot_slot(op, xv, yv, xv, nxy, 3 * nxy, 36)
+        y3 = ctx.vec_download(yv)
+        assert np.array_equal(y3[nxy:3 * nxy], y_sym[nxy:3 * nxy]) and np.all(y3[:nxy] == -5.0) and np.all(y3[3 * nxy:] == -5.0)
+        assert abs(ctx.slots_download(36, 1)[0] - x[nxy:3 * nxy] @ ref[nxy:3 * nxy]) <= 1e-13 * (np.abs(x) @ rowabs)
+        ctx.tune(6, 0)               # march off: the row-order kernel gives the same rows
+        ctx.vec_fill(yv, -5.0)
+        ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 37)
+        assert np.array_equal(ctx.vec_download(yv), y_sym)
+        ctx.tune(6, 16)
     # the solve: same solution with and without the symmetric storage
     b = A @ rng.uniform(-1, 1, n)
     sols = []

@@ -1,5 +1,6 @@
 """A/B of the PCG product (y = A p with the fused p.q partial sums) from the CSR form (k_spmv_csr_dict16) and from
-the symmetric half storage (k_spmv_sym) on an n^3 P1 BoxMesh, interleaved rounds in one process.
+the symmetric half storage (k_spmv_sym in row order, k_spmv_sym_grid3 marching along z with x in LDS) on an n^3 P1
+BoxMesh, interleaved rounds in one process.
 
     python tools/bench_spmv_sym.py [n ...]      (default: 256)
 """
@@ -32,11 +33,10 @@ def main():
         print(f"n={n}^3 nv={nv} nnz={nnz}: symmetric storage usable: {used}", flush=True)
         ctx.flags_reset()
         for rnd in range(2):
-            for sym, strip, pad in ((0, 0, 0), (1, 0, 0), (1, 8, 0), (1, 16, 0), (1, 32, 0), (1, 64, 0), (1, 128, 0)):
-                # strip = planes per z-march (0: row-order kernel), pad = workgroups per CU
+            for sym, zchunk in ((0, 0), (1, 0), (1, 4), (1, 8), (1, 16), (1, 32), (1, 64)):
+                # zchunk = planes per workgroup march of k_spmv_sym_grid3 (0: k_spmv_sym in row order)
                 ctx.tune(3, sym)
-                ctx.tune(6, strip)
-                ctx.tune(7, pad)
+                ctx.tune(6, zchunk)
                 for _ in range(3):
                     ctx.spmv_dot_slot(op, x, y, x, 0, nv, 30)
                 ctx.sync()
@@ -46,11 +46,10 @@ def main():
                     ctx.spmv_dot_slot(op, x, y, x, 0, nv, 30)
                 ctx.sync()
                 wall = (time.time() - t0) / reps
-                print(f"  round {rnd} sym {sym} zchunk {strip} wg/cu {pad}: {wall*1e6:.1f} us per product+reduce (wall) -> {alg/wall/1e9:.0f} GB/s of the CSR "
+                print(f"  round {rnd} sym {sym} zchunk {zchunk}: {wall*1e6:.1f} us per product+reduce (wall) -> {alg/wall/1e9:.0f} GB/s of the CSR "
                       f"formula = {alg/wall/8e12*100:.1f}% of 8 TB/s; p.q = {ctx.slots_download(30, 1)[0]:.12e}", flush=True)
         ctx.tune(3, 1)
-        ctx.tune(6, 32)
-        ctx.tune(7, 3)
+        ctx.tune(6, 16)
         for v in (x, y):
             ctx.vec_free(v)
         for a in (ak, am, op):

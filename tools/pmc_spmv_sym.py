@@ -1,7 +1,7 @@
 """A few launches of the PCG product on the n^3 P1 BoxMesh for rocprofv3 --pmc passes.
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_x -- python3 tools/pmc_spmv_sym.py 256 MODE
-    MODE: csr (k_spmv_csr_dict16) | rows (k_spmv_sym, row order) | grid (k_spmv_sym_grid, z-march) [zchunk [wg_per_cu]]
+    MODE: csr (k_spmv_csr_dict16) | rows (k_spmv_sym, row order) | grid (k_spmv_sym_grid3, z-march, x in LDS) [zchunk]
 """
 import os
 import sys
@@ -25,9 +25,7 @@ nv = ctx.mesh_info(mesh)["nv"]
 x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, nv))
 y = ctx.vec_alloc(nv)
 ctx.tune(3, 0 if mode == "csr" else 1)
-ctx.tune(4, 0)
 ctx.tune(6, zchunk if mode == "grid" else 0)
-ctx.tune(7, wg)
 if mode != "csr":
     assert ctx.op_symmetrize(op)
 ctx.flags_reset()
