@@ -165,6 +165,15 @@ def main():
     if patterns:
         spmv_kernel = ("k_spmv_csr_dict16<dot,store>" if max_row <= 16 else "k_spmv_csr_dict<dot,store,64>") + \
             " (%d relative column patterns)" % patterns
+    sym = be.ctx.mesh_sym_info(space.handle())
+    sym_bytes = None
+    if sym["slots"]:
+        # the SPD solves read the operator from its symmetric half storage: every off-diagonal value once
+        spmv_kernel = ("k_spmv_sym_grid3<dot,store> (symmetric half storage, %d slots/row, z-march over the %d x %d vertex "
+                       "grid with the x planes in LDS, %d relative patterns)" % (sym["slots"], sym["nx"], sym["ny"], patterns)
+                       if sym["nx"] else "k_spmv_sym<dot,store,%d> (symmetric half storage, %d relative patterns)" % (sym["slots"], patterns))
+        rows_local = n_sp // world if sharded else n_sp
+        sym_bytes = rows_local * (8 * sym["slots"] + 8 + 8 + 2)     # slot values + x + y + pattern id
     out = {
         "metric": "PGD fixed-point iters/sec + SpMV HBM GB/s, 256^3 P1 space x 1D param",
         "value": K / elapsed, "unit": "fixed-point iterations/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -182,6 +191,14 @@ def main():
                      "launches": prof["launches"], "avg_launch_us": 1e6 * prof["seconds"] / max(prof["launches"], 1),
                      "algorithmic_bytes_per_launch": prof["bytes"] / max(prof["launches"], 1)},
     }
+    if sym_bytes:
+        # `achieved` / `frac` use the CSR byte formula of SURVEY 8d whatever form the kernel reads (so frac can
+        # exceed 1: the symmetric storage moves about 0.45 x those bytes); the kernel's own minimum traffic and the
+        # rate it reaches on THAT are given beside it
+        avg = prof["seconds"] / max(prof["launches"], 1)
+        out["roofline"]["kernel_min_bytes_per_launch"] = sym_bytes
+        out["roofline"]["kernel_min_bytes_GBps"] = sym_bytes / avg / 1e9 if avg > 0 else 0.0
+        out["roofline"]["kernel_min_bytes_frac"] = out["roofline"]["kernel_min_bytes_GBps"] / 8000.0
     pmc = os.path.join(ROOT, "profiles", "pmc_spmv_latest.json")
     if n == 256 and os.path.exists(pmc):
         # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950

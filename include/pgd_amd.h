@@ -87,6 +87,10 @@ int pgd_mesh_info(pgd_handle ctx, pgd_handle mesh, int64_t *nv, int64_t *nc, int
 int pgd_mesh_pattern_download(pgd_handle ctx, pgd_handle mesh, int32_t *row_ptr, int32_t *cols);
 /* number of distinct relative column patterns held in the mesh's column dictionary
  * (0: the pattern is too irregular, SpMV streams the column ids)                   */
+/* Which form of the SPD product the mesh's patterns allow: slots = 0 (CSR kernels only), 4 or 8 upper slots
+ * per row of the symmetric half storage (k_spmv_sym); nx, ny > 0 when the rows also form a full structured
+ * vertex grid (row = x + nx y + nx ny z): k_spmv_sym_grid3 marches along z with its x planes in LDS.          */
+int pgd_mesh_sym_info(pgd_handle ctx, pgd_handle mesh, int32_t *slots, int32_t *nx, int32_t *ny);
 int pgd_mesh_dict_count(pgd_handle ctx, pgd_handle mesh, int32_t *count);
 int pgd_mesh_free(pgd_handle ctx, pgd_handle mesh);
 
@@ -242,8 +246,9 @@ int pgd_pcg_solve_sharded(pgd_handle ctx, pgd_handle A, pgd_handle b, pgd_handle
 enum {
     PGD_TUNE_SPMV_ROWS = 1,  /* rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256 */
     PGD_TUNE_SPMV_GRID_MIN_BYTES = 8, /* ... used when a grid plane of values has at least this many bytes (default 0) */
-    PGD_TUNE_SPMV_ZCHUNK = 6,   /* k_spmv_sym_grid3 (structured vertex grids, x planes in LDS): planes per workgroup
-                                   march (default 16); 0 = off (k_spmv_sym in row order) */
+    PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */
+    PGD_TUNE_SPMV_ZCHUNK = 6,   /* k_spmv_sym_grid3 (structured vertex grids, x planes in LDS): most planes per
+                                   workgroup march (default 16; fewer while that keeps 8 workgroups per CU); 0 = off */
     PGD_TUNE_SPMV_SYM = 3,   /* 1 (default): the products of the SPD solves (pgd_pcg_solve, pgd_pcg_solve_sharded,
                                 pgd_spmv_dot_slot after pgd_op_symmetrize) read the operator from its symmetric
                                 half storage when the mesh qualifies (k_spmv_sym); 0: always the CSR kernels */

@@ -40,6 +40,7 @@ SIGNATURES = {
     "pgd_atom_embed": (C.c_int, [H, H, H, C.c_int, C.c_int, F64, H, PH]),
     "pgd_mesh_info": (C.c_int, [H, H, PI64, PI64, PI64, PI32, PI32, PI32]),
     "pgd_mesh_pattern_download": (C.c_int, [H, H, PI32, PI32]),
+    "pgd_mesh_sym_info": (C.c_int, [H, H, PI32, PI32, PI32]),
     "pgd_mesh_dict_count": (C.c_int, [H, H, PI32]),
     "pgd_mesh_free": (C.c_int, [H, H]),
     "pgd_vec_alloc": (C.c_int, [H, I64, PH]),
@@ -223,6 +224,11 @@ class Context:
         cols = np.empty(max(info["nnz"], 1), dtype=np.int32)
         self._ck(self.lib.pgd_mesh_pattern_download(self.h, mesh, iptr(rp), iptr(cols)))
         return rp, cols[: info["nnz"]]
+
+    def mesh_sym_info(self, mesh):
+        w, nx, ny = I32(), I32(), I32()
+        self._ck(self.lib.pgd_mesh_sym_info(self.h, mesh, C.byref(w), C.byref(nx), C.byref(ny)))
+        return {"slots": w.value, "nx": nx.value, "ny": ny.value}
 
     def mesh_dict_count(self, mesh):
         n = I32()

@@ -137,7 +137,8 @@ struct Ctx {
     int spmv_dict = 1;            // use the column dictionary when the mesh has one
     int spmv_rows = 64;           // rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256
     int64_t spmv_grid_min_plane_bytes = 0;   // structured grids whose planes of values are at least this large take k_spmv_sym_grid3
-    int spmv_zchunk = 16;         // k_spmv_sym_grid3: planes a workgroup marches through (0: never use that kernel)
+    int spmv_zchunk_force = 0;    // > 0: exactly this many planes per march whatever the grid size (tests)
+    int spmv_zchunk = 16;         // k_spmv_sym_grid3: most planes a workgroup marches through (0: never use that kernel)
     int spmv_sym = 1;             // PCG products from the symmetric half storage when the mesh qualifies
 
     // SpMV launch timing (HIP events on `stream`)

@@ -704,6 +704,16 @@ int pgd_mesh_dict_count(pgd_handle h, pgd_handle mh, int32_t *count) {
     return PGD_OK;
 }
 
+int pgd_mesh_sym_info(pgd_handle h, pgd_handle mh, int32_t *slots, int32_t *nx, int32_t *ny) {
+    PGD_CTX(c, h);
+    Mesh *m = get_mesh(c, mh);
+    if (!m) return fail(c, PGD_ERR_INVALID, "mesh_sym_info: invalid handle");
+    if (slots) *slots = m->sym_w;
+    if (nx) *nx = m->sym_nx;
+    if (ny) *ny = m->sym_ny;
+    return PGD_OK;
+}
+
 int pgd_mesh_free(pgd_handle h, pgd_handle mh) {
     PGD_CTX(c, h);
     return free_obj(c, mh, Obj::MESH);

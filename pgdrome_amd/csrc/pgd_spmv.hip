@@ -415,7 +415,7 @@ __device__ bool sym_describe(const int *__restrict__ row_ptr, const int *__restr
 
 __global__ __launch_bounds__(TPB) void k_sym_rep(const uint16_t *__restrict__ pids, int64_t n, int *__restrict__ rep) {
     const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (i < n) atomicMin(&rep[pids[i]], (int)i);
+    if (i < n && (int)i < rep[pids[i]]) atomicMin(&rep[pids[i]], (int)i);     // almost every row loses the first test
 }
 
 __global__ void k_sym_build(const int *__restrict__ row_ptr, const int *__restrict__ cols, const int *__restrict__ rep,
@@ -791,13 +791,17 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         SymGridArgs &G = H.g;
         G.a = A;
         G.nx = m->sym_nx; G.ny = m->sym_ny; G.z0 = (int)(r0 / plane); G.z1 = (int)(r1 / plane);
-        G.zchunk = c->spmv_zchunk;
         G.npat = m->dict_count;
         G.tiles_x = (G.nx + 63) / 64; G.tiles_y = (G.ny + 3) / 4;
         H.ld = m->sym_ld; H.nzgrid = (int)(m->nv / plane);
-        const int chunks = (G.z1 - G.z0 + G.zchunk - 1) / G.zchunk;
+        // planes per march: as long as the launch still has ~8 workgroups per CU (a march of fewer than 4 planes pays
+        // its 3-plane prologue too often; below that the row-order kernel is the faster one: 64^3 11 us vs 15 us)
+        const int64_t tile_planes = (int64_t)G.tiles_x * G.tiles_y * (G.z1 - G.z0);
+        G.zchunk = (int)std::min<int64_t>(c->spmv_zchunk, tile_planes / (8 * (int64_t)c->num_cu));
+        if (c->spmv_zchunk_force > 0) G.zchunk = c->spmv_zchunk_force;       // tests: the march on any grid size
+        const int chunks = (G.zchunk >= 4 || c->spmv_zchunk_force > 0) ? (G.z1 - G.z0 + G.zchunk - 1) / G.zchunk : 0;
         const int64_t gg = (int64_t)chunks * G.tiles_x * G.tiles_y;
-        if (gg < ((int64_t)1 << 30)) {
+        if (gg > 0 && gg < ((int64_t)1 << 30)) {
             const int wgs = (int)gg;
             if (nparts_out) *nparts_out = wgs;
             if (dot) PGD_TRY(ensure_partials(c, (int64_t)wgs > 4 * MAX_VEC_BLOCKS ? wgs : 4 * MAX_VEC_BLOCKS));
@@ -863,6 +867,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_SPMV_DICT && value >= 0 && value <= 2) { c->spmv_dict = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_SYM && value >= 0 && value <= 1) { c->spmv_sym = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_GRID_MIN_BYTES && value >= 0) { c->spmv_grid_min_plane_bytes = value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_ZCHUNK_FORCE && value >= 0 && value <= 65536) { c->spmv_zchunk_force = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK && value >= 0 && value <= 65536) { c->spmv_zchunk = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }

@@ -314,22 +314,22 @@ def test_symmetric_half_storage_products(ctx, name):
         # structured vertex grids: the z-marching kernel with x planes in LDS, on the whole grid and on a slab of
         # planes as a row-sharded rank calls it
         nxy = {"box6x5x4": 6 * 5, "box20": 20 * 20}[name]
-        for zc in (1, 3, 16):        # planes per workgroup march; w = x: the PCG product x . A x
-            ctx.tune(6, zc)
+        for zc in (1, 3, 16):        # planes per workgroup march (forced: grids this small take the row-order kernel)
+            ctx.tune(7, zc)
             ctx.vec_fill(yv, -5.0)
             ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 35)
             assert np.array_equal(ctx.vec_download(yv), y_sym)              # same per-row arithmetic, bit for bit
             assert abs(ctx.slots_download(35, 1)[0] - x @ ref) <= 1e-13 * (np.abs(x) @ rowabs)
+        ctx.tune(7, 2)
         ctx.vec_fill(yv, -5.0)
         ctx.spmv_dot_slot(op, xv, yv, xv, nxy, 3 * nxy, 36)
         y3 = ctx.vec_download(yv)
         assert np.array_equal(y3[nxy:3 * nxy], y_sym[nxy:3 * nxy]) and np.all(y3[:nxy] == -5.0) and np.all(y3[3 * nxy:] == -5.0)
         assert abs(ctx.slots_download(36, 1)[0] - x[nxy:3 * nxy] @ ref[nxy:3 * nxy]) <= 1e-13 * (np.abs(x) @ rowabs)
-        ctx.tune(6, 0)               # march off: the row-order kernel gives the same rows
+        ctx.tune(7, 0)               # adaptive again: the row-order kernel gives the same rows
         ctx.vec_fill(yv, -5.0)
         ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 37)
         assert np.array_equal(ctx.vec_download(yv), y_sym)
-        ctx.tune(6, 16)
     # the solve: same solution with and without the symmetric storage
     b = A @ rng.uniform(-1, 1, n)
     sols = []

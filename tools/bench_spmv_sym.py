@@ -33,10 +33,11 @@ def main():
         print(f"n={n}^3 nv={nv} nnz={nnz}: symmetric storage usable: {used}", flush=True)
         ctx.flags_reset()
         for rnd in range(2):
-            for sym, zchunk in ((0, 0), (1, 0), (1, 4), (1, 8), (1, 16), (1, 32), (1, 64)):
-                # zchunk = planes per workgroup march of k_spmv_sym_grid3 (0: k_spmv_sym in row order)
+            for sym, zchunk in ((0, 0), (1, -1), (1, 0), (1, 4), (1, 8), (1, 16), (1, 32), (1, 64)):
+                # zchunk = planes per workgroup march of k_spmv_sym_grid3, forced (-1: k_spmv_sym in row order, 0: adaptive)
                 ctx.tune(3, sym)
-                ctx.tune(6, zchunk)
+                ctx.tune(6, 0 if zchunk < 0 else 16)
+                ctx.tune(7, max(zchunk, 0))
                 for _ in range(3):
                     ctx.spmv_dot_slot(op, x, y, x, 0, nv, 30)
                 ctx.sync()
@@ -50,6 +51,7 @@ def main():
                       f"formula = {alg/wall/8e12*100:.1f}% of 8 TB/s; p.q = {ctx.slots_download(30, 1)[0]:.12e}", flush=True)
         ctx.tune(3, 1)
         ctx.tune(6, 16)
+        ctx.tune(7, 0)
         for v in (x, y):
             ctx.vec_free(v)
         for a in (ak, am, op):
