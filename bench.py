@@ -200,7 +200,7 @@ def main():
         out["roofline"]["kernel_min_bytes_GBps"] = sym_bytes / avg / 1e9 if avg > 0 else 0.0
         out["roofline"]["kernel_min_bytes_frac"] = out["roofline"]["kernel_min_bytes_GBps"] / 8000.0
     pmc = os.path.join(ROOT, "profiles", "pmc_spmv_latest.json")
-    if n == 256 and os.path.exists(pmc):
+    if n == 256 and world == 1 and sym["nx"] and os.path.exists(pmc):
         # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
         # correction + WRITE_SIZE); collected with tools/pmc_spmv.py, not in this process
         with open(pmc) as f:
