@@ -24,7 +24,7 @@ constexpr int DICT_DLEN = 32;       // max row length representable (ints per pa
 constexpr size_t PAD_BYTES = 256;   // slack after every device array (vector over-reads)
 
 // slots of the device scalar bank used by the library's own PCG loop
-enum { S_PQ = 2, S_TOL2 = 5, S_TMP = 8 /* ..15: batched functionals */ };   // 16..22: PCG r.z / r.r / b.b
+enum { S_PQ = 2, S_TOL2 = 5, S_DMIN = 7 /* smallest diagonal entry (scaled PCG) */, S_TMP = 8 /* ..15: batched functionals */ };   // 16..22: PCG r.z / r.r / b.b
 
 struct Ctx;
 void dev_release(Ctx *c, void *p, size_t bytes);   // back to the context's buffer pool
@@ -84,6 +84,7 @@ struct Csr : Obj {
     // uvals[s * nv + i] (slot 0 = diagonal, then the entries right of it; zero padded)
     double *uvals = nullptr;
     bool uvals_valid = false;
+    bool uvals_scaled = false;  // the slot arrays hold D^-1/2 A D^-1/2 (inside pgd_pcg_solve only)
     int64_t uvals_stride = 0;  // doubles between two slot arrays (rows + padding)
     size_t vals_bytes = 0, dinv_bytes = 0, uvals_bytes = 0;
     ~Csr() override {
@@ -139,6 +140,7 @@ struct Ctx {
     int64_t spmv_grid_min_plane_bytes = 0;   // structured grids whose planes of values are at least this large take k_spmv_sym_grid3
     int spmv_zchunk_force = 0;    // > 0: exactly this many planes per march whatever the grid size (tests)
     int spmv_zchunk = 16;         // k_spmv_sym_grid3: most planes a workgroup marches through (0: never use that kernel)
+    int pcg_scaled = 1;           // pgd_pcg_solve on the symmetrically scaled system (no dinv / z passes) when the symmetric storage applies
     int spmv_sym = 1;             // PCG products from the symmetric half storage when the mesh qualifies
 
     // SpMV launch timing (HIP events on `stream`)
@@ -167,6 +169,7 @@ struct Mesh;
 struct Csr;
 int build_sym_tables(Ctx *c, Mesh *m);                       // pgd_spmv.hip
 int ensure_sym(Ctx *c, const Mesh *m, Csr *a, bool *usable);  // pgd_spmv.hip: convert (once per operator)
+int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *s);   // pgd_spmv.hip: slot values *= s_i s_j
 int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0,
                    int64_t r1, bool dot, bool store, const int *flags, int *nparts_out);
 

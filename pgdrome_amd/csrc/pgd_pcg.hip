@@ -313,6 +313,107 @@ __global__ __launch_bounds__(TPB) void k_band_solve(const int *__restrict__ row_
     for (int i = threadIdx.x; i < n; i += TPB) x[i] = rhs[i];
 }
 
+// ---- the same Jacobi-PCG on the symmetrically scaled system  A~ = D^-1/2 A D^-1/2,  x~ = D^1/2 x,  b~ = D^-1/2 b:
+// plain CG on A~ walks exactly the iterates of Jacobi-PCG on A (x_k = D^-1/2 x~_k, r~ = D^-1/2 r, r~.r~ = r.z), but no
+// kernel reads dinv or writes z any more: 9 vector passes per iteration instead of 11.  The stop test stays the TRUE
+// residual norm r.r = sum d_i r~_i^2; it needs one more read (s), so it is only formed in the "exact phase", entered
+// when d_min r~.r~ - a lower bound of r.r - comes within 10^4 of the tolerance (see k_reduce_partials, check_mode 2).
+
+// s = sqrt(dinv) (= d^-1/2); x <- x / s; the largest dinv (1 / d_min) by an ordered-bits atomic max
+__global__ __launch_bounds__(TPB) void k_scale_in(const double *__restrict__ dinv, double *__restrict__ s,
+                                                  double *__restrict__ x, int64_t n, unsigned long long *__restrict__ dmax_bits) {
+    double mx = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const double di = dinv[i], si = sqrt(di);
+        s[i] = si;
+        x[i] = x[i] / si;
+        mx = fmax(mx, di);
+    }
+    for (int o = 32; o > 0; o >>= 1) mx = fmax(mx, __shfl_xor(mx, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(dmax_bits, (unsigned long long)__double_as_longlong(mx));   // positive doubles order like integers
+}
+
+__global__ void k_dmin_slot(const unsigned long long *__restrict__ dmax_bits, double *__restrict__ slots, int *__restrict__ flags) {
+    const double dmax_inv = __longlong_as_double((long long)dmax_bits[0]);
+    slots[S_DMIN] = dmax_inv > 0.0 ? 1.0 / dmax_inv : 0.0;
+    if (!(dmax_inv > 0.0) || !(dmax_inv < 1e300)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; }   // a non-positive diagonal
+}
+
+// r = s b - q; p = r; partials (r.r, sum r^2 / s^2 = true r.r, b.b)
+__global__ __launch_bounds__(TPB) void k_pcg_init_s(const double *__restrict__ b, const double *__restrict__ q,
+                                                    const double *__restrict__ s, double *__restrict__ r,
+                                                    double *__restrict__ p, int64_t n, double *__restrict__ partials) {
+    __shared__ double s_red[4];
+    double rz = 0.0, rr = 0.0, bb = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const double bi = b[i], si = s[i], ri = si * bi - q[i], ti = ri / si;
+        r[i] = ri; p[i] = ri;
+        rz = fma(ri, ri, rz); rr = fma(ti, ti, rr); bb = fma(bi, bi, bb);
+    }
+    rz = block_sum(rz, s_red);
+    rr = block_sum(rr, s_red);
+    bb = block_sum(bb, s_red);
+    if (threadIdx.x == 0) {
+        partials[3 * blockIdx.x + 0] = rz;
+        partials[3 * blockIdx.x + 1] = rr;
+        partials[3 * blockIdx.x + 2] = bb;
+    }
+}
+
+// alpha = S[rz] / S[pq]; x += alpha p; r -= alpha q; partials (r.r, exact phase ? sum r^2 / s^2 : r.r)
+__global__ __launch_bounds__(TPB) void k_pcg_xr_s(double *__restrict__ x, double *__restrict__ r, const double *__restrict__ p,
+                                                  const double *__restrict__ q, const double *__restrict__ s, int64_t n,
+                                                  const double *__restrict__ slots, int slot_rz, int slot_pq,
+                                                  double *__restrict__ partials, const int *__restrict__ flags) {
+    if (flags[0]) return;
+    __shared__ double s_red[4];
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const double alpha = slots[slot_rz] / slots[slot_pq];
+    const bool exact = flags[3] != 0;
+    double rz = 0.0, rr = 0.0;
+    const int64_t npair = n >> 1;
+    for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < npair; k += (int64_t)gridDim.x * TPB) {
+        const int64_t i = 2 * k;
+        const d2 pi = *reinterpret_cast<const d2 *>(p + i), qi = *reinterpret_cast<const d2 *>(q + i);
+        d2 xi = *reinterpret_cast<d2 *>(x + i), ri = *reinterpret_cast<d2 *>(r + i);
+        xi.x = fma(alpha, pi.x, xi.x); xi.y = fma(alpha, pi.y, xi.y);
+        ri.x = fma(-alpha, qi.x, ri.x); ri.y = fma(-alpha, qi.y, ri.y);
+        *reinterpret_cast<d2 *>(x + i) = xi;
+        *reinterpret_cast<d2 *>(r + i) = ri;
+        rz = fma(ri.x, ri.x, rz); rz = fma(ri.y, ri.y, rz);
+        if (exact) {
+            const d2 si = *reinterpret_cast<const d2 *>(s + i);
+            const double tx = ri.x / si.x, ty = ri.y / si.y;
+            rr = fma(tx, tx, rr); rr = fma(ty, ty, rr);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        x[i] = fma(alpha, p[i], x[i]);
+        const double ri = fma(-alpha, q[i], r[i]);
+        r[i] = ri;
+        rz = fma(ri, ri, rz);
+        if (exact) { const double t = ri / s[i]; rr = fma(t, t, rr); }
+    }
+    rz = block_sum(rz, s_red);
+    rr = block_sum(rr, s_red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = rz; partials[2 * blockIdx.x + 1] = exact ? rr : rz; }
+}
+
+// x <- s x (back to the unscaled unknown); partial sum r^2 / s^2 (the true r.r, for the report)
+__global__ __launch_bounds__(TPB) void k_scale_out(double *__restrict__ x, const double *__restrict__ r, const double *__restrict__ s,
+                                                   int64_t n, double *__restrict__ partials) {
+    __shared__ double s_red[4];
+    double rr = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const double si = s[i], t = r[i] / si;
+        x[i] *= si;
+        rr = fma(t, t, rr);
+    }
+    rr = block_sum(rr, s_red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = rr;
+}
+
 int csr_diag_inv(Ctx *c, const Mesh *m, Csr *a) {
     if (a->dinv_valid) return PGD_OK;
     if (!a->dinv) {
@@ -447,8 +548,26 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     // 16 + 2 (k & 1), +1, so iteration 0 finds "the previous r.z" in slot 18 like every even iteration:
     // all 16-iteration chunks are identical and can be replayed as one hipGraph.
     constexpr int S_INIT = 18, S_PAIR = 16;
-    PGD_TRY(launch_spmv_op(c, m, o, x->d, q, nullptr, 0, n, false, true, nullptr, nullptr));
-    PGD_TRY(pcg_init(c, b->d, q, o->dinv, r, z, p, 0, n, S_INIT));
+    const bool scaled = sym && c->pcg_scaled && n >= 2;
+    double *sc = z;                     // the scaled recurrence has no z: its buffer holds s = d^-1/2
+    if (scaled) {
+        PGD_TRY(ensure_work(c, 5, 4096));
+        unsigned long long *bits = reinterpret_cast<unsigned long long *>(c->work[5]);
+        PGD_HIP(c, hipMemsetAsync(bits, 0, sizeof(unsigned long long), c->stream));
+        k_scale_in<<<grid_for(n), TPB, 0, c->stream>>>(o->dinv, sc, x->d, n, bits);
+        k_dmin_slot<<<1, 1, 0, c->stream>>>(bits, c->slots, c->flags);
+        PGD_LAUNCH_CHECK(c);
+        PGD_TRY(sym_scale(c, m, o, sc));
+        PGD_TRY(launch_spmv_op(c, m, o, x->d, q, nullptr, 0, n, false, true, nullptr, nullptr));
+        const int g = grid_for(n);
+        PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS));
+        k_pcg_init_s<<<g, TPB, 0, c->stream>>>(b->d, q, sc, r, p, n, c->partials);
+        PGD_LAUNCH_CHECK(c);
+        PGD_TRY(reduce_partials(c, c->partials, g, 3, S_INIT, -1, 0, 0));
+    } else {
+        PGD_TRY(launch_spmv_op(c, m, o, x->d, q, nullptr, 0, n, false, true, nullptr, nullptr));
+        PGD_TRY(pcg_init(c, b->d, q, o->dinv, r, z, p, 0, n, S_INIT));
+    }
     k_pcg_tol<<<1, 64, 0, c->stream>>>(c->slots, c->flags, rtol, atol, S_INIT + 1, S_INIT + 2, S_TOL2);
     PGD_LAUNCH_CHECK(c);
 
@@ -458,6 +577,14 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
             int nparts = 0;
             PGD_TRY(launch_spmv_op(c, m, o, p, q, p, 0, n, true, true, c->flags, &nparts));
             PGD_TRY(reduce_partials(c, c->partials, nparts, 1, S_PQ, 0, 0, 0));
+            if (scaled) {
+                const int g2 = grid_for((n + 1) / 2);
+                k_pcg_xr_s<<<g2, TPB, 0, c->stream>>>(x->d, r, p, q, sc, n, c->slots, rz_old, S_PQ, c->partials, c->flags);
+                PGD_LAUNCH_CHECK(c);
+                PGD_TRY(reduce_partials(c, c->partials, g2, 2, out, 2, out + 1, S_TOL2));
+                k_pcg_p<true><<<grid_for((n + 1) / 2), TPB, 0, c->stream>>>(p, r, 0, n, c->slots, out, rz_old, c->flags);
+                continue;
+            }
             // x, r, z update; the final reduction also runs the convergence test on r.r
             PGD_TRY(pcg_xr(c, x->d, r, p, q, o->dinv, z, 0, n, rz_old, S_PQ, out, 1, S_TOL2));
             k_pcg_p<true><<<grid_for((n + 1) / 2), TPB, 0, c->stream>>>(p, z, 0, n, c->slots, out, rz_old, c->flags);
@@ -500,12 +627,20 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     }
     if (gexec) (void)hipGraphExecDestroy(gexec);
     if (rc_loop != PGD_OK) return rc_loop;
+    if (scaled) {      // x = D^-1/2 x~, and the true r.r of the last iterate for the report
+        const int g = grid_for(n);
+        k_scale_out<<<g, TPB, 0, c->stream>>>(x->d, r, sc, n, c->partials);
+        PGD_LAUNCH_CHECK(c);
+        PGD_TRY(reduce_partials(c, c->partials, g, 1, S_TMP, -1, 0, 0));
+        o->uvals_valid = false;        // the slot arrays hold the scaled operator: nobody else may take them for A
+        o->uvals_scaled = false;
+    }
     PGD_LAUNCH_CHECK(c);
     double s[PGD_NSLOTS];
     PGD_HIP(c, hipMemcpyAsync(s, c->slots, sizeof s, hipMemcpyDeviceToHost, c->stream));
     PGD_HIP(c, hipStreamSynchronize(c->stream));
     if (iters) *iters = f[1];
-    const double rr = (f[1] > 0) ? s[S_PAIR + 2 * ((f[1] - 1) & 1) + 1] : s[S_INIT + 1];
+    const double rr = scaled ? s[S_TMP] : (f[1] > 0) ? s[S_PAIR + 2 * ((f[1] - 1) & 1) + 1] : s[S_INIT + 1];
     const double bb = s[S_INIT + 2];
     if (relres) *relres = (bb > 0.0) ? sqrt(rr / bb) : 0.0;
     if (f[2] != 0) return fail(c, f[2], "pcg_solve: breakdown (NaN residual) after %d iterations", f[1]);

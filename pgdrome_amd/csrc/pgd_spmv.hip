@@ -738,10 +738,35 @@ int build_sym_tables(Ctx *c, Mesh *m) {
     return PGD_OK;
 }
 
+// slot s of row i holds a(i, i + off_s): times s_i s_{i + off_s}
+template <int W>
+__global__ __launch_bounds__(TPB) void k_sym_scale(double *__restrict__ uvals, int64_t stride, const uint16_t *__restrict__ pids,
+                                                   const int *__restrict__ tab, const double *__restrict__ sc, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int *t = tab + (int)pids[i] * 16;
+    const int ulen = t[0] & 15;
+    const double si = sc[i];
+#pragma unroll
+    for (int s = 0; s < W; ++s)
+        if (s < ulen) uvals[(int64_t)s * stride + i] *= si * sc[i + (s > 0 ? t[s] : 0)];
+}
+
+int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *sc) {
+    if (!(a->uvals && a->uvals_valid) || a->uvals_scaled) return fail(c, PGD_ERR_INVALID, "sym_scale: no unscaled symmetric copy");
+    const int g = (int)((m->nv + TPB - 1) / TPB);
+    if (m->sym_w == 4) k_sym_scale<4><<<g, TPB, 0, c->stream>>>(a->uvals, a->uvals_stride, m->pids, m->sym_tab, sc, m->nv);
+    else k_sym_scale<8><<<g, TPB, 0, c->stream>>>(a->uvals, a->uvals_stride, m->pids, m->sym_tab, sc, m->nv);
+    PGD_LAUNCH_CHECK(c);
+    a->uvals_scaled = true;
+    return PGD_OK;
+}
+
 int ensure_sym(Ctx *c, const Mesh *m, Csr *a, bool *usable) {
     *usable = false;
     if (!c->spmv_sym || m->sym_w == 0) return PGD_OK;
-    if (a->uvals_valid) { *usable = a->uvals != nullptr; return PGD_OK; }
+    if (a->uvals_valid && !a->uvals_scaled) { *usable = a->uvals != nullptr; return PGD_OK; }
+    a->uvals_scaled = false;
     a->uvals_valid = true;                       // decided for this set of values, whatever the outcome
     const int64_t stride = m->nv;      // (padding the arrays apart - 2^27-byte strides at 256^3 - measured no difference)
     if (a->uvals && a->uvals_stride != stride) { dev_release(c, a->uvals, a->uvals_bytes); a->uvals = nullptr; }
@@ -868,6 +893,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_SPMV_SYM && value >= 0 && value <= 1) { c->spmv_sym = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_GRID_MIN_BYTES && value >= 0) { c->spmv_grid_min_plane_bytes = value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK_FORCE && value >= 0 && value <= 65536) { c->spmv_zchunk_force = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_PCG_SCALED && value >= 0 && value <= 1) { c->pcg_scaled = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK && value >= 0 && value <= 65536) { c->spmv_zchunk = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }

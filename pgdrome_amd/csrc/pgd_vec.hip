@@ -94,6 +94,17 @@ __global__ __launch_bounds__(1024) void k_reduce_partials(const double *__restri
         if (!(rr == rr)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; }   // NaN: breakdown
         else if (rr <= tol2) flags[0] = 1;
     }
+    // check_mode 2: the diagonally scaled recurrence (pgd_pcg.hip).  slots[slot0] = r~.r~; slots[slot_rr] is the TRUE
+    // r.r only once flags[3] (exact phase) is set - until then r.r >= d_min r~.r~ proves that the test cannot pass yet,
+    // and the phase is entered two orders of magnitude (in the norm) before it could.
+    if (check_mode == 2 && threadIdx.x == 0) {
+        __threadfence_block();
+        const double rz = slots[slot0], rr = slots[slot_rr], tol2 = slots[slot_tol2];
+        flags[1] += 1;
+        if (!(rz == rz) || !(rr == rr)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; }
+        else if (flags[3]) { if (rr <= tol2) flags[0] = 1; }
+        else if (rz * slots[S_DMIN] <= 1e4 * tol2) flags[3] = 1;
+    }
 }
 
 // ---- int32 exclusive scan (setup only): 1024 items per workgroup, recursive on block sums

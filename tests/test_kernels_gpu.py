@@ -343,6 +343,23 @@ def test_symmetric_half_storage_products(ctx, name):
         ctx.vec_free(sv)
     ctx.tune(3, 1)
     assert np.linalg.norm(sols[0][0] - sols[1][0]) <= 1e-9 * np.linalg.norm(sols[1][0]) and abs(sols[0][1] - sols[1][1]) <= 2
+    # ... and on the symmetrically scaled system (default) vs the unscaled recurrence on the same storage: the same
+    # Krylov iterates up to rounding, the same stop test on the true residual
+    ctx.tune(10, 0)
+    bv, sv = ctx.vec_from(b), ctx.vec_from(0.1 * np.ones(n))
+    its_u, rel_u = ctx.pcg_solve(op, bv, sv, 1e-12, 0.0, 5000)
+    x_u = ctx.vec_download(sv)
+    ctx.tune(10, 1)
+    ctx.vec_upload(sv, 0.1 * np.ones(n))
+    its_s, rel_s = ctx.pcg_solve(op, bv, sv, 1e-12, 0.0, 5000)
+    x_s = ctx.vec_download(sv)
+    assert rel_u <= 1e-12 and rel_s <= 1e-12 and abs(its_u - its_s) <= 2
+    assert np.linalg.norm(x_s - x_u) <= 1e-9 * np.linalg.norm(x_u)
+    assert np.linalg.norm(A @ x_s - b) <= 1.01e-12 * np.linalg.norm(b)            # the reported residual is the true one
+    its0, rel0 = ctx.pcg_solve(op, bv, sv, 1e-12, 0.0, 5000)                        # converged start: nothing to do
+    assert its0 == 0 and np.array_equal(ctx.vec_download(sv), x_s) or its0 <= 1
+    ctx.vec_free(bv)
+    ctx.vec_free(sv)
     # new values through the same handle: the copy is rebuilt
     op = ctx.op_combine(h, [ak, am], [2.0, 0.1], bc, op=op)
     assert ctx.op_symmetrize(op) is True
