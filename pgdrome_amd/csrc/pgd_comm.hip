@@ -254,19 +254,32 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         PGD_TRY(comm_halo(c, uu, get_vec(c, uu)->d, own0, own1, lo_g, hi_g));
         return pgd_spmv_dot_slot(h, oh, uu, ww, uu, own0, own1, B + 2);
     };
-    {
-        Mesh *m = get_mesh(c, op->mesh);
-        bool sym = false;
-        if (m) PGD_TRY(ensure_sym(c, m, op, &sym));
-    }
+    Mesh *m = get_mesh(c, op->mesh);
+    bool sym = false;
+    if (m) PGD_TRY(ensure_sym(c, m, op, &sym));
     PGD_TRY(pgd_flags_reset(h));
     const double zeros[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     PGD_TRY(pgd_slots_upload(h, zeros, B, 9));
     PGD_TRY(pgd_op_diag_inv(h, oh, dinv));
-    PGD_TRY(comm_halo(c, xh, x->d, own0, own1, lo_g, hi_g));
-    PGD_TRY(pgd_spmv(h, oh, xh, q, own0, own1));
-    PGD_TRY(pgd_cg_init_slot(h, bh, q, dinv, r, u, p, s, own0, own1, B));
-    PGD_TRY(spmv_dot3(u, w));
+    // With the symmetric storage in place the recurrence runs on the diagonally scaled system (k_cg_update_s: u = r, no
+    // dinv / u passes).  sc = d^-1/2 of the ghost rows comes from their owners (their local diagonals are partial sums).
+    const bool scaled = sym && c->pcg_scaled;
+    double *scp = get_vec(c, dinv)->d;
+    double *xd = x->d, *rd = get_vec(c, r)->d, *wd = get_vec(c, w)->d, *pd = get_vec(c, p)->d, *sd = get_vec(c, s)->d,
+           *qd = get_vec(c, q)->d;
+    if (scaled) {
+        PGD_TRY(vec_sqrt(c, scp, n));
+        PGD_TRY(comm_halo(c, dinv, scp, own0, own1, lo_g, hi_g));
+        PGD_TRY(sym_scale(c, m, op, scp));
+        PGD_TRY(vec_div_mul(c, xd, scp, n, 0));                      // x~ = x / sc on owned and ghost rows alike
+    }
+    PGD_TRY(comm_halo(c, xh, xd, own0, own1, lo_g, hi_g));
+    if (scaled) PGD_TRY(launch_spmv_op(c, m, op, xd, qd, nullptr, own0, own1, false, true, nullptr, nullptr));   // the scaled slots
+    else PGD_TRY(pgd_spmv(h, oh, xh, q, own0, own1));
+    if (scaled) PGD_TRY(cg_init_s(c, b->d, qd, scp, rd, pd, sd, own0, own1, B));
+    else PGD_TRY(pgd_cg_init_slot(h, bh, q, dinv, r, u, p, s, own0, own1, B));
+    const pgd_handle mv = scaled ? r : u;                            // the vector the product is applied to
+    PGD_TRY(spmv_dot3(mv, w));
     PGD_TRY(comm_allreduce(c, B, 9));
     PGD_TRY(pgd_cg_scalars_slot(h, B, 1, rtol, atol));
     int32_t done = 0, it = 0, status = 0;
@@ -276,11 +289,17 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         if (done || kk >= maxit) break;
         const int chunk = std::min(CHECK, maxit - kk);
         for (int j = 0; j < chunk; ++j, ++kk) {
-            PGD_TRY(pgd_cg_update_slot(h, xh, r, u, w, p, s, dinv, own0, own1, B));
-            PGD_TRY(spmv_dot3(u, w));
+            if (scaled) PGD_TRY(cg_update_s(c, xd, rd, wd, pd, sd, scp, own0, own1, B));
+            else PGD_TRY(pgd_cg_update_slot(h, xh, r, u, w, p, s, dinv, own0, own1, B));
+            PGD_TRY(spmv_dot3(mv, w));
             PGD_TRY(comm_allreduce(c, B, 5));
             PGD_TRY(pgd_cg_scalars_slot(h, B, 0, rtol, atol));
         }
+    }
+    if (scaled) {
+        PGD_TRY(vec_div_mul(c, xd, scp, n, 1));                      // back to x = sc x~ (ghosts too; refreshed below)
+        op->uvals_valid = false;                                     // the slot arrays hold the scaled operator
+        op->uvals_scaled = false;
     }
     if (status != 0) return fail(c, PGD_ERR_SINGULAR, "sharded PCG breakdown (NaN) after %d iterations", it);
     double sl[40];

@@ -169,6 +169,12 @@ struct Mesh;
 struct Csr;
 int build_sym_tables(Ctx *c, Mesh *m);                       // pgd_spmv.hip
 int ensure_sym(Ctx *c, const Mesh *m, Csr *a, bool *usable);  // pgd_spmv.hip: convert (once per operator)
+int cg_init_s(Ctx *c, const double *b, const double *q, const double *sc, double *r, double *p, double *s, int64_t lo,
+              int64_t hi, int base);                                   // pgd_pcg.hip: scaled sharded recurrence
+int cg_update_s(Ctx *c, double *x, double *r, const double *w, double *p, double *s, const double *sc, int64_t lo, int64_t hi,
+                int base);
+int vec_sqrt(Ctx *c, double *v, int64_t n);
+int vec_div_mul(Ctx *c, double *x, const double *sc, int64_t n, int mul);
 int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *s);   // pgd_spmv.hip: slot values *= s_i s_j
 int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0,
                    int64_t r1, bool dot, bool store, const int *flags, int *nparts_out);

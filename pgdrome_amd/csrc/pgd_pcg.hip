@@ -223,6 +223,61 @@ __global__ __launch_bounds__(TPB) void k_cg_init(const double *__restrict__ b, c
     }
 }
 
+// The single-reduction recurrence on the diagonally scaled system (see k_scale_in): u = r, so no dinv read and no u
+// pass - 10 vector passes instead of 12; sc = d^-1/2 is read only for the true residual norm.
+//   p = r + beta p;  s = w + beta s;  x += alpha p;  r -= alpha s;  partial (r.r, sum r^2 / sc^2)
+__global__ __launch_bounds__(TPB) void k_cg_update_s(double *__restrict__ x, double *__restrict__ r, const double *__restrict__ w,
+                                                     double *__restrict__ p, double *__restrict__ s, const double *__restrict__ sc,
+                                                     int64_t lo, int64_t hi, const double *__restrict__ slots, int base,
+                                                     double *__restrict__ partials, const int *__restrict__ flags) {
+    if (flags[0]) return;
+    __shared__ double s_red[4];
+    const double alpha = slots[base + 5], beta = slots[base + 6];
+    double ru = 0.0, rr = 0.0;
+    for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB) {
+        const double pi = fma(beta, p[i], r[i]), si = fma(beta, s[i], w[i]);
+        p[i] = pi; s[i] = si;
+        x[i] = fma(alpha, pi, x[i]);
+        const double ri = fma(-alpha, si, r[i]), ti = ri / sc[i];
+        r[i] = ri;
+        ru = fma(ri, ri, ru); rr = fma(ti, ti, rr);
+    }
+    ru = block_sum(ru, s_red);
+    rr = block_sum(rr, s_red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = ru; partials[2 * blockIdx.x + 1] = rr; }
+}
+
+// r = sc b - q; p = s = 0; partials (r.r, true r.r, b.b)
+__global__ __launch_bounds__(TPB) void k_cg_init_s(const double *__restrict__ b, const double *__restrict__ q,
+                                                   const double *__restrict__ sc, double *__restrict__ r, double *__restrict__ p,
+                                                   double *__restrict__ s, int64_t lo, int64_t hi, double *__restrict__ partials) {
+    __shared__ double s_red[4];
+    double ru = 0.0, rr = 0.0, bb = 0.0;
+    for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB) {
+        const double bi = b[i], si = sc[i], ri = si * bi - q[i], ti = ri / si;
+        r[i] = ri; p[i] = 0.0; s[i] = 0.0;
+        ru = fma(ri, ri, ru); rr = fma(ti, ti, rr); bb = fma(bi, bi, bb);
+    }
+    ru = block_sum(ru, s_red);
+    rr = block_sum(rr, s_red);
+    bb = block_sum(bb, s_red);
+    if (threadIdx.x == 0) {
+        partials[3 * blockIdx.x + 0] = ru;
+        partials[3 * blockIdx.x + 1] = rr;
+        partials[3 * blockIdx.x + 2] = bb;
+    }
+}
+
+// v <- sqrt(v) (dinv -> d^-1/2) / x <- x / sc / x <- x sc on a row range
+__global__ __launch_bounds__(TPB) void k_vec_sqrt(double *__restrict__ v, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) v[i] = sqrt(v[i]);
+}
+
+__global__ __launch_bounds__(TPB) void k_vec_div_mul(double *__restrict__ x, const double *__restrict__ sc, int64_t n, int mul) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB)
+        x[i] = mul ? x[i] * sc[i] : x[i] / sc[i];
+}
+
 // after the all-reduce: next alpha / beta, iteration count, convergence
 __global__ void k_cg_scalars(double *__restrict__ slots, int *__restrict__ flags, int base, int init, double rtol,
                              double atol) {
@@ -436,6 +491,42 @@ static int pcg_init(Ctx *c, const double *b, const double *q, const double *dinv
     k_pcg_init<<<g, TPB, 0, c->stream>>>(b, q, dinv, r, z, p, lo, hi, c->partials);
     PGD_LAUNCH_CHECK(c);
     return reduce_partials(c, c->partials, g, 3, slot, -1, 0, 0);
+}
+
+// launchers of the scaled sharded recurrence (pgd_comm.hip)
+int cg_init_s(Ctx *c, const double *b, const double *q, const double *sc, double *r, double *p, double *s, int64_t lo,
+              int64_t hi, int base) {
+    if (hi == lo) return PGD_OK;
+    const int g = grid_for(hi - lo);
+    PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS));
+    k_cg_init_s<<<g, TPB, 0, c->stream>>>(b, q, sc, r, p, s, lo, hi, c->partials);
+    PGD_LAUNCH_CHECK(c);
+    PGD_TRY(reduce_partials(c, c->partials, g, 3, 40, -1, 0, 0));
+    PGD_HIP(c, hipMemcpyAsync(c->slots + base, c->slots + 40, 2 * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    PGD_HIP(c, hipMemcpyAsync(c->slots + base + 8, c->slots + 42, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    return PGD_OK;
+}
+
+int cg_update_s(Ctx *c, double *x, double *r, const double *w, double *p, double *s, const double *sc, int64_t lo, int64_t hi,
+                int base) {
+    if (hi == lo) return PGD_OK;
+    const int g = grid_for(hi - lo);
+    PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS));
+    k_cg_update_s<<<g, TPB, 0, c->stream>>>(x, r, w, p, s, sc, lo, hi, c->slots, base, c->partials, c->flags);
+    PGD_LAUNCH_CHECK(c);
+    return reduce_partials(c, c->partials, g, 2, base, 0, 0, 0);
+}
+
+int vec_sqrt(Ctx *c, double *v, int64_t n) {
+    k_vec_sqrt<<<grid_for(n), TPB, 0, c->stream>>>(v, n);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int vec_div_mul(Ctx *c, double *x, const double *sc, int64_t n, int mul) {
+    k_vec_div_mul<<<grid_for(n), TPB, 0, c->stream>>>(x, sc, n, mul);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
 }
 
 static int pcg_xr(Ctx *c, double *x, double *r, const double *p, const double *q, const double *dinv, double *z,
