@@ -25,7 +25,8 @@ nv = ctx.mesh_info(mesh)["nv"]
 x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, nv))
 y = ctx.vec_alloc(nv)
 ctx.tune(3, 0 if mode == "csr" else 1)
-ctx.tune(6, zchunk if mode == "grid" else 0)
+ctx.tune(6, 64 if mode == "grid" else 0)
+ctx.tune(7, zchunk if mode == "grid" else 0)      # exactly this many planes per march
 if mode != "csr":
     assert ctx.op_symmetrize(op)
 ctx.flags_reset()
