@@ -15,7 +15,7 @@ namespace pgd {
 
 constexpr int MAXT = 8;          // atoms per combine launch
 constexpr int CHECK_EVERY = 16;  // PCG iterations enqueued between two host looks at the flag
-constexpr int64_t GRAPH_MAX_ROWS = 1 << 21;   // systems up to this size replay their chunks as a hipGraph
+constexpr int PROF_EAGER_EVERY = 8;   // with launch timing on, one chunk in this many is issued eagerly (with its events)
 
 struct CombineArgs {
     const double *in[MAXT];
@@ -683,13 +683,16 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         return PGD_OK;
     };
 
-    // Small systems are launch-bound (5 launches of a few microseconds per iteration): replay the
-    // chunk as a graph.  Large ones gain nothing and keep eager launches (and their event timing).
+    // The 16-iteration chunk (80 dependent launches) is replayed as a hipGraph: small systems are launch-bound, and at
+    // 256^3 the replay still saves ~2 % (549 vs 560 us per iteration).  With launch timing on, every PROF_EAGER_EVERY-th
+    // chunk is issued eagerly so that its products carry their HIP events; the capture itself records none.
     hipGraphExec_t gexec = nullptr;
-    if (!c->prof && n <= GRAPH_MAX_ROWS && maxit >= CHECK_EVERY) {
+    if (maxit >= CHECK_EVERY) {
         // everything a chunk allocates lazily must exist before the capture starts
         PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS > (n + 63) / 64 ? 4 * (int64_t)MAX_VEC_BLOCKS : (n + 63) / 64));
         PGD_TRY(ensure_work(c, 5, 4096));
+        const bool prof_saved = c->prof;
+        c->prof = false;
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
             const int rc = enqueue(0, CHECK_EVERY);
@@ -700,6 +703,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
             if (graph) (void)hipGraphDestroy(graph);
             (void)hipGetLastError();
         }
+        c->prof = prof_saved;
     }
     int f[4] = {0, 0, 0, 0};
     int enq = 0, rc_loop = PGD_OK;
@@ -709,7 +713,8 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         if (e != hipSuccess) { rc_loop = fail(c, PGD_ERR_HIP, "pcg_solve: %s", hipGetErrorString(e)); break; }
         if (f[0] || enq >= maxit) break;
         const int chunk = (maxit - enq < CHECK_EVERY) ? maxit - enq : CHECK_EVERY;
-        if (gexec && chunk == CHECK_EVERY) {
+        const bool eager_for_timing = c->prof && ((enq / CHECK_EVERY) % PROF_EAGER_EVERY == 0);
+        if (gexec && chunk == CHECK_EVERY && !eager_for_timing) {
             if (hipGraphLaunch(gexec, c->stream) != hipSuccess) { rc_loop = fail(c, PGD_ERR_HIP, "pcg_solve: hipGraphLaunch failed"); break; }
         } else if ((rc_loop = enqueue(enq, chunk)) != PGD_OK) {
             break;
