@@ -199,6 +199,9 @@ def main():
         out["roofline"]["kernel_min_bytes_per_launch"] = sym_bytes
         out["roofline"]["kernel_min_bytes_GBps"] = sym_bytes / avg / 1e9 if avg > 0 else 0.0
         out["roofline"]["kernel_min_bytes_frac"] = out["roofline"]["kernel_min_bytes_GBps"] / 8000.0
+        out["roofline"]["note"] = ("achieved/frac are priced with the CSR byte formula 12 nnz + 20 n of SURVEY 8d as required; "
+                                   "frac > 1 means the kernel does not move those bytes (symmetric half storage: each "
+                                   "off-diagonal value once) - see traffic (PMC) and kernel_min_bytes_* for what it does move")
     pmc = os.path.join(ROOT, "profiles", "pmc_spmv_latest.json")
     if n == 256 and world == 1 and sym["nx"] and os.path.exists(pmc):
         # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
