@@ -246,6 +246,8 @@ int pgd_pcg_solve_sharded(pgd_handle ctx, pgd_handle A, pgd_handle b, pgd_handle
 enum {
     PGD_TUNE_SPMV_ROWS = 1,  /* rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256 */
     PGD_TUNE_SPMV_GRID_MIN_BYTES = 8, /* ... used when a grid plane of values has at least this many bytes (default 0) */
+    PGD_TUNE_PCG_FOLD_REDUCE = 12, /* 1 (default): the scaled recurrence sums its reduction partials inside the vector kernels
+                                      (3 dependent launches per iteration instead of 5) for systems of up to 2^20 rows */
     PGD_TUNE_PCG_SCALED = 10,   /* 1 (default): pgd_pcg_solve runs CG on D^-1/2 A D^-1/2 (the same iterates as Jacobi-PCG,
                                    two vector passes per iteration fewer) when the symmetric storage applies; 0: unscaled */
     PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */

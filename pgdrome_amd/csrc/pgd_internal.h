@@ -125,8 +125,8 @@ struct Ctx {
     int *flags = nullptr;         // [0] done, [1] iters, [2] status
     double *partials = nullptr;   // reduction scratch
     int64_t partials_cap = 0;
-    double *work[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    int64_t work_cap[6] = {0, 0, 0, 0, 0, 0};
+    double *work[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t work_cap[7] = {0, 0, 0, 0, 0, 0, 0};
     uint8_t *mask = nullptr;      // Dirichlet column mask scratch
     int64_t mask_cap = 0;
     int *ibuf = nullptr;          // small int32 scratch (bc dofs, index lists)
@@ -140,6 +140,7 @@ struct Ctx {
     int64_t spmv_grid_min_plane_bytes = 0;   // structured grids whose planes of values are at least this large take k_spmv_sym_grid3
     int spmv_zchunk_force = 0;    // > 0: exactly this many planes per march whatever the grid size (tests)
     int spmv_zchunk = 16;         // k_spmv_sym_grid3: most planes a workgroup marches through (0: never use that kernel)
+    int pcg_fold_reduce = 1;      // scaled recurrence: final reduction passes folded into the vector kernels (3 launches / iteration)
     int pcg_scaled = 1;           // pgd_pcg_solve on the symmetrically scaled system (no dinv / z passes) when the symmetric storage applies
     int spmv_sym = 1;             // PCG products from the symmetric half storage when the mesh qualifies
 

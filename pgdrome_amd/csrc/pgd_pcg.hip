@@ -469,6 +469,94 @@ __global__ __launch_bounds__(TPB) void k_scale_out(double *__restrict__ x, const
     if (threadIdx.x == 0) partials[blockIdx.x] = rr;
 }
 
+// ---- the scaled recurrence with the final reduction passes folded into their consumers: every workgroup of the
+// x / r update sums the product's partials itself (<= 8192 of them, the same fixed order in every workgroup: one
+// value, bit for bit), every workgroup of the p update sums the x / r update's partials, and its workgroup 0 also
+// keeps the scalar bank and the convergence test.  3 dependent launches per iteration instead of 5.
+__device__ __forceinline__ double block_total(const double *__restrict__ part, int n, int stride, int off, double *s_red) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += TPB) a += part[(int64_t)i * stride + off];
+    a = block_sum(a, s_red);
+    __shared__ double s_bc;
+    __syncthreads();
+    if (threadIdx.x == 0) s_bc = a;
+    __syncthreads();
+    const double v = s_bc;
+    __syncthreads();
+    return v;
+}
+
+__global__ __launch_bounds__(TPB) void k_pcg_xr_s2(double *__restrict__ x, double *__restrict__ r, const double *__restrict__ p,
+                                                   const double *__restrict__ q, const double *__restrict__ s, int64_t n,
+                                                   const double *__restrict__ slots, int slot_rz,
+                                                   const double *__restrict__ pq_part, int npq,
+                                                   double *__restrict__ partials, const int *__restrict__ flags) {
+    if (flags[0]) return;
+    __shared__ double s_red[4];
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const double pq = block_total(pq_part, npq, 1, 0, s_red);
+    const double alpha = slots[slot_rz] / pq;
+    const bool exact = flags[3] != 0;
+    double rz = 0.0, rr = 0.0;
+    const int64_t npair = n >> 1;
+    for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < npair; k += (int64_t)gridDim.x * TPB) {
+        const int64_t i = 2 * k;
+        const d2 pi = *reinterpret_cast<const d2 *>(p + i), qi = *reinterpret_cast<const d2 *>(q + i);
+        d2 xi = *reinterpret_cast<d2 *>(x + i), ri = *reinterpret_cast<d2 *>(r + i);
+        xi.x = fma(alpha, pi.x, xi.x); xi.y = fma(alpha, pi.y, xi.y);
+        ri.x = fma(-alpha, qi.x, ri.x); ri.y = fma(-alpha, qi.y, ri.y);
+        *reinterpret_cast<d2 *>(x + i) = xi;
+        *reinterpret_cast<d2 *>(r + i) = ri;
+        rz = fma(ri.x, ri.x, rz); rz = fma(ri.y, ri.y, rz);
+        if (exact) {
+            const d2 si = *reinterpret_cast<const d2 *>(s + i);
+            const double tx = ri.x / si.x, ty = ri.y / si.y;
+            rr = fma(tx, tx, rr); rr = fma(ty, ty, rr);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        x[i] = fma(alpha, p[i], x[i]);
+        const double ri = fma(-alpha, q[i], r[i]);
+        r[i] = ri;
+        rz = fma(ri, ri, rz);
+        if (exact) { const double t = ri / s[i]; rr = fma(t, t, rr); }
+    }
+    rz = block_sum(rz, s_red);
+    rr = block_sum(rr, s_red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = rz; partials[2 * blockIdx.x + 1] = exact ? rr : rz; }
+}
+
+// p = r + beta p with beta = (r.r) / S[rz_old]; workgroup 0 stores (r.r, true r.r) in S[out], S[out+1], counts the
+// iteration and runs the stop test (the logic of k_reduce_partials' check_mode 2)
+__global__ __launch_bounds__(TPB) void k_pcg_p_s2(double *__restrict__ p, const double *__restrict__ r, int64_t n,
+                                                  const double *__restrict__ part, int npart, double *__restrict__ slots,
+                                                  int out, int rz_old, int slot_tol2, int *__restrict__ flags) {
+    if (flags[0]) return;
+    __shared__ double s_red[4];
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const double rz = block_total(part, npart, 2, 0, s_red);
+    const double rr = block_total(part, npart, 2, 1, s_red);
+    const double beta = rz / slots[rz_old];
+    const int64_t npair = n >> 1;
+    for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < npair; k += (int64_t)gridDim.x * TPB) {
+        const int64_t i = 2 * k;
+        const d2 ri = *reinterpret_cast<const d2 *>(r + i);
+        d2 pi = *reinterpret_cast<d2 *>(p + i);
+        pi.x = fma(beta, pi.x, ri.x); pi.y = fma(beta, pi.y, ri.y);
+        *reinterpret_cast<d2 *>(p + i) = pi;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (n & 1) p[n - 1] = fma(beta, p[n - 1], r[n - 1]);
+        slots[out] = rz; slots[out + 1] = rr;
+        const double tol2 = slots[slot_tol2];
+        flags[1] += 1;
+        if (!(rz == rz) || !(rr == rr)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; }
+        else if (flags[3]) { if (rr <= tol2) flags[0] = 1; }
+        else if (rz * slots[S_DMIN] <= 1e4 * tol2) flags[3] = 1;
+    }
+}
+
 int csr_diag_inv(Ctx *c, const Mesh *m, Csr *a) {
     if (a->dinv_valid) return PGD_OK;
     if (!a->dinv) {
@@ -662,11 +750,22 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     k_pcg_tol<<<1, 64, 0, c->stream>>>(c->slots, c->flags, rtol, atol, S_INIT + 1, S_INIT + 2, S_TOL2);
     PGD_LAUNCH_CHECK(c);
 
+    // second partials buffer for the folded reductions (the x / r update reads the product's partials while writing its own)
+    PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS));
+    double *part2 = c->work[6];
     auto enqueue = [&](int start, int count) -> int {
         for (int k = 0; k < count; ++k) {
             const int out = S_PAIR + 2 * ((start + k) & 1), rz_old = S_PAIR + 2 * ((start + k + 1) & 1);
             int nparts = 0;
             PGD_TRY(launch_spmv_op(c, m, o, p, q, p, 0, n, true, true, c->flags, &nparts));
+            // (pays only where the launches, not the bytes, set the pace: 256^2 rows +22 %, 128^3 +-0, 256^3 -2 %)
+            if (scaled && c->pcg_fold_reduce && nparts > 0 && nparts <= 8192 && n <= ((int64_t)1 << 20)) {
+                const int g2 = grid_for((n + 1) / 2);
+                k_pcg_xr_s2<<<g2, TPB, 0, c->stream>>>(x->d, r, p, q, sc, n, c->slots, rz_old, c->partials, nparts, part2, c->flags);
+                k_pcg_p_s2<<<g2, TPB, 0, c->stream>>>(p, r, n, part2, g2, c->slots, out, rz_old, S_TOL2, c->flags);
+                PGD_LAUNCH_CHECK(c);
+                continue;
+            }
             PGD_TRY(reduce_partials(c, c->partials, nparts, 1, S_PQ, 0, 0, 0));
             if (scaled) {
                 const int g2 = grid_for((n + 1) / 2);

@@ -893,6 +893,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_SPMV_SYM && value >= 0 && value <= 1) { c->spmv_sym = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_GRID_MIN_BYTES && value >= 0) { c->spmv_grid_min_plane_bytes = value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK_FORCE && value >= 0 && value <= 65536) { c->spmv_zchunk_force = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_PCG_FOLD_REDUCE && value >= 0 && value <= 1) { c->pcg_fold_reduce = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_SCALED && value >= 0 && value <= 1) { c->pcg_scaled = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK && value >= 0 && value <= 65536) { c->spmv_zchunk = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
