@@ -282,6 +282,10 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     PGD_TRY(spmv_dot3(mv, w));
     PGD_TRY(comm_allreduce(c, B, 9));
     PGD_TRY(pgd_cg_scalars_slot(h, B, 1, rtol, atol));
+    if (scaled) {     // the folded form reads "previous alpha, previous r.r" from the slot set of its parity: seed set 0
+        PGD_HIP(c, hipMemcpyAsync(c->slots + B + 9, c->slots + B + 5, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        PGD_HIP(c, hipMemcpyAsync(c->slots + B + 10, c->slots + B + 7, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
     int32_t done = 0, it = 0, status = 0;
     int kk = 0;
     for (;;) {
@@ -289,12 +293,27 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         if (done || kk >= maxit) break;
         const int chunk = std::min(CHECK, maxit - kk);
         for (int j = 0; j < chunk; ++j, ++kk) {
+            if (scaled && kk > 0) {
+                // 3 kernels per iteration: vector step (forms alpha / beta itself, counts, tests), product, one reduction
+                int nb = 0, np = 0;
+                PGD_TRY(cg_update_s2(c, xd, rd, wd, pd, sd, scp, own0, own1, B, (kk - 1) & 1, &nb));
+                PGD_TRY(comm_halo(c, mv, rd, own0, own1, lo_g, hi_g));
+                PGD_TRY(launch_spmv_op(c, m, op, rd, wd, rd, own0, own1, true, true, c->flags, &np));
+                PGD_TRY(reduce_two_slots(c, nb, np, B));
+                PGD_TRY(comm_allreduce(c, B, 5));
+                continue;
+            }
             if (scaled) PGD_TRY(cg_update_s(c, xd, rd, wd, pd, sd, scp, own0, own1, B));
             else PGD_TRY(pgd_cg_update_slot(h, xh, r, u, w, p, s, dinv, own0, own1, B));
             PGD_TRY(spmv_dot3(mv, w));
             PGD_TRY(comm_allreduce(c, B, 5));
-            PGD_TRY(pgd_cg_scalars_slot(h, B, 0, rtol, atol));
+            if (!scaled) PGD_TRY(pgd_cg_scalars_slot(h, B, 0, rtol, atol));
         }
+    }
+    if (scaled && !done && kk > 0) {
+        // the last enqueued iteration's scalars are still unprocessed in the folded form: count and test them
+        PGD_TRY(pgd_cg_scalars_slot(h, B, 0, rtol, atol));
+        PGD_TRY(pgd_flags_download(h, &done, &it, &status));
     }
     if (scaled) {
         PGD_TRY(vec_div_mul(c, xd, scp, n, 1));                      // back to x = sc x~ (ghosts too; refreshed below)

@@ -174,6 +174,9 @@ int cg_init_s(Ctx *c, const double *b, const double *q, const double *sc, double
               int64_t hi, int base);                                   // pgd_pcg.hip: scaled sharded recurrence
 int cg_update_s(Ctx *c, double *x, double *r, const double *w, double *p, double *s, const double *sc, int64_t lo, int64_t hi,
                 int base);
+int cg_update_s2(Ctx *c, double *x, double *r, const double *w, double *p, double *s, const double *sc, int64_t lo, int64_t hi,
+                 int base, int parity, int *nblocks);
+int reduce_two_slots(Ctx *c, int na, int nb, int base);
 int vec_sqrt(Ctx *c, double *v, int64_t n);
 int vec_div_mul(Ctx *c, double *x, const double *sc, int64_t n, int mul);
 int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *s);   // pgd_spmv.hip: slot values *= s_i s_j

@@ -278,6 +278,68 @@ __global__ __launch_bounds__(TPB) void k_vec_div_mul(double *__restrict__ x, con
         x[i] = mul ? x[i] * sc[i] : x[i] / sc[i];
 }
 
+// The scaled single-reduction recurrence with the scalar step folded in: every workgroup forms alpha / beta itself from
+// the all-reduced slots (pure functions of them), workgroup 0 also keeps the iteration count, the stop flag and the
+// two scalars the NEXT iteration's formula needs - in the slot set of the other parity, so nobody reads what it
+// writes.  S[b..b+4] all-reduced (r.r, true r.r, w.r, 0, 0); set q at b + 9 + 2 q: (previous alpha, previous r.r).
+__global__ __launch_bounds__(TPB) void k_cg_update_s2(double *__restrict__ x, double *__restrict__ r, const double *__restrict__ w,
+                                                      double *__restrict__ p, double *__restrict__ s, const double *__restrict__ sc,
+                                                      int64_t lo, int64_t hi, double *__restrict__ slots, int base, int parity,
+                                                      double *__restrict__ partials, int *__restrict__ flags) {
+    if (flags[0]) return;
+    __shared__ double s_red[4];
+    const double g = slots[base], rr_in = slots[base + 1], d = slots[base + 2] + slots[base + 3] + slots[base + 4];
+    const double a_prev = slots[base + 9 + 2 * parity], g_prev = slots[base + 10 + 2 * parity];
+    const bool bad = !(rr_in == rr_in) || !(d == d), done = rr_in <= slots[S_TOL2];
+    const double beta = g / g_prev, alpha = g / (d - beta * g / a_prev);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        flags[1] += 1;
+        slots[6] = rr_in;
+        if (bad) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; }
+        else if (done) flags[0] = 1;
+        slots[base + 9 + 2 * (1 - parity)] = alpha;
+        slots[base + 10 + 2 * (1 - parity)] = g;
+    }
+    if (bad || done) return;                                   // uniform: every workgroup sees the same slots
+    double ru = 0.0, rr = 0.0;
+    for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB) {
+        const double pi = fma(beta, p[i], r[i]), si = fma(beta, s[i], w[i]);
+        p[i] = pi; s[i] = si;
+        x[i] = fma(alpha, pi, x[i]);
+        const double ri = fma(-alpha, si, r[i]), ti = ri / sc[i];
+        r[i] = ri;
+        ru = fma(ri, ri, ru); rr = fma(ti, ti, rr);
+    }
+    ru = block_sum(ru, s_red);
+    rr = block_sum(rr, s_red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = ru; partials[2 * blockIdx.x + 1] = rr; }
+}
+
+// S[b], S[b+1] <- sums of the update's partial pairs; S[b+2] <- sum of the product's partials; S[b+3] = S[b+4] = 0
+__global__ __launch_bounds__(1024) void k_reduce_two(const double *__restrict__ pa, int na, const double *__restrict__ pb, int nb,
+                                                     double *__restrict__ slots, int base, const int *__restrict__ flags) {
+    __shared__ double s_w[16];
+    if (flags[0]) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int v = 0; v < 3; ++v) {
+        const double *src = v < 2 ? pa : pb;
+        const int n = v < 2 ? na : nb, stride = v < 2 ? 2 : 1, off = v < 2 ? v : 0;
+        double acc = 0.0;
+        for (int i = threadIdx.x; i < n; i += 1024) acc += src[(int64_t)i * stride + off];
+        acc = wave_sum(acc);
+        __syncthreads();
+        if (lane == 0) s_w[wv] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) t += s_w[k];
+            slots[base + v] = t;
+        }
+    }
+    if (threadIdx.x == 0) { slots[base + 3] = 0.0; slots[base + 4] = 0.0; }
+}
+
 // after the all-reduce: next alpha / beta, iteration count, convergence
 __global__ void k_cg_scalars(double *__restrict__ slots, int *__restrict__ flags, int base, int init, double rtol,
                              double atol) {
@@ -603,6 +665,25 @@ int cg_update_s(Ctx *c, double *x, double *r, const double *w, double *p, double
     k_cg_update_s<<<g, TPB, 0, c->stream>>>(x, r, w, p, s, sc, lo, hi, c->slots, base, c->partials, c->flags);
     PGD_LAUNCH_CHECK(c);
     return reduce_partials(c, c->partials, g, 2, base, 0, 0, 0);
+}
+
+// one iteration's vector step of the folded form; its partials stay in work[6] until reduce_two_slots
+int cg_update_s2(Ctx *c, double *x, double *r, const double *w, double *p, double *s, const double *sc, int64_t lo, int64_t hi,
+                 int base, int parity, int *nblocks) {
+    *nblocks = 0;
+    if (hi == lo) return PGD_OK;
+    const int g = grid_for(hi - lo);
+    PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS));
+    k_cg_update_s2<<<g, TPB, 0, c->stream>>>(x, r, w, p, s, sc, lo, hi, c->slots, base, parity, c->work[6], c->flags);
+    PGD_LAUNCH_CHECK(c);
+    *nblocks = g;
+    return PGD_OK;
+}
+
+int reduce_two_slots(Ctx *c, int na, int nb, int base) {
+    k_reduce_two<<<1, 1024, 0, c->stream>>>(c->work[6], na, c->partials, nb, c->slots, base, c->flags);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
 }
 
 int vec_sqrt(Ctx *c, double *v, int64_t n) {
