@@ -40,9 +40,15 @@ def test_native_library_is_the_one_running(hip_backend):
         assert "libpgd_amd.so" in f.read()
 
 
-def test_gpu_run_equals_oracle_run_on_a_mid_size_problem(hip_backend):
-    """Sizes between the fixtures and the bench: 33^3 x 17, HIP vs the oracle backend, same host code."""
+@pytest.mark.parametrize("solver_form", ["default", "z-march", "textbook"])
+def test_gpu_run_equals_oracle_run_on_a_mid_size_problem(hip_backend, solver_form):
+    """Sizes between the fixtures and the bench: 33^3 x 17, HIP vs the oracle backend, same host code - with the
+    solver forms the library chooses by itself at this size (symmetric storage in row order, scaled recurrence, folded
+    reductions), with the z-march kernel of the bench sizes forced onto this small grid, and with the textbook kernels
+    (CSR product, unscaled Jacobi-PCG)."""
     from oracle.backend_numpy import NumpyBackend
+    knobs = {"default": [], "z-march": [(7, 3)], "textbook": [(3, 0), (10, 0)]}[solver_form]
+    reset = {7: 0, 3: 1, 10: 1}
 
     def run(backend):
         fem.set_backend(backend)
@@ -52,9 +58,13 @@ def test_gpu_run_equals_oracle_run_on_a_mid_size_problem(hip_backend):
         p.solve_PGD(_problem="linear")
         return p, [[f.compute_vertex_values() for f in p.PGD_func[d]] for d in range(2)]
     try:
+        for knob, value in knobs:
+            hip_backend.ctx.tune(knob, value)
         pg, mg = run(hip_backend)
         po, mo = run(NumpyBackend())
     finally:
+        for knob, _ in knobs:
+            hip_backend.ctx.tune(knob, reset[knob])
         fem.set_backend(hip_backend)
         fem.clear_caches()
     assert pg.num_fp_it == po.num_fp_it and pg.PGD_modes == po.PGD_modes
