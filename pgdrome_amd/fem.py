@@ -2507,28 +2507,59 @@ class _Params(dict):
 
 
 SMALL_DIRECT_N = 20000   # systems up to this size on 1-D meshes take the banded direct path
-WARM_START_RESCALE = True  # scale the PCG start vector to its energy-optimal length (see _solve_linear)
+WARM_START_RESCALE = True  # scale the PCG start vector to its energy-optimal length (see _rescale_start)
+START_SPACE_MAX = 8        # stored modes that may join the Galerkin start of a solve (most recent ones)
 
 
 def _rescale_start(lay, op, b, x):
     """The warm start of a PCG solve is the previous iterate of the same dimension, NORMALISED by the fixed-point loop:
     the right shape, an arbitrary length.  gamma = (x . b) / (x . A x) is the best multiple of it in the energy norm
-    (one product, two dots); on the bench problem it saves 23 % of the PCG iterations of a pass."""
+    (one product, two dots); on the bench problem it saves 23 % of the PCG iterations of a pass.
+
+    When the caller names further vectors (``x._start_space``: the stored modes of this dimension - the right-hand side
+    of an enrichment step is the load minus the operator applied to them) the start is the Galerkin projection onto
+    span{x, v_1, ..., v_k}: k + 1 products, (k + 1)(k + 4) / 2 dots and a (k + 1) x (k + 1) solve on the host; it is
+    never worse than the scaled x in the energy norm."""
     be = get_backend()
     lo, hi = lay.owned_range()
-    _halo(lay, x)
-    tmp = be.vec_zeros(lay.n)
+    extras = [v for v in getattr(x, "_start_space", ()) if v is not x][-START_SPACE_MAX:]
+    vecs = [x] + extras
+    for v in vecs:
+        _halo(lay, v)
+    k = len(vecs)
+    prods = [be.vec_zeros(lay.n) for _ in range(k)]
     try:
-        be.spmv(op, x.dev(), tmp, lo, hi)
-        xax = _allreduce_sum(lay.mesh, be.vec_dot(x.dev(), tmp, lo, hi))
-        xb = _allreduce_sum(lay.mesh, be.vec_dot(x.dev(), b.dev(), lo, hi))
+        for v, w in zip(vecs, prods):
+            be.spmv(op, v.dev(), w, lo, hi)
+        G = np.zeros((k, k))
+        g = np.zeros(k)
+        for i in range(k):
+            g[i] = _allreduce_sum(lay.mesh, be.vec_dot(vecs[i].dev(), b.dev(), lo, hi))
+            for j in range(i, k):
+                G[i, j] = G[j, i] = _allreduce_sum(lay.mesh, be.vec_dot(vecs[i].dev(), prods[j], lo, hi))
     finally:
-        be.vec_free(tmp)
-    if xax > 0.0 and math.isfinite(xb / xax) and xb != 0.0:
-        be.vec_scale(x.dev(), xb / xax)
-        x.touched_dev()
-        if lay.part is not None:
-            x._halo_version = x.version        # scaled owned and ghost entries alike: the planes are still current
+        for w in prods:
+            be.vec_free(w)
+    if not (np.all(np.isfinite(G)) and np.all(np.isfinite(g)) and G[0, 0] > 0.0):
+        return
+    if k == 1:
+        coef = np.array([g[0] / G[0, 0]])
+    else:
+        d = np.sqrt(np.abs(np.diag(G)))
+        d[d == 0.0] = 1.0
+        coef = np.linalg.lstsq(G / np.outer(d, d), g / d, rcond=1e-10)[0] / d        # equilibrated, rank-revealing
+    if not np.all(np.isfinite(coef)) or not np.any(coef):
+        return
+    if k == 1:
+        be.vec_scale(x.dev(), float(coef[0]))
+    else:
+        out = be.vec_zeros(lay.n)
+        be.vec_lincomb(out, [v.dev() for v in vecs], [float(c) for c in coef])
+        be.vec_copy(x.dev(), out)
+        be.vec_free(out)
+    x.touched_dev()
+    if lay.part is not None:
+        x._halo_version = x.version        # a combination of vectors with current ghost planes
 
 
 def _solve_linear(A, b, x, prm):

@@ -117,6 +117,8 @@ class PGDProblem:
         return fem.norm(F)
 
     # ------------------------------------------------------------------------ initial modes
+    start_from_modes = True     # PCG starts: Galerkin projection onto {previous iterate, stored modes} (fem._rescale_start)
+
     def get_Fsinit(self, V, bc=None, solve_modes=None):
         """Ones, Dirichlet values imposed, optional random fill, normalised (solver.py:158-304)."""
         Fs_init = [None] * len(V)
@@ -338,6 +340,8 @@ class PGDProblem:
             elif kind == "linear":
                 a, l = forms(fem.TrialFunction(V))
                 fct_F.vector().assign_from(Fs[dim].vector())     # PCG start vector (ignored by the direct path)
+                if self.start_from_modes:                       # ... improved by the stored modes of this dimension
+                    fct_F.vector()._start_space = [f.vector() for f in self.PGD_func[dim]]
                 problem = fem.LinearVariationalProblem(a, l, fct_F, bc if bc != 0 else None)
                 solver = fem.LinearVariationalSolver(problem)
                 prm = solver.parameters
