@@ -117,7 +117,9 @@ class PGDProblem:
         return fem.norm(F)
 
     # ------------------------------------------------------------------------ initial modes
-    start_from_modes = True     # PCG starts: Galerkin projection onto {previous iterate, stored modes} (fem._rescale_start)
+    start_from_modes = True     # PCG starts: Galerkin projection onto {previous iterate, stored modes, the iterate of the
+                                # same pass of the previous enrichment step} (fem._rescale_start)
+    PASS_SOLS_KEPT = 3          # passes per dimension whose iterates are kept for that purpose
 
     def get_Fsinit(self, V, bc=None, solve_modes=None):
         """Ones, Dirichlet values imposed, optional random fill, normalised (solver.py:158-304)."""
@@ -156,6 +158,7 @@ class PGDProblem:
                 n_enr += 1
                 if n_enr == 0:
                     self.PGD_func = [[] for _ in range(D)]
+                    self._pass_sols = [[None] * self.PASS_SOLS_KEPT for _ in range(D)]
                     normConv, relConv = [], []
                 self.logger.info("enrichment step %s ", n_enr)
                 Fs_init = self.get_Fsinit(self.V, self.bc, solve_modes)
@@ -248,8 +251,14 @@ class PGDProblem:
         Fs = np.copy(np.array(Fs_init, dtype=object))
         D = self.num_pgd_var
         for fpi in range(self.max_fp_it):
+            self._fp_pass = fpi
             for dim in self.seq_fp:
                 fct_F = self._solve_dim(dim, Fs, n_enr, _problem, solve_modes, settings)
+                if self.start_from_modes and hasattr(self, "_pass_sols") and fpi < len(self._pass_sols[dim]):
+                    # iterate of pass `fpi` of this enrichment step: start material for the same pass of the next one
+                    # (in its first pass every step solves with the SAME operator - the other dimensions start from the
+                    # same initial functions - and a right-hand side that differs by the terms of one mode)
+                    self._pass_sols[dim][fpi] = fem.Function(fct_F.function_space(), fct_F)
                 Fs[dim] = fct_F
                 norm_Fs[dim] = self._norm(fct_F, solve_modes, dim)
             self.fp_passes += 1
@@ -341,7 +350,11 @@ class PGDProblem:
                 a, l = forms(fem.TrialFunction(V))
                 fct_F.vector().assign_from(Fs[dim].vector())     # PCG start vector (ignored by the direct path)
                 if self.start_from_modes:                       # ... improved by the stored modes of this dimension
-                    fct_F.vector()._start_space = [f.vector() for f in self.PGD_func[dim]]
+                    space = [f.vector() for f in self.PGD_func[dim]]                    # and by the iterate the same
+                    k = getattr(self, "_fp_pass", 0)                                    # pass of the previous step reached
+                    if hasattr(self, "_pass_sols") and k < len(self._pass_sols[dim]) and self._pass_sols[dim][k] is not None:
+                        space.append(self._pass_sols[dim][k].vector())
+                    fct_F.vector()._start_space = space
                 problem = fem.LinearVariationalProblem(a, l, fct_F, bc if bc != 0 else None)
                 solver = fem.LinearVariationalSolver(problem)
                 prm = solver.parameters
