@@ -297,3 +297,33 @@ def test_vector_space_basics():
     assert np.isclose(fem.assemble(fem.Constant(1.0) * a0 * fem.ds(mesh)), 0.5 * 4 / 2 + 1.0 + 2 * 0.5)   # int xy over the boundary
     bc = fem.DirichletBC(V, fem.Constant((0.5, -0.5)), mf, 7)
     assert bc.vertices().size == 2 * 5 and set(np.unique(bc.vertex_values())) == {0.5, -0.5}
+
+
+def test_galerkin_start_of_the_pcg_solves_changes_only_the_iteration_counts():
+    """The start vector of every PCG solve is the Galerkin projection of the solution onto {previous iterate, stored
+    modes, iterate of the same pass of the previous enrichment step} (fem._rescale_start): the same systems are solved
+    to the same tolerance - modes, amplitudes and pass counts do not move - in fewer iterations."""
+    from pgdrome_amd import problems
+    from pgdrome_amd.solver import PGDProblem
+
+    def run(modes_in_start, rescale):
+        fem.clear_caches()
+        fem.WARM_START_RESCALE = rescale
+        fem.STATS["pcg_iterations"] = 0
+        spec = problems.reaction_diffusion(fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), 10, 10, 10), 9, PGD_nmax=4)
+        p = PGDProblem(**spec)
+        p.start_from_modes = modes_in_start
+        p.solve_PGD(_problem="linear")
+        return p, fem.STATS["pcg_iterations"], [f.compute_vertex_values() for f in p.PGD_func[0]]
+    try:
+        p0, its0, m0 = run(False, False)      # the previous iterate as it is
+        p1, its1, m1 = run(False, True)       # ... scaled to its energy-optimal length
+        p2, its2, m2 = run(True, True)        # ... plus stored modes and the previous step's iterates
+    finally:
+        fem.WARM_START_RESCALE = True
+    assert p0.num_fp_it == p1.num_fp_it == p2.num_fp_it and p0.PGD_modes == p2.PGD_modes
+    np.testing.assert_allclose(p1.amplitude, p0.amplitude, rtol=1e-7)
+    np.testing.assert_allclose(p2.amplitude, p0.amplitude, rtol=1e-7)
+    for a, b, c in zip(m0, m1, m2):
+        assert np.linalg.norm(b - a) <= 1e-6 * np.linalg.norm(a) and np.linalg.norm(c - a) <= 1e-6 * np.linalg.norm(a)
+    assert its2 < its1 < its0
