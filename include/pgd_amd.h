@@ -251,6 +251,7 @@ enum {
     PGD_TUNE_PCG_SCALED = 10,   /* 1 (default): pgd_pcg_solve runs CG on D^-1/2 A D^-1/2 (the same iterates as Jacobi-PCG,
                                    two vector passes per iteration fewer) when the symmetric storage applies; 0: unscaled */
     PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */
+    PGD_TUNE_SPMV_VARIANT = 13, /* k_spmv_dia_march: occupancy / pipelining variant (0 default; measuring only) */
     PGD_TUNE_SPMV_ZCHUNK = 6,   /* k_spmv_sym_grid3 (structured vertex grids, x planes in LDS): most planes per
                                    workgroup march (default 16; fewer while that keeps 8 workgroups per CU); 0 = off */
     PGD_TUNE_SPMV_SYM = 3,   /* 1 (default): the products of the SPD solves (pgd_pcg_solve, pgd_pcg_solve_sharded,
@@ -268,6 +269,21 @@ int pgd_tune(pgd_handle ctx, int knob, int64_t value);
  * on = 1: every launch; on = 2: only the PCG instance (fused dot, stores y).     */
 int pgd_prof_enable(pgd_handle ctx, int on);
 int pgd_prof_read(pgd_handle ctx, int64_t *launches, double *seconds, double *alg_bytes);
+/* ... and the least bytes the timed kernels must move in the storage form they actually read (diagonal /
+ * symmetric half storage: 8 W + 16..18 B per row; CSR forms: 12 or 8 B per entry + 20..22 B per row): the
+ * physical numerator of roofline.frac when the kernel does not stream the CSR arrays.              */
+int pgd_prof_read_own(pgd_handle ctx, double *own_bytes);
+/* Launch counts per product kernel family since the context was created: [0] k_spmv_csr, [1] k_spmv_csr_dict*,
+ * [2] k_spmv_sym (row order), [3] k_spmv_dia_rows, [4] k_spmv_dia_march, [5] k_spmv_multi; tests use them to
+ * prove which kernel a call reached, bench.py for its per-kernel breakdown.                          */
+int pgd_kernel_counts(pgd_handle ctx, int64_t *out, int n);
+/* One HIP-event stopwatch on the context's stream (bench.py's micro-sections: N launches between start
+ * and stop; stop synchronises on its event).                                                        */
+/* Calibration of the PMC byte model: one pass over `vec` with 8- or 16-byte loads (store = 0) or stores (store = 1)
+ * per lane - a known byte count to read FETCH_SIZE / WRITE_SIZE against (tools/pmc_calib.py).         */
+int pgd_calib_stream(pgd_handle ctx, pgd_handle vec, int bytes_per_lane, int store);
+int pgd_timer_start(pgd_handle ctx);
+int pgd_timer_stop(pgd_handle ctx, double *seconds);
 
 #ifdef __cplusplus
 }

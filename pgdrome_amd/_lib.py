@@ -93,6 +93,11 @@ SIGNATURES = {
     "pgd_tune": (C.c_int, [H, C.c_int, I64]),
     "pgd_prof_enable": (C.c_int, [H, C.c_int]),
     "pgd_prof_read": (C.c_int, [H, PI64, PD, PD]),
+    "pgd_prof_read_own": (C.c_int, [H, PD]),
+    "pgd_kernel_counts": (C.c_int, [H, PI64, C.c_int]),
+    "pgd_calib_stream": (C.c_int, [H, H, C.c_int, C.c_int]),
+    "pgd_timer_start": (C.c_int, [H]),
+    "pgd_timer_stop": (C.c_int, [H, PD]),
 }
 
 NSLOTS = 64
@@ -489,4 +494,24 @@ class Context:
     def prof_read(self):
         n, s, b = I64(), F64(), F64()
         self._ck(self.lib.pgd_prof_read(self.h, C.byref(n), C.byref(s), C.byref(b)))
-        return dict(launches=n.value, seconds=s.value, bytes=b.value)
+        own = F64()
+        self._ck(self.lib.pgd_prof_read_own(self.h, C.byref(own)))
+        return dict(launches=n.value, seconds=s.value, bytes=b.value, own_bytes=own.value)
+
+    KERNEL_FAMILIES = ("csr", "csr_dict", "sym_rows", "dia_rows", "dia_march", "multi")
+
+    def kernel_counts(self):
+        out = (C.c_int64 * 8)()
+        self._ck(self.lib.pgd_kernel_counts(self.h, out, 8))
+        return {k: int(out[i]) for i, k in enumerate(self.KERNEL_FAMILIES)}
+
+    def calib_stream(self, v, bytes_per_lane, store=False):
+        self._ck(self.lib.pgd_calib_stream(self.h, v, int(bytes_per_lane), int(bool(store))))
+
+    def timer_start(self):
+        self._ck(self.lib.pgd_timer_start(self.h))
+
+    def timer_stop(self):
+        s = F64()
+        self._ck(self.lib.pgd_timer_stop(self.h, C.byref(s)))
+        return s.value

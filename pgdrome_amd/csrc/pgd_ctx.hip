@@ -180,6 +180,7 @@ int pgd_ctx_destroy(pgd_handle h) {
     for (auto &kv : c->pool) (void)hipFree(kv.second);
     c->pool.clear();
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->timer_ev) if (e) (void)hipEventDestroy(e);
     for (void *p : {(void *)c->slots, (void *)c->flags, (void *)c->partials, (void *)c->mask,
                     (void *)c->ibuf})
         if (p) (void)hipFree(p);
@@ -322,6 +323,7 @@ int pgd_prof_enable(pgd_handle h, int on) {
         c->prof_launches = 0;
         c->prof_seconds = 0.0;
         c->prof_bytes = 0.0;
+        c->prof_own_bytes = 0.0;
         if (c->ev.empty()) {
             c->ev.resize(2048);
             for (auto &e : c->ev) PGD_HIP(c, hipEventCreate(&e));
@@ -336,6 +338,39 @@ int pgd_prof_read(pgd_handle h, int64_t *launches, double *seconds, double *byte
     if (launches) *launches = c->prof_launches;
     if (seconds) *seconds = c->prof_seconds;
     if (bytes) *bytes = c->prof_bytes;
+    return PGD_OK;
+}
+
+int pgd_prof_read_own(pgd_handle h, double *own_bytes) {
+    PGD_CTX(c, h);
+    prof_flush(c);
+    if (own_bytes) *own_bytes = c->prof_own_bytes;
+    return PGD_OK;
+}
+
+int pgd_kernel_counts(pgd_handle h, int64_t *out, int n) {
+    PGD_CTX(c, h);
+    if (!out || n < 0) return fail(c, PGD_ERR_INVALID, "kernel_counts: invalid arguments");
+    for (int k = 0; k < n; ++k) out[k] = k < 8 ? c->kcount[k] : 0;
+    return PGD_OK;
+}
+
+int pgd_timer_start(pgd_handle h) {
+    PGD_CTX(c, h);
+    for (auto &e : c->timer_ev)
+        if (!e) PGD_HIP(c, hipEventCreate(&e));
+    PGD_HIP(c, hipEventRecord(c->timer_ev[0], c->stream));
+    return PGD_OK;
+}
+
+int pgd_timer_stop(pgd_handle h, double *seconds) {
+    PGD_CTX(c, h);
+    if (!c->timer_ev[0] || !c->timer_ev[1] || !seconds) return fail(c, PGD_ERR_INVALID, "timer_stop: no timer running");
+    PGD_HIP(c, hipEventRecord(c->timer_ev[1], c->stream));
+    PGD_HIP(c, hipEventSynchronize(c->timer_ev[1]));
+    float ms = 0.f;
+    PGD_HIP(c, hipEventElapsedTime(&ms, c->timer_ev[0], c->timer_ev[1]));
+    *seconds = 1e-3 * (double)ms;
     return PGD_OK;
 }
 

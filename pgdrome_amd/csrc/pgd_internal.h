@@ -62,15 +62,17 @@ struct Mesh : Obj {
     // slots (diagonal first) per row, 0 = the mesh does not qualify (rows longer than 8 + 7, or the slot of a
     // row in its lower neighbours' rows is not a function of its own pattern)
     int *sym_tab = nullptr;
-    int *sym_ld = nullptr;      // LDS deltas of the pattern slots for k_spmv_sym_grid3 (structured grids only)
     int sym_w = 0;
-    int sym_nx = 0, sym_ny = 0; // full structured vertex grid: row = x + nx y + nx ny z (0: not one)
+    // full structured vertex grid (row = x + nx y + nx ny z, every column a grid neighbour on one of eight diagonals;
+    // 0: not one): the slot arrays are then in DIAGONAL form - slot dx + 2 dy + 4 dz of row i = a(i, i + dx + nx dy + nx ny dz)
+    // - and the products are k_spmv_dia_march / k_spmv_dia_rows (pgd_spmv.hip)
+    int sym_nx = 0, sym_ny = 0;
     uint16_t *pids = nullptr;    // nv
     int *dict_off = nullptr;     // dict_count x DICT_DLEN relative offsets
     int dict_count = 0;          // 0: dictionary not available (irregular pattern) -> plain CSR kernel
     ~Mesh() override {
         for (void *p : {(void *)coords, (void *)cells, (void *)cellsN, (void *)v2c_ptr, (void *)v2c,
-                        (void *)row_ptr, (void *)cols, (void *)pids, (void *)dict_off, (void *)sym_tab, (void *)sym_ld})
+                        (void *)row_ptr, (void *)cols, (void *)pids, (void *)dict_off, (void *)sym_tab})
             if (p) (void)hipFree(p);
     }
 };
@@ -81,7 +83,8 @@ struct Csr : Obj {
     double *dinv = nullptr;    // lazily built inverse diagonal
     bool dinv_valid = false;
     // symmetric half storage of the same operator: sym_w arrays of nv doubles, slot s of row i at
-    // uvals[s * nv + i] (slot 0 = diagonal, then the entries right of it; zero padded)
+    // uvals[s * nv + i] (slot 0 = diagonal, then the entries right of it; zero padded); on structured vertex grids
+    // (Mesh::sym_nx > 0) the slots are the eight diagonals instead
     double *uvals = nullptr;
     bool uvals_valid = false;
     bool uvals_scaled = false;  // the slot arrays hold D^-1/2 A D^-1/2 (inside pgd_pcg_solve only)
@@ -139,6 +142,7 @@ struct Ctx {
     int spmv_rows = 64;           // rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256
     int64_t spmv_grid_min_plane_bytes = 0;   // structured grids whose planes of values are at least this large take k_spmv_sym_grid3
     int spmv_zchunk_force = 0;    // > 0: exactly this many planes per march whatever the grid size (tests)
+    int spmv_variant = 0;         // k_spmv_dia_march: register budget / pipelining variant (measuring)
     int spmv_zchunk = 16;         // k_spmv_sym_grid3: most planes a workgroup marches through (0: never use that kernel)
     int pcg_fold_reduce = 1;      // scaled recurrence: final reduction passes folded into the vector kernels (3 launches / iteration)
     int pcg_scaled = 1;           // pgd_pcg_solve on the symmetrically scaled system (no dinv / z passes) when the symmetric storage applies
@@ -151,7 +155,12 @@ struct Ctx {
     size_t ev_used = 0;
     int64_t prof_launches = 0, prof_seen = 0;
     double prof_seconds = 0.0, prof_bytes = 0.0;
+    double prof_own_bytes = 0.0;  // least bytes the kernels that were timed must move in their own storage form
+    int64_t kcount[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // launches per product kernel family (KC_*)
+    hipEvent_t timer_ev[2] = {nullptr, nullptr};     // pgd_timer_start / pgd_timer_stop
 };
+
+enum { KC_CSR = 0, KC_CSR_DICT = 1, KC_SYM_ROWS = 2, KC_DIA_ROWS = 3, KC_DIA_MARCH = 4, KC_MULTI = 5 };
 
 // ---- helpers implemented in pgd_ctx.hip
 Ctx *get_ctx(pgd_handle h);

@@ -302,12 +302,16 @@ static int prof_begin(Ctx *c, bool dot, bool store, bool *timed) {
     return PGD_OK;
 }
 
-static int prof_end(Ctx *c, const Mesh *m, int64_t nrows) {
+// own_per_row > 0: bytes per row the kernel that ran must move at least (its own storage form); < 0: -(bytes per
+// stored entry) of a CSR form, plus row pointer / pattern id, x and y per row
+static int prof_end(Ctx *c, const Mesh *m, int64_t nrows, double own_per_row) {
     PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
     c->ev_used += 2;
     c->prof_launches += 1;
     const double frac = m->nv > 0 ? (double)nrows / (double)m->nv : 0.0;
     c->prof_bytes += 12.0 * (double)m->nnz * frac + 20.0 * (double)nrows;
+    c->prof_own_bytes += own_per_row > 0 ? own_per_row * (double)nrows
+                                         : -own_per_row * (double)m->nnz * frac + (own_per_row < -10.0 ? 20.0 : 22.0) * (double)nrows;
     return PGD_OK;
 }
 
@@ -345,7 +349,8 @@ int launch_spmv(Ctx *c, const Mesh *m, const double *vals, const double *x, doub
     else if (dot) PGD_SPMV_LAUNCH(true, false);
     else PGD_SPMV_LAUNCH(false, true);
 #undef PGD_SPMV_LAUNCH
-    if (timed) PGD_TRY(prof_end(c, m, nrows));
+    c->kcount[use_dict ? KC_CSR_DICT : KC_CSR] += 1;
+    if (timed) PGD_TRY(prof_end(c, m, nrows, -(use_dict ? 8.0 : 12.0)));
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
 }
@@ -511,121 +516,181 @@ __global__ __launch_bounds__(64) void k_spmv_sym(SymArgs A) {
     }
 }
 
-// Structured vertex grids (row = x + nx y + nx ny z): a workgroup owns a 64 x 4 patch of (x, y) and MARCHES along z
-// through its chunk of planes.
-struct SymGridArgs {
-    SymArgs a;
-    int nx, ny, z0, z1, zchunk, tiles_x, tiles_y, npat;
+// ------------------------------------------------------------------ structured vertex grids: diagonal form
+// A full structured vertex grid (row = x + nx y + nx ny z; the 15-point pattern of the 6-tetrahedra-per-cube BoxMesh)
+// keeps the symmetric half storage in DIAGONAL form: slot s = dx + 2 dy + 4 dz of row i holds a(i, i + dx + nx dy + P dz),
+// (dx, dy, dz) in {0, 1}^3, P = nx ny; slots whose neighbour lies outside the grid hold 0.  Same 8 arrays of n doubles as
+// the position-ordered form of k_spmv_sym, but the slot of a coupling no longer depends on the row's pattern: no pattern
+// id, no table, no selects in the product - and the four couplings to the plane below are exactly what the workgroup
+// marching along z loaded one step earlier (its own slots 4..7), so they are handed on through LDS instead of being
+// fetched a second time over the fabric (r01: 0.63 GB of 2.0 GB per launch at 256^3 were those re-reads).
+// Summation order per row = ascending columns, like the sorted CSR row; absent couplings add an exact 0.
+struct DiaArgs {
+    const double *uvals, *x, *w;
+    double *y, *partials;
+    const int *flags;
+    int64_t n;              // slot stride in doubles
+    int nx, ny, nz;         // vertex grid of the (local) mesh
+    int row_begin, row_end; // k_spmv_dia_rows
+    int z0, z1, zchunk, tiles_x, tiles_y;   // k_spmv_dia_march
 };
 
-// x is served from LDS.  rocprofv3 --pmc showed the L1 address/data path (TA_BUSY 82-84 % of the launch), not HBM,
-// pacing both the CSR kernels and k_spmv_sym: per row they pull ~256 B through the L1 (values + 15 eight-byte x
-// gathers) although only 90-150 B cross the fabric; every re-ordering of the same loads (strips of planes, a march
-// with x through the L1, two rows per lane with 16-byte loads) ran at the same 430-450 us or slower on 256^3.
-// Here the workgroup keeps the three planes of x its patch touches (patch + one halo cell each way) in LDS -
-// each x value enters the L1 once per patch and plane - and every neighbour read is a ds_read_b64 at
-// centre + delta, delta looked up per pattern slot (sym_ld: dx + 66 dy and the plane dz).  The pattern records are
-// read from an LDS copy too.  Only the slot values and y still use the vector-memory path.
-constexpr int G3_HX = 66, G3_HY = 6, G3_SLICE = G3_HX * G3_HY;      // 64 x 4 patch + halo = 396 doubles per plane
-constexpr int G3_MAXP = 64;                                        // pattern records copied to LDS
-
-struct SymGrid3Args {
-    SymGridArgs g;
-    const int *ld;          // per pattern 16 ints: [k] = ((dz + 1) << 12) | (dx + 66 dy + 2048) for slot k (1..7 upper, 8.. lower)
-    int nzgrid;             // planes of the whole (local) grid
-};
-
+// row order, any row range: small grids, ranges that are not whole planes, products with w != x
 template <bool DOT, bool STORE>
-__global__ __launch_bounds__(256) void k_spmv_sym_grid3(SymGrid3Args H) {
-    __shared__ double s_x[3 * G3_SLICE];
-    __shared__ __align__(16) int s_tab[G3_MAXP * 16];
-    __shared__ __align__(16) int s_ld[G3_MAXP * 16];
+__global__ __launch_bounds__(64) void k_spmv_dia_rows(DiaArgs A) {
+    if (A.flags && A.flags[0]) return;
+    const int tid = threadIdx.x;
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int r0 = A.row_begin + b * 64;
+    const int nr = min(64, A.row_end - r0);
+    const int64_t row = r0 + (tid < nr ? tid : 0);
+    const int64_t P = (int64_t)A.nx * A.ny;
+    const int z = (int)(row / P);
+    const int rem = (int)(row - (int64_t)z * P);
+    const int y = rem / A.nx, x = rem - y * A.nx;
+    double uv[8], ux[8], lv[8], lx[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int dx = s & 1, dy = (s >> 1) & 1, dz = s >> 2;
+        const int64_t off = dx + (int64_t)A.nx * dy + P * dz;
+        const bool up = x + dx < A.nx && y + dy < A.ny && z + dz < A.nz;
+        const bool lo = s > 0 && x >= dx && y >= dy && z >= dz;
+        uv[s] = A.uvals[(int64_t)s * A.n + row];                        // 0 where the neighbour does not exist
+        ux[s] = A.x[up ? row + off : row];
+        const double t = A.uvals[(int64_t)s * A.n + (lo ? row - off : row)];
+        lv[s] = lo ? t : 0.0;
+        lx[s] = A.x[lo ? row - off : row];
+    }
+    double acc = 0.0;
+#pragma unroll
+    for (int s = 7; s >= 1; --s) acc = fma(lv[s], lx[s], acc);          // ascending columns: lower entries first
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc = fma(uv[s], ux[s], acc);
+    if (STORE && tid < nr) A.y[r0 + tid] = acc;
+    if (DOT) {
+        const double v = (tid < nr) ? acc * A.w[r0 + tid] : 0.0;
+        const double sum = wave_sum(v);
+        if (tid == 0) A.partials[b] = sum;
+    }
+}
+
+// A 256-thread workgroup owns a 64 x 4 patch of (x, y) and MARCHES along z through its chunk of planes.
+// rocprofv3 --pmc (r01g) showed the L1 address/data path, not HBM, pacing every product that gathers x through the L1;
+// so the three planes of x the patch touches (patch + one halo cell each way) live in an LDS ring - each x value enters
+// the L1 once per patch and plane, the next plane's cells are fetched while the current plane is computed - and every
+// neighbour read is a ds_read_b64 at centre + constant.  The plane-below couplings come from the LDS copy the workgroup
+// made of its own slots 4..7 one step earlier; only the patch's low-x lane and low-y wave fetch theirs (they belong to
+// the neighbouring patch).  The vector-memory path carries the own slot values (64 B per row), the three in-plane lower
+// couplings (served by L1 / L2: the neighbouring lanes and waves load them as their own in the same step) and y.
+constexpr int DM_HX = 66, DM_HY = 6, DM_SLICE = DM_HX * DM_HY;      // 64 x 4 patch + halo = 396 doubles per plane
+
+// uniform base pointer + 32-bit byte offset per lane: the saddr form of global_load (one offset VGPR serves all slots)
+__device__ __forceinline__ double ldo(const double *base, unsigned byte_off) {
+    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+
+template <bool DOT, bool STORE, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_spmv_dia_march(DiaArgs A) {
+    __shared__ double s_x[3 * DM_SLICE];
+    __shared__ double s_lo[4 * 256];                        // slots 4..7 of the plane below, one cell per thread
     __shared__ double s_red[4];
-    const SymGridArgs &G = H.g;
-    const SymArgs &A = G.a;
     if (A.flags && A.flags[0]) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    for (int k = tid; k < G.npat * 16; k += 256) { s_tab[k] = A.tab[k]; s_ld[k] = H.ld[k]; }
     const int b = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_chunk = G.tiles_x * G.tiles_y;
+    const int per_chunk = A.tiles_x * A.tiles_y;
     const int chunk = b / per_chunk, tile = b - chunk * per_chunk;
-    const int ty = tile / G.tiles_x, tx = tile - ty * G.tiles_x;
+    const int ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
     const int x0 = tx * 64, y0 = ty * 4;
     const int x = x0 + lane, y = y0 + wv;
-    const bool live = x < G.nx && y < G.ny;
-    const int64_t plane = (int64_t)G.nx * G.ny;
-    const int64_t base = (live ? x : 0) + (int64_t)G.nx * (live ? y : 0);
-    const int centre = (wv + 1) * G3_HX + lane + 1;
-    const int za = G.z0 + chunk * G.zchunk, zb = min(G.z1, za + G.zchunk);
+    const bool live = x < A.nx && y < A.ny;
+    const bool inx = live && x > 0, iny = live && y > 0, inxy = inx && iny;
+    const bool ldx = lane > 0, ldy = wv > 0;               // the lower neighbour in x / y is a thread of this workgroup
+    const unsigned nx8 = 8u * (unsigned)A.nx;
+    const int64_t P = (int64_t)A.nx * A.ny, n = A.n;
+    const unsigned P8 = 8u * (unsigned)P;                   // a plane of doubles is < 4 GB (n < 2^31 rows)
+    const unsigned boff = live ? 8u * (unsigned)(x + A.nx * y) : 0u;      // byte offset of the row inside its plane
+    const int centre = (wv + 1) * DM_HX + lane + 1;
+    const int za = A.z0 + chunk * A.zchunk, zb = min(A.z1, za + A.zchunk);
     // the two halo-patch cells this thread stages per plane (396 cells, 256 threads)
-    int64_t goff[2];
+    unsigned goff[2];
     bool gok[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int i = tid + q * 256;
-        const int ly = i / G3_HX, lx = i - ly * G3_HX;
+        const int ly = i / DM_HX, lx = i - ly * DM_HX;
         const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-        gok[q] = i < G3_SLICE && gx >= 0 && gx < G.nx && gy >= 0 && gy < G.ny;
-        goff[q] = gok[q] ? gx + (int64_t)G.nx * gy : 0;
+        gok[q] = i < DM_SLICE && gx >= 0 && gx < A.nx && gy >= 0 && gy < A.ny;
+        goff[q] = gok[q] ? 8u * (unsigned)(gx + A.nx * gy) : 0u;
     }
     auto fetch = [&](int z, double v[2]) {
-        const bool zok = z >= 0 && z < H.nzgrid;
+        const bool zok = z >= 0 && z < A.nz;
+        const double *xz = A.x + P * (zok ? z : 0);         // uniform
 #pragma unroll
-        for (int q = 0; q < 2; ++q) v[q] = (zok && gok[q]) ? A.x[goff[q] + plane * z] : 0.0;
+        for (int q = 0; q < 2; ++q) v[q] = (zok && gok[q]) ? ldo(xz, goff[q]) : 0.0;
     };
     auto put = [&](int z, const double v[2]) {
         const int sl = ((z % 3) + 3) % 3;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-            if (tid + q * 256 < G3_SLICE) s_x[sl * G3_SLICE + tid + q * 256] = v[q];
+            if (tid + q * 256 < DM_SLICE) s_x[sl * DM_SLICE + tid + q * 256] = v[q];
     };
     double dot = 0.0;
     if (za < zb) {
         double v[2];
         for (int z = za - 1; z <= za + 1; ++z) { fetch(z, v); put(z, v); }
+        if (za > 0) {
+            const double *ub = A.uvals + P * (za - 1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) s_lo[s * 256 + tid] = ldo(ub + (int64_t)(4 + s) * n, boff);
+        }
     }
     __syncthreads();
     for (int z = za; z < zb; ++z) {
         double vn[2];
         fetch(z + 2, vn);                                   // in flight while this plane is computed
-        const int64_t row = base + plane * z;
-        const int pid = A.pids[row];
-        const int *t = s_tab + pid * 16, *ld = s_ld + pid * 16;
-        const int hdr = t[0], ulen = hdr & 15, llen = (hdr >> 4) & 15;
+        const double *uz = A.uvals + P * z;                 // uniform: slot 0 of this plane; slot s at + s n
+        double uv[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) uv[s] = ldo(uz + (int64_t)s * n, boff);
+        // in-plane lower couplings: slot s of the row s names (L1 / L2 hits)
+        const double t1 = ldo(uz + n, inx ? boff - 8u : boff);
+        const double t2 = ldo(uz + 2 * n, iny ? boff - nx8 : boff);
+        const double t3 = ldo(uz + 3 * n, inxy ? boff - nx8 - 8u : boff);
+        double l4 = 0.0, l5 = 0.0, l6 = 0.0, l7 = 0.0;
+        if (z > 0) {                                        // uniform
+            const double *um = uz - P;                      // the plane below
+            l4 = live ? s_lo[tid] : 0.0;
+            if (inx) l5 = ldx ? s_lo[256 + tid - 1] : ldo(um + 5 * n, boff - 8u);
+            if (iny) l6 = ldy ? s_lo[512 + tid - 64] : ldo(um + 6 * n, boff - nx8);
+            if (inxy) l7 = (ldx && ldy) ? s_lo[768 + tid - 65] : ldo(um + 7 * n, boff - nx8 - 8u);
+        }
+        const double l1 = inx ? t1 : 0.0, l2 = iny ? t2 : 0.0, l3 = inxy ? t3 : 0.0;
         const int sl0 = ((z - 1) % 3 + 3) % 3;             // slice of plane z - 1; planes z, z + 1 follow cyclically
-        int sb[3];
-        sb[0] = sl0 * G3_SLICE; sb[1] = ((sl0 + 1) % 3) * G3_SLICE; sb[2] = ((sl0 + 2) % 3) * G3_SLICE;
-        double uv[8], lv[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) uv[s] = A.uvals[(int64_t)s * A.n + row];                  // zero beyond ulen
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {
-            const bool on = m < llen;
-            const int64_t src = row - (on ? t[8 + m] : 0);
-            const int slot = on ? (hdr >> (8 + 3 * m)) & 7 : 0;
-            lv[m] = A.uvals[(int64_t)slot * A.n + src];
-        }
-        const double xc = s_x[sb[1] + centre];
-        double acc = 0.0;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) {                      // ascending columns: lower entries first
-            const bool on = m < llen;
-            const int code = on ? ld[8 + m] : ((1 << 12) | 2048);
-            const double xv = s_x[sb[code >> 12] + centre + (code & 4095) - 2048];
-            acc = fma(on ? lv[m] : 0.0, xv, acc);
-        }
-        acc = fma(uv[0], xc, acc);
-#pragma unroll
-        for (int s = 1; s < 8; ++s) {
-            const bool on = s < ulen;
-            const int code = on ? ld[s] : ((1 << 12) | 2048);
-            const double xv = s_x[sb[code >> 12] + centre + (code & 4095) - 2048];
-            acc = fma(uv[s], xv, acc);
-        }
-        if (STORE && live) A.y[row] = acc;
-        if (DOT && live) dot = fma(acc, xc, dot);           // the PCG product: w is x itself (checked by the launcher)
-        __syncthreads();                                    // everyone is done with plane z - 1
+        const double *xm = s_x + sl0 * DM_SLICE + centre;
+        const double *xc = s_x + ((sl0 + 1) % 3) * DM_SLICE + centre;
+        const double *xp = s_x + ((sl0 + 2) % 3) * DM_SLICE + centre;
+        const double x00 = xc[0];
+        double acc = l7 * xm[-DM_HX - 1];                   // ascending columns: lower entries first
+        acc = fma(l6, xm[-DM_HX], acc);
+        acc = fma(l5, xm[-1], acc);
+        acc = fma(l4, xm[0], acc);
+        acc = fma(l3, xc[-DM_HX - 1], acc);
+        acc = fma(l2, xc[-DM_HX], acc);
+        acc = fma(l1, xc[-1], acc);
+        acc = fma(uv[0], x00, acc);
+        acc = fma(uv[1], xc[1], acc);
+        acc = fma(uv[2], xc[DM_HX], acc);
+        acc = fma(uv[3], xc[DM_HX + 1], acc);
+        acc = fma(uv[4], xp[0], acc);
+        acc = fma(uv[5], xp[1], acc);
+        acc = fma(uv[6], xp[DM_HX], acc);
+        acc = fma(uv[7], xp[DM_HX + 1], acc);
+        if (STORE && live) *reinterpret_cast<double *>(reinterpret_cast<char *>(A.y + P * z) + boff) = acc;
+        if (DOT && live) dot = fma(acc, x00, dot);          // the PCG product: w is x itself (checked by the launcher)
+        __syncthreads();                                    // everyone is done with plane z - 1 and with s_lo
         put(z + 2, vn);                                     // ... whose slice receives plane z + 2
+#pragma unroll
+        for (int s = 0; s < 4; ++s) s_lo[s * 256 + tid] = uv[4 + s];
         __syncthreads();
     }
     if (DOT) {
@@ -636,25 +701,200 @@ __global__ __launch_bounds__(256) void k_spmv_sym_grid3(SymGrid3Args H) {
     }
 }
 
-// every neighbour a pattern names must be a grid neighbour of the row (x + dx, y + dy, z + dz inside the grid): only
-// then is "x at row + offset" the LDS cell centre + delta of k_spmv_sym_grid3
-__global__ __launch_bounds__(TPB) void k_grid_verify(const uint16_t *__restrict__ pids, const int *__restrict__ tab,
-                                                     const int *__restrict__ ld, int64_t n, int nx, int ny, int nz,
-                                                     int *__restrict__ flags) {
-    const int64_t r = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (r >= n) return;
-    const int64_t P = (int64_t)nx * ny;
-    const int z = (int)(r / P), y = (int)((r - z * P) / nx), x = (int)(r - z * P - (int64_t)y * nx);
-    const int *t = tab + (int)pids[r] * 16, *l = ld + (int)pids[r] * 16;
-    const int hdr = t[0], ulen = hdr & 15, llen = (hdr >> 4) & 15;
-    bool ok = true;
-    for (int k = 1; k < 16; ++k) {
-        if ((k < 8 && k >= ulen) || (k >= 8 && k - 8 >= llen)) continue;
-        const int code = l[k], dz = (code >> 12) - 1, in = (code & 4095) - 2048;
-        const int dy = (in + G3_HX + G3_HX / 2) / G3_HX - 1, dx = in - dy * G3_HX;      // in = dx + 66 dy
-        if (x + dx < 0 || x + dx >= nx || y + dy < 0 || y + dy >= ny || z + dz < 0 || z + dz >= nz) ok = false;
+// The same march with BUFFER loads: one resource descriptor per array (SGPRs), the row's byte offset inside its plane
+// in ONE VGPR for all slots, slot and plane offsets in the scalar offset operand - no 64-bit address arithmetic per
+// lane, ~30 VGPRs fewer, so 8 waves per SIMD fit without spilling.  Needs 8 n doubles of slot arrays within the
+// 4 GiB range of a descriptor (n < 2^26 rows; the launcher checks).
+typedef int v2i_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ double bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+
+template <bool DOT, bool STORE, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_spmv_dia_march_buf(DiaArgs A) {
+    __shared__ double s_x[3 * DM_SLICE];
+    __shared__ double s_lo[4 * 256];
+    __shared__ double s_red[4];
+    if (A.flags && A.flags[0]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_chunk = A.tiles_x * A.tiles_y;
+    const int chunk = b / per_chunk, tile = b - chunk * per_chunk;
+    const int ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+    const int x0 = tx * 64, y0 = ty * 4;
+    const int x = x0 + lane, y = y0 + wv;
+    const bool live = x < A.nx && y < A.ny;
+    const bool inx = live && x > 0, iny = live && y > 0, inxy = inx && iny;
+    const bool ldx = lane > 0, ldy = wv > 0;
+    const unsigned nx8 = 8u * (unsigned)A.nx;
+    const unsigned P8 = 8u * (unsigned)A.nx * (unsigned)A.ny, n8 = 8u * (unsigned)A.n;
+    const unsigned boff = live ? 8u * (unsigned)(x + A.nx * y) : 0u;
+    const int centre = (wv + 1) * DM_HX + lane + 1;
+    const int za = A.z0 + chunk * A.zchunk, zb = min(A.z1, za + A.zchunk);
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(A.uvals, 8u * n8);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(A.x, P8 * (unsigned)A.nz);
+    unsigned goff[2];
+    bool gok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = tid + q * 256;
+        const int ly = i / DM_HX, lx = i - ly * DM_HX;
+        const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+        gok[q] = i < DM_SLICE && gx >= 0 && gx < A.nx && gy >= 0 && gy < A.ny;
+        goff[q] = gok[q] ? 8u * (unsigned)(gx + A.nx * gy) : 0u;
     }
-    if (!ok) flags[0] = 1;
+    auto fetch = [&](int z, double v[2]) {
+        const bool zok = z >= 0 && z < A.nz;
+        const unsigned so = zok ? P8 * (unsigned)z : 0u;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const double t = bld(rx, goff[q], so); v[q] = (zok && gok[q]) ? t : 0.0; }
+    };
+    auto put = [&](int z, const double v[2]) {
+        const int sl = ((z % 3) + 3) % 3;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (tid + q * 256 < DM_SLICE) s_x[sl * DM_SLICE + tid + q * 256] = v[q];
+    };
+    double dot = 0.0;
+    if (za < zb) {
+        double v[2];
+        for (int z = za - 1; z <= za + 1; ++z) { fetch(z, v); put(z, v); }
+        if (za > 0) {
+            const unsigned so = P8 * (unsigned)(za - 1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) s_lo[s * 256 + tid] = bld(ru, boff, so + (unsigned)(4 + s) * n8);
+        }
+    }
+    __syncthreads();
+    for (int z = za; z < zb; ++z) {
+        double vn[2];
+        fetch(z + 2, vn);
+        const unsigned so = P8 * (unsigned)z;               // scalar: this plane inside slot 0; slot s at + s n8
+        double uv[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) uv[s] = bld(ru, boff, so + (unsigned)s * n8);
+        const double t1 = bld(ru, inx ? boff - 8u : boff, so + n8);
+        const double t2 = bld(ru, iny ? boff - nx8 : boff, so + 2u * n8);
+        const double t3 = bld(ru, inxy ? boff - nx8 - 8u : boff, so + 3u * n8);
+        double l4 = 0.0, l5 = 0.0, l6 = 0.0, l7 = 0.0;
+        if (z > 0) {                                        // uniform
+            const unsigned sm = so - P8;                    // the plane below
+            l4 = live ? s_lo[tid] : 0.0;
+            if (inx) l5 = ldx ? s_lo[256 + tid - 1] : bld(ru, boff - 8u, sm + 5u * n8);
+            if (iny) l6 = ldy ? s_lo[512 + tid - 64] : bld(ru, boff - nx8, sm + 6u * n8);
+            if (inxy) l7 = (ldx && ldy) ? s_lo[768 + tid - 65] : bld(ru, boff - nx8 - 8u, sm + 7u * n8);
+        }
+        const double l1 = inx ? t1 : 0.0, l2 = iny ? t2 : 0.0, l3 = inxy ? t3 : 0.0;
+        const int sl0 = ((z - 1) % 3 + 3) % 3;
+        const double *xm = s_x + sl0 * DM_SLICE + centre;
+        const double *xc = s_x + ((sl0 + 1) % 3) * DM_SLICE + centre;
+        const double *xp = s_x + ((sl0 + 2) % 3) * DM_SLICE + centre;
+        const double x00 = xc[0];
+        double acc = l7 * xm[-DM_HX - 1];
+        acc = fma(l6, xm[-DM_HX], acc);
+        acc = fma(l5, xm[-1], acc);
+        acc = fma(l4, xm[0], acc);
+        acc = fma(l3, xc[-DM_HX - 1], acc);
+        acc = fma(l2, xc[-DM_HX], acc);
+        acc = fma(l1, xc[-1], acc);
+        acc = fma(uv[0], x00, acc);
+        acc = fma(uv[1], xc[1], acc);
+        acc = fma(uv[2], xc[DM_HX], acc);
+        acc = fma(uv[3], xc[DM_HX + 1], acc);
+        acc = fma(uv[4], xp[0], acc);
+        acc = fma(uv[5], xp[1], acc);
+        acc = fma(uv[6], xp[DM_HX], acc);
+        acc = fma(uv[7], xp[DM_HX + 1], acc);
+        if (STORE && live) *reinterpret_cast<double *>(reinterpret_cast<char *>(A.y) + (size_t)so + boff) = acc;
+        if (DOT && live) dot = fma(acc, x00, dot);
+        __syncthreads();
+        put(z + 2, vn);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) s_lo[s * 256 + tid] = uv[4 + s];
+        __syncthreads();
+    }
+    if (DOT) {
+        const double sum = wave_sum(dot);
+        if (lane == 0) s_red[wv] = sum;
+        __syncthreads();
+        if (tid == 0) A.partials[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    }
+}
+
+// every column of every row must be a grid neighbour (dx, dy, dz) in {-1, 0, 1}^3 of the row with |offset| one of the
+// eight diagonals: only then is the diagonal form lossless.  Checked once per mesh.
+__device__ __forceinline__ int dia_slot(int64_t d, int64_t nx, int64_t P, int *dx, int *dy, int *dz) {
+    const int64_t z = d / P, rem = d - z * P, yy = rem / nx, xx = rem - yy * nx;
+    *dx = (int)xx; *dy = (int)yy; *dz = (int)z;
+    return (z <= 1 && yy <= 1 && xx <= 1) ? (int)(xx + 2 * yy + 4 * z) : -1;
+}
+
+__global__ __launch_bounds__(TPB) void k_dia_verify(const int *__restrict__ row_ptr, const int *__restrict__ cols, int64_t nv,
+                                                    int nx, int ny, int nz, int *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= nv) return;
+    const int64_t P = (int64_t)nx * ny;
+    const int z = (int)(i / P), rem = (int)(i - (int64_t)z * P), y = rem / nx, x = rem - y * nx;
+    bool ok = true, diag = false;
+    for (int k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+        const int64_t d = (int64_t)cols[k] - i;
+        int dx, dy, dz;
+        const int s = dia_slot(d < 0 ? -d : d, nx, P, &dx, &dy, &dz);
+        if (s < 0) { ok = false; continue; }
+        if (d == 0) diag = true;
+        if (d > 0 && !(x + dx < nx && y + dy < ny && z + dz < nz)) ok = false;
+        if (d < 0 && !(x >= dx && y >= dy && z >= dz)) ok = false;
+    }
+    if (!ok || !diag) flags[0] = 1;
+}
+
+// CSR values -> the eight diagonals; also checks a_ij == a_ji to rounding (flags[1] counts violations)
+__global__ __launch_bounds__(TPB) void k_csr_to_dia(const int *__restrict__ row_ptr, const int *__restrict__ cols,
+                                                    const double *__restrict__ vals, int64_t nv, int nx, int ny,
+                                                    int64_t stride, double *__restrict__ uvals, int *__restrict__ flags) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= nv) return;
+    const int64_t P = (int64_t)nx * ny;
+    double out[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) out[s] = 0.0;
+    bool asym = false;
+    for (int k = row_ptr[i]; k < row_ptr[i + 1]; ++k) {
+        const int col = cols[k];
+        const int64_t d = (int64_t)col - i;
+        int dx, dy, dz;
+        if (d >= 0) {
+            const int s = dia_slot(d, nx, P, &dx, &dy, &dz);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) if (q == s) out[q] = vals[k];
+        } else {
+            double aji = 0.0;
+            for (int t = row_ptr[col]; t < row_ptr[col + 1]; ++t) if (cols[t] == (int)i) aji = vals[t];
+            const double aij = vals[k];
+            if (fabs(aij - aji) > 1e-12 * (fabs(aij) + fabs(aji))) asym = true;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) uvals[(int64_t)s * stride + i] = out[s];
+    if (asym) atomicAdd(&flags[1], 1);
+}
+
+// slot s of row i holds a(i, i + off_s): times s_i s_{i + off_s}
+__global__ __launch_bounds__(TPB) void k_dia_scale(double *__restrict__ uvals, int64_t stride, const double *__restrict__ sc,
+                                                   int64_t nv, int nx, int ny) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= nv) return;
+    const int64_t P = (int64_t)nx * ny;
+    const double si = sc[i];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        const int64_t j = i + (s & 1) + (int64_t)nx * ((s >> 1) & 1) + P * (s >> 2);
+        if (j < nv) uvals[(int64_t)s * stride + i] *= si * sc[j];      // slots without a neighbour hold 0 and keep it
+    }
 }
 
 int build_sym_tables(Ctx *c, Mesh *m) {
@@ -701,39 +941,18 @@ int build_sym_tables(Ctx *c, Mesh *m) {
         m->sym_ny = d[3] / d[1];
     }
     if (m->sym_nx > 0) {
-        // LDS deltas of every slot of every pattern for k_spmv_sym_grid3: offset = dx + nx dy + nx ny dz, each in -1..1
-        const int64_t nx = m->sym_nx, P = (int64_t)m->sym_nx * m->sym_ny;
-        std::vector<int> ld((size_t)DICT_MAXP * 16, (1 << 12) | 2048);
-        bool ok = true;
-        auto code = [&](int64_t off) -> int {
-            const int64_t dz = (off >= 0 ? (off + P / 2) / P : -((-off + P / 2) / P));
-            const int64_t rem = off - dz * P;
-            const int64_t dy = (rem >= 0 ? (rem + nx / 2) / nx : -((-rem + nx / 2) / nx));
-            const int64_t dx = rem - dy * nx;
-            if (dz < -1 || dz > 1 || dy < -1 || dy > 1 || dx < -1 || dx > 1) { ok = false; return (1 << 12) | 2048; }
-            return (int)(((dz + 1) << 12) | (dx + G3_HX * dy + 2048));
-        };
-        for (int q = 0; q < m->dict_count; ++q) {
-            const int hdr = tab[(size_t)q * 16], ulen = hdr & 15, llen = (hdr >> 4) & 15;
-            for (int sidx = 1; sidx < ulen; ++sidx) ld[(size_t)q * 16 + sidx] = code(tab[(size_t)q * 16 + sidx]);
-            for (int k = 0; k < llen; ++k) ld[(size_t)q * 16 + 8 + k] = code(-(int64_t)tab[(size_t)q * 16 + 8 + k]);
-        }
-        if (ok) {
-            PGD_TRY(dev_alloc(c, &p, ld.size() * sizeof(int))); m->sym_ld = (int *)p;
-            int *vf = nullptr;
-            PGD_TRY(dev_alloc(c, &p, 8 * sizeof(int))); vf = (int *)p;
-            PGD_HIP(c, hipMemsetAsync(vf, 0, 8 * sizeof(int), st));
-            PGD_HIP(c, hipMemcpyAsync(m->sym_ld, ld.data(), ld.size() * sizeof(int), hipMemcpyHostToDevice, st));
-            k_grid_verify<<<(int)((m->nv + TPB - 1) / TPB), TPB, 0, st>>>(m->pids, m->sym_tab, m->sym_ld, m->nv, m->sym_nx,
-                                                                        m->sym_ny, (int)(m->nv / P), vf);
-            int bad = 1;
-            PGD_HIP(c, hipMemcpyAsync(&bad, vf, sizeof bad, hipMemcpyDeviceToHost, st));
-            PGD_HIP(c, hipStreamSynchronize(st));
-            (void)hipFree(vf);
-            PGD_LAUNCH_CHECK(c);
-            if (bad) { (void)hipFree(m->sym_ld); m->sym_ld = nullptr; }
-        }
-        if (!m->sym_ld) m->sym_nx = m->sym_ny = 0;
+        // the diagonal form needs every column of every row to be a grid neighbour on one of the eight diagonals
+        const int nzg = (int)(m->nv / ((int64_t)m->sym_nx * m->sym_ny));
+        int *vf = nullptr;
+        PGD_TRY(dev_alloc(c, &p, 8 * sizeof(int))); vf = (int *)p;
+        PGD_HIP(c, hipMemsetAsync(vf, 0, 8 * sizeof(int), st));
+        k_dia_verify<<<(int)((m->nv + TPB - 1) / TPB), TPB, 0, st>>>(m->row_ptr, m->cols, m->nv, m->sym_nx, m->sym_ny, nzg, vf);
+        int bad = 1;
+        PGD_HIP(c, hipMemcpyAsync(&bad, vf, sizeof bad, hipMemcpyDeviceToHost, st));
+        PGD_HIP(c, hipStreamSynchronize(st));
+        (void)hipFree(vf);
+        PGD_LAUNCH_CHECK(c);
+        if (bad) m->sym_nx = m->sym_ny = 0;
     }
     return PGD_OK;
 }
@@ -755,7 +974,8 @@ __global__ __launch_bounds__(TPB) void k_sym_scale(double *__restrict__ uvals, i
 int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *sc) {
     if (!(a->uvals && a->uvals_valid) || a->uvals_scaled) return fail(c, PGD_ERR_INVALID, "sym_scale: no unscaled symmetric copy");
     const int g = (int)((m->nv + TPB - 1) / TPB);
-    if (m->sym_w == 4) k_sym_scale<4><<<g, TPB, 0, c->stream>>>(a->uvals, a->uvals_stride, m->pids, m->sym_tab, sc, m->nv);
+    if (m->sym_nx > 0) k_dia_scale<<<g, TPB, 0, c->stream>>>(a->uvals, a->uvals_stride, sc, m->nv, m->sym_nx, m->sym_ny);
+    else if (m->sym_w == 4) k_sym_scale<4><<<g, TPB, 0, c->stream>>>(a->uvals, a->uvals_stride, m->pids, m->sym_tab, sc, m->nv);
     else k_sym_scale<8><<<g, TPB, 0, c->stream>>>(a->uvals, a->uvals_stride, m->pids, m->sym_tab, sc, m->nv);
     PGD_LAUNCH_CHECK(c);
     a->uvals_scaled = true;
@@ -779,7 +999,8 @@ int ensure_sym(Ctx *c, const Mesh *m, Csr *a, bool *usable) {
     }
     PGD_HIP(c, hipMemsetAsync(c->flags + 4, 0, 4 * sizeof(int), c->stream));
     const int g = (int)((m->nv + TPB - 1) / TPB);
-    if (m->sym_w == 4) k_csr_to_sym<4><<<g, TPB, 0, c->stream>>>(m->row_ptr, a->vals, m->pids, m->sym_tab, m->nv, stride, a->uvals, c->flags + 4);
+    if (m->sym_nx > 0) k_csr_to_dia<<<g, TPB, 0, c->stream>>>(m->row_ptr, m->cols, a->vals, m->nv, m->sym_nx, m->sym_ny, stride, a->uvals, c->flags + 4);
+    else if (m->sym_w == 4) k_csr_to_sym<4><<<g, TPB, 0, c->stream>>>(m->row_ptr, a->vals, m->pids, m->sym_tab, m->nv, stride, a->uvals, c->flags + 4);
     else k_csr_to_sym<8><<<g, TPB, 0, c->stream>>>(m->row_ptr, a->vals, m->pids, m->sym_tab, m->nv, stride, a->uvals, c->flags + 4);
     int f[2] = {0, 0};
     PGD_HIP(c, hipMemcpyAsync(f, c->flags + 4, sizeof f, hipMemcpyDeviceToHost, c->stream));
@@ -808,38 +1029,66 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
     SymArgs A;
     A.uvals = a->uvals; A.x = x; A.w = w; A.y = y; A.partials = c->partials; A.flags = flags;
     A.tab = m->sym_tab; A.pids = m->pids; A.n = a->uvals_stride; A.row_begin = (int)r0; A.row_end = (int)r1;
-    // structured grid, plane-aligned row range, PCG product (w = x) or plain product: the LDS march
-    const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
-    if (c->spmv_zchunk > 0 && m->sym_w == 8 && plane > 0 && m->sym_ld && m->dict_count <= G3_MAXP && (!dot || w == x) &&
-        r0 % plane == 0 && r1 % plane == 0 && plane * 8 * m->sym_w >= c->spmv_grid_min_plane_bytes) {
-        SymGrid3Args H;
-        SymGridArgs &G = H.g;
-        G.a = A;
-        G.nx = m->sym_nx; G.ny = m->sym_ny; G.z0 = (int)(r0 / plane); G.z1 = (int)(r1 / plane);
-        G.npat = m->dict_count;
-        G.tiles_x = (G.nx + 63) / 64; G.tiles_y = (G.ny + 3) / 4;
-        H.ld = m->sym_ld; H.nzgrid = (int)(m->nv / plane);
-        // planes per march: as long as the launch still has ~8 workgroups per CU (a march of fewer than 4 planes pays
-        // its 3-plane prologue too often; below that the row-order kernel is the faster one: 64^3 11 us vs 15 us)
-        const int64_t tile_planes = (int64_t)G.tiles_x * G.tiles_y * (G.z1 - G.z0);
-        G.zchunk = (int)std::min<int64_t>(c->spmv_zchunk, tile_planes / (8 * (int64_t)c->num_cu));
-        if (c->spmv_zchunk_force > 0) G.zchunk = c->spmv_zchunk_force;       // tests: the march on any grid size
-        const int chunks = (G.zchunk >= 4 || c->spmv_zchunk_force > 0) ? (G.z1 - G.z0 + G.zchunk - 1) / G.zchunk : 0;
-        const int64_t gg = (int64_t)chunks * G.tiles_x * G.tiles_y;
+    if (m->sym_nx > 0) {
+        // structured vertex grid: the operator is held in diagonal form
+        const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
+        DiaArgs D;
+        D.uvals = a->uvals; D.x = x; D.w = w; D.y = y; D.partials = c->partials; D.flags = flags; D.n = a->uvals_stride;
+        D.nx = m->sym_nx; D.ny = m->sym_ny; D.nz = (int)(m->nv / plane);
+        D.row_begin = (int)r0; D.row_end = (int)r1;
+        D.z0 = (int)(r0 / plane); D.z1 = (int)(r1 / plane);
+        D.tiles_x = (D.nx + 63) / 64; D.tiles_y = (D.ny + 3) / 4; D.zchunk = 0;
+        // plane-aligned row range, PCG product (w = x) or plain product, planes large enough: the LDS march
+        int chunks = 0;
+        if (c->spmv_zchunk > 0 && (!dot || w == x) && r0 % plane == 0 && r1 % plane == 0 &&
+            plane * 64 >= c->spmv_grid_min_plane_bytes) {
+            // planes per march: as long as the launch still has ~8 workgroups per CU (a march of fewer than 4 planes pays
+            // its prologue too often; below that the row-order kernel is the faster one: 64^3 11 us vs 15 us)
+            const int64_t tile_planes = (int64_t)D.tiles_x * D.tiles_y * (D.z1 - D.z0);
+            D.zchunk = (int)std::min<int64_t>(c->spmv_zchunk, tile_planes / (8 * (int64_t)c->num_cu));
+            if (c->spmv_zchunk_force > 0) D.zchunk = c->spmv_zchunk_force;       // tests: the march on any grid size
+            chunks = (D.zchunk >= 4 || c->spmv_zchunk_force > 0) ? (D.z1 - D.z0 + D.zchunk - 1) / D.zchunk : 0;
+        }
+        const int64_t gg = (int64_t)chunks * D.tiles_x * D.tiles_y;
+        bool timed2 = false;
         if (gg > 0 && gg < ((int64_t)1 << 30)) {
             const int wgs = (int)gg;
             if (nparts_out) *nparts_out = wgs;
             if (dot) PGD_TRY(ensure_partials(c, (int64_t)wgs > 4 * MAX_VEC_BLOCKS ? wgs : 4 * MAX_VEC_BLOCKS));
-            G.a.partials = c->partials;
-            bool timed2 = false;
+            D.partials = c->partials;
             PGD_TRY(prof_begin(c, dot, store, &timed2));
-            if (dot && store) k_spmv_sym_grid3<true, true><<<wgs, 256, 0, c->stream>>>(H);
-            else if (dot) k_spmv_sym_grid3<true, false><<<wgs, 256, 0, c->stream>>>(H);
-            else k_spmv_sym_grid3<false, true><<<wgs, 256, 0, c->stream>>>(H);
-            if (timed2) PGD_TRY(prof_end(c, m, nrows));
-            PGD_LAUNCH_CHECK(c);
-            return PGD_OK;
+#define PGD_MARCH(W)                                                                                   \
+    do {                                                                                               \
+        if (dot && store) k_spmv_dia_march<true, true, W><<<wgs, 256, 0, c->stream>>>(D);              \
+        else if (dot) k_spmv_dia_march<true, false, W><<<wgs, 256, 0, c->stream>>>(D);                 \
+        else k_spmv_dia_march<false, true, W><<<wgs, 256, 0, c->stream>>>(D);                          \
+    } while (0)
+#define PGD_MARCHB(W)                                                                                  \
+    do {                                                                                               \
+        if (dot && store) k_spmv_dia_march_buf<true, true, W><<<wgs, 256, 0, c->stream>>>(D);          \
+        else if (dot) k_spmv_dia_march_buf<true, false, W><<<wgs, 256, 0, c->stream>>>(D);             \
+        else k_spmv_dia_march_buf<false, true, W><<<wgs, 256, 0, c->stream>>>(D);                      \
+    } while (0)
+            const bool buf_ok = (int64_t)a->uvals_stride * 64 < ((int64_t)1 << 32);
+            if (c->spmv_variant == 1) PGD_MARCH(8);
+            else if (c->spmv_variant == 2) PGD_MARCH(6);
+            else if (c->spmv_variant == 3 && buf_ok) PGD_MARCHB(1);
+            else if (c->spmv_variant == 4 && buf_ok) PGD_MARCHB(8);
+            else if (c->spmv_variant == 5 && buf_ok) PGD_MARCHB(6);
+            else PGD_MARCH(1);
+#undef PGD_MARCH
+#undef PGD_MARCHB
+            c->kcount[KC_DIA_MARCH] += 1;
+        } else {
+            PGD_TRY(prof_begin(c, dot, store, &timed2));
+            if (dot && store) k_spmv_dia_rows<true, true><<<nblk, 64, 0, c->stream>>>(D);
+            else if (dot) k_spmv_dia_rows<true, false><<<nblk, 64, 0, c->stream>>>(D);
+            else k_spmv_dia_rows<false, true><<<nblk, 64, 0, c->stream>>>(D);
+            c->kcount[KC_DIA_ROWS] += 1;
         }
+        if (timed2) PGD_TRY(prof_end(c, m, nrows, 8.0 * 8 + 16));
+        PGD_LAUNCH_CHECK(c);
+        return PGD_OK;
     }
     const int grid = nblk;
     bool timed = false;
@@ -853,7 +1102,8 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
     else if (dot) PGD_SYM_LAUNCH(true, false);
     else PGD_SYM_LAUNCH(false, true);
 #undef PGD_SYM_LAUNCH
-    if (timed) PGD_TRY(prof_end(c, m, nrows));
+    c->kcount[KC_SYM_ROWS] += 1;
+    if (timed) PGD_TRY(prof_end(c, m, nrows, 8.0 * m->sym_w + 18));
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
 }
@@ -872,6 +1122,7 @@ int launch_spmv_multi(Ctx *c, const Mesh *m, const double *vals, const double *x
         A.row_begin = (int)r0; A.row_end = (int)r1; A.ny = cnt;
         for (int k = 0; k < MAXY; ++k) A.ys[k] = ys[first + (k < cnt ? k : 0)];
         k_spmv_multi<<<nblk, TPB, 0, c->stream>>>(A);
+        c->kcount[KC_MULTI] += 1;
         PGD_LAUNCH_CHECK(c);
         PGD_TRY(reduce_partials(c, c->partials, nblk, cnt, S_TMP, -1, 0, 0));
         PGD_HIP(c, hipMemcpyAsync(out_host + first, c->slots + S_TMP, cnt * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -896,6 +1147,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_PCG_FOLD_REDUCE && value >= 0 && value <= 1) { c->pcg_fold_reduce = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_SCALED && value >= 0 && value <= 1) { c->pcg_scaled = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK && value >= 0 && value <= 65536) { c->spmv_zchunk = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_VARIANT && value >= 0 && value <= 16) { c->spmv_variant = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }
 

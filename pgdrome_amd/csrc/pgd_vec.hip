@@ -229,6 +229,30 @@ int vec_dot_range(Ctx *c, const double *x, const double *y, int64_t lo, int64_t 
     return reduce_partials(c, c->partials, g, 1, slot, -1, 0, 0);
 }
 
+// Calibration stream for the PMC byte model (tools/pmc_calib.py): one pass over a buffer with 8- or 16-byte loads
+// per lane, or one pass of 8- / 16-byte stores; the byte count is known, FETCH_SIZE / WRITE_SIZE are read beside it.
+template <int W, bool STORE>
+__global__ __launch_bounds__(TPB) void k_calib_stream(double *__restrict__ v, int64_t n, double *__restrict__ partials) {
+    typedef double d2_t __attribute__((ext_vector_type(2)));
+    const int64_t stride = (int64_t)gridDim.x * TPB;
+    double acc = 0.0;
+    if (W == 8) {
+        for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
+            if (STORE) v[i] = 1.0; else acc += v[i];
+        }
+    } else {
+        d2_t *v2 = reinterpret_cast<d2_t *>(v);
+        for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n / 2; i += stride) {
+            if (STORE) { d2_t o; o.x = 1.0; o.y = 1.0; v2[i] = o; } else { const d2_t t = v2[i]; acc += t.x + t.y; }
+        }
+    }
+    if (!STORE) {
+        __shared__ double s_red[4];
+        const double sum = block_sum(acc, s_red);
+        if (threadIdx.x == 0) partials[blockIdx.x] = sum;
+    }
+}
+
 }  // namespace pgd
 
 using namespace pgd;
@@ -319,6 +343,24 @@ int pgd_vec_dot(pgd_handle h, pgd_handle xh, pgd_handle yh, int64_t lo, int64_t 
     PGD_TRY(vec_dot_range(c, x->d, y->d, lo, hi, S_TMP));
     PGD_HIP(c, hipMemcpyAsync(out, c->slots + S_TMP, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PGD_HIP(c, hipStreamSynchronize(c->stream));
+    return PGD_OK;
+}
+
+int pgd_calib_stream(pgd_handle h, pgd_handle vh, int bytes_per_lane, int store) {
+    PGD_CTX(c, h);
+    Vec *v = get_vec(c, vh);
+    if (!v || (bytes_per_lane != 8 && bytes_per_lane != 16) || (v->n & 1))
+        return fail(c, PGD_ERR_INVALID, "calib_stream: invalid vector or width");
+    const int g = 4 * MAX_VEC_BLOCKS;
+    PGD_TRY(ensure_partials(c, g));
+    if (bytes_per_lane == 8) {
+        if (store) k_calib_stream<8, true><<<g, TPB, 0, c->stream>>>(v->d, v->n, c->partials);
+        else k_calib_stream<8, false><<<g, TPB, 0, c->stream>>>(v->d, v->n, c->partials);
+    } else {
+        if (store) k_calib_stream<16, true><<<g, TPB, 0, c->stream>>>(v->d, v->n, c->partials);
+        else k_calib_stream<16, false><<<g, TPB, 0, c->stream>>>(v->d, v->n, c->partials);
+    }
+    PGD_LAUNCH_CHECK(c);
     return PGD_OK;
 }
 

@@ -381,6 +381,171 @@ def test_symmetric_half_storage_products(ctx, name):
     ctx.mesh_free(h)
 
 
+GRID_SHAPES = {                      # vertices per axis: >= 2 x-tiles with a partial last tile, partial y-tiles, odd plane counts
+    "130x37x41": (130, 37, 41),
+    "65x4x9": (65, 4, 9),
+    "257x9x33": (257, 9, 33),
+    "64x8x5": (64, 8, 5),             # exactly one full tile in x
+}
+
+
+@pytest.mark.parametrize("shape", sorted(GRID_SHAPES))
+def test_grid_march_in_multi_tile_launch_shapes(ctx, shape):
+    """k_spmv_dia_march in the launch shapes the bench uses (several x-tiles, halo cells fetched from a neighbouring
+    tile, partial last tiles, several chunks per column with the prologue at za > 0, plane-aligned slabs) against the
+    oracle's product: <= 4e-15 * (|A| |x|) per row, and bit-identical to the row-order kernel of the same storage and to
+    the CSR kernels (same products, same order; absent couplings add an exact zero)."""
+    nx, ny, nz = GRID_SHAPES[shape]
+    coords, cells = F.box_mesh((0, 0, 0), (1.0, 0.7, 1.3), nx - 1, ny - 1, nz - 1)
+    h = ctx.mesh_upload(coords, cells)
+    n = coords.shape[0]
+    info = ctx.mesh_sym_info(h)
+    assert (info["slots"], info["nx"], info["ny"]) == (8, nx, ny)
+    K, M = F.assemble_atom(coords, cells, F.STIFF), F.assemble_atom(coords, cells, F.MASS)
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bc = boundary_dofs(coords)[::3].astype(np.int32)                 # a scattered part of the boundary is Dirichlet
+    op = ctx.op_combine(h, [ak, am], [1.0, 0.37], bc)
+    A, _ = F.apply_dirichlet((K + 0.37 * M).tocsr(), np.zeros(n), bc)
+    rng = np.random.default_rng(1234)
+    x = rng.uniform(-1, 1, n)
+    ref, rowabs = A @ x, np.abs(A) @ np.abs(x)
+    xv, yv = ctx.vec_from(x), ctx.vec_alloc(n)
+    ctx.flags_reset()
+    ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)                      # CSR (dictionary) kernel: no symmetric copy yet
+    y_csr = ctx.vec_download(yv)
+    assert np.all(np.abs(y_csr - ref) <= 4e-15 * rowabs + 1e-300)
+    assert ctx.op_symmetrize(op) is True
+    k0 = ctx.kernel_counts()
+    ctx.tune(7, 0)                                                   # adaptive: grids this small take the row-order kernel
+    ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 31)
+    y_rows, d_rows = ctx.vec_download(yv), ctx.slots_download(31, 1)[0]
+    k1 = ctx.kernel_counts()
+    assert k1["dia_rows"] == k0["dia_rows"] + 1 and k1["dia_march"] == k0["dia_march"]
+    assert np.all(np.abs(y_rows - ref) <= 4e-15 * rowabs + 1e-300)
+    assert np.array_equal(y_rows, y_csr)
+    assert abs(d_rows - x @ ref) <= 1e-13 * (np.abs(x) @ rowabs)
+    plane = nx * ny
+    try:
+        for zc in (1, 4, 16, 1000):                                  # planes per march, forced
+            ctx.tune(7, zc)
+            ctx.vec_fill(yv, -5.0)
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 32)
+            y = ctx.vec_download(yv)
+            assert ctx.kernel_counts()["dia_march"] > k1["dia_march"]
+            k1 = ctx.kernel_counts()
+            assert np.array_equal(y, y_rows), (shape, zc, np.abs(y - y_rows).max())
+            assert abs(ctx.slots_download(32, 1)[0] - x @ ref) <= 1e-13 * (np.abs(x) @ rowabs)
+            # a slab of whole planes, as a row-sharded rank calls it: rows outside untouched, halo planes read
+            z0, z1 = 1, nz - 2
+            ctx.vec_fill(yv, -7.0)
+            ctx.spmv_dot_slot(op, xv, yv, xv, z0 * plane, z1 * plane, 33)
+            y2 = ctx.vec_download(yv)
+            assert np.array_equal(y2[z0 * plane:z1 * plane], y_rows[z0 * plane:z1 * plane])
+            assert np.all(y2[:z0 * plane] == -7.0) and np.all(y2[z1 * plane:] == -7.0)
+            assert abs(ctx.slots_download(33, 1)[0] - x[z0 * plane:z1 * plane] @ ref[z0 * plane:z1 * plane]) <= \
+                1e-13 * (np.abs(x) @ rowabs)
+        # the plain product (no dot) takes the march as well
+        ctx.tune(7, 4)
+        # the scaled operator inside the PCG: D^-1/2 A D^-1/2 through k_dia_scale, checked through the solve
+        b = A @ rng.uniform(-1, 1, n)
+        bv, sv = ctx.vec_from(b), ctx.vec_alloc(n)
+        its, rel = ctx.pcg_solve(op, bv, sv, 1e-12, 0.0, 5000)
+        xs = ctx.vec_download(sv)
+        assert rel <= 1e-12 and np.linalg.norm(A @ xs - b) <= 1.01e-12 * np.linalg.norm(b)
+        ctx.tune(3, 0)                                               # ... and the same solve on the CSR kernels
+        ctx.vec_fill(sv, 0.0)
+        its_c, rel_c = ctx.pcg_solve(op, bv, sv, 1e-12, 0.0, 5000)
+        assert abs(its - its_c) <= 2 and np.linalg.norm(ctx.vec_download(sv) - xs) <= 1e-9 * np.linalg.norm(xs)
+    finally:
+        ctx.tune(7, 0)
+        ctx.tune(3, 1)
+    for v in (xv, yv, bv, sv):
+        ctx.vec_free(v)
+    for a in (op, ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
+@pytest.mark.parametrize("npts", [128, 256])
+def test_products_agree_at_bench_size(ctx, npts):
+    """The BENCH configuration's operator (256^3 P1 dofs, 255^3 x 6 tetrahedra; 128^3 = config 3's) through every product
+    kernel: k_spmv_dia_march with its adaptive march (16 planes at 256^3, 4 at 128^3), the row-order kernel, the
+    dictionary CSR kernel and the plain CSR kernel give the same y bit for bit; at 128^3 the CSR arrays are downloaded
+    and the oracle's C product and scipy's agree to rounding; at both sizes the size-independent properties hold
+    (K annihilates linear fields, M 1 sums to the volume, symmetry x.(A w) = w.(A x))."""
+    from pgdrome_amd import fem
+    from oracle import c_oracle
+    mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), npts - 1, npts - 1, npts - 1)
+    coords, cells = mesh.coordinates(), mesh.cells()
+    n = coords.shape[0]
+    h = ctx.mesh_upload(coords, cells)
+    del cells
+    assert ctx.mesh_sym_info(h) == {"slots": 8, "nx": npts, "ny": npts}
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    on_bnd = np.any((coords <= 1e-12) | (coords >= 1 - 1e-12), axis=1)
+    bc = np.where(on_bnd)[0].astype(np.int32)
+    op = ctx.op_combine(h, [ak, am], [1.0, 5.5], bc)
+    rng = np.random.default_rng(1234)
+    x = rng.uniform(-1, 1, n)
+    xv, yv, wv = ctx.vec_from(x), ctx.vec_alloc(n), ctx.vec_from(rng.uniform(-1, 1, n))
+    ys = {}
+    try:
+        ctx.flags_reset()
+        for name, knobs in (("csr", [(2, 0)]), ("csr_dict", [(2, 1)])):
+            for k, v in knobs:
+                ctx.tune(k, v)
+            c0 = ctx.kernel_counts()
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
+            assert ctx.kernel_counts()[name] == c0[name] + 1
+            ys[name] = (ctx.vec_download(yv), ctx.slots_download(30, 1)[0])
+        assert ctx.op_symmetrize(op) is True
+        for name, knobs in (("dia_march", [(6, 16)]), ("dia_rows", [(6, 0)])):
+            for k, v in knobs:
+                ctx.tune(k, v)
+            c0 = ctx.kernel_counts()
+            ctx.vec_fill(yv, -1.0)
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
+            assert ctx.kernel_counts()[name] == c0[name] + 1
+            ys[name] = (ctx.vec_download(yv), ctx.slots_download(30, 1)[0])
+    finally:
+        ctx.tune(2, 1)
+        ctx.tune(6, 16)
+    base = ys["csr"][0]
+    for name in ("csr_dict", "dia_march", "dia_rows"):
+        assert np.array_equal(ys[name][0], base), (name, np.abs(ys[name][0] - base).max())
+        assert abs(ys[name][1] - ys["csr"][1]) <= 1e-12 * np.abs(x) @ np.abs(base)
+    assert np.all(base[bc] == x[bc])                                   # Dirichlet rows are identity rows
+    # symmetry of the eliminated operator: w.(A x) = x.(A w)
+    ctx.spmv_dot_slot(op, xv, yv, wv, 0, n, 31)
+    d1 = ctx.slots_download(31, 1)[0]
+    tv = ctx.vec_alloc(n)
+    ctx.spmv_dot_slot(op, wv, tv, xv, 0, n, 32)
+    d2 = ctx.slots_download(32, 1)[0]
+    assert abs(d1 - d2) <= 1e-12 * np.abs(x) @ np.abs(base)
+    # size-independent properties of the atoms: K (a + b.x) = 0 in the interior, sum(M 1) = |Omega| = 1
+    lin = ctx.vec_from(0.3 + coords @ np.array([1.0, -2.0, 0.5]))
+    ctx.spmv(ak, lin, tv)
+    kl = ctx.vec_download(tv)
+    scale = 3.0 * (1.0 / (npts - 1))                                    # |K| |x| per interior row is O(h)
+    assert np.abs(kl[~on_bnd]).max() <= 1e-12 * scale
+    ones = ctx.vec_from(np.ones(n))
+    assert abs(ctx.bilinear(am, ones, ones) - 1.0) <= 1e-12
+    if npts == 128:
+        rp, cols = ctx.mesh_pattern(h)
+        vals = ctx.atom_download(op, cols.size)
+        y_c = c_oracle.spmv(rp, cols, vals, x)
+        A = sps.csr_matrix((vals, cols, rp), shape=(n, n))
+        rowabs = np.abs(A) @ np.abs(x)
+        assert np.all(np.abs(base - y_c) <= 4e-15 * rowabs + 1e-300)
+        assert np.all(np.abs(base - A @ x) <= 4e-15 * rowabs + 1e-300)
+        assert abs(A - A.T).max() <= 1e-12 * np.abs(vals).max()
+    for v in (xv, yv, wv, tv, lin, ones):
+        ctx.vec_free(v)
+    for a in (op, ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
 def test_vector_ops(ctx):
     rng = np.random.default_rng(5)
     for n in (1, 63, 64, 257, 100_003):

@@ -1,18 +1,25 @@
-"""A/B of the PCG product (y = A p with the fused p.q partial sums) from the CSR form (k_spmv_csr_dict16) and from
-the symmetric half storage (k_spmv_sym in row order, k_spmv_sym_grid3 marching along z with x in LDS) on an n^3 P1
-BoxMesh, interleaved rounds in one process.
+"""A/B of the PCG product (y = A p with the fused p.q partial sums) from the CSR forms (k_spmv_csr, k_spmv_csr_dict16)
+and from the symmetric half storage in diagonal form (k_spmv_dia_rows in row order, k_spmv_dia_march marching along
+z with x and the plane-below couplings in LDS) on an n^3 P1 BoxMesh; interleaved rounds in one process, every figure
+a HIP-event time over `reps` back-to-back launches on the library's stream.
 
     python tools/bench_spmv_sym.py [n ...]      (default: 256)
 """
 import os
 import sys
-import time
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pgdrome_amd import _lib, fem
 from pgdrome_amd import sizes as psizes
+
+MODES = [  # name, sym, dict, zchunk knob, zchunk force, variant
+    ("csr", 0, 0, 16, 0, 0), ("csr_dict16", 0, 1, 16, 0, 0), ("dia_rows", 1, 1, 0, 0, 0),
+    ("march adaptive v0", 1, 1, 16, 0, 0), ("march adaptive v1", 1, 1, 16, 0, 1), ("march adaptive v2", 1, 1, 16, 0, 2),
+    ("march 8 v0", 1, 1, 16, 8, 0), ("march 32 v0", 1, 1, 16, 32, 0), ("march 64 v0", 1, 1, 16, 64, 0),
+    ("march 32 v1", 1, 1, 16, 32, 1), ("march 64 v1", 1, 1, 16, 64, 1),
+]
 
 
 def main():
@@ -29,29 +36,25 @@ def main():
         x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, nv))
         y = ctx.vec_alloc(nv)
         alg = psizes.spmv_bytes(nv, nnz)
+        own = {"csr": alg, "csr_dict16": 8 * nnz + 22 * nv}
         used = ctx.op_symmetrize(op)
         print(f"n={n}^3 nv={nv} nnz={nnz}: symmetric storage usable: {used}", flush=True)
         ctx.flags_reset()
         for rnd in range(2):
-            for sym, zchunk in ((0, 0), (1, -1), (1, 0), (1, 4), (1, 8), (1, 16), (1, 32), (1, 64)):
-                # zchunk = planes per workgroup march of k_spmv_sym_grid3, forced (-1: k_spmv_sym in row order, 0: adaptive)
-                ctx.tune(3, sym)
-                ctx.tune(6, 0 if zchunk < 0 else 16)
-                ctx.tune(7, max(zchunk, 0))
+            for name, sym, dct, zk, zf, var in MODES:
+                ctx.tune(3, sym); ctx.tune(2, dct); ctx.tune(6, zk); ctx.tune(7, zf); ctx.tune(13, var)
                 for _ in range(3):
                     ctx.spmv_dot_slot(op, x, y, x, 0, nv, 30)
-                ctx.sync()
                 reps = 40
-                t0 = time.time()
+                ctx.timer_start()
                 for _ in range(reps):
                     ctx.spmv_dot_slot(op, x, y, x, 0, nv, 30)
-                ctx.sync()
-                wall = (time.time() - t0) / reps
-                print(f"  round {rnd} sym {sym} zchunk {zchunk}: {wall*1e6:.1f} us per product+reduce (wall) -> {alg/wall/1e9:.0f} GB/s of the CSR "
-                      f"formula = {alg/wall/8e12*100:.1f}% of 8 TB/s; p.q = {ctx.slots_download(30, 1)[0]:.12e}", flush=True)
-        ctx.tune(3, 1)
-        ctx.tune(6, 16)
-        ctx.tune(7, 0)
+                t = ctx.timer_stop() / reps
+                mine = own.get(name, 80 * nv)
+                print(f"  round {rnd} {name:20s}: {t*1e6:7.1f} us per product+reduce; CSR formula {alg/t/1e9:6.0f} GB/s; own minimum "
+                      f"{mine/1e9:.3f} GB -> {mine/t/1e9:5.0f} GB/s = {mine/t/8e12*100:4.1f}% of 8 TB/s; p.q = {ctx.slots_download(30, 1)[0]:.12e}",
+                      flush=True)
+        ctx.tune(3, 1); ctx.tune(2, 1); ctx.tune(6, 16); ctx.tune(7, 0); ctx.tune(13, 0)
         for v in (x, y):
             ctx.vec_free(v)
         for a in (ak, am, op):
