@@ -251,7 +251,7 @@ enum {
     PGD_TUNE_PCG_SCALED = 10,   /* 1 (default): pgd_pcg_solve runs CG on D^-1/2 A D^-1/2 (the same iterates as Jacobi-PCG,
                                    two vector passes per iteration fewer) when the symmetric storage applies; 0: unscaled */
     PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */
-    PGD_TUNE_SPMV_VARIANT = 13, /* k_spmv_dia_march: occupancy / pipelining variant (0 default; measuring only) */
+    PGD_TUNE_SPMV_VARIANT = 13, /* k_spmv_dia_march: 0 (default) 64 x 4 patches, 256 threads; 1: 64 x 8 patches, 512 threads */
     PGD_TUNE_SPMV_ZCHUNK = 6,   /* k_spmv_sym_grid3 (structured vertex grids, x planes in LDS): most planes per
                                    workgroup march (default 16; fewer while that keeps 8 workgroups per CU); 0 = off */
     PGD_TUNE_SPMV_SYM = 3,   /* 1 (default): the products of the SPD solves (pgd_pcg_solve, pgd_pcg_solve_sharded,

@@ -584,91 +584,91 @@ __global__ __launch_bounds__(64) void k_spmv_dia_rows(DiaArgs A) {
 // couplings (served by L1 / L2: the neighbouring lanes and waves load them as their own in the same step) and y.
 constexpr int DM_HX = 66, DM_HY = 6, DM_SLICE = DM_HX * DM_HY;      // 64 x 4 patch + halo = 396 doubles per plane
 
-// uniform base pointer + 32-bit byte offset per lane: the saddr form of global_load (one offset VGPR serves all slots)
-__device__ __forceinline__ double ldo(const double *base, unsigned byte_off) {
-    return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(base) + byte_off);
-}
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier, and on gfx9
+// the fence waits with vmcnt(0), i.e. also for the acknowledgement of the y store issued just before it in every step
+// of the march.  Nothing another wave reads through LDS depends on that store, so the march waits for its LDS
+// operations only (measured A/B in one process at 256^3: no difference with five workgroups per CU to overlap the
+// wait; kept because it is the weaker - and sufficient - ordering).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <bool DOT, bool STORE, int MINW>
-__global__ __launch_bounds__(256, MINW) void k_spmv_dia_march(DiaArgs A) {
-    __shared__ double s_x[3 * DM_SLICE];
-    __shared__ double s_lo[4 * 256];                        // slots 4..7 of the plane below, one cell per thread
-    __shared__ double s_red[4];
+template <bool DOT, bool STORE, int WY>
+__global__ __launch_bounds__(64 * WY) void k_spmv_dia_march(DiaArgs A) {
+    constexpr int NT = 64 * WY, HY = WY + 2, SLICE = DM_HX * HY;     // 64 x WY patch + halo
+    static_assert(2 * NT >= SLICE, "two staged cells per thread must cover the halo patch");
+    __shared__ double s_x[3 * SLICE];
+    __shared__ double s_lo[4 * NT];                         // slots 4..7 of the plane below, one cell per thread
+    __shared__ double s_red[WY];
     if (A.flags && A.flags[0]) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int b = xcd_remap(blockIdx.x, gridDim.x);
     const int per_chunk = A.tiles_x * A.tiles_y;
     const int chunk = b / per_chunk, tile = b - chunk * per_chunk;
     const int ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
-    const int x0 = tx * 64, y0 = ty * 4;
+    const int x0 = tx * 64, y0 = ty * WY;
     const int x = x0 + lane, y = y0 + wv;
     const bool live = x < A.nx && y < A.ny;
     const bool inx = live && x > 0, iny = live && y > 0, inxy = inx && iny;
     const bool ldx = lane > 0, ldy = wv > 0;               // the lower neighbour in x / y is a thread of this workgroup
-    const unsigned nx8 = 8u * (unsigned)A.nx;
-    const int64_t P = (int64_t)A.nx * A.ny, n = A.n;
-    const unsigned P8 = 8u * (unsigned)P;                   // a plane of doubles is < 4 GB (n < 2^31 rows)
-    const unsigned boff = live ? 8u * (unsigned)(x + A.nx * y) : 0u;      // byte offset of the row inside its plane
+    const int64_t nx = A.nx, P = (int64_t)A.nx * A.ny, n = A.n;
+    const int64_t base = live ? x + nx * y : 0;
     const int centre = (wv + 1) * DM_HX + lane + 1;
     const int za = A.z0 + chunk * A.zchunk, zb = min(A.z1, za + A.zchunk);
-    // the two halo-patch cells this thread stages per plane (396 cells, 256 threads)
-    unsigned goff[2];
+    // the two halo-patch cells this thread stages per plane
+    int64_t goff[2];
     bool gok[2];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
-        const int i = tid + q * 256;
+        const int i = tid + q * NT;
         const int ly = i / DM_HX, lx = i - ly * DM_HX;
         const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-        gok[q] = i < DM_SLICE && gx >= 0 && gx < A.nx && gy >= 0 && gy < A.ny;
-        goff[q] = gok[q] ? 8u * (unsigned)(gx + A.nx * gy) : 0u;
+        gok[q] = i < SLICE && gx >= 0 && gx < A.nx && gy >= 0 && gy < A.ny;
+        goff[q] = gok[q] ? gx + nx * gy : 0;
     }
     auto fetch = [&](int z, double v[2]) {
         const bool zok = z >= 0 && z < A.nz;
-        const double *xz = A.x + P * (zok ? z : 0);         // uniform
 #pragma unroll
-        for (int q = 0; q < 2; ++q) v[q] = (zok && gok[q]) ? ldo(xz, goff[q]) : 0.0;
+        for (int q = 0; q < 2; ++q) v[q] = (zok && gok[q]) ? A.x[goff[q] + P * z] : 0.0;
     };
     auto put = [&](int z, const double v[2]) {
         const int sl = ((z % 3) + 3) % 3;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-            if (tid + q * 256 < DM_SLICE) s_x[sl * DM_SLICE + tid + q * 256] = v[q];
+            if (tid + q * NT < SLICE) s_x[sl * SLICE + tid + q * NT] = v[q];
     };
     double dot = 0.0;
     if (za < zb) {
         double v[2];
         for (int z = za - 1; z <= za + 1; ++z) { fetch(z, v); put(z, v); }
         if (za > 0) {
-            const double *ub = A.uvals + P * (za - 1);
+            const int64_t rb = base + P * (za - 1);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) s_lo[s * 256 + tid] = ldo(ub + (int64_t)(4 + s) * n, boff);
+            for (int s = 0; s < 4; ++s) s_lo[s * NT + tid] = A.uvals[(int64_t)(4 + s) * n + rb];
         }
     }
     __syncthreads();
     for (int z = za; z < zb; ++z) {
         double vn[2];
         fetch(z + 2, vn);                                   // in flight while this plane is computed
-        const double *uz = A.uvals + P * z;                 // uniform: slot 0 of this plane; slot s at + s n
+        const int64_t row = base + P * z;
         double uv[8];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) uv[s] = ldo(uz + (int64_t)s * n, boff);
-        // in-plane lower couplings: slot s of the row s names (L1 / L2 hits)
-        const double t1 = ldo(uz + n, inx ? boff - 8u : boff);
-        const double t2 = ldo(uz + 2 * n, iny ? boff - nx8 : boff);
-        const double t3 = ldo(uz + 3 * n, inxy ? boff - nx8 - 8u : boff);
+        for (int s = 0; s < 8; ++s) uv[s] = A.uvals[(int64_t)s * n + row];
+        // in-plane lower couplings: slot s of the row s names (L1 / L2 hits, except across the patch border)
+        const double t1 = A.uvals[1 * n + (inx ? row - 1 : row)];
+        const double t2 = A.uvals[2 * n + (iny ? row - nx : row)];
+        const double t3 = A.uvals[3 * n + (inxy ? row - nx - 1 : row)];
         double l4 = 0.0, l5 = 0.0, l6 = 0.0, l7 = 0.0;
         if (z > 0) {                                        // uniform
-            const double *um = uz - P;                      // the plane below
             l4 = live ? s_lo[tid] : 0.0;
-            if (inx) l5 = ldx ? s_lo[256 + tid - 1] : ldo(um + 5 * n, boff - 8u);
-            if (iny) l6 = ldy ? s_lo[512 + tid - 64] : ldo(um + 6 * n, boff - nx8);
-            if (inxy) l7 = (ldx && ldy) ? s_lo[768 + tid - 65] : ldo(um + 7 * n, boff - nx8 - 8u);
+            if (inx) l5 = ldx ? s_lo[NT + tid - 1] : A.uvals[5 * n + row - P - 1];
+            if (iny) l6 = ldy ? s_lo[2 * NT + tid - 64] : A.uvals[6 * n + row - P - nx];
+            if (inxy) l7 = (ldx && ldy) ? s_lo[3 * NT + tid - 65] : A.uvals[7 * n + row - P - nx - 1];
         }
         const double l1 = inx ? t1 : 0.0, l2 = iny ? t2 : 0.0, l3 = inxy ? t3 : 0.0;
         const int sl0 = ((z - 1) % 3 + 3) % 3;             // slice of plane z - 1; planes z, z + 1 follow cyclically
-        const double *xm = s_x + sl0 * DM_SLICE + centre;
-        const double *xc = s_x + ((sl0 + 1) % 3) * DM_SLICE + centre;
-        const double *xp = s_x + ((sl0 + 2) % 3) * DM_SLICE + centre;
+        const double *xm = s_x + sl0 * SLICE + centre;
+        const double *xc = s_x + ((sl0 + 1) % 3) * SLICE + centre;
+        const double *xp = s_x + ((sl0 + 2) % 3) * SLICE + centre;
         const double x00 = xc[0];
         double acc = l7 * xm[-DM_HX - 1];                   // ascending columns: lower entries first
         acc = fma(l6, xm[-DM_HX], acc);
@@ -685,143 +685,24 @@ __global__ __launch_bounds__(256, MINW) void k_spmv_dia_march(DiaArgs A) {
         acc = fma(uv[5], xp[1], acc);
         acc = fma(uv[6], xp[DM_HX], acc);
         acc = fma(uv[7], xp[DM_HX + 1], acc);
-        if (STORE && live) *reinterpret_cast<double *>(reinterpret_cast<char *>(A.y + P * z) + boff) = acc;
+        if (STORE && live) A.y[row] = acc;
         if (DOT && live) dot = fma(acc, x00, dot);          // the PCG product: w is x itself (checked by the launcher)
-        __syncthreads();                                    // everyone is done with plane z - 1 and with s_lo
+        lds_barrier();                                      // everyone is done with plane z - 1 and with s_lo
         put(z + 2, vn);                                     // ... whose slice receives plane z + 2
 #pragma unroll
-        for (int s = 0; s < 4; ++s) s_lo[s * 256 + tid] = uv[4 + s];
-        __syncthreads();
+        for (int s = 0; s < 4; ++s) s_lo[s * NT + tid] = uv[4 + s];
+        lds_barrier();
     }
     if (DOT) {
         const double sum = wave_sum(dot);
         if (lane == 0) s_red[wv] = sum;
         __syncthreads();
-        if (tid == 0) A.partials[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-    }
-}
-
-// The same march with BUFFER loads: one resource descriptor per array (SGPRs), the row's byte offset inside its plane
-// in ONE VGPR for all slots, slot and plane offsets in the scalar offset operand - no 64-bit address arithmetic per
-// lane, ~30 VGPRs fewer, so 8 waves per SIMD fit without spilling.  Needs 8 n doubles of slot arrays within the
-// 4 GiB range of a descriptor (n < 2^26 rows; the launcher checks).
-typedef int v2i_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(p), 0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ double bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
-}
-
-template <bool DOT, bool STORE, int MINW>
-__global__ __launch_bounds__(256, MINW) void k_spmv_dia_march_buf(DiaArgs A) {
-    __shared__ double s_x[3 * DM_SLICE];
-    __shared__ double s_lo[4 * 256];
-    __shared__ double s_red[4];
-    if (A.flags && A.flags[0]) return;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int b = xcd_remap(blockIdx.x, gridDim.x);
-    const int per_chunk = A.tiles_x * A.tiles_y;
-    const int chunk = b / per_chunk, tile = b - chunk * per_chunk;
-    const int ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
-    const int x0 = tx * 64, y0 = ty * 4;
-    const int x = x0 + lane, y = y0 + wv;
-    const bool live = x < A.nx && y < A.ny;
-    const bool inx = live && x > 0, iny = live && y > 0, inxy = inx && iny;
-    const bool ldx = lane > 0, ldy = wv > 0;
-    const unsigned nx8 = 8u * (unsigned)A.nx;
-    const unsigned P8 = 8u * (unsigned)A.nx * (unsigned)A.ny, n8 = 8u * (unsigned)A.n;
-    const unsigned boff = live ? 8u * (unsigned)(x + A.nx * y) : 0u;
-    const int centre = (wv + 1) * DM_HX + lane + 1;
-    const int za = A.z0 + chunk * A.zchunk, zb = min(A.z1, za + A.zchunk);
-    const __amdgpu_buffer_rsrc_t ru = make_rsrc(A.uvals, 8u * n8);
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(A.x, P8 * (unsigned)A.nz);
-    unsigned goff[2];
-    bool gok[2];
+        if (tid == 0) {
+            double t = 0.0;
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int i = tid + q * 256;
-        const int ly = i / DM_HX, lx = i - ly * DM_HX;
-        const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
-        gok[q] = i < DM_SLICE && gx >= 0 && gx < A.nx && gy >= 0 && gy < A.ny;
-        goff[q] = gok[q] ? 8u * (unsigned)(gx + A.nx * gy) : 0u;
-    }
-    auto fetch = [&](int z, double v[2]) {
-        const bool zok = z >= 0 && z < A.nz;
-        const unsigned so = zok ? P8 * (unsigned)z : 0u;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) { const double t = bld(rx, goff[q], so); v[q] = (zok && gok[q]) ? t : 0.0; }
-    };
-    auto put = [&](int z, const double v[2]) {
-        const int sl = ((z % 3) + 3) % 3;
-#pragma unroll
-        for (int q = 0; q < 2; ++q)
-            if (tid + q * 256 < DM_SLICE) s_x[sl * DM_SLICE + tid + q * 256] = v[q];
-    };
-    double dot = 0.0;
-    if (za < zb) {
-        double v[2];
-        for (int z = za - 1; z <= za + 1; ++z) { fetch(z, v); put(z, v); }
-        if (za > 0) {
-            const unsigned so = P8 * (unsigned)(za - 1);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) s_lo[s * 256 + tid] = bld(ru, boff, so + (unsigned)(4 + s) * n8);
+            for (int k = 0; k < WY; k += 4) t += (s_red[k] + s_red[k + 1]) + (s_red[k + 2] + s_red[k + 3]);
+            A.partials[b] = t;
         }
-    }
-    __syncthreads();
-    for (int z = za; z < zb; ++z) {
-        double vn[2];
-        fetch(z + 2, vn);
-        const unsigned so = P8 * (unsigned)z;               // scalar: this plane inside slot 0; slot s at + s n8
-        double uv[8];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) uv[s] = bld(ru, boff, so + (unsigned)s * n8);
-        const double t1 = bld(ru, inx ? boff - 8u : boff, so + n8);
-        const double t2 = bld(ru, iny ? boff - nx8 : boff, so + 2u * n8);
-        const double t3 = bld(ru, inxy ? boff - nx8 - 8u : boff, so + 3u * n8);
-        double l4 = 0.0, l5 = 0.0, l6 = 0.0, l7 = 0.0;
-        if (z > 0) {                                        // uniform
-            const unsigned sm = so - P8;                    // the plane below
-            l4 = live ? s_lo[tid] : 0.0;
-            if (inx) l5 = ldx ? s_lo[256 + tid - 1] : bld(ru, boff - 8u, sm + 5u * n8);
-            if (iny) l6 = ldy ? s_lo[512 + tid - 64] : bld(ru, boff - nx8, sm + 6u * n8);
-            if (inxy) l7 = (ldx && ldy) ? s_lo[768 + tid - 65] : bld(ru, boff - nx8 - 8u, sm + 7u * n8);
-        }
-        const double l1 = inx ? t1 : 0.0, l2 = iny ? t2 : 0.0, l3 = inxy ? t3 : 0.0;
-        const int sl0 = ((z - 1) % 3 + 3) % 3;
-        const double *xm = s_x + sl0 * DM_SLICE + centre;
-        const double *xc = s_x + ((sl0 + 1) % 3) * DM_SLICE + centre;
-        const double *xp = s_x + ((sl0 + 2) % 3) * DM_SLICE + centre;
-        const double x00 = xc[0];
-        double acc = l7 * xm[-DM_HX - 1];
-        acc = fma(l6, xm[-DM_HX], acc);
-        acc = fma(l5, xm[-1], acc);
-        acc = fma(l4, xm[0], acc);
-        acc = fma(l3, xc[-DM_HX - 1], acc);
-        acc = fma(l2, xc[-DM_HX], acc);
-        acc = fma(l1, xc[-1], acc);
-        acc = fma(uv[0], x00, acc);
-        acc = fma(uv[1], xc[1], acc);
-        acc = fma(uv[2], xc[DM_HX], acc);
-        acc = fma(uv[3], xc[DM_HX + 1], acc);
-        acc = fma(uv[4], xp[0], acc);
-        acc = fma(uv[5], xp[1], acc);
-        acc = fma(uv[6], xp[DM_HX], acc);
-        acc = fma(uv[7], xp[DM_HX + 1], acc);
-        if (STORE && live) *reinterpret_cast<double *>(reinterpret_cast<char *>(A.y) + (size_t)so + boff) = acc;
-        if (DOT && live) dot = fma(acc, x00, dot);
-        __syncthreads();
-        put(z + 2, vn);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) s_lo[s * 256 + tid] = uv[4 + s];
-        __syncthreads();
-    }
-    if (DOT) {
-        const double sum = wave_sum(dot);
-        if (lane == 0) s_red[wv] = sum;
-        __syncthreads();
-        if (tid == 0) A.partials[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     }
 }
 
@@ -1037,7 +918,8 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         D.nx = m->sym_nx; D.ny = m->sym_ny; D.nz = (int)(m->nv / plane);
         D.row_begin = (int)r0; D.row_end = (int)r1;
         D.z0 = (int)(r0 / plane); D.z1 = (int)(r1 / plane);
-        D.tiles_x = (D.nx + 63) / 64; D.tiles_y = (D.ny + 3) / 4; D.zchunk = 0;
+        const int wy = c->spmv_variant == 1 ? 8 : 4;        // patch rows = waves per workgroup
+        D.tiles_x = (D.nx + 63) / 64; D.tiles_y = (D.ny + wy - 1) / wy; D.zchunk = 0;
         // plane-aligned row range, PCG product (w = x) or plain product, planes large enough: the LDS march
         int chunks = 0;
         if (c->spmv_zchunk > 0 && (!dot || w == x) && r0 % plane == 0 && r1 % plane == 0 &&
@@ -1045,7 +927,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
             // planes per march: as long as the launch still has ~8 workgroups per CU (a march of fewer than 4 planes pays
             // its prologue too often; below that the row-order kernel is the faster one: 64^3 11 us vs 15 us)
             const int64_t tile_planes = (int64_t)D.tiles_x * D.tiles_y * (D.z1 - D.z0);
-            D.zchunk = (int)std::min<int64_t>(c->spmv_zchunk, tile_planes / (8 * (int64_t)c->num_cu));
+            D.zchunk = (int)std::min<int64_t>(c->spmv_zchunk, tile_planes * (wy / 4) / (8 * (int64_t)c->num_cu));
             if (c->spmv_zchunk_force > 0) D.zchunk = c->spmv_zchunk_force;       // tests: the march on any grid size
             chunks = (D.zchunk >= 4 || c->spmv_zchunk_force > 0) ? (D.z1 - D.z0 + D.zchunk - 1) / D.zchunk : 0;
         }
@@ -1057,27 +939,14 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
             if (dot) PGD_TRY(ensure_partials(c, (int64_t)wgs > 4 * MAX_VEC_BLOCKS ? wgs : 4 * MAX_VEC_BLOCKS));
             D.partials = c->partials;
             PGD_TRY(prof_begin(c, dot, store, &timed2));
-#define PGD_MARCH(W)                                                                                   \
+#define PGD_MARCH(WY)                                                                                  \
     do {                                                                                               \
-        if (dot && store) k_spmv_dia_march<true, true, W><<<wgs, 256, 0, c->stream>>>(D);              \
-        else if (dot) k_spmv_dia_march<true, false, W><<<wgs, 256, 0, c->stream>>>(D);                 \
-        else k_spmv_dia_march<false, true, W><<<wgs, 256, 0, c->stream>>>(D);                          \
+        if (dot && store) k_spmv_dia_march<true, true, WY><<<wgs, 64 * WY, 0, c->stream>>>(D);         \
+        else if (dot) k_spmv_dia_march<true, false, WY><<<wgs, 64 * WY, 0, c->stream>>>(D);            \
+        else k_spmv_dia_march<false, true, WY><<<wgs, 64 * WY, 0, c->stream>>>(D);                     \
     } while (0)
-#define PGD_MARCHB(W)                                                                                  \
-    do {                                                                                               \
-        if (dot && store) k_spmv_dia_march_buf<true, true, W><<<wgs, 256, 0, c->stream>>>(D);          \
-        else if (dot) k_spmv_dia_march_buf<true, false, W><<<wgs, 256, 0, c->stream>>>(D);             \
-        else k_spmv_dia_march_buf<false, true, W><<<wgs, 256, 0, c->stream>>>(D);                      \
-    } while (0)
-            const bool buf_ok = (int64_t)a->uvals_stride * 64 < ((int64_t)1 << 32);
-            if (c->spmv_variant == 1) PGD_MARCH(8);
-            else if (c->spmv_variant == 2) PGD_MARCH(6);
-            else if (c->spmv_variant == 3 && buf_ok) PGD_MARCHB(1);
-            else if (c->spmv_variant == 4 && buf_ok) PGD_MARCHB(8);
-            else if (c->spmv_variant == 5 && buf_ok) PGD_MARCHB(6);
-            else PGD_MARCH(1);
+            if (wy == 8) PGD_MARCH(8); else PGD_MARCH(4);
 #undef PGD_MARCH
-#undef PGD_MARCHB
             c->kcount[KC_DIA_MARCH] += 1;
         } else {
             PGD_TRY(prof_begin(c, dot, store, &timed2));
@@ -1147,7 +1016,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_PCG_FOLD_REDUCE && value >= 0 && value <= 1) { c->pcg_fold_reduce = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_SCALED && value >= 0 && value <= 1) { c->pcg_scaled = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK && value >= 0 && value <= 65536) { c->spmv_zchunk = (int)value; return PGD_OK; }
-    if (knob == PGD_TUNE_SPMV_VARIANT && value >= 0 && value <= 16) { c->spmv_variant = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_VARIANT && value >= 0 && value <= 1) { c->spmv_variant = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }
 

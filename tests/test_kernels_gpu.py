@@ -426,8 +426,9 @@ def test_grid_march_in_multi_tile_launch_shapes(ctx, shape):
     assert abs(d_rows - x @ ref) <= 1e-13 * (np.abs(x) @ rowabs)
     plane = nx * ny
     try:
-        for zc in (1, 4, 16, 1000):                                  # planes per march, forced
+        for zc, patch in ((1, 0), (4, 0), (16, 0), (1000, 0), (1, 1), (5, 1), (1000, 1)):   # planes per march (forced), patch form
             ctx.tune(7, zc)
+            ctx.tune(13, patch)                                      # 0: 64 x 4 patches, 1: 64 x 8 patches
             ctx.vec_fill(yv, -5.0)
             ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 32)
             y = ctx.vec_download(yv)
@@ -444,7 +445,7 @@ def test_grid_march_in_multi_tile_launch_shapes(ctx, shape):
             assert np.all(y2[:z0 * plane] == -7.0) and np.all(y2[z1 * plane:] == -7.0)
             assert abs(ctx.slots_download(33, 1)[0] - x[z0 * plane:z1 * plane] @ ref[z0 * plane:z1 * plane]) <= \
                 1e-13 * (np.abs(x) @ rowabs)
-        # the plain product (no dot) takes the march as well
+        ctx.tune(13, 0)
         ctx.tune(7, 4)
         # the scaled operator inside the PCG: D^-1/2 A D^-1/2 through k_dia_scale, checked through the solve
         b = A @ rng.uniform(-1, 1, n)
@@ -458,6 +459,7 @@ def test_grid_march_in_multi_tile_launch_shapes(ctx, shape):
         assert abs(its - its_c) <= 2 and np.linalg.norm(ctx.vec_download(sv) - xs) <= 1e-9 * np.linalg.norm(xs)
     finally:
         ctx.tune(7, 0)
+        ctx.tune(13, 0)
         ctx.tune(3, 1)
     for v in (xv, yv, bv, sv):
         ctx.vec_free(v)

@@ -16,9 +16,8 @@ from pgdrome_amd import sizes as psizes
 
 MODES = [  # name, sym, dict, zchunk knob, zchunk force, variant
     ("csr", 0, 0, 16, 0, 0), ("csr_dict16", 0, 1, 16, 0, 0), ("dia_rows", 1, 1, 0, 0, 0),
-    ("march adaptive v0", 1, 1, 16, 0, 0), ("march adaptive v1", 1, 1, 16, 0, 1), ("march adaptive v2", 1, 1, 16, 0, 2),
-    ("march 8 v0", 1, 1, 16, 8, 0), ("march 32 v0", 1, 1, 16, 32, 0), ("march 64 v0", 1, 1, 16, 64, 0),
-    ("march 32 v1", 1, 1, 16, 32, 1), ("march 64 v1", 1, 1, 16, 64, 1),
+    ("march 64x4", 1, 1, 16, 0, 0), ("march 64x8", 1, 1, 16, 0, 1), ("march 64x4 z8", 1, 1, 16, 8, 0),
+    ("march 64x4 z32", 1, 1, 16, 32, 0), ("march 64x8 z32", 1, 1, 16, 32, 1),
 ]
 
 

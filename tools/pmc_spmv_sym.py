@@ -1,7 +1,7 @@
 """A few launches of the PCG product on the n^3 P1 BoxMesh for rocprofv3 --pmc passes.
 
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_x -- python3 tools/pmc_spmv_sym.py 256 MODE
-    MODE: csr (k_spmv_csr_dict16) | rows (k_spmv_sym, row order) | grid (k_spmv_sym_grid3, z-march, x in LDS) [zchunk]
+    MODE: csr (k_spmv_csr_dict16) | rows (k_spmv_dia_rows, row order) | grid (k_spmv_dia_march, z-march, x in LDS) [zchunk] [variant]
 """
 import os
 import sys
@@ -14,7 +14,7 @@ from pgdrome_amd import _lib, fem
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 mode = sys.argv[2] if len(sys.argv) > 2 else "grid"
 zchunk = int(sys.argv[3]) if len(sys.argv) > 3 else 32
-wg = int(sys.argv[4]) if len(sys.argv) > 4 else 3
+variant = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 ctx = _lib.Context(0)
 coords, cells = fem.box_mesh_arrays((0, 0, 0), (1, 1, 1), n - 1, n - 1, n - 1)
 mesh = ctx.mesh_upload(coords, cells)
@@ -27,10 +27,11 @@ y = ctx.vec_alloc(nv)
 ctx.tune(3, 0 if mode == "csr" else 1)
 ctx.tune(6, 64 if mode == "grid" else 0)
 ctx.tune(7, zchunk if mode == "grid" else 0)      # exactly this many planes per march
+ctx.tune(13, variant)
 if mode != "csr":
     assert ctx.op_symmetrize(op)
 ctx.flags_reset()
 for _ in range(6):
     ctx.spmv_dot_slot(op, x, y, x, 0, nv, 30)
 ctx.sync()
-print("done", n, mode, zchunk, wg)
+print("done", n, mode, zchunk, variant, ctx.kernel_counts())
