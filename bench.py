@@ -51,6 +51,8 @@ def parse():
                     help="sharded runs: drive the PCG recurrence from Python over torch.distributed instead of "
                          "the in-library loop (pgd_pcg_solve_sharded over RCCL)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-pmc", action="store_true", help="do not start rocprofv3 --pmc child processes for roofline.traffic")
+    ap.add_argument("--no-csr-section", action="store_true", help="skip the timed CSR products (roofline.csr_product)")
     return ap.parse_args()
 
 
@@ -118,19 +120,25 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    state = {"t0": None, "t1": None, "its0": 0, "its1": 0}
+    state = {"t0": None, "t1": None, "its0": 0, "its1": 0, "pcg0": 0.0, "pcg1": 0.0}
+    kc0 = kc1 = None
     W, K = args.warmup, args.steps
 
     def hook(passes):
+        nonlocal kc0, kc1
         if passes == W:
             barrier()
-            be.prof_enable(2)        # time the PCG instance of k_spmv_csr only
+            be.prof_enable(2)        # HIP events on the PCG instance of the product (fused dot, y stored) only
+            kc0 = be.ctx.kernel_counts()
             state["its0"] = fem.STATS["pcg_iterations"]
+            state["pcg0"] = fem.STATS["pcg_seconds"]
             state["t0"] = time.perf_counter()
         elif passes == W + K:
             barrier()
             state["t1"] = time.perf_counter()
             state["its1"] = fem.STATS["pcg_iterations"]
+            state["pcg1"] = fem.STATS["pcg_seconds"]
+            kc1 = be.ctx.kernel_counts()
             raise _Done()
 
     prob.pass_hook = hook
@@ -157,23 +165,26 @@ def main():
     from pgdrome_amd.sizes import nnz_p1_box
     nnz = nnz_p1_box(n)
     pcg_its = state["its1"] - state["its0"]
-    achieved = prof["bytes"] / prof["seconds"] / 1e9 if prof["seconds"] > 0 else 0.0
-    # which form of the CSR product ran: column ids decoded from the mesh's pattern dictionary, or streamed
+    pcg_seconds = state["pcg1"] - state["pcg0"]
+    launches = max(prof["launches"], 1)
+    avg = prof["seconds"] / launches
+    rows_local = n_sp // world if sharded else n_sp
+    # which product ran in the SPD solves (launch counters of the library, not a guess)
+    kc = {k: kc1[k] - kc0[k] for k in kc1}
     patterns = be.ctx.mesh_dict_count(space.handle())
-    max_row = be.ctx.mesh_info(space.handle())["max_row"]
-    spmv_kernel = "k_spmv_csr<dot,store,64>"
-    if patterns:
-        spmv_kernel = ("k_spmv_csr_dict16<dot,store>" if max_row <= 16 else "k_spmv_csr_dict<dot,store,64>") + \
-            " (%d relative column patterns)" % patterns
     sym = be.ctx.mesh_sym_info(space.handle())
-    sym_bytes = None
-    if sym["slots"]:
-        # the SPD solves read the operator from its symmetric half storage: every off-diagonal value once
-        spmv_kernel = ("k_spmv_sym_grid3<dot,store> (symmetric half storage, %d slots/row, z-march over the %d x %d vertex "
-                       "grid with the x planes in LDS, %d relative patterns)" % (sym["slots"], sym["nx"], sym["ny"], patterns)
-                       if sym["nx"] else "k_spmv_sym<dot,store,%d> (symmetric half storage, %d relative patterns)" % (sym["slots"], patterns))
-        rows_local = n_sp // world if sharded else n_sp
-        sym_bytes = rows_local * (8 * sym["slots"] + 8 + 8 + 2)     # slot values + x + y + pattern id
+    ran = max(("dia_march", "dia_rows", "sym_rows", "csr_dict", "csr"), key=lambda k: kc[k])
+    kernel_names = {
+        "dia_march": "k_spmv_dia_march<dot,store,4> (symmetric half storage in diagonal form: 8 slot arrays of n doubles, a 64 x 4 "
+                     "patch of the %d x %d vertex grid marching along z, x planes and the plane-below couplings in LDS)" % (sym["nx"], sym["ny"]),
+        "dia_rows": "k_spmv_dia_rows<dot,store> (symmetric half storage in diagonal form, row order)",
+        "sym_rows": "k_spmv_sym<dot,store,%d> (symmetric half storage, %d relative patterns)" % (sym["slots"], patterns),
+        "csr_dict": "k_spmv_csr_dict16<dot,store> (CSR values, column ids from %d relative patterns)" % patterns,
+        "csr": "k_spmv_csr<dot,store,64>",
+    }
+    own = prof["own_bytes"] / launches                       # least bytes that kernel must move, per launch
+    alg = prof["bytes"] / launches                           # 12 nnz + 20 n for the rows covered
+    achieved = own / avg / 1e9 if avg > 0 else 0.0
     out = {
         "metric": "PGD fixed-point iters/sec + SpMV HBM GB/s, 256^3 P1 space x 1D param",
         "value": K / elapsed, "unit": "fixed-point iterations/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -184,30 +195,29 @@ def main():
                    "spatial_dofs": n_sp, "nnz": nnz, "parallelism": "z-slab row sharding x%d" % world if sharded else "single GPU",
                    "sharded_pcg_driver": (("in-library loop, RCCL" if comm.in_library == "rccl" else
                                            "python loop, torch.distributed") if sharded else None),
+                   "rccl_world": (be.comm_info()["world"] if sharded and comm.in_library == "rccl" else
+                                  (dist.get_world_size() if sharded else None)),
                    "pcg_iterations_per_step": pcg_its / K, "modes_completed": len(prob.num_fp_it),
+                   "us_per_pcg_iteration": 1e6 * pcg_seconds / max(pcg_its, 1),
+                   "pcg_iteration_breakdown_us": {"product": 1e6 * avg, "vector_kernels_reductions_and_solve_setup":
+                                                  1e6 * (pcg_seconds / max(pcg_its, 1) - avg)},
+                   "seconds_in_pcg_solves": pcg_seconds, "seconds_timed": elapsed,
+                   "product_launches_by_kernel": kc,
                    "setup_seconds_untimed": t_setup},
-        "roofline": {"bound": "hbm", "kernel": spmv_kernel, "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                     "frac": achieved / 8000.0, "traffic": None,
-                     "launches": prof["launches"], "avg_launch_us": 1e6 * prof["seconds"] / max(prof["launches"], 1),
-                     "algorithmic_bytes_per_launch": prof["bytes"] / max(prof["launches"], 1)},
+        "roofline": {"bound": "hbm", "kernel": kernel_names[ran],
+                     # PHYSICAL pricing: the bytes this kernel must move in the storage form it reads (diagonal form:
+                     # 8 slots x 8 B + x + y = 80 B per row) / its average launch time (HIP events, this run)
+                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
+                     "launches": prof["launches"], "avg_launch_us": 1e6 * avg,
+                     "bytes_per_launch": own, "bytes_per_row": own / max(rows_local, 1),
+                     # SURVEY 8d's CSR formula priced on the same launch time: NOT a physical rate for this kernel (it does
+                     # not stream the CSR arrays) - the CSR kernels' own measurement is in csr_product below
+                     "csr_formula_bytes_per_launch": alg, "csr_formula_equivalent_GBps": alg / avg / 1e9 if avg > 0 else 0.0},
     }
-    if sym_bytes:
-        # `achieved` / `frac` use the CSR byte formula of SURVEY 8d whatever form the kernel reads (so frac can
-        # exceed 1: the symmetric storage moves about 0.45 x those bytes); the kernel's own minimum traffic and the
-        # rate it reaches on THAT are given beside it
-        avg = prof["seconds"] / max(prof["launches"], 1)
-        out["roofline"]["kernel_min_bytes_per_launch"] = sym_bytes
-        out["roofline"]["kernel_min_bytes_GBps"] = sym_bytes / avg / 1e9 if avg > 0 else 0.0
-        out["roofline"]["kernel_min_bytes_frac"] = out["roofline"]["kernel_min_bytes_GBps"] / 8000.0
-        out["roofline"]["note"] = ("achieved/frac are priced with the CSR byte formula 12 nnz + 20 n of SURVEY 8d as required; "
-                                   "frac > 1 means the kernel does not move those bytes (symmetric half storage: each "
-                                   "off-diagonal value once) - see traffic (PMC) and kernel_min_bytes_* for what it does move")
-    pmc = os.path.join(ROOT, "profiles", "pmc_spmv_latest.json")
-    if n == 256 and world == 1 and sym["nx"] and os.path.exists(pmc):
-        # HBM bytes per launch from the separate rocprofv3 --pmc passes (FETCH_SIZE doubled per the gfx950
-        # correction + WRITE_SIZE); collected with tools/pmc_spmv.py, not in this process
-        with open(pmc) as f:
-            out["roofline"]["traffic"] = json.load(f)["hbm_bytes_per_launch"]
+    if rank == 0 and world == 1 and not args.no_csr_section:
+        out["roofline"]["csr_product"] = csr_section(be, prob, n_sp, nnz)
+    if rank == 0 and world == 1 and n == 256 and sym["nx"] and not args.no_pmc:
+        out["roofline"].update(pmc_traffic(own))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(prob, spec, be, pcg_its / K, args)
     if rank == 0:
@@ -216,6 +226,113 @@ def main():
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def csr_section(be, prob, n_sp, nnz):
+    """The north star's "Jacobi-PCG built from CSR SpMV": the CSR products of the library (plain k_spmv_csr and the
+    column-dictionary form that is the default for the CSR path) timed in THIS run on the bench operator - the first
+    spatial system of the problem - as the PCG instance (fused dot, y stored), >= 100 HIP-event samples each, priced with
+    SURVEY 8d's formula 12 nnz + 20 n, which is what k_spmv_csr streams."""
+    import numpy as np
+    from pgdrome_amd import fem
+    ctx = be.ctx
+    op = _first_spatial_operator(prob)
+    x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, n_sp))
+    y = ctx.vec_alloc(n_sp)
+    alg = 12.0 * nnz + 20.0 * n_sp
+    res = {}
+    try:
+        ctx.tune(3, 0)                                # products from the CSR arrays, not the symmetric storage
+        for name, dict_knob, own in (("k_spmv_csr<dot,store,64>", 0, alg), ("k_spmv_csr_dict16<dot,store>", 1, 8.0 * nnz + 22.0 * n_sp)):
+            ctx.tune(2, dict_knob)
+            ctx.flags_reset()
+            for _ in range(3):
+                ctx.spmv_dot_slot(op, x, y, x, 0, n_sp, 30)
+            ctx.prof_enable(2)
+            for _ in range(400):                      # one launch in four carries HIP events: 100 samples
+                ctx.spmv_dot_slot(op, x, y, x, 0, n_sp, 30)
+            p = ctx.prof_read()
+            ctx.prof_enable(0)
+            t = p["seconds"] / max(p["launches"], 1)
+            res[name] = {"launches_timed": p["launches"], "launches": 400, "avg_launch_us": 1e6 * t,
+                         "bytes_per_launch_survey_8d": alg, "achieved": alg / t / 1e9, "unit": "GB/s", "frac": alg / t / 8e12,
+                         "kernel_min_bytes_per_launch": own, "kernel_min_bytes_frac": own / t / 8e12}
+    finally:
+        ctx.tune(3, 1)
+        ctx.tune(2, 1)
+        ctx.vec_free(x)
+        ctx.vec_free(y)
+        be.atom_free(op)
+    res["note"] = ("frac of k_spmv_csr is physical (it streams values, column ids, row pointers, x, y = the 8d formula); the dictionary "
+                   "form reads no column ids, so its physical fraction is kernel_min_bytes_frac")
+    return res
+
+
+def _first_spatial_operator(prob):
+    from pgdrome_amd import fem
+    V = prob.V[0]
+    bcs = prob.bc
+    Fs = prob.get_Fsinit(prob.V, bcs, None)
+    u, v = fem.TrialFunction(V), fem.TestFunction(V)
+    a = prob.lhs_fct(u, v, Fs, prob.meshes, prob.dom, prob.param, prob.prob[0], 0)
+    A = fem.assemble(a)
+    if bcs[0] != 0:
+        for bc in fem._bc_list(bcs[0]):
+            A.apply_dirichlet(bc)
+    return A.op()
+
+
+def pmc_traffic(own_bytes):
+    """HBM-side bytes per launch of the dominant kernel.  bench.py cannot read PMC counters of its own process, so it
+    starts `rocprofv3 --pmc` CHILD processes (one counter per pass, as MI355X_MICROARCH.md prescribes) on
+    tools/pmc_spmv_sym.py - the same kernel on the same 256^3 operator shape - and applies the calibrated factors of
+    profiles/r02a_pmc_calibration_and_march.json (FETCH_SIZE x 2 for 8 B/lane streaming loads, measured on a known 1 GiB
+    stream; WRITE_SIZE exact).  Falls back to the committed profile when no profiler can be started."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    fallback = os.path.join(ROOT, "profiles", "pmc_spmv_latest.json")
+    res = {"traffic": None, "traffic_source": None}
+    rp = shutil.which("rocprofv3")
+    nested = any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if rp and not nested:
+        env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCPROF", "ROCP_", "HSA_TOOLS")) and k != "LD_PRELOAD"}
+        env["TMPDIR"] = "/tmp"
+        vals = {}
+        try:
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                d = tempfile.mkdtemp(prefix="pgd_pmc_", dir="/tmp")
+                subprocess.run([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
+                                os.path.join(ROOT, "tools", "pmc_spmv_sym.py"), "256", "grid", "0"],
+                               check=True, timeout=180, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                got = []
+                for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                    with open(f) as fh:
+                        for row in csv.DictReader(fh):
+                            if row.get("Counter_Name") == counter and "k_spmv_dia_march" in row.get("Kernel_Name", ""):
+                                got.append(float(row["Counter_Value"]))
+                shutil.rmtree(d, ignore_errors=True)
+                if not got:
+                    raise RuntimeError("no %s rows for the product" % counter)
+                v = sum(got) / len(got)
+                if v * 1024.0 < 64.0 * own_bytes:           # the counter is reported in KiB on ROCm 7.x
+                    v *= 1024.0
+                vals[counter] = v
+            res["traffic"] = 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
+            res["traffic_source"] = ("rocprofv3 --pmc child processes of this run (tools/pmc_spmv_sym.py 256 grid): FETCH_SIZE x 2 "
+                                     "(calibrated, profiles/r02a_pmc_calibration_and_march.json) + WRITE_SIZE; counts Infinity-Cache hits")
+            res["traffic_over_kernel_min"] = res["traffic"] / own_bytes
+            return res
+        except Exception as e:      # noqa: BLE001 - the bench line must still be printed
+            res["traffic_error"] = repr(e)[:200]
+    if os.path.exists(fallback):
+        with open(fallback) as f:
+            res["traffic"] = json.load(f)["hbm_bytes_per_launch"]
+        res["traffic_source"] = "profiles/pmc_spmv_latest.json (separate rocprofv3 --pmc passes, not this run)"
+        res["traffic_over_kernel_min"] = res["traffic"] / own_bytes
+    return res
 
 
 def cpu_baseline(prob, spec, be, pcg_its_per_step, args):

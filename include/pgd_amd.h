@@ -240,6 +240,13 @@ int pgd_pcg_solve_sharded(pgd_handle ctx, pgd_handle A, pgd_handle b, pgd_handle
                           int64_t own1, int64_t lo_ghost, int64_t hi_ghost, double rtol, double atol,
                           int maxit, int *iters, double *rel_res);
 
+/* Gram data of the Galerkin start of a PCG solve (the warm start x0 = sum_j c_j v_j with G c = g; this library's
+ * addition in front of the solve that replaces solver.py:636,716): out[i*k + j] = v_i . (A v_j) over rows
+ * [r0, r1), out[k*k + j] = v_j . b, k <= 9.  k products from the operator's fastest storage form, every dot on
+ * the device, ONE host synchronisation; a sharded caller all-reduces `out` once.                        */
+int pgd_start_gram(pgd_handle ctx, pgd_handle A, const pgd_handle *vecs, int k, pgd_handle b, int64_t r0,
+                   int64_t r1, double *out);
+
 /* ------------------------------------------------------------------ tuning --- */
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed.                                        */
@@ -251,6 +258,8 @@ enum {
     PGD_TUNE_PCG_SCALED = 10,   /* 1 (default): pgd_pcg_solve runs CG on D^-1/2 A D^-1/2 (the same iterates as Jacobi-PCG,
                                    two vector passes per iteration fewer) when the symmetric storage applies; 0: unscaled */
     PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */
+    PGD_TUNE_COMBINE_DIA = 14, /* 1 (default): on structured vertex grids pgd_op_combine also forms the operator's diagonal
+                                  (symmetric half) storage from the atoms' diagonal forms; 0: converted from CSR per solve */
     PGD_TUNE_SPMV_VARIANT = 13, /* k_spmv_dia_march: 0 (default) 64 x 4 patches, 256 threads; 1: 64 x 8 patches, 512 threads */
     PGD_TUNE_SPMV_ZCHUNK = 6,   /* k_spmv_sym_grid3 (structured vertex grids, x planes in LDS): most planes per
                                    workgroup march (default 16; fewer while that keeps 8 workgroups per CU); 0 = off */

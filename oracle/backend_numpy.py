@@ -189,6 +189,17 @@ class NumpyBackend:
         return np.array([self.bilinear(A, x, y, r0, r1) for y in ys])
 
     # ---- solvers
+    def start_gram(self, op, vecs, b, r0=0, r1=-1):
+        A = self._obj[op][1]
+        n = A.shape[0]
+        r1 = n if r1 < 0 else r1
+        V = [self._obj[v] for v in vecs]
+        W = [(A @ v)[r0:r1] for v in V]
+        G = np.array([[float(vi[r0:r1] @ wj) for wj in W] for vi in V])
+        G = 0.5 * (G + G.T)
+        g = np.array([float(v[r0:r1] @ self._obj[b][r0:r1]) for v in V])
+        return G, g
+
     def pcg(self, op, b, x, rtol, atol, maxit):
         A = self._obj[op][1]
         if self.direct_above is not None and A.shape[0] > self.direct_above:

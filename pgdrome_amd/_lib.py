@@ -64,6 +64,7 @@ SIGNATURES = {
     "pgd_spmv": (C.c_int, [H, H, H, H, I64, I64]),
     "pgd_bilinear": (C.c_int, [H, H, H, H, I64, I64, PD]),
     "pgd_bilinear_many": (C.c_int, [H, H, H, PH, C.c_int, I64, I64, PD]),
+    "pgd_start_gram": (C.c_int, [H, H, PH, C.c_int, H, I64, I64, PD]),
     "pgd_pcg_solve": (C.c_int, [H, H, H, H, F64, F64, C.c_int, C.POINTER(C.c_int), PD]),
     "pgd_band_solve": (C.c_int, [H, H, H, H]),
     "pgd_slots_ptr": (C.c_int, [H, C.POINTER(VP)]),
@@ -351,6 +352,14 @@ class Context:
         arr = (H * max(n, 1))(*[int(v) for v in ys])
         self._ck(self.lib.pgd_bilinear_many(self.h, A, x, arr, n, int(r0), int(r1), dptr(out)))
         return out[:n]
+
+    def start_gram(self, A, vecs, b, r0=0, r1=-1):
+        """(G, g): G[i, j] = v_i . (A v_j), g[j] = v_j . b over rows [r0, r1); one host synchronisation."""
+        k = len(vecs)
+        arr = (H * k)(*[int(v) for v in vecs])
+        out = np.zeros(k * k + k, dtype=np.float64)
+        self._ck(self.lib.pgd_start_gram(self.h, A, arr, k, b, int(r0), int(r1), dptr(out)))
+        return out[:k * k].reshape(k, k).copy(), out[k * k:].copy()
 
     def pcg_solve(self, op, b, x, rtol=1e-10, atol=0.0, maxit=10000):
         it = C.c_int()

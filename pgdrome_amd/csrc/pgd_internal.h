@@ -146,6 +146,7 @@ struct Ctx {
     int spmv_zchunk = 16;         // k_spmv_sym_grid3: most planes a workgroup marches through (0: never use that kernel)
     int pcg_fold_reduce = 1;      // scaled recurrence: final reduction passes folded into the vector kernels (3 launches / iteration)
     int pcg_scaled = 1;           // pgd_pcg_solve on the symmetrically scaled system (no dinv / z passes) when the symmetric storage applies
+    int spmv_combine_dia = 1;     // structured grids: op_combine also forms the diagonal form from the atoms' diagonal forms
     int spmv_sym = 1;             // PCG products from the symmetric half storage when the mesh qualifies
 
     // SpMV launch timing (HIP events on `stream`)
@@ -189,6 +190,7 @@ int reduce_two_slots(Ctx *c, int na, int nb, int base);
 int vec_sqrt(Ctx *c, double *v, int64_t n);
 int vec_div_mul(Ctx *c, double *x, const double *sc, int64_t n, int mul);
 int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *s);   // pgd_spmv.hip: slot values *= s_i s_j
+int combine_dia(Ctx *c, const Mesh *m, Csr *o, Csr *const *atoms, const double *coefs, int n, const uint8_t *mask);
 int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0,
                    int64_t r1, bool dot, bool store, const int *flags, int *nparts_out);
 
@@ -229,6 +231,7 @@ inline int grid_for(int64_t n, int per_block = TPB, int cap = MAX_VEC_BLOCKS) {
 int scan_exclusive_i32(Ctx *c, const int *in, int *out, int64_t n);   // out has n+1 entries
 int reduce_partials(Ctx *c, const double *partials, int nparts, int nvals, int slot0, int check_mode,
                     int slot_rr, int slot_tol2);
+int reduce_partials_to(Ctx *c, const double *partials, int nparts, int nvals, double *dest);
 int vec_dot_range(Ctx *c, const double *x, const double *y, int64_t lo, int64_t hi, int slot);
 // pgd_spmv.hip
 int launch_spmv(Ctx *c, const Mesh *m, const double *vals, const double *x, double *y,

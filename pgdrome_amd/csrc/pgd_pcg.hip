@@ -726,11 +726,13 @@ int pgd_op_combine(pgd_handle h, pgd_handle mh, const pgd_handle *atoms, const d
     if (!m || !atoms || !coefs || !op || n < 1 || nbc < 0 || (nbc > 0 && !bc_dofs))
         return fail(c, PGD_ERR_INVALID, "op_combine: invalid arguments");
     std::vector<const double *> in((size_t)n);
+    std::vector<Csr *> atom_objs((size_t)n);
     for (int t = 0; t < n; ++t) {
         Csr *a = get_csr(c, atoms[t]);
         if (!a || a->mesh != mh) return fail(c, PGD_ERR_INVALID, "op_combine: atom %d is not on this mesh", t);
         if (*op && atoms[t] == *op) return fail(c, PGD_ERR_INVALID, "op_combine: output aliases an input");
         in[t] = a->vals;
+        atom_objs[t] = a;
     }
     for (int64_t i = 0; i < nbc; ++i)
         if (bc_dofs[i] < 0 || bc_dofs[i] >= m->nv) return fail(c, PGD_ERR_INVALID, "op_combine: bc dof out of range");
@@ -774,6 +776,8 @@ int pgd_op_combine(pgd_handle h, pgd_handle mh, const pgd_handle *atoms, const d
     }
     if (nbc > 0) k_dirichlet_rows<<<grid_for(nbc), TPB, 0, c->stream>>>(c->ibuf, nbc, m->row_ptr, m->cols, o->vals);
     PGD_LAUNCH_CHECK(c);
+    // structured grids: the diagonal form of the same operator from the atoms' diagonal forms (no per-solve conversion)
+    PGD_TRY(combine_dia(c, m, o, atom_objs.data(), coefs, n, mask));
     PGD_HIP(c, hipStreamSynchronize(c->stream));   // bc_dofs is caller-owned
     return PGD_OK;
 }

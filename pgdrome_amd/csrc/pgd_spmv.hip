@@ -582,7 +582,7 @@ __global__ __launch_bounds__(64) void k_spmv_dia_rows(DiaArgs A) {
 // made of its own slots 4..7 one step earlier; only the patch's low-x lane and low-y wave fetch theirs (they belong to
 // the neighbouring patch).  The vector-memory path carries the own slot values (64 B per row), the three in-plane lower
 // couplings (served by L1 / L2: the neighbouring lanes and waves load them as their own in the same step) and y.
-constexpr int DM_HX = 66, DM_HY = 6, DM_SLICE = DM_HX * DM_HY;      // 64 x 4 patch + halo = 396 doubles per plane
+constexpr int DM_HX = 66;            // cells per line of the staged x patch: 64 + one halo cell each way
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a workgroup-scope fence + s_barrier, and on gfx9
 // the fence waits with vmcnt(0), i.e. also for the acknowledgement of the y store issued just before it in every step
@@ -896,6 +896,85 @@ int ensure_sym(Ctx *c, const Mesh *m, Csr *a, bool *usable) {
     return PGD_OK;
 }
 
+// Structured grids: the diagonal form of A = sum_t c_t A_t straight from the atoms' diagonal forms (built once per atom
+// and kept), with the symmetric Dirichlet elimination and 1 / diagonal in the same pass - 8 (T + 1) n doubles of
+// streaming instead of the per-solve conversion from CSR (k_csr_to_dia: 7.3 ms at 256^3, uncoalesced 180-byte rows and
+// a search in every lower neighbour's row) and the diagonal search of k_diag_inv.  Same products in the same order as
+// k_combine, so the slot values are bit-identical to the converted ones.
+constexpr int DIA_MAXT = 8;
+struct CombineDiaArgs {
+    const double *in[DIA_MAXT];
+    double coef[DIA_MAXT];
+    int n;
+};
+
+__global__ __launch_bounds__(TPB) void k_combine_dia(CombineDiaArgs A, double *__restrict__ out, int64_t stride,
+                                                     const uint8_t *__restrict__ mask, double *__restrict__ dinv, int64_t nv,
+                                                     int nx, int ny) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= nv) return;
+    const int64_t P = (int64_t)nx * ny;
+    const bool bi = mask && mask[i];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        double v = 0.0;
+#pragma unroll
+        for (int t = 0; t < DIA_MAXT; ++t)
+            if (t < A.n) v = fma(A.coef[t], A.in[t][(int64_t)s * stride + i], v);
+        if (mask) {
+            const int64_t j = i + (s & 1) + (int64_t)nx * ((s >> 1) & 1) + P * (s >> 2);
+            const bool bj = j < nv && mask[j];
+            if (s == 0) { if (bi) v = 1.0; }
+            else if (bi || bj) v = 0.0;
+        }
+        out[(int64_t)s * stride + i] = v;
+        if (s == 0 && dinv) dinv[i] = 1.0 / v;
+    }
+}
+
+// mask: Dirichlet flags per row (or null) - only valid on the LAST pass, like k_combine's column mask
+int combine_dia(Ctx *c, const Mesh *m, Csr *o, Csr *const *atoms, const double *coefs, int n, const uint8_t *mask) {
+    o->uvals_valid = false;
+    if (!c->spmv_sym || m->sym_nx <= 0 || !c->spmv_combine_dia) return PGD_OK;
+    for (int t = 0; t < n; ++t) {
+        bool usable = false;
+        PGD_TRY(ensure_sym(c, m, atoms[t], &usable));     // once per atom: conversion + symmetry check, then cached
+        if (!usable) return PGD_OK;                       // a non-symmetric atom: the operator keeps the CSR kernels
+    }
+    const int64_t stride = m->nv;
+    if (o->uvals && o->uvals_stride != stride) { dev_release(c, o->uvals, o->uvals_bytes); o->uvals = nullptr; }
+    if (!o->uvals) {
+        void *p;
+        o->uvals_bytes = (size_t)8 * (size_t)stride * sizeof(double);
+        PGD_TRY(dev_alloc(c, &p, o->uvals_bytes));
+        o->uvals = (double *)p;
+        o->uvals_stride = stride;
+    }
+    if (!o->dinv) {
+        void *p;
+        o->dinv_bytes = (size_t)m->nv * sizeof(double);
+        PGD_TRY(dev_alloc(c, &p, o->dinv_bytes));
+        o->dinv = (double *)p;
+    }
+    const int g = (int)((m->nv + TPB - 1) / TPB);
+    for (int t = 0, pass = 0; t < n; ++pass) {
+        CombineDiaArgs A;
+        int cnt = 0;
+        if (pass > 0) { A.in[0] = o->uvals; A.coef[0] = 1.0; cnt = 1; }
+        while (t < n && cnt < DIA_MAXT) { A.in[cnt] = atoms[t]->uvals; A.coef[cnt] = coefs[t]; ++cnt; ++t; }
+        for (int k = cnt; k < DIA_MAXT; ++k) { A.in[k] = atoms[0]->uvals; A.coef[k] = 0.0; }
+        A.n = cnt;
+        const bool last = t >= n;
+        k_combine_dia<<<g, TPB, 0, c->stream>>>(A, o->uvals, stride, last ? mask : nullptr, last ? o->dinv : nullptr, m->nv,
+                                                m->sym_nx, m->sym_ny);
+    }
+    PGD_LAUNCH_CHECK(c);
+    o->uvals_valid = true;
+    o->uvals_scaled = false;
+    o->dinv_valid = true;
+    return PGD_OK;
+}
+
 int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0,
                    int64_t r1, bool dot, bool store, const int *flags, int *nparts_out) {
     if (!(c->spmv_sym && m->sym_w && a->uvals_valid && a->uvals))
@@ -977,6 +1056,39 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
     return PGD_OK;
 }
 
+// Gram matrix of the Galerkin start of a PCG solve (fem._rescale_start): column j needs w = A v_j, then the dots
+// v_i . w for i <= j and v_j . b - one pass over w and the v_i, partial sums per workgroup, fixed order.
+constexpr int GRAM_MAXV = 9;
+struct MultiDotArgs {
+    const double *w, *b;
+    const double *v[GRAM_MAXV];
+    int nv;                      // v[0..nv): dots with w; the last one also with b
+    int64_t lo, hi;
+    double *partials;            // [block][nv + 1]
+};
+
+__global__ __launch_bounds__(TPB) void k_multidot(MultiDotArgs A) {
+    __shared__ double s_red[4];
+    double acc[GRAM_MAXV + 1];
+#pragma unroll
+    for (int m = 0; m <= GRAM_MAXV; ++m) acc[m] = 0.0;
+    for (int64_t i = A.lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < A.hi; i += (int64_t)gridDim.x * TPB) {
+        const double wi = A.w[i];
+        double last = 0.0;
+#pragma unroll
+        for (int m = 0; m < GRAM_MAXV; ++m)
+            if (m < A.nv) { last = A.v[m][i]; acc[m] = fma(last, wi, acc[m]); }
+        acc[GRAM_MAXV] = fma(last, A.b[i], acc[GRAM_MAXV]);
+    }
+#pragma unroll
+    for (int m = 0; m <= GRAM_MAXV; ++m) {
+        if (m < A.nv || m == GRAM_MAXV) {
+            const double sum = block_sum(acc[m], s_red);
+            if (threadIdx.x == 0) A.partials[(int64_t)blockIdx.x * (A.nv + 1) + (m == GRAM_MAXV ? A.nv : m)] = sum;
+        }
+    }
+}
+
 int launch_spmv_multi(Ctx *c, const Mesh *m, const double *vals, const double *x, const double *const *ys,
                       int ny, int64_t r0, int64_t r1, double *out_host) {
     if (r1 < 0) r1 = m->nv;
@@ -1016,6 +1128,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_PCG_FOLD_REDUCE && value >= 0 && value <= 1) { c->pcg_fold_reduce = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_SCALED && value >= 0 && value <= 1) { c->pcg_scaled = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK && value >= 0 && value <= 65536) { c->spmv_zchunk = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_COMBINE_DIA && value >= 0 && value <= 1) { c->spmv_combine_dia = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_VARIANT && value >= 0 && value <= 1) { c->spmv_variant = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }
@@ -1091,6 +1204,54 @@ int pgd_spmv_dot_slot(pgd_handle h, pgd_handle ah, pgd_handle xh, pgd_handle yh,
         return PGD_OK;
     }
     return reduce_partials(c, c->partials, nparts, 1, slot, 0, 0, 0);
+}
+
+int pgd_start_gram(pgd_handle h, pgd_handle ah, const pgd_handle *vhs, int k, pgd_handle bh, int64_t r0, int64_t r1,
+                   double *out) {
+    PGD_CTX(c, h);
+    Csr *a = get_csr(c, ah);
+    Mesh *m = a ? get_mesh(c, a->mesh) : nullptr;
+    Vec *b = get_vec(c, bh);
+    if (!a || !m || !b || !vhs || !out || k < 1 || k > GRAM_MAXV || b->n != m->nv)
+        return fail(c, PGD_ERR_INVALID, "start_gram: invalid handles or more than %d vectors", GRAM_MAXV);
+    if (r1 < 0) r1 = m->nv;
+    if (r0 < 0 || r0 > r1 || r1 > m->nv) return fail(c, PGD_ERR_INVALID, "start_gram: bad row range");
+    const double *v[GRAM_MAXV];
+    for (int j = 0; j < k; ++j) {
+        Vec *x = get_vec(c, vhs[j]);
+        if (!x || x->n != m->nv) return fail(c, PGD_ERR_INVALID, "start_gram: invalid vector %d", j);
+        v[j] = x->d;
+    }
+    for (int q = 0; q < k * k + k; ++q) out[q] = 0.0;
+    if (r1 == r0) return PGD_OK;
+    bool sym = false;
+    PGD_TRY(ensure_sym(c, m, a, &sym));                 // the SPD solve that follows reads the same copy
+    PGD_TRY(ensure_work(c, 3, m->nv));                  // w: the PCG's q buffer (no solve is running)
+    PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS > 256 ? 2 * (int64_t)MAX_VEC_BLOCKS : 256));
+    double *w = c->work[3], *res = c->work[6];          // res: k columns of (j + 2) values, packed
+    const int g = grid_for(r1 - r0);
+    int off = 0;
+    for (int j = 0; j < k; ++j) {
+        PGD_TRY(launch_spmv_op(c, m, a, v[j], w, nullptr, r0, r1, false, true, nullptr, nullptr));
+        PGD_TRY(ensure_partials(c, (int64_t)g * (GRAM_MAXV + 1) > 4 * MAX_VEC_BLOCKS ? (int64_t)g * (GRAM_MAXV + 1) : 4 * MAX_VEC_BLOCKS));
+        MultiDotArgs A;
+        A.w = w; A.b = b->d; A.nv = j + 1; A.lo = r0; A.hi = r1; A.partials = c->partials;
+        for (int q = 0; q < GRAM_MAXV; ++q) A.v[q] = v[q <= j ? q : j];
+        k_multidot<<<g, TPB, 0, c->stream>>>(A);
+        PGD_LAUNCH_CHECK(c);
+        PGD_TRY(reduce_partials_to(c, c->partials, g, j + 2, res + off));
+        off += j + 2;
+    }
+    std::vector<double> host((size_t)off);
+    PGD_HIP(c, hipMemcpyAsync(host.data(), res, (size_t)off * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));       // the one host synchronisation of the call
+    off = 0;
+    for (int j = 0; j < k; ++j) {
+        for (int i = 0; i <= j; ++i) out[i * k + j] = out[j * k + i] = host[(size_t)off + i];
+        out[k * k + j] = host[(size_t)off + j + 1];
+        off += j + 2;
+    }
+    return PGD_OK;
 }
 
 }  // extern "C"

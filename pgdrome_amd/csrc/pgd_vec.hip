@@ -221,6 +221,20 @@ int reduce_partials(Ctx *c, const double *partials, int nparts, int nvals, int s
     return PGD_OK;
 }
 
+// the same final pass into any device array (dest[0..nvals))
+int reduce_partials_to(Ctx *c, const double *partials, int nparts, int nvals, double *dest) {
+    if (nparts > 8192) {
+        const int nb = (nparts + 1023) / 1024;
+        PGD_TRY(ensure_work(c, 5, (int64_t)nb * nvals > 4096 ? (int64_t)nb * nvals : 4096));
+        k_reduce_stage1<<<nb, TPB, 0, c->stream>>>(partials, nparts, nvals, c->work[5], nullptr, -1);
+        partials = c->work[5];
+        nparts = nb;
+    }
+    k_reduce_partials<<<1, 1024, 0, c->stream>>>(partials, nparts, nvals, dest, 0, -1, 0, 0, nullptr);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
 int vec_dot_range(Ctx *c, const double *x, const double *y, int64_t lo, int64_t hi, int slot) {
     const int g = grid_for(hi - lo);
     PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS));

@@ -131,6 +131,14 @@ class TorchComm:
         self.stats["allreduce"] += 1
         return float(t.item())
 
+    def allreduce_array(self, values):
+        """Sum of a small host array over the ranks in ONE collective (Gram data of the Galerkin start, batched functionals)."""
+        dev = "cpu" if self.dist.get_backend() == "gloo" else self._scalar_device()
+        t = self.torch.tensor(np.asarray(values, dtype=np.float64), dtype=self.torch.float64, device=dev)
+        self.dist.all_reduce(t)
+        self.stats["allreduce"] += 1
+        return t.cpu().numpy()
+
     def _staged(self, t):
         """gloo cannot move device memory: stage through the host (test configuration: several ranks
         sharing one GPU over gloo; production runs use RCCL and never take this path)."""

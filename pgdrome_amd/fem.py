@@ -31,6 +31,7 @@ from __future__ import annotations
 import logging
 import math
 import numbers
+import time
 
 import numpy as np
 
@@ -2527,19 +2528,13 @@ def _rescale_start(lay, op, b, x):
     for v in vecs:
         _halo(lay, v)
     k = len(vecs)
-    prods = [be.vec_zeros(lay.n) for _ in range(k)]
-    try:
-        for v, w in zip(vecs, prods):
-            be.spmv(op, v.dev(), w, lo, hi)
-        G = np.zeros((k, k))
-        g = np.zeros(k)
-        for i in range(k):
-            g[i] = _allreduce_sum(lay.mesh, be.vec_dot(vecs[i].dev(), b.dev(), lo, hi))
-            for j in range(i, k):
-                G[i, j] = G[j, i] = _allreduce_sum(lay.mesh, be.vec_dot(vecs[i].dev(), prods[j], lo, hi))
-    finally:
-        for w in prods:
-            be.vec_free(w)
+    # k products from the operator's fastest storage form and all (k + 1)(k + 2) / 2 - 1 dots on the device: one host
+    # synchronisation (one D2H copy), and ONE all-reduce of the packed result when the rows are sharded
+    G, g = be.start_gram(op, [v.dev() for v in vecs], b.dev(), lo, hi)
+    STATS["host_syncs_start"] = STATS.get("host_syncs_start", 0) + 1
+    if lay.part is not None:
+        packed = lay.part.comm.allreduce_array(np.concatenate([G.ravel(), g]))
+        G, g = packed[:k * k].reshape(k, k), packed[k * k:]
     if not (np.all(np.isfinite(G)) and np.all(np.isfinite(g)) and G[0, 0] > 0.0):
         return
     if k == 1:
@@ -2585,6 +2580,7 @@ def _solve_linear(A, b, x, prm):
             rtol = float(prm.get("relative_tolerance", 1e-10)) if not isinstance(prm.get("relative_tolerance"), _Params) else 1e-10
             atol = float(prm.get("absolute_tolerance", 0.0)) if not isinstance(prm.get("absolute_tolerance"), _Params) else 0.0
             maxit = int(prm.get("maximum_iterations", 20000)) if not isinstance(prm.get("maximum_iterations"), _Params) else 20000
+            t_solve = time.perf_counter()
             if WARM_START_RESCALE and not x._zero:
                 _rescale_start(A.lay, op, b, x)
             if mesh.part is not None:
@@ -2592,6 +2588,7 @@ def _solve_linear(A, b, x, prm):
             else:
                 it, rel = be.pcg(op, b.dev(), x.dev(), rtol, atol, maxit)
                 x.touched_dev()
+            STATS["pcg_seconds"] += time.perf_counter() - t_solve      # the solve returns synchronised
             info.update(method="jacobi_pcg", iterations=it, relres=rel)
             if rel > max(rtol, 1e-14) * 1.0001 and it >= maxit:
                 LOG.error("PCG did not reach rtol %g in %d iterations (relres %g)", rtol, it, rel)
@@ -2603,7 +2600,7 @@ def _solve_linear(A, b, x, prm):
     return info
 
 
-STATS = {"linear_solves": 0, "pcg_iterations": 0}
+STATS = {"linear_solves": 0, "pcg_iterations": 0, "pcg_seconds": 0.0}
 
 
 def _apply_bcs_system(A, b, bcs):

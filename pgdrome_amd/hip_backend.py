@@ -96,6 +96,9 @@ class HipBackend:
         return self.ctx.bilinear_many(A, x, ys, r0, r1)
 
     # ---- solvers
+    def start_gram(self, op, vecs, b, r0=0, r1=-1):
+        return self.ctx.start_gram(op, vecs, b, r0, r1)
+
     def pcg(self, op, b, x, rtol, atol, maxit):
         return self.ctx.pcg_solve(op, b, x, rtol, atol, maxit)
 

@@ -294,7 +294,9 @@ def test_symmetric_half_storage_products(ctx, name):
     x, w = rng.uniform(-1, 1, n), rng.uniform(-1, 1, n)
     xv, wv, yv = ctx.vec_from(x), ctx.vec_from(w), ctx.vec_alloc(n)
     ctx.flags_reset()
+    ctx.tune(3, 0)                         # CSR kernels
     ctx.spmv_dot_slot(op, xv, yv, wv, 0, n, 30)
+    ctx.tune(3, 1)
     y_csr, d_csr = ctx.vec_download(yv), ctx.slots_download(30, 1)[0]
     assert ctx.op_symmetrize(op) is True
     ctx.vec_fill(yv, -3.0)
@@ -411,10 +413,22 @@ def test_grid_march_in_multi_tile_launch_shapes(ctx, shape):
     ref, rowabs = A @ x, np.abs(A) @ np.abs(x)
     xv, yv = ctx.vec_from(x), ctx.vec_alloc(n)
     ctx.flags_reset()
-    ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)                      # CSR (dictionary) kernel: no symmetric copy yet
+    k0 = ctx.kernel_counts()
+    ctx.tune(3, 0)                                                   # the CSR (dictionary) kernel
+    ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
+    ctx.tune(3, 1)
+    assert ctx.kernel_counts()["csr_dict"] == k0["csr_dict"] + 1
     y_csr = ctx.vec_download(yv)
     assert np.all(np.abs(y_csr - ref) <= 4e-15 * rowabs + 1e-300)
-    assert ctx.op_symmetrize(op) is True
+    assert ctx.op_symmetrize(op) is True           # already there: op_combine formed it from the atoms' diagonal forms
+    # ... and it is the same, bit for bit, as the diagonal form converted from the operator's CSR values
+    ctx.tune(14, 0)
+    op_conv = ctx.op_combine(h, [ak, am], [1.0, 0.37], bc)
+    ctx.tune(14, 1)
+    assert ctx.op_symmetrize(op_conv) is True
+    ctx.spmv_dot_slot(op_conv, xv, yv, xv, 0, n, 30)
+    y_conv = ctx.vec_download(yv)
+    ctx.atom_free(op_conv)
     k0 = ctx.kernel_counts()
     ctx.tune(7, 0)                                                   # adaptive: grids this small take the row-order kernel
     ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 31)
@@ -422,7 +436,7 @@ def test_grid_march_in_multi_tile_launch_shapes(ctx, shape):
     k1 = ctx.kernel_counts()
     assert k1["dia_rows"] == k0["dia_rows"] + 1 and k1["dia_march"] == k0["dia_march"]
     assert np.all(np.abs(y_rows - ref) <= 4e-15 * rowabs + 1e-300)
-    assert np.array_equal(y_rows, y_csr)
+    assert np.array_equal(y_rows, y_csr) and np.array_equal(y_rows, y_conv)
     assert abs(d_rows - x @ ref) <= 1e-13 * (np.abs(x) @ rowabs)
     plane = nx * ny
     try:
@@ -493,13 +507,14 @@ def test_products_agree_at_bench_size(ctx, npts):
     ys = {}
     try:
         ctx.flags_reset()
-        for name, knobs in (("csr", [(2, 0)]), ("csr_dict", [(2, 1)])):
+        for name, knobs in (("csr", [(3, 0), (2, 0)]), ("csr_dict", [(3, 0), (2, 1)])):
             for k, v in knobs:
                 ctx.tune(k, v)
             c0 = ctx.kernel_counts()
             ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
             assert ctx.kernel_counts()[name] == c0[name] + 1
             ys[name] = (ctx.vec_download(yv), ctx.slots_download(30, 1)[0])
+        ctx.tune(3, 1)
         assert ctx.op_symmetrize(op) is True
         for name, knobs in (("dia_march", [(6, 16)]), ("dia_rows", [(6, 0)])):
             for k, v in knobs:
@@ -510,6 +525,7 @@ def test_products_agree_at_bench_size(ctx, npts):
             assert ctx.kernel_counts()[name] == c0[name] + 1
             ys[name] = (ctx.vec_download(yv), ctx.slots_download(30, 1)[0])
     finally:
+        ctx.tune(3, 1)
         ctx.tune(2, 1)
         ctx.tune(6, 16)
     base = ys["csr"][0]
@@ -542,6 +558,40 @@ def test_products_agree_at_bench_size(ctx, npts):
         assert np.all(np.abs(base - A @ x) <= 4e-15 * rowabs + 1e-300)
         assert abs(A - A.T).max() <= 1e-12 * np.abs(vals).max()
     for v in (xv, yv, wv, tv, lin, ones):
+        ctx.vec_free(v)
+    for a in (op, ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
+@pytest.mark.parametrize("name", ["rect17x9", "box20"])
+def test_start_gram_matches_oracle(ctx, name):
+    """pgd_start_gram (Galerkin start of a PCG solve): G[i, j] = v_i . (A v_j), g[j] = v_j . b, full and partial row
+    ranges, 1 .. 9 vectors, products from the symmetric storage (diagonal form on the box grid)."""
+    coords, cells = MESHES[name]()
+    h = ctx.mesh_upload(coords, cells)
+    n = coords.shape[0]
+    K, M = F.assemble_atom(coords, cells, F.STIFF), F.assemble_atom(coords, cells, F.MASS)
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bc = boundary_dofs(coords)
+    op = ctx.op_combine(h, [ak, am], [1.0, 2.0], bc)
+    A, _ = F.apply_dirichlet((K + 2.0 * M).tocsr(), np.zeros(n), bc)
+    rng = np.random.default_rng(77)
+    V = rng.uniform(-1, 1, (9, n))
+    b = rng.uniform(-1, 1, n)
+    vs, bv = [ctx.vec_from(v) for v in V], ctx.vec_from(b)
+    for k, (r0, r1) in ((1, (0, n)), (4, (0, n)), (9, (0, n)), (3, (n // 4, 3 * n // 4))):
+        G, g = ctx.start_gram(op, vs[:k], bv, r0, r1)
+        W = (A @ V[:k].T)[r0:r1]                                   # columns A v_j on the row range
+        G_ref = V[:k, r0:r1] @ W
+        scale = (np.abs(V[:k, r0:r1]) @ (np.abs(A) @ np.abs(V[:k].T))[r0:r1]).max()
+        # the upper triangle is computed (i <= j) and mirrored: on a row sub-range only the SUM over the ranges is symmetric
+        assert np.abs(np.triu(G - G_ref)).max() <= 1e-13 * scale and np.array_equal(G, G.T)
+        assert np.abs(g - V[:k, r0:r1] @ b[r0:r1]).max() <= 1e-13 * n
+    from pgdrome_amd._lib import PgdError
+    with pytest.raises(PgdError):
+        ctx.start_gram(op, vs + [bv], bv)                          # more than 9 vectors
+    for v in vs + [bv]:
         ctx.vec_free(v)
     for a in (op, ak, am):
         ctx.atom_free(a)

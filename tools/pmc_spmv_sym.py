@@ -13,7 +13,7 @@ from pgdrome_amd import _lib, fem
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 mode = sys.argv[2] if len(sys.argv) > 2 else "grid"
-zchunk = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+zchunk = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # 0: the adaptive march length the solves use
 variant = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 ctx = _lib.Context(0)
 coords, cells = fem.box_mesh_arrays((0, 0, 0), (1, 1, 1), n - 1, n - 1, n - 1)
@@ -25,7 +25,7 @@ nv = ctx.mesh_info(mesh)["nv"]
 x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, nv))
 y = ctx.vec_alloc(nv)
 ctx.tune(3, 0 if mode == "csr" else 1)
-ctx.tune(6, 64 if mode == "grid" else 0)
+ctx.tune(6, 16 if mode == "grid" else 0)       # the library default (0 turns the march off)
 ctx.tune(7, zchunk if mode == "grid" else 0)      # exactly this many planes per march
 ctx.tune(13, variant)
 if mode != "csr":
