@@ -131,6 +131,15 @@ class TorchComm:
         self.stats["allreduce"] += 1
         return float(t.item())
 
+    def allreduce_maxloc(self, value, payload):
+        """(max over ranks of value, payload of the rank that holds it; the lowest such rank on ties): the "delta" stop
+        test of the fixed-point loop on a row-sharded dimension (solver.py:763-776 is written for one process)."""
+        box = [None] * self.world
+        self.dist.all_gather_object(box, (float(value), float(payload)))
+        self.stats["allreduce"] += 1
+        best = max(range(self.world), key=lambda r: (box[r][0], -r))
+        return box[best]
+
     def allreduce_array(self, values):
         """Sum of a small host array over the ranks in ONE collective (Gram data of the Galerkin start, batched functionals)."""
         dev = "cpu" if self.dist.get_backend() == "gloo" else self._scalar_device()

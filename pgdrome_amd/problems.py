@@ -50,6 +50,56 @@ def poisson_1d1d(n=32):
                 PGD_nmax=3, PGD_tol=1e-10)
 
 
+# ------------------------------------------------- an ALGEBRAIC parameter dimension (solve mode "direct")
+def reaction_direct_param(n_x=33, n_e=17, e_range=(1.0, 20.0), PGD_nmax=4, PGD_tol=1e-8):
+    """-u'' + E u = 1 on (0, 1), u(0) = u(1) = 0, u = sum X(x) G(E): config 2's physics in 1-D with the parameter
+    dimension solved ALGEBRAICALLY, ``solve_modes = ["FEM", "direct"]`` (/root/reference/pgdrome/solver.py:637-638,
+    717-718 -> direct_solve :909-925): for that dimension the callbacks return plain arrays, one value per dof
+    (a_i = X'.X' + E_i X.X, b_i = the load minus the stored modes' terms at E_i), and the new factor is b / a.
+    Called for the "stiff" normalisation (solver.py:424-441: Functions in both slots, ``dim`` out of range) the
+    left-hand-side callback returns the scalar the reference takes as ``norm_aux`` (:439-441)."""
+    meshes = [fem.IntervalMesh(n_x - 1, 0.0, 1.0), fem.IntervalMesh(n_e - 1, e_range[0], e_range[1])]
+    Vs = [fem.FunctionSpace(m, "CG", 1) for m in meshes]
+    load = [[fem.interpolate(fem.Expression("1.0", degree=1), V)] for V in Vs]
+    param = {"E": fem.interpolate(fem.Expression("x[0]", degree=1), Vs[1])}
+
+    def bc_fct(Vs, dom, param):
+        return [fem.DirichletBC(Vs[0], 0, _on_boundary), 0]
+
+    def lhs_fct(u, v, Fs, meshes, dom, param, typ, dim):
+        E = param["E"]
+        if typ == "x":
+            return (fem.Constant(fem.assemble(Fs[1] * Fs[1] * fem.dx(meshes[1]))) * u.dx(0) * v.dx(0) * fem.dx(meshes[0])
+                    + fem.Constant(fem.assemble(E * Fs[1] * Fs[1] * fem.dx(meshes[1]))) * u * v * fem.dx(meshes[0]))
+        c_k = fem.assemble(Fs[0].dx(0) * Fs[0].dx(0) * fem.dx(meshes[0]))
+        c_m = fem.assemble(Fs[0] * Fs[0] * fem.dx(meshes[0]))
+        if dim >= len(Fs):
+            return (c_k * fem.assemble(Fs[1] * Fs[1] * fem.dx(meshes[1]))
+                    + c_m * fem.assemble(E * Fs[1] * Fs[1] * fem.dx(meshes[1])))
+        return c_k + c_m * E.vector()[:]
+
+    def rhs_fct(u, v, Fs, meshes, dom, param, Q, PGD_func, typ, nE, dim):
+        E = param["E"]
+        if typ == "x":
+            l = fem.Constant(fem.assemble(Q[1][0] * Fs[1] * fem.dx(meshes[1]))) * Q[0][0] * v * fem.dx(meshes[0])
+            for old in range(nE):
+                l += (-fem.Constant(fem.assemble(PGD_func[1][old] * Fs[1] * fem.dx(meshes[1])))
+                      * PGD_func[0][old].dx(0) * v.dx(0) * fem.dx(meshes[0])
+                      - fem.Constant(fem.assemble(E * PGD_func[1][old] * Fs[1] * fem.dx(meshes[1])))
+                      * PGD_func[0][old] * v * fem.dx(meshes[0]))
+            return l
+        b = fem.assemble(Q[0][0] * Fs[0] * fem.dx(meshes[0])) * Q[1][0].vector()[:]
+        for old in range(nE):
+            b = b - ((fem.assemble(PGD_func[0][old].dx(0) * Fs[0].dx(0) * fem.dx(meshes[0]))
+                      + fem.assemble(PGD_func[0][old] * Fs[0] * fem.dx(meshes[0])) * E.vector()[:])
+                     * PGD_func[1][old].vector()[:])
+        return b
+
+    return dict(name="reaction_direct_param", name_coord=["X", "E"], modes_info=["U", "Node", "Scalar"], Vs=Vs,
+                bc_fct=bc_fct, load=load, param=param, rhs_fct=rhs_fct, lhs_fct=lhs_fct, probs=["x", "e"],
+                PGD_nmax=PGD_nmax, PGD_tol=PGD_tol)
+
+
 # ------------------------------------- configs 2 and 4: -Laplace(u) + mu u = 1, u(x; mu)
 def reaction_diffusion(space_mesh, n_mu=128, mu_range=(1.0, 10.0), PGD_nmax=10, PGD_tol=1e-8):
     """Space (2-D or 3-D, P1) x 1-D parameter mu: atoms K_x (x) M_mu + M_x (x) Mw_mu, w = mu."""

@@ -269,9 +269,18 @@ class PGDProblem:
             if crit == "delta":
                 for d in range(D):
                     new, old = Fs[d].vector()[:], Fs_init[d].vector()[:]
+                    part = getattr(self.meshes[d], "part", None)
+                    if part is not None:
+                        # row-sharded dimension: the owned rows only (ghost planes are copies), then the GLOBAL maximum
+                        # with the value at its position - every rank must take the same branch below, or the next
+                        # solve's halo exchanges and all-reduces no longer match across ranks
+                        new, old = new[part.own0:part.own1], old[part.own0:part.own1]
                     diff = np.absolute(new - old)
                     k = int(np.argmax(diff))
-                    delta[d] = diff.max() if np.absolute(new[k]) < 1e-8 else diff.max() / np.absolute(new[k])
+                    dmax, at = float(diff[k]), float(np.absolute(new[k]))
+                    if part is not None:
+                        dmax, at = part.comm.allreduce_maxloc(dmax, at)
+                    delta[d] = dmax if at < 1e-8 else dmax / at
                 open_dims = len(np.where(delta > self.tol_fp_it)[0]) > 0
                 if open_dims and fpi < self.max_fp_it - 1:
                     Fs_init = np.copy(Fs)

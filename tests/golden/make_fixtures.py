@@ -47,6 +47,7 @@ def case_specs():
         "cfg4_small": lambda: problems.reaction_diffusion(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), 4, 4, 4), 9, PGD_nmax=4),
         "cfg3_small": lambda: problems.transient_heat(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), 4, 4, 4), 9, PGD_nmax=5),
         "cfg5_small": lambda: problems.transient_heat(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), 4, 4, 4), 9, 5, PGD_nmax=5),
+        "direct_param": lambda: problems.reaction_direct_param(33, 17),
     }
 
 
@@ -62,20 +63,42 @@ RUNS = [
     ("cfg4_small", "nonlinear", "l2", "norm", {"PGD_nmax": 3}),
     ("cfg3_small", "linear", "stiff", "norm", {}),
     ("cfg5_small", "linear", "stiff", "norm", {}),
+    # an algebraic parameter dimension: solve_modes = ["FEM", "direct"] (solver.py:637-638, 909-925), both the scalar
+    # norm_aux branch of the "stiff" normalisation (:439-441) and the "l2" one
+    ("direct_param", "linear", "stiff", "norm", {}, ["FEM", "direct"]),
+    ("direct_param", "nonlinear", "l2", "norm", {}, ["FEM", "direct"]),
 ]
 
 
-def run_reference(case, prob_kind, norm_modes, stop_fp, knobs):
+def run_reference(case, prob_kind, norm_modes, stop_fp, knobs, solve_modes=None):
+    import re
     spec = case_specs()[case]()
     p = RefPGDProblem(**spec)
     p.norm_modes, p.stop_fp = norm_modes, stop_fp
     for k, v in knobs.items():
         setattr(p, k, v)
-    p.solve_PGD(_problem=prob_kind)
+    # per-solve trace of what the reference hands to the linear solver: the coefficients c_t of the
+    # operator A = sum_t c_t A_t as its callbacks produced them, |b|_2 and |x|_2 of every FEM solve, in order
+    trace = []
+    inner = fem._solve_linear
+
+    def traced(A, b, x, prm):
+        info = inner(A, b, x, prm)
+        trace.append({"n": int(A.lay.n), "coefs": [float(c) for c in A.merged()[1]],
+                      "b_norm": float(b.norm("l2")), "x_norm": float(x.norm("l2"))})
+        return info
+    fem._solve_linear = traced
+    try:
+        p.solve_PGD(_problem=prob_kind, **({"solve_modes": solve_modes} if solve_modes else {}))
+    finally:
+        fem._solve_linear = inner
     modes = [[f.compute_vertex_values().tolist() for f in p.PGD_func[d]] for d in range(p.num_pgd_var)]
     err = [np.asarray(e, dtype=float).tolist() for e in p.err_fp_it]
+    res_error = [float(v) for v in re.findall(r"-- residuum norm: (\S+) --", p.simulation_info)]
     return {
         "case": case, "problem": prob_kind, "norm_modes": norm_modes, "stop_fp": stop_fp, "knobs": knobs,
+        "solve_modes": solve_modes, "res_error": res_error, "solve_trace": trace,
+        "stopped_on_residual": p.simulation_info.count("residuum norm smaller 1e-10"),
         "dims": [V.dim() for V in spec["Vs"]],
         "PGD_modes": int(p.PGD_modes), "num_fp_it": [int(v) for v in p.num_fp_it], "err_fp_it": err,
         "amplitude": [float(v) for v in p.amplitude], "alpha": [float(v) for v in p.alpha],

@@ -23,15 +23,36 @@ def build_case(case):
         "cfg4_small": lambda: problems.reaction_diffusion(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), 4, 4, 4), 9, PGD_nmax=4),
         "cfg3_small": lambda: problems.transient_heat(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), 4, 4, 4), 9, PGD_nmax=5),
         "cfg5_small": lambda: problems.transient_heat(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), 4, 4, 4), 9, 5, PGD_nmax=5),
+        "direct_param": lambda: problems.reaction_direct_param(33, 17),
     }[case]()
 
 
 def run_case(run, settings=None):
+    """The run of a fixture on this repository's PGDProblem; the per-solve trace (operator coefficients, |b|, |x|) is
+    recorded the way tests/golden/make_fixtures.py recorded the reference's and left on the problem as ``solve_trace``."""
     p = PGDProblem(**build_case(run["case"]))
     p.norm_modes, p.stop_fp = run["norm_modes"], run["stop_fp"]
     for k, v in run["knobs"].items():
         setattr(p, k, v)
-    p.solve_PGD(_problem=run["problem"], **({"settings": settings} if settings else {}))
+    kw = {}
+    if settings:
+        kw["settings"] = settings
+    if run.get("solve_modes"):
+        kw["solve_modes"] = run["solve_modes"]
+    trace = []
+    inner = fem._solve_linear
+
+    def traced(A, b, x, prm):
+        info = inner(A, b, x, prm)
+        trace.append({"n": int(A.lay.n), "coefs": [float(c) for c in A.merged()[1]],
+                      "b_norm": float(b.norm("l2")), "x_norm": float(x.norm("l2"))})
+        return info
+    fem._solve_linear = traced
+    try:
+        p.solve_PGD(_problem=run["problem"], **kw)
+    finally:
+        fem._solve_linear = inner
+    p.solve_trace = trace
     return p
 
 
@@ -61,6 +82,27 @@ def check_against_golden(p, run, mode_tol=1e-6, scalar_rtol=1e-7):
         # err_fp_it is a difference of nearly equal products: compare absolutely at the FP tolerance scale
         np.testing.assert_allclose(p.err_fp_it, run["err_fp_it"], rtol=1e-3, atol=1e-9)
     assert p.simulation_info.count("NOT converged") == run["not_converged_logged"]
+    if "res_error" in run:
+        # the residual pre-check of every enrichment step (solver.py:347-395) and whether it ended the run
+        import re
+        mine = [float(v) for v in re.findall(r"-- residuum norm: (\S+) --", p.simulation_info)]
+        assert len(mine) == len(run["res_error"])
+        np.testing.assert_allclose(mine, run["res_error"], rtol=1e-6, atol=1e-12)
+        assert p.simulation_info.count("residuum norm smaller 1e-10") == run["stopped_on_residual"]
+    if "solve_trace" in run and hasattr(p, "solve_trace"):
+        # every FEM solve in order: same system size, operator coefficients, |b| and |x| (SURVEY 8c's per-solve trace).
+        # Solves of modes whose amplitude is far below the first one's inherit the relative error of the earlier modes
+        # divided by that amplitude, so the bar is 1e-6 relative on the first two modes' solves, 1e-4 after
+        assert len(p.solve_trace) == len(run["solve_trace"])
+        per_mode = np.cumsum([0] + [k * len([1 for s in (run.get("solve_modes") or [None] * p.num_pgd_var)
+                                                if s in (None, "FEM")]) for k in run["num_fp_it"]])
+        for i, (a, b) in enumerate(zip(p.solve_trace, run["solve_trace"])):
+            mode = int(np.searchsorted(per_mode, i, side="right")) - 1
+            tol = 1e-6 if mode < 2 else 1e-4
+            assert a["n"] == b["n"] and len(a["coefs"]) == len(b["coefs"]), i
+            np.testing.assert_allclose(a["coefs"], b["coefs"], rtol=tol, atol=1e-14, err_msg="solve %d" % i)
+            np.testing.assert_allclose([a["b_norm"], a["x_norm"]], [b["b_norm"], b["x_norm"]], rtol=tol, atol=1e-14,
+                                       err_msg="solve %d" % i)
     # every stored mode, factor by factor (signs included: same start vector, same iteration)
     for d in range(p.num_pgd_var):
         for m in range(p.PGD_modes):

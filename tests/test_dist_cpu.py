@@ -20,7 +20,7 @@ def _problem(space, n_mu=9):
     return problems.reaction_diffusion(space, n_mu, PGD_nmax=3)
 
 
-def _worker(rank, world, port, shape, q, single_reduction=None):
+def _worker(rank, world, port, shape, q, single_reduction=None, stop_fp="norm"):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -34,6 +34,9 @@ def _worker(rank, world, port, shape, q, single_reduction=None):
         P = fem.Point
         mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
         p = PGDProblem(**_problem(mesh))
+        p.stop_fp = stop_fp
+        if stop_fp == "delta":
+            p.tol_fp_it = 1e-4
         p.solve_PGD(_problem="linear")
         modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values()) for f in p.PGD_func[0]]
         modes_mu = [f.compute_vertex_values() for f in p.PGD_func[1]]
@@ -52,11 +55,13 @@ def _worker(rank, world, port, shape, q, single_reduction=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shape,single_reduction", [(2, (4, 3, 5), True), (3, (3, 4, 6), True),
-                                                          (2, (4, 3, 5), False), (4, (3, 3, 4), True)])
-def test_sharded_solve_equals_single_process(world, shape, single_reduction):
+@pytest.mark.parametrize("world,shape,single_reduction,stop_fp", [
+    (2, (4, 3, 5), True, "norm"), (3, (3, 4, 6), True, "norm"), (2, (4, 3, 5), False, "norm"), (4, (3, 3, 4), True, "norm"),
+    (2, (4, 3, 5), True, "delta"), (3, (3, 4, 6), True, "delta")])
+def test_sharded_solve_equals_single_process(world, shape, single_reduction, stop_fp):
     """Both recurrences of the sharded solve (two-reduction PCG, single-reduction Chronopoulos-Gear with
-    halo/interior overlap; (4, (3,3,4)) has ranks that own a single plane)."""
+    halo/interior overlap; (4, (3,3,4)) has ranks that own a single plane), and both stop tests of the fixed-point
+    loop: "delta" takes its maximum over the OWNED rows of all ranks, so every rank leaves the loop in the same pass."""
     from oracle.backend_numpy import NumpyBackend
     from pgdrome_amd import fem
     from pgdrome_amd.solver import PGDProblem
@@ -66,6 +71,9 @@ def test_sharded_solve_equals_single_process(world, shape, single_reduction):
     try:
         P = fem.Point
         ref = PGDProblem(**_problem(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape)))
+        ref.stop_fp = stop_fp
+        if stop_fp == "delta":
+            ref.tol_fp_it = 1e-4
         ref.solve_PGD(_problem="linear")
         ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
         ref_mu = [f.compute_vertex_values() for f in ref.PGD_func[1]]
@@ -76,7 +84,7 @@ def test_sharded_solve_equals_single_process(world, shape, single_reduction):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, q, single_reduction)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, shape, q, single_reduction, stop_fp)) for r in range(world)]
     for pr in procs:
         pr.start()
     out = q.get(timeout=240)
