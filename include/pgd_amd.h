@@ -228,6 +228,12 @@ int pgd_comm_bind_callbacks(pgd_handle ctx, pgd_halo_fn halo, pgd_allreduce_fn a
                             int rank, int world);
 int pgd_comm_unique_id(pgd_handle ctx, uint8_t *out128);
 int pgd_comm_bind_rccl(pgd_handle ctx, const uint8_t *id128, int rank, int world);
+/* Halo exchange concurrent with the product of the rows that read no ghost entry: a second
+ * communicator (ncclCommSplit) on its own HIP stream, ordered against the compute stream by two events.
+ * mode 1: try to enable - COLLECTIVE, call on every rank after all ranks bound successfully; the ranks must then
+ * agree (e.g. MIN all-reduce of *state) and call mode 0 everywhere if any rank reports 0.  mode 0: disable.
+ * mode -1: query.  *state: 1 = the sharded solve overlaps, 0 = the exchange stays on the compute stream.   */
+int pgd_comm_overlap(pgd_handle ctx, int mode, int *state);
 int pgd_comm_unbind(pgd_handle ctx);
 int pgd_comm_info(pgd_handle ctx, int *kind /* 0 none, 1 callbacks, 2 rccl */, int *rank, int *world);
 int pgd_comm_halo(pgd_handle ctx, pgd_handle vec, int64_t own0, int64_t own1, int64_t lo_ghost,
@@ -249,7 +255,7 @@ int pgd_start_gram(pgd_handle ctx, pgd_handle A, const pgd_handle *vecs, int k, 
 
 /* ------------------------------------------------------------------ tuning --- */
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
- * sums), never which result is computed.                                        */
+ * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
     PGD_TUNE_SPMV_ROWS = 1,  /* rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256 */
     PGD_TUNE_SPMV_GRID_MIN_BYTES = 8, /* ... used when a grid plane of values has at least this many bytes (default 0) */
@@ -258,6 +264,8 @@ enum {
     PGD_TUNE_PCG_SCALED = 10,   /* 1 (default): pgd_pcg_solve runs CG on D^-1/2 A D^-1/2 (the same iterates as Jacobi-PCG,
                                    two vector passes per iteration fewer) when the symmetric storage applies; 0: unscaled */
     PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */
+    PGD_TUNE_FAULT_ITERATION = 15, /* tests only: pgd_pcg_solve_sharded fails on this rank in that iteration, once (-1: never) -
+                                      the other ranks must come out of the solve with an error instead of waiting for it */
     PGD_TUNE_COMBINE_DIA = 14, /* 1 (default): on structured vertex grids pgd_op_combine also forms the operator's diagonal
                                   (symmetric half) storage from the atoms' diagonal forms; 0: converted from CSR per solve */
     PGD_TUNE_SPMV_VARIANT = 13, /* k_spmv_dia_march: 0 (default) 64 x 4 patches, 256 threads; 1: 64 x 8 patches, 512 threads */

@@ -85,6 +85,7 @@ SIGNATURES = {
     "pgd_comm_bind_callbacks": (C.c_int, [H, HALO_FN, ALLREDUCE_FN, VP, C.c_int, C.c_int]),
     "pgd_comm_unique_id": (C.c_int, [H, PU8]),
     "pgd_comm_bind_rccl": (C.c_int, [H, PU8, C.c_int, C.c_int]),
+    "pgd_comm_overlap": (C.c_int, [H, C.c_int, C.POINTER(C.c_int)]),
     "pgd_comm_unbind": (C.c_int, [H]),
     "pgd_comm_info": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pgd_comm_halo": (C.c_int, [H, H, I64, I64, I64, I64]),
@@ -459,6 +460,12 @@ class Context:
             raise ValueError("RCCL unique id must be 128 bytes")
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._ck(self.lib.pgd_comm_bind_rccl(self.h, buf, int(rank), int(world)))
+
+    def comm_overlap(self, mode=-1):
+        """mode 1: try to enable the halo/interior overlap (collective), 0: disable, -1: query; returns the state."""
+        st = C.c_int(0)
+        self._ck(self.lib.pgd_comm_overlap(self.h, int(mode), C.byref(st)))
+        return bool(st.value)
 
     def comm_unbind(self):
         self._ck(self.lib.pgd_comm_unbind(self.h))

@@ -17,6 +17,8 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
+
 namespace pgd {
 
 struct NcclId { char internal[128]; };
@@ -32,6 +34,7 @@ struct RcclApi {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
+    int (*CommSplit)(void *, int, int, void **, void *) = nullptr;      // optional (RCCL >= 2.18)
 };
 constexpr int NCCL_F64 = 8, NCCL_SUM = 0;   // ncclFloat64, ncclSum (rccl.h)
 
@@ -58,6 +61,7 @@ static RcclApi *rccl_api(std::string &why) {
             api.GroupStart = (int (*)())sym("ncclGroupStart");
             api.GroupEnd = (int (*)())sym("ncclGroupEnd");
             api.GetErrorString = (const char *(*)(int))sym("ncclGetErrorString");
+            api.CommSplit = (int (*)(void *, int, int, void **, void *))dlsym(api.lib, "ncclCommSplit");
         }
     }
     why = err;
@@ -74,14 +78,22 @@ void comm_release(Ctx *c) {
     Comm &k = c->comm;
     if (k.kind == 2 && k.nccl) {
         std::string why;
-        if (RcclApi *api = rccl_api(why)) (void)api->CommDestroy(k.nccl);
+        if (RcclApi *api = rccl_api(why)) {
+            if (k.nccl_halo) (void)api->CommDestroy(k.nccl_halo);
+            (void)api->CommDestroy(k.nccl);
+        }
     }
+    if (k.ev_ready) (void)hipEventDestroy(k.ev_ready);
+    if (k.ev_halo) (void)hipEventDestroy(k.ev_halo);
+    if (k.halo_stream) (void)hipStreamDestroy(k.halo_stream);
     k = Comm();
 }
 
 // neighbour planes -> ghost planes of v (local numbering: [0, lo_g) ghost below, [own0, own1) owned,
-// [own1, own1 + hi_g) ghost above); stream-ordered
-static int comm_halo(Ctx *c, pgd_handle vh, double *v, int64_t own0, int64_t own1, int64_t lo_g, int64_t hi_g) {
+// [own1, own1 + hi_g) ghost above).  `async` (RCCL binding with a halo communicator only): the exchange runs on the
+// halo stream behind an event of the compute stream, and comm_halo_wait makes the compute stream wait for it - rows
+// that read no ghost entry can be multiplied in between.  Otherwise stream-ordered on the compute stream.
+static int comm_halo_begin(Ctx *c, pgd_handle vh, double *v, int64_t own0, int64_t own1, int64_t lo_g, int64_t hi_g, bool async) {
     Comm &k = c->comm;
     if (k.kind == 1) {
         const int rc = k.halo_cb(k.user, vh, own0, own1, lo_g, hi_g);
@@ -92,17 +104,35 @@ static int comm_halo(Ctx *c, pgd_handle vh, double *v, int64_t own0, int64_t own
     std::string why;
     RcclApi *api = rccl_api(why);
     if (!api) return fail(c, PGD_ERR_INVALID, "rccl: %s", why.c_str());
+    const bool over = async && k.overlap;
+    hipStream_t st = over ? k.halo_stream : c->stream;
+    void *comm = over ? k.nccl_halo : k.nccl;
+    if (over) {
+        PGD_HIP(c, hipEventRecord(k.ev_ready, c->stream));               // v is complete on the compute stream
+        PGD_HIP(c, hipStreamWaitEvent(k.halo_stream, k.ev_ready, 0));
+    }
     PGD_NCCL(c, api, api->GroupStart());
     if (lo_g) {
-        PGD_NCCL(c, api, api->Send(v + own0, (size_t)lo_g, NCCL_F64, k.rank - 1, k.nccl, c->stream));
-        PGD_NCCL(c, api, api->Recv(v, (size_t)lo_g, NCCL_F64, k.rank - 1, k.nccl, c->stream));
+        PGD_NCCL(c, api, api->Send(v + own0, (size_t)lo_g, NCCL_F64, k.rank - 1, comm, st));
+        PGD_NCCL(c, api, api->Recv(v, (size_t)lo_g, NCCL_F64, k.rank - 1, comm, st));
     }
     if (hi_g) {
-        PGD_NCCL(c, api, api->Send(v + own1 - hi_g, (size_t)hi_g, NCCL_F64, k.rank + 1, k.nccl, c->stream));
-        PGD_NCCL(c, api, api->Recv(v + own1, (size_t)hi_g, NCCL_F64, k.rank + 1, k.nccl, c->stream));
+        PGD_NCCL(c, api, api->Send(v + own1 - hi_g, (size_t)hi_g, NCCL_F64, k.rank + 1, comm, st));
+        PGD_NCCL(c, api, api->Recv(v + own1, (size_t)hi_g, NCCL_F64, k.rank + 1, comm, st));
     }
     PGD_NCCL(c, api, api->GroupEnd());
+    if (over) PGD_HIP(c, hipEventRecord(k.ev_halo, k.halo_stream));
     return PGD_OK;
+}
+
+static int comm_halo_wait(Ctx *c, int64_t lo_g, int64_t hi_g, bool async) {
+    Comm &k = c->comm;
+    if (k.kind == 2 && async && k.overlap && (lo_g || hi_g)) PGD_HIP(c, hipStreamWaitEvent(c->stream, k.ev_halo, 0));
+    return PGD_OK;
+}
+
+static int comm_halo(Ctx *c, pgd_handle vh, double *v, int64_t own0, int64_t own1, int64_t lo_g, int64_t hi_g) {
+    return comm_halo_begin(c, vh, v, own0, own1, lo_g, hi_g, false);
 }
 
 static int comm_allreduce(Ctx *c, int first, int count) {
@@ -156,6 +186,41 @@ static int comm_selftest(Ctx *c) {
     return PGD_OK;
 }
 
+// The halo communicator (a split of the first) on its own stream, ordered against the compute stream by the two events
+// exactly as the solve uses them: fill on the compute stream -> ring shift on the halo stream -> read on the compute
+// stream.  Any failure simply leaves the overlap off (the exchange then stays on the compute stream).
+static void comm_setup_overlap(Ctx *c) {
+    Comm &k = c->comm;
+    k.overlap = false;
+    const char *env = getenv("PGD_HALO_OVERLAP");
+    if (env && env[0] == '0') return;
+    std::string why;
+    RcclApi *api = rccl_api(why);
+    if (!api || !api->CommSplit) return;
+    if (api->CommSplit(k.nccl, 0, k.rank, &k.nccl_halo, nullptr) != 0 || !k.nccl_halo) { k.nccl_halo = nullptr; return; }
+    if (hipStreamCreateWithFlags(&k.halo_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&k.ev_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&k.ev_halo, hipEventDisableTiming) != hipSuccess)
+        return;
+    constexpr int N = 256;
+    if (ensure_work(c, 5, 2 * N) != PGD_OK) return;
+    double *snd = c->work[5], *rcv = c->work[5] + N;
+    k_comm_fill<<<1, N, 0, c->stream>>>(snd, N, 2000.0 + k.rank);
+    k_comm_fill<<<1, N, 0, c->stream>>>(rcv, N, -1.0);
+    const int next = (k.rank + 1) % k.world, prev = (k.rank + k.world - 1) % k.world;
+    bool ok = hipEventRecord(k.ev_ready, c->stream) == hipSuccess && hipStreamWaitEvent(k.halo_stream, k.ev_ready, 0) == hipSuccess;
+    ok = ok && api->GroupStart() == 0;
+    ok = ok && api->Send(snd, N, NCCL_F64, next, k.nccl_halo, k.halo_stream) == 0;
+    ok = ok && api->Recv(rcv, N, NCCL_F64, prev, k.nccl_halo, k.halo_stream) == 0;
+    ok = ok && api->GroupEnd() == 0;
+    ok = ok && hipEventRecord(k.ev_halo, k.halo_stream) == hipSuccess && hipStreamWaitEvent(c->stream, k.ev_halo, 0) == hipSuccess;
+    double got = 0.0;
+    ok = ok && hipMemcpyAsync(&got, rcv + N / 2, sizeof(double), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess;
+    k.overlap = ok && got == 2000.0 + prev;
+    (void)hipGetLastError();
+}
+
 }  // namespace pgd
 
 using namespace pgd;
@@ -195,8 +260,25 @@ int pgd_comm_bind_rccl(pgd_handle h, const uint8_t *id128, int rank, int world) 
     PGD_NCCL(c, api, api->CommInitRank(&comm, world, id, rank));
     c->comm.kind = 2; c->comm.rank = rank; c->comm.world = world; c->comm.nccl = comm;
     const int rc = comm_selftest(c);
-    if (rc != PGD_OK) { const std::string keep = c->err; comm_release(c); c->err = keep; }
+    if (rc != PGD_OK) { const std::string keep = c->err; comm_release(c); c->err = keep; return rc; }
     return rc;
+}
+
+int pgd_comm_overlap(pgd_handle h, int mode, int *state) {
+    PGD_CTX(c, h);
+    Comm &k = c->comm;
+    if (mode == 1) {
+        // COLLECTIVE over the bound RCCL communicator (ncclCommSplit + a ring shift on the halo stream): call it on every
+        // rank, and only after every rank reported a successful pgd_comm_bind_rccl
+        if (k.kind != 2) return fail(c, PGD_ERR_INVALID, "comm_overlap: needs the RCCL binding");
+        if (!k.nccl_halo) comm_setup_overlap(c);
+    } else if (mode == 0) {
+        k.overlap = false;
+    } else if (mode != -1) {
+        return fail(c, PGD_ERR_INVALID, "comm_overlap: mode must be 1 (enable), 0 (disable) or -1 (query)");
+    }
+    if (state) *state = k.overlap ? 1 : 0;
+    return PGD_OK;
 }
 
 int pgd_comm_unbind(pgd_handle h) {
@@ -241,37 +323,98 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     if (k.kind == 0) return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: no communication binding");
     if ((lo_g > 0) != (k.rank > 0) || (hi_g > 0) != (k.rank < k.world - 1))
         return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: ghost planes do not match the rank's position");
-    if (k.work_n != n) {      // r, u, w, p, s, q, dinv as library vectors (the slot kernels take handles)
-        for (pgd_handle &wh : k.work) { if (wh) (void)pgd_vec_free(h, wh); wh = 0; }
-        for (pgd_handle &wh : k.work) PGD_TRY(pgd_vec_alloc(h, n, &wh));
-        k.work_n = n;
-    }
-    const pgd_handle r = k.work[0], u = k.work[1], w = k.work[2], p = k.work[3], s = k.work[4], q = k.work[5], dinv = k.work[6];
     constexpr int B = 24, CHECK = 16;       // slot base of the recurrence (pgdrome_amd/dist.py uses the same)
-    // The exchange is stream-ordered before the product, so the owned rows go in ONE launch; the slots of the
-    // two boundary-row partials (kept for the overlapped host-driven variant) stay zero.
-    auto spmv_dot3 = [&](pgd_handle uu, pgd_handle ww) -> int {
-        PGD_TRY(comm_halo(c, uu, get_vec(c, uu)->d, own0, own1, lo_g, hi_g));
-        return pgd_spmv_dot_slot(h, oh, uu, ww, uu, own0, own1, B + 2);
-    };
     Mesh *m = get_mesh(c, op->mesh);
+
+    // ---- phase A: everything that can fail on ONE rank (allocations, the symmetric copy) happens before the first
+    // collective, and its outcome is agreed on: a rank that fails here must not leave the others waiting in a halo
+    // exchange, and a rank whose operator did not qualify for the symmetric storage must not take another branch
+    // (the scaled recurrence has one more halo exchange) than its neighbours.
     bool sym = false;
-    if (m) PGD_TRY(ensure_sym(c, m, op, &sym));
-    PGD_TRY(pgd_flags_reset(h));
+    auto setup = [&]() -> int {
+        if (!m) return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: operator without a mesh");
+        if (k.work_n != n) {      // r, u, w, p, s, q, dinv as library vectors (the slot kernels take handles)
+            for (pgd_handle &wh : k.work) { if (wh) (void)pgd_vec_free(h, wh); wh = 0; }
+            k.work_n = 0;
+            for (pgd_handle &wh : k.work) PGD_TRY(pgd_vec_alloc(h, n, &wh));
+            k.work_n = n;
+        }
+        PGD_TRY(ensure_sym(c, m, op, &sym));
+        PGD_TRY(ensure_partials(c, std::max<int64_t>((own1 - own0) / 64 + 64, 4 * (int64_t)MAX_VEC_BLOCKS)));
+        PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS));
+        PGD_TRY(pgd_flags_reset(h));
+        return PGD_OK;
+    };
+    const int rc_setup = setup();
+    const std::string err_setup = c->err;
+    {
+        const double vote[2] = {rc_setup != PGD_OK ? 1.0 : 0.0, (rc_setup == PGD_OK && sym && c->pcg_scaled) ? 0.0 : 1.0};
+        double got[2] = {1.0, 1.0};
+        int rc = pgd_slots_upload(h, vote, B, 2);
+        if (rc == PGD_OK) rc = comm_allreduce(c, B, 2);
+        if (rc == PGD_OK) rc = pgd_slots_download(h, got, B, 2);
+        if (rc_setup != PGD_OK) { c->err = err_setup; return rc_setup; }
+        if (rc != PGD_OK) return rc;
+        if (got[0] != 0.0) return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: the setup failed on another rank");
+        sym = sym && got[1] == 0.0;                     // scaled only if EVERY rank can
+    }
+    const bool scaled = sym && c->pcg_scaled;
+    const pgd_handle r = k.work[0], u = k.work[1], w = k.work[2], p = k.work[3], s = k.work[4], q = k.work[5], dinv = k.work[6];
     const double zeros[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     PGD_TRY(pgd_slots_upload(h, zeros, B, 9));
     PGD_TRY(pgd_op_diag_inv(h, oh, dinv));
-    // With the symmetric storage in place the recurrence runs on the diagonally scaled system (k_cg_update_s: u = r, no
-    // dinv / u passes).  sc = d^-1/2 of the ghost rows comes from their owners (their local diagonals are partial sums).
-    const bool scaled = sym && c->pcg_scaled;
     double *scp = get_vec(c, dinv)->d;
     double *xd = x->d, *rd = get_vec(c, r)->d, *wd = get_vec(c, w)->d, *pd = get_vec(c, p)->d, *sd = get_vec(c, s)->d,
            *qd = get_vec(c, q)->d;
+
+    // On every exit after the operator and x were scaled: x back to sc x~, the slot arrays no longer taken for A.
+    struct ScaleGuard {
+        Ctx *c; Csr *op; double *x; const double *sc; int64_t n; bool active;
+        ~ScaleGuard() {
+            if (!active) return;
+            (void)vec_div_mul(c, x, sc, n, 1);
+            op->uvals_valid = false;
+            op->uvals_scaled = false;
+        }
+    } guard{c, op, xd, scp, n, false};
+
+    // w = A u on the owned rows, S[B + 2] (+ S[B + 3], S[B + 4]) <- local w.u: the rows that read no ghost entry first,
+    // while the boundary planes travel (overlap binding) - the same three launches in the same order either way, so the
+    // overlapped and the stream-ordered solve are bit-identical.  `folded`: partial sums of all three ranges side by
+    // side in the scratch, one later reduction (k_reduce_two); else one reduction per range into its own slot.
+    int64_t glo = lo_g, ghi = hi_g;
+    if (own1 - own0 < glo + ghi) { glo = own1 - own0; ghi = 0; }     // a rank that owns a single plane: nothing to overlap
+    bool halo_pending = false;
+    auto product = [&](pgd_handle uh, double *ud, double *wdst, bool folded, int *np_total) -> int {
+        const bool async = k.overlap && own1 - ghi > own0 + glo;
+        halo_pending = false;
+        PGD_TRY(comm_halo_begin(c, uh, ud, own0, own1, lo_g, hi_g, async));
+        halo_pending = async;
+        const int64_t lo[3] = {own0 + glo, own0, own1 - ghi}, hi[3] = {own1 - ghi, own0 + glo, own1};
+        int total = 0;
+        for (int part = 0; part < 3; ++part) {
+            if (part == 1) { PGD_TRY(comm_halo_wait(c, lo_g, hi_g, async)); halo_pending = false; }
+            if (folded) {
+                int np = 0;
+                c->partials_off = total;
+                const int rc = launch_spmv_op(c, m, op, ud, wdst, ud, lo[part], hi[part], true, true, c->flags, &np);
+                c->partials_off = 0;
+                PGD_TRY(rc);
+                total += np;
+            } else {
+                PGD_TRY(pgd_spmv_dot_slot(h, oh, uh, (wdst == wd) ? w : q, uh, lo[part], hi[part], B + 2 + part));
+            }
+        }
+        if (np_total) *np_total = total;
+        return PGD_OK;
+    };
+
     if (scaled) {
         PGD_TRY(vec_sqrt(c, scp, n));
         PGD_TRY(comm_halo(c, dinv, scp, own0, own1, lo_g, hi_g));
         PGD_TRY(sym_scale(c, m, op, scp));
         PGD_TRY(vec_div_mul(c, xd, scp, n, 0));                      // x~ = x / sc on owned and ghost rows alike
+        guard.active = true;
     }
     PGD_TRY(comm_halo(c, xh, xd, own0, own1, lo_g, hi_g));
     if (scaled) PGD_TRY(launch_spmv_op(c, m, op, xd, qd, nullptr, own0, own1, false, true, nullptr, nullptr));   // the scaled slots
@@ -279,7 +422,8 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     if (scaled) PGD_TRY(cg_init_s(c, b->d, qd, scp, rd, pd, sd, own0, own1, B));
     else PGD_TRY(pgd_cg_init_slot(h, bh, q, dinv, r, u, p, s, own0, own1, B));
     const pgd_handle mv = scaled ? r : u;                            // the vector the product is applied to
-    PGD_TRY(spmv_dot3(mv, w));
+    double *mvd = get_vec(c, mv)->d;
+    PGD_TRY(product(mv, mvd, wd, false, nullptr));
     PGD_TRY(comm_allreduce(c, B, 9));
     PGD_TRY(pgd_cg_scalars_slot(h, B, 1, rtol, atol));
     if (scaled) {     // the folded form reads "previous alpha, previous r.r" from the slot set of its parity: seed set 0
@@ -288,39 +432,72 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     }
     int32_t done = 0, it = 0, status = 0;
     int kk = 0;
-    for (;;) {
-        PGD_TRY(pgd_flags_download(h, &done, &it, &status));     // the only host synchronisation of the loop
-        if (done || kk >= maxit) break;
-        const int chunk = std::min(CHECK, maxit - kk);
-        for (int j = 0; j < chunk; ++j, ++kk) {
-            if (scaled && kk > 0) {
-                // 3 kernels per iteration: vector step (forms alpha / beta itself, counts, tests), product, one reduction
-                int nb = 0, np = 0;
-                PGD_TRY(cg_update_s2(c, xd, rd, wd, pd, sd, scp, own0, own1, B, (kk - 1) & 1, &nb));
-                PGD_TRY(comm_halo(c, mv, rd, own0, own1, lo_g, hi_g));
-                PGD_TRY(launch_spmv_op(c, m, op, rd, wd, rd, own0, own1, true, true, c->flags, &np));
-                PGD_TRY(reduce_two_slots(c, nb, np, B));
-                PGD_TRY(comm_allreduce(c, B, 5));
-                continue;
-            }
+    // One iteration; did_halo / did_ar say which of its two collectives were issued when it fails half way.
+    bool did_halo = false, did_ar = false;
+    auto iterate = [&](int kidx) -> int {
+        did_halo = did_ar = false;
+        if (c->fault_iteration >= 0 && kidx == c->fault_iteration) {      // tests: a rank-local failure in mid-solve
+            c->fault_iteration = -1;
+            return fail(c, PGD_ERR_HIP, "pcg_solve_sharded: injected fault in iteration %d (PGD_TUNE_FAULT_ITERATION)", kidx);
+        }
+        if (scaled && kidx > 0) {
+            // 3 kernels per iteration: vector step (forms alpha / beta itself, counts, tests), product, one reduction
+            int nb = 0, np = 0;
+            PGD_TRY(cg_update_s2(c, xd, rd, wd, pd, sd, scp, own0, own1, B, (kidx - 1) & 1, &nb));
+            const int rc = product(mv, rd, wd, true, &np);
+            did_halo = true;                                         // the exchange is the first thing product() issues
+            PGD_TRY(rc);
+            PGD_TRY(reduce_two_slots(c, nb, np, B));
+        } else {
             if (scaled) PGD_TRY(cg_update_s(c, xd, rd, wd, pd, sd, scp, own0, own1, B));
             else PGD_TRY(pgd_cg_update_slot(h, xh, r, u, w, p, s, dinv, own0, own1, B));
-            PGD_TRY(spmv_dot3(mv, w));
-            PGD_TRY(comm_allreduce(c, B, 5));
-            if (!scaled) PGD_TRY(pgd_cg_scalars_slot(h, B, 0, rtol, atol));
+            const int rc = product(mv, mvd, wd, false, nullptr);
+            did_halo = true;
+            PGD_TRY(rc);
+        }
+        did_ar = true;
+        PGD_TRY(comm_allreduce(c, B, 5));
+        if (!(scaled && kidx > 0) && !scaled) PGD_TRY(pgd_cg_scalars_slot(h, B, 0, rtol, atol));
+        return PGD_OK;
+    };
+    int rc_loop = PGD_OK;
+    std::string err_loop;
+    for (;;) {
+        if (rc_loop == PGD_OK) PGD_TRY(pgd_flags_download(h, &done, &it, &status));     // the only host synchronisation of the loop
+        if (done || kk >= maxit || rc_loop != PGD_OK) break;
+        const int chunk = std::min(CHECK, maxit - kk);
+        for (int j = 0; j < chunk; ++j, ++kk) {
+            if (rc_loop == PGD_OK) {
+                rc_loop = iterate(kk);
+                if (rc_loop == PGD_OK) continue;
+                err_loop = c->err;
+            } else {
+                did_halo = did_ar = false;
+            }
+            // POISONED: this rank failed in the middle of the chunk.  It keeps issuing the chunk's collectives - with
+            // NaN in its partial sums, so that every rank's convergence test trips on the all-reduced values and all of
+            // them leave at the next look at the flags - instead of dropping out and leaving its neighbours waiting.
+            if (halo_pending) { (void)comm_halo_wait(c, lo_g, hi_g, true); halo_pending = false; }
+            if (!did_halo) (void)comm_halo(c, mv, mvd, own0, own1, lo_g, hi_g);
+            if (!did_ar) {
+                (void)hipMemsetAsync(c->slots + B, 0xFF, 5 * sizeof(double), c->stream);       // five NaNs
+                (void)comm_allreduce(c, B, 5);
+            }
         }
     }
+    if (rc_loop != PGD_OK) { c->err = err_loop; return rc_loop; }
     if (scaled && !done && kk > 0) {
         // the last enqueued iteration's scalars are still unprocessed in the folded form: count and test them
         PGD_TRY(pgd_cg_scalars_slot(h, B, 0, rtol, atol));
         PGD_TRY(pgd_flags_download(h, &done, &it, &status));
     }
+    if (status != 0) return fail(c, PGD_ERR_SINGULAR, "sharded PCG breakdown (NaN) after %d iterations", it);
     if (scaled) {
+        guard.active = false;
         PGD_TRY(vec_div_mul(c, xd, scp, n, 1));                      // back to x = sc x~ (ghosts too; refreshed below)
         op->uvals_valid = false;                                     // the slot arrays hold the scaled operator
         op->uvals_scaled = false;
     }
-    if (status != 0) return fail(c, PGD_ERR_SINGULAR, "sharded PCG breakdown (NaN) after %d iterations", it);
     double sl[40];
     PGD_TRY(pgd_slots_download(h, sl, 0, 40));
     PGD_TRY(comm_halo(c, xh, x->d, own0, own1, lo_g, hi_g));     // the caller's x: ghosts current

@@ -105,6 +105,10 @@ struct Comm {
     pgd_allreduce_fn allreduce_cb = nullptr;
     void *user = nullptr;
     void *nccl = nullptr;         // ncclComm_t
+    void *nccl_halo = nullptr;    // second communicator (ncclCommSplit) for the halo exchange on its own stream
+    hipStream_t halo_stream = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
+    bool overlap = false;         // halo exchange concurrent with the interior rows' product
     pgd_handle work[7] = {0, 0, 0, 0, 0, 0, 0};   // r, u, w, p, s, q, dinv of the sharded PCG
     int64_t work_n = 0;
 };
@@ -128,6 +132,7 @@ struct Ctx {
     int *flags = nullptr;         // [0] done, [1] iters, [2] status
     double *partials = nullptr;   // reduction scratch
     int64_t partials_cap = 0;
+    int64_t partials_off = 0;     // the product launchers write their partial sums from here on (several row ranges, one reduction)
     double *work[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     int64_t work_cap[7] = {0, 0, 0, 0, 0, 0, 0};
     uint8_t *mask = nullptr;      // Dirichlet column mask scratch
@@ -142,6 +147,7 @@ struct Ctx {
     int spmv_rows = 64;           // rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256
     int64_t spmv_grid_min_plane_bytes = 0;   // structured grids whose planes of values are at least this large take k_spmv_sym_grid3
     int spmv_zchunk_force = 0;    // > 0: exactly this many planes per march whatever the grid size (tests)
+    int fault_iteration = -1;     // tests: pgd_pcg_solve_sharded fails on this rank in that iteration (once)
     int spmv_variant = 0;         // k_spmv_dia_march: 0 = 64 x 4 patches (256 threads), 1 = 64 x 8 patches (512 threads)
     int spmv_zchunk = 16;         // k_spmv_sym_grid3: most planes a workgroup marches through (0: never use that kernel)
     int pcg_fold_reduce = 1;      // scaled recurrence: final reduction passes folded into the vector kernels (3 launches / iteration)

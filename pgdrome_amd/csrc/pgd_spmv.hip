@@ -19,6 +19,8 @@
 // of row blocks (neighbouring blocks share x planes in that XCD's L2).
 #include "pgd_internal.h"
 
+#include <algorithm>
+
 namespace pgd {
 
 constexpr int SPMV_CAP = 4096;                       // staged entries per 256-row workgroup (k_spmv_multi)
@@ -324,10 +326,10 @@ int launch_spmv(Ctx *c, const Mesh *m, const double *vals, const double *x, doub
     const int nblk = (int)((nrows + R - 1) / R);
     if (nparts_out) *nparts_out = nblk;
     if (nblk == 0) return PGD_OK;
-    if (dot) PGD_TRY(ensure_partials(c, (int64_t)nblk > 4 * MAX_VEC_BLOCKS ? nblk : 4 * MAX_VEC_BLOCKS));
+    if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + nblk, 4 * MAX_VEC_BLOCKS)));
     SpmvArgs A;
     A.row_ptr = m->row_ptr; A.cols = m->cols; A.vals = vals; A.x = x; A.w = w; A.y = y;
-    A.partials = c->partials; A.flags = flags; A.row_begin = (int)r0; A.row_end = (int)r1;
+    A.partials = c->partials + c->partials_off; A.flags = flags; A.row_begin = (int)r0; A.row_end = (int)r1;
     bool timed = false;
     PGD_TRY(prof_begin(c, dot, store, &timed));
     const bool use_dict = c->spmv_dict && m->dict_count > 0;
@@ -985,15 +987,15 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
     const int nblk = (int)((nrows + 63) / 64);
     if (nparts_out) *nparts_out = nblk;
     if (nblk == 0) return PGD_OK;
-    if (dot) PGD_TRY(ensure_partials(c, (int64_t)nblk > 4 * MAX_VEC_BLOCKS ? nblk : 4 * MAX_VEC_BLOCKS));
+    if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + nblk, 4 * MAX_VEC_BLOCKS)));
     SymArgs A;
-    A.uvals = a->uvals; A.x = x; A.w = w; A.y = y; A.partials = c->partials; A.flags = flags;
+    A.uvals = a->uvals; A.x = x; A.w = w; A.y = y; A.partials = c->partials + c->partials_off; A.flags = flags;
     A.tab = m->sym_tab; A.pids = m->pids; A.n = a->uvals_stride; A.row_begin = (int)r0; A.row_end = (int)r1;
     if (m->sym_nx > 0) {
         // structured vertex grid: the operator is held in diagonal form
         const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
         DiaArgs D;
-        D.uvals = a->uvals; D.x = x; D.w = w; D.y = y; D.partials = c->partials; D.flags = flags; D.n = a->uvals_stride;
+        D.uvals = a->uvals; D.x = x; D.w = w; D.y = y; D.partials = c->partials + c->partials_off; D.flags = flags; D.n = a->uvals_stride;
         D.nx = m->sym_nx; D.ny = m->sym_ny; D.nz = (int)(m->nv / plane);
         D.row_begin = (int)r0; D.row_end = (int)r1;
         D.z0 = (int)(r0 / plane); D.z1 = (int)(r1 / plane);
@@ -1015,8 +1017,8 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         if (gg > 0 && gg < ((int64_t)1 << 30)) {
             const int wgs = (int)gg;
             if (nparts_out) *nparts_out = wgs;
-            if (dot) PGD_TRY(ensure_partials(c, (int64_t)wgs > 4 * MAX_VEC_BLOCKS ? wgs : 4 * MAX_VEC_BLOCKS));
-            D.partials = c->partials;
+            if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + wgs, 4 * MAX_VEC_BLOCKS)));
+            D.partials = c->partials + c->partials_off;
             PGD_TRY(prof_begin(c, dot, store, &timed2));
 #define PGD_MARCH(WY)                                                                                  \
     do {                                                                                               \
@@ -1128,6 +1130,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_PCG_FOLD_REDUCE && value >= 0 && value <= 1) { c->pcg_fold_reduce = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_SCALED && value >= 0 && value <= 1) { c->pcg_scaled = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK && value >= 0 && value <= 65536) { c->spmv_zchunk = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_FAULT_ITERATION && value >= -1 && value <= (1 << 30)) { c->fault_iteration = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_COMBINE_DIA && value >= 0 && value <= 1) { c->spmv_combine_dia = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_VARIANT && value >= 0 && value <= 1) { c->spmv_variant = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);

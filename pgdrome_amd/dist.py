@@ -61,6 +61,8 @@ class TorchComm:
         if in_library and getattr(backend, "name", "") == "hip" and os.environ.get("PGD_SHARDED_DRIVER", "library") != "python":
             self.bind_library()
 
+    halo_overlap = False
+
     def bind_library(self):
         """Hand the sharded PCG loop and its two communication steps to the HIP library.
 
@@ -94,6 +96,18 @@ class TorchComm:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if float(flag.item()) == 1.0:
             self.in_library = "rccl"
+            # halo exchange concurrent with the interior rows' product: every rank tries (collective inside the library),
+            # all ranks must agree, else it stays off everywhere
+            ok = 0.0
+            try:
+                ok = 1.0 if be.comm_overlap(1) else 0.0
+            except Exception as e:          # noqa: BLE001
+                why = str(e)
+            flag = self.torch.tensor([ok], dtype=self.torch.float64, device=self._scalar_device())
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) != 1.0:
+                be.comm_overlap(0)
+            self.halo_overlap = float(flag.item()) == 1.0
         else:
             be.comm_unbind()
             warnings.warn("in-library RCCL binding not available on every rank (%s): the sharded PCG is driven "

@@ -165,6 +165,9 @@ class HipBackend:
     def comm_bind_rccl(self, unique_id, rank, world):
         self.ctx.comm_bind_rccl(unique_id, rank, world)
 
+    def comm_overlap(self, mode=-1):
+        return self.ctx.comm_overlap(mode)
+
     def comm_unbind(self):
         self.ctx.comm_unbind()
 

@@ -57,6 +57,8 @@ def test_sharded_driver_world1_matches_library_pcg():
             comm = pdist.TorchComm(dist, be2, in_library=in_library)
             if in_library:     # the library opened its own RCCL communicator and passed its ring-shift check
                 assert comm.in_library == "rccl" and be2.comm_info() == {"kind": "rccl", "rank": 0, "world": 1}
+                # the halo communicator (ncclCommSplit) on its own stream passed its event-ordered ring shift as well
+                assert comm.halo_overlap is True and be2.comm_overlap() is True
             else:
                 assert comm.in_library is None
             mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
@@ -153,3 +155,53 @@ def test_sharded_solve_with_real_halos_on_one_gpu(world, in_library):
     for m in range(ref.PGD_modes):
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
     assert out["stats"]["halo"] > 100
+
+
+def _faulty_worker(rank, world, port, shape, q):
+    """Rank 1 fails (rank-locally, injected) in iteration 7 of its first sharded solve."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    msg = "no error"
+    try:
+        from pgdrome_amd import dist as pdist, fem, problems
+        from pgdrome_amd.hip_backend import HipBackend
+        from pgdrome_amd.solver import PGDProblem
+        torch.cuda.set_device(0)
+        tstream = torch.cuda.Stream(device=0)
+        torch.cuda.set_stream(tstream)
+        be = fem.set_backend(HipBackend(0, tstream.cuda_stream))
+        comm = pdist.TorchComm(dist, be, in_library=True)
+        P = fem.Point
+        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+        p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=2))
+        if rank == 1:
+            be.ctx.tune(15, 7)
+        try:
+            p.solve_PGD(_problem="linear")
+        except Exception as e:      # noqa: BLE001 - the point of the test
+            msg = "%s: %s" % (type(e).__name__, e)
+    finally:
+        q.put((rank, msg))
+        dist.destroy_process_group()
+
+
+def test_a_rank_failing_in_mid_solve_takes_the_others_out_with_an_error():
+    """A rank-local failure inside the in-library sharded loop must end the solve on EVERY rank with an error - the
+    failing rank keeps issuing the chunk's collectives with NaN partial sums, so the others' convergence test trips -
+    instead of leaving them blocked in a halo exchange or an all-reduce."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_faulty_worker, args=(r, 2, port, (16, 12, 21), q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=240) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert "injected fault" in got[1]
+    assert "breakdown" in got[0] or "NaN" in got[0]
