@@ -153,8 +153,13 @@ int pgd_bilinear_many(pgd_handle ctx, pgd_handle A, pgd_handle x, const pgd_hand
 
 /* ----------------------------------------------------------------- solvers --- */
 /* Jacobi-preconditioned CG, x holds the start vector and receives the solution.
- * Stops when ||r||_2 <= max(rtol ||b||_2, atol).  Replaces PETSc/MUMPS behind
- * solver.solve() (solver.py:592-595, 633-636) for the SPD spatial systems.      */
+ * Stops when ||r||_2 <= max(rtol ||b||_2, atol) on the TRUE residual (PETSc's CG tests the preconditioned
+ * norm by default; the reference solves directly, so either is a tolerance on an exact answer).  Replaces
+ * PETSc/MUMPS behind solver.solve() (solver.py:592-595, 633-636) for the SPD spatial systems.
+ * Reaching maxit is NOT an error here (iters == maxit, relres > rtol: the caller decides - pgdrome_amd.fem raises
+ * like dolfin's error_on_nonconvergence).  On an error return (a failing launch or copy in mid-loop) x is handed
+ * back in its own coordinates, never in the scaled ones the recurrence works in, and the operator's symmetric
+ * copy is dropped.                                                                                         */
 int pgd_pcg_solve(pgd_handle ctx, pgd_handle op, pgd_handle b, pgd_handle x, double rtol,
                   double atol, int maxit, int *iters, double *relres);
 /* Banded LU with partial pivoting in one workgroup, for the small and possibly

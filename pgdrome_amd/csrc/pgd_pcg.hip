@@ -814,6 +814,18 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     constexpr int S_INIT = 18, S_PAIR = 16;
     const bool scaled = sym && c->pcg_scaled && n >= 2;
     double *sc = z;                     // the scaled recurrence has no z: its buffer holds s = d^-1/2
+    // On EVERY exit after x and the slot arrays were scaled (a failing launch, graph replay or copy included): x back to
+    // D^-1/2 x~ and the slot arrays no longer taken for A - a later product with this operator must not read the scaled
+    // matrix, and the caller must not get x in scaled coordinates.
+    struct ScaleGuard {
+        Ctx *c; Csr *o; double *x; const double *sc; int64_t n; bool active;
+        ~ScaleGuard() {
+            if (!active) return;
+            (void)vec_div_mul(c, x, sc, n, 1);
+            o->uvals_valid = false;
+            o->uvals_scaled = false;
+        }
+    } guard{c, o, x->d, sc, n, false};
     if (scaled) {
         PGD_TRY(ensure_work(c, 5, 4096));
         unsigned long long *bits = reinterpret_cast<unsigned long long *>(c->work[5]);
@@ -821,6 +833,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         k_scale_in<<<grid_for(n), TPB, 0, c->stream>>>(o->dinv, sc, x->d, n, bits);
         k_dmin_slot<<<1, 1, 0, c->stream>>>(bits, c->slots, c->flags);
         PGD_LAUNCH_CHECK(c);
+        guard.active = true;            // x is scaled from here on
         PGD_TRY(sym_scale(c, m, o, sc));
         PGD_TRY(launch_spmv_op(c, m, o, x->d, q, nullptr, 0, n, false, true, nullptr, nullptr));
         const int g = grid_for(n);
@@ -909,6 +922,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     if (rc_loop != PGD_OK) return rc_loop;
     if (scaled) {      // x = D^-1/2 x~, and the true r.r of the last iterate for the report
         const int g = grid_for(n);
+        guard.active = false;
         k_scale_out<<<g, TPB, 0, c->stream>>>(x->d, r, sc, n, c->partials);
         PGD_LAUNCH_CHECK(c);
         PGD_TRY(reduce_partials(c, c->partials, g, 1, S_TMP, -1, 0, 0));

@@ -32,6 +32,7 @@ import logging
 import math
 import numbers
 import time
+import weakref
 
 import numpy as np
 
@@ -131,16 +132,22 @@ class Partition:
 class Mesh:
     _CELL_NAMES = {1: "interval", 2: "triangle", 3: "tetrahedron"}
 
-    def __init__(self, coords, cells, part=None):
+    def __init__(self, coords=None, cells=None, part=None):
+        # ``Mesh()`` is the empty mesh dolfin lets ``HDF5File.read(mesh, name, False)`` fill (model.py:455-458)
+        self.part = part
+        self._set_geometry(np.zeros((0, 1)) if coords is None else coords,
+                           np.zeros((0, 2), dtype=np.int32) if cells is None else cells)
+
+    def _set_geometry(self, coords, cells):
         coords = np.ascontiguousarray(coords, dtype=np.float64)
         if coords.ndim == 1:
             coords = coords.reshape(-1, 1)
         self._coords = coords
         self._cells = np.ascontiguousarray(cells, dtype=np.int32)
         self._gdim = coords.shape[1]
-        self.part = part
         self._layouts = {}       # degree -> DofLayout
         self._on_boundary = None
+        self._facets = None
 
     def coordinates(self):
         return self._coords
@@ -2011,7 +2018,7 @@ def _matvec_cached(lay, atom, g):
     """A g as a Vector; cached while g is unchanged (stored modes and loads never change)."""
     key = (atom, id(g))
     hit = _MV_CACHE.get(key)
-    if hit is not None and hit[0] == g.version and hit[2] is g:
+    if hit is not None and hit[0] == g.version and hit[2]() is g:
         return hit[1]
     be = get_backend()
     out = Vector(g.V)
@@ -2021,7 +2028,8 @@ def _matvec_cached(lay, atom, g):
     out.touched_dev()
     if len(_MV_CACHE) > 4096:
         _MV_CACHE.clear()
-    _MV_CACHE[key] = (g.version, out, g)
+    # g is held WEAKLY: the cache must not keep an iterate (134 MB of HBM at 256^3) alive, and the product goes with it
+    _MV_CACHE[key] = (g.version, out, weakref.ref(g, lambda _r, key=key: _MV_CACHE.pop(key, None)))
     return out
 
 
@@ -2035,7 +2043,7 @@ _SYMMETRIC_KINDS = (MASS, STIFF, WMASS, WSTIFF)
 
 def _cached_product(atom, v):
     hit = _MV_CACHE.get((atom, id(v)))
-    if hit is not None and hit[0] == v.version and hit[2] is v:
+    if hit is not None and hit[0] == v.version and hit[2]() is v:
         return hit[1]
     return None
 
@@ -2048,7 +2056,7 @@ def _bilinear_scalar(lay, atom, f, g, symmetric=False):
     product (2 vector reads) instead of a pass over the matrix."""
     key = (atom, id(f), f.version, id(g), g.version)
     hit = _SCALAR_MEMO.get(key)
-    if hit is not None and hit[1] is f and hit[2] is g:
+    if hit is not None and hit[1]() is f and hit[2]() is g:
         return hit[0]
     be = get_backend()
     lo, hi = lay.owned_range()
@@ -2065,7 +2073,7 @@ def _bilinear_scalar(lay, atom, f, g, symmetric=False):
         val = _allreduce_sum(lay.mesh, be.bilinear(atom, f.dev(), g.dev(), lo, hi))
     if len(_SCALAR_MEMO) > _SCALAR_MEMO_MAX:
         _SCALAR_MEMO.clear()
-    _SCALAR_MEMO[key] = (val, f, g)
+    _SCALAR_MEMO[key] = (val, weakref.ref(f), weakref.ref(g))       # weak: a memoised scalar pins no vector
     return val
 
 
@@ -2591,7 +2599,13 @@ def _solve_linear(A, b, x, prm):
             STATS["pcg_seconds"] += time.perf_counter() - t_solve      # the solve returns synchronised
             info.update(method="jacobi_pcg", iterations=it, relres=rel)
             if rel > max(rtol, 1e-14) * 1.0001 and it >= maxit:
-                LOG.error("PCG did not reach rtol %g in %d iterations (relres %g)", rtol, it, rel)
+                # dolfin's Krylov solvers raise on non-convergence unless told otherwise (error_on_nonconvergence,
+                # default True): an unconverged mode must not be stored silently
+                msg = "PCG did not reach rtol %g in %d iterations (relres %g)" % (rtol, it, rel)
+                eon = prm.get("error_on_nonconvergence", True)
+                if isinstance(eon, _Params) or eon:
+                    raise RuntimeError(msg)
+                LOG.error(msg)
         LOG.debug("linear solve (%s requested): %s", method, info)
     finally:
         be.atom_free(op)
@@ -2722,3 +2736,7 @@ def clear_caches():
     _SCALAR_MEMO.clear()
     _MV_CACHE.clear()
     _DS_CACHE.clear()
+
+
+# result files: dolfin.HDF5File / dolfin.XDMFFile / dolfin.MPI (pgdrome_amd/io.py, real HDF5 through pgdrome_amd.h5lite)
+from .io import HDF5File, MPI, XDMFFile      # noqa: E402,F401

@@ -1,0 +1,248 @@
+"""dolfin.HDF5File / dolfin.XDMFFile for the form frontend, on pgdrome_amd.h5lite (real HDF5 files).
+
+The reference's result container writes its heavy data through these two classes and reads it back with h5py
+(/root/reference/pgdrome/model.py:162-196 ``write_hdf5`` / ``_write_xdmf``, :264-306 and :470-560 the HDF items of
+the pxdmf file, :668-700 the mode functions).  The dataset names and shapes below are those of dolfin 2019.1.0,
+as far as the reference relies on them:
+
+XDMFFile(path) -> ``<path>.xdmf`` (XML) + ``<path>.h5``:
+    /Mesh/0/mesh/topology   (cells, nodes per cell) int64      (model.py:266, 281)
+    /Mesh/0/mesh/geometry   (vertices, 2 or 3) float64; 1-D meshes padded with a zero column   (model.py:287-306)
+    /VisualisationVector/k  (vertices, 1) for scalar fields, (vertices, 3) zero-padded for vector fields, one per
+                            ``write(function, t)`` call                                        (model.py:316, 383)
+HDF5File(comm, path, mode):
+    /<name>/coordinates, /<name>/topology (attribute celltype), /<name>/cell_indices         write(mesh, name)
+    /<name>/vector_0, /<name>/cell_dofs, /<name>/x_cell_dofs, /<name>/cells (group attribute signature)
+                                                                                              write(function, name)
+Functions are read back through cell_dofs (file dof numbering -> the numbering of the space they are read into), so a
+file whose dofs are numbered differently (another partitioning, real dolfin) is mapped, not assumed.  Lagrange P1 and
+P2, scalar and vector-valued (component-major local dofs as FFC orders a VectorElement).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import h5lite
+
+_CELLTYPE = {1: "interval", 2: "triangle", 3: "tetrahedron"}
+_XDMF_TOPOLOGY = {1: "PolyLine", 2: "Triangle", 3: "Tetrahedron"}
+
+
+class _Comm:
+    """Stand-in for an MPI communicator handle: the reference passes ``dolfin.MPI.comm_world`` to HDF5File."""
+    rank, size = 0, 1
+
+
+class MPI:
+    comm_world = _Comm()
+    comm_self = _Comm()
+
+    @staticmethod
+    def rank(comm=None):
+        return 0
+
+    @staticmethod
+    def size(comm=None):
+        return 1
+
+
+def _cell_dofs(V):
+    """(cells, local dofs) global dof numbers of the space, local order = vertices then edges (UFC), vector-valued
+    spaces component-major."""
+    lay = V._lay
+    base = lay.base if hasattr(lay, "base") else lay
+    nodes = np.asarray(base.cells, dtype=np.int64)                     # node numbers per cell
+    nc = V._ncomp
+    if nc == 1:
+        node_dofs = nodes
+        return node_dofs if V._d2v is None else np.asarray(V._d2v)[node_dofs]
+    return np.concatenate([nc * nodes + c for c in range(nc)], axis=1)
+
+
+class HDF5File:
+    def __init__(self, comm, filename, mode):
+        self._path, self._mode = str(filename), mode
+        if mode == "r" and not os.path.exists(self._path):
+            raise RuntimeError("Unable to open HDF5 file %s: file does not exist" % self._path)      # dolfin raises RuntimeError
+        try:
+            self._f = h5lite.File(self._path, "w" if mode in ("w", "a") else "r")
+        except (OSError, h5lite.H5Error) as e:
+            raise RuntimeError("Unable to open HDF5 file %s: %s" % (self._path, e)) from e
+
+    def close(self):
+        if self._f is not None:
+            self._f.close()
+            self._f = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def has_dataset(self, name):
+        return self._f.get(name) is not None
+
+    # ---- write
+    def write(self, obj, name, *args):
+        from . import fem
+        name = "/" + str(name).strip("/")
+        if isinstance(obj, fem.Mesh):
+            tdim = obj.topology().dim()
+            self._f.create_dataset(name + "/coordinates", data=np.asarray(obj.coordinates(), dtype=np.float64))
+            t = self._f.create_dataset(name + "/topology", data=np.asarray(obj.cells(), dtype=np.int64))
+            t.attrs["celltype"] = _CELLTYPE[tdim]
+            t.attrs["partition"] = np.array([0], dtype=np.uint64)
+            self._f.create_dataset(name + "/cell_indices", data=np.arange(obj.num_cells(), dtype=np.uint64))
+        elif isinstance(obj, fem.Function):
+            V = obj.function_space()
+            cd = _cell_dofs(V)
+            v = self._f.create_dataset(name + "/vector_0", data=np.asarray(obj.vector()[:], dtype=np.float64))
+            v.attrs["partition"] = np.array([0], dtype=np.uint64)
+            self._f.create_dataset(name + "/cell_dofs", data=cd.reshape(-1).astype(np.int64))
+            self._f.create_dataset(name + "/x_cell_dofs", data=(np.arange(cd.shape[0] + 1, dtype=np.int64) * cd.shape[1]))
+            self._f.create_dataset(name + "/cells", data=np.arange(cd.shape[0], dtype=np.int64))
+            g = self._f[name]
+            g.attrs["signature"] = repr(V.ufl_element())
+            g.attrs["count"] = np.uint64(1)
+        elif isinstance(obj, fem.Vector):
+            self._f.create_dataset(name, data=np.asarray(obj[:], dtype=np.float64))
+        else:
+            raise NotImplementedError("HDF5File.write of %r" % type(obj).__name__)
+
+    # ---- read
+    def read(self, obj, name, *args):
+        from . import fem
+        name = "/" + str(name).strip("/")
+        if isinstance(obj, fem.Mesh):
+            co, to = self._f.get(name + "/coordinates"), self._f.get(name + "/topology")
+            if co is None or to is None:
+                raise RuntimeError("HDF5File.read: no mesh %r in %s" % (name, self._path))
+            obj._set_geometry(np.array(co, dtype=np.float64), np.array(to).astype(np.int32))
+            return
+        if isinstance(obj, fem.Function):
+            vec = self._f.get(name + "/vector_0")
+            if vec is None:
+                raise RuntimeError("HDF5File.read: no function %r in %s" % (name, self._path))
+            vals = np.array(vec, dtype=np.float64).reshape(-1)
+            V = obj.function_space()
+            mine = _cell_dofs(V)
+            cd, x = self._f.get(name + "/cell_dofs"), self._f.get(name + "/x_cell_dofs")
+            if cd is None or x is None:
+                if vals.size != V.dim():
+                    raise RuntimeError("HDF5File.read: %d values for a space of dimension %d" % (vals.size, V.dim()))
+                obj.vector()[:] = vals
+                return
+            cd, x = np.array(cd).astype(np.int64).reshape(-1), np.array(x).astype(np.int64).reshape(-1)
+            per = np.diff(x)
+            if per.size != mine.shape[0] or np.any(per != mine.shape[1]):
+                raise RuntimeError("HDF5File.read: the stored function has %d cells with %s dofs each, the space it is "
+                                   "read into %d cells with %d (element %s stored)" % (
+                                       per.size, sorted(set(per.tolist()))[:3], mine.shape[0], mine.shape[1],
+                                       self._f[name].attrs.get("signature", "?")))
+            cells = self._f.get(name + "/cells")
+            order = np.array(cells).astype(np.int64).reshape(-1) if cells is not None else np.arange(per.size)
+            out = np.zeros(V.dim())
+            out[mine[order].reshape(-1)] = vals[cd]
+            obj.vector()[:] = out
+            return
+        raise NotImplementedError("HDF5File.read into %r" % type(obj).__name__)
+
+
+class XDMFFile:
+    """Visualisation output: every ``write(function, t)`` stores the VERTEX values of the function (dolfin's XDMFFile.write
+    does the same for a P2 function) in ``/VisualisationVector/<k>``."""
+
+    def __init__(self, *args):
+        self._path = str(args[-1])
+        self._h5name = os.path.splitext(self._path)[0] + ".h5"
+        self._f = h5lite.File(self._h5name, "w")
+        self._mesh = None
+        self._steps = []          # (k, t, name, attribute type, shape)
+        self.parameters = {"flush_output": False, "functions_share_mesh": True, "rewrite_function_mesh": False}
+
+    def _write_mesh(self, mesh):
+        if self._mesh is not None:
+            return
+        geom = np.asarray(mesh.coordinates(), dtype=np.float64)
+        if geom.shape[1] == 1:                                # XDMF has no 1-D geometry: dolfin pads with zeros
+            geom = np.concatenate([geom, np.zeros_like(geom)], axis=1)
+        topo = np.asarray(mesh.cells(), dtype=np.int64)
+        self._f.create_dataset("/Mesh/0/mesh/geometry", data=geom)
+        t = self._f.create_dataset("/Mesh/0/mesh/topology", data=topo)
+        t.attrs["celltype"] = _CELLTYPE[mesh.topology().dim()]
+        t.attrs["partition"] = np.array([0], dtype=np.uint64)
+        self._mesh = (mesh, geom.shape, topo.shape)
+
+    def write(self, obj, t=None, *args):
+        from . import fem
+        if isinstance(obj, fem.Mesh):
+            self._write_mesh(obj)
+            return
+        if not isinstance(obj, fem.Function):
+            raise NotImplementedError("XDMFFile.write of %r" % type(obj).__name__)
+        V = obj.function_space()
+        self._write_mesh(V.mesh())
+        nv = V.mesh().num_vertices()
+        vals = obj.compute_vertex_values()
+        if V._ncomp > 1:
+            comp = vals.reshape(V._ncomp, nv).T
+            data = np.zeros((nv, 3))
+            data[:, :V._ncomp] = comp
+            kind = "Vector"
+        else:
+            data = vals.reshape(nv, 1)
+            kind = "Scalar"
+        k = len(self._steps)
+        self._f.create_dataset("/VisualisationVector/%d" % k, data=data)
+        self._steps.append((k, float(k if t is None else t), obj.name(), kind, data.shape))
+
+    def close(self):
+        if self._f is None:
+            return
+        self._f.close()
+        self._f = None
+        h5 = os.path.basename(self._h5name)
+        out = ['<?xml version="1.0"?>', '<!DOCTYPE Xdmf SYSTEM "Xdmf.dtd" []>',
+               '<Xdmf Version="3.0" xmlns:xi="http://www.w3.org/2001/XInclude">', "  <Domain>"]
+        if self._mesh is not None:
+            mesh, gshape, tshape = self._mesh
+            grid = ['      <Topology NumberOfElements="%d" TopologyType="%s" NodesPerElement="%d">' % (
+                        tshape[0], _XDMF_TOPOLOGY[mesh.topology().dim()], tshape[1]),
+                    '        <DataItem Dimensions="%d %d" NumberType="UInt" Format="HDF">%s:/Mesh/0/mesh/topology</DataItem>' % (
+                        tshape[0], tshape[1], h5),
+                    "      </Topology>",
+                    '      <Geometry GeometryType="%s">' % ("XY" if gshape[1] == 2 else "XYZ"),
+                    '        <DataItem Dimensions="%d %d" Format="HDF">%s:/Mesh/0/mesh/geometry</DataItem>' % (gshape[0], gshape[1], h5),
+                    "      </Geometry>"]
+            if not self._steps:
+                out += ['    <Grid Name="mesh" GridType="Uniform">'] + grid + ["    </Grid>"]
+            else:
+                out.append('    <Grid Name="TimeSeries" GridType="Collection" CollectionType="Temporal">')
+                for k, t, name, kind, shape in self._steps:
+                    out += ['    <Grid Name="mesh" GridType="Uniform">'] + grid
+                    out += ['      <Time Value="%.16g" />' % t,
+                            '      <Attribute Name="%s" AttributeType="%s" Center="Node">' % (name, kind),
+                            '        <DataItem Dimensions="%d %d" Format="HDF">%s:/VisualisationVector/%d</DataItem>' % (
+                                shape[0], shape[1], h5, k),
+                            "      </Attribute>", "    </Grid>"]
+                out.append("    </Grid>")
+        out += ["  </Domain>", "</Xdmf>"]
+        with open(self._path, "w") as fx:
+            fx.write("\n".join(out) + "\n")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001
+            pass

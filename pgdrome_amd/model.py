@@ -15,12 +15,13 @@ after the hot path:
   coordinates and relative l2 errors against a full-order model callable.
 
 * result files (model.py:162-575, 1414-1453): ``write_pxdmf`` / ``_write_xdmf`` / ``write_hdf5`` /
-  ``load_pxdmf`` / ``save_modes_latex``.  The reference stores the heavy data in HDF5 through
-  ``dolfin.HDF5File`` / ``XDMFFile`` and reads it back with h5py; neither exists in this image, so the
-  same XML layout (Grid / Information / Topology / Geometry / Attribute per PGD coordinate, the layout the
-  ParaView PGD plugin reads) is written with XDMF ``Format="Binary"`` data items (raw little-endian files
-  next to the .pxdmf, ``Seek`` offsets) and the mode functions go to ``<grid>_data.npz``.  ``load_pxdmf``
-  reads the XML, Binary and - when h5py is importable - HDF items, i.e. also reference-written files.
+  ``load_pxdmf`` / ``save_modes_latex`` in the reference's own file layout: per PGD coordinate ``<grid>.xdmf`` +
+  ``<grid>.h5`` (XDMFFile: /Mesh/0/mesh/topology, /Mesh/0/mesh/geometry, /VisualisationVector/<k>) and
+  ``<grid>_data.h5`` (HDF5File: mesh + MODE_<k> functions), and one ``<name>.pxdmf`` whose data items point into the
+  .h5 files (Grid / Information / Topology / Geometry / Attribute per coordinate - what the ParaView PGD plugin
+  reads).  The HDF5 files are real HDF5, written and read by ``pgdrome_amd.h5lite`` (h5py is used for reading
+  when it is installed); ``load_pxdmf`` also reads inline-XML items and the raw-binary items of this
+  repository's first round.
 
 * sensor responses and parameter derivatives (model.py:107-131, 862-953, 1088-1412): ``eval_fixed_modes``
   (the reference evaluates the fixed-dimension modes at the sensor points with ``fenicstools.Probes``; here by
@@ -39,7 +40,7 @@ import numpy as np
 from scipy import interpolate
 from scipy.stats import qmc
 
-from . import fem
+from . import fem, h5lite
 
 LOGGER = logging.getLogger(__name__)
 
@@ -171,86 +172,79 @@ class PGD:
         return a
 
     def write_hdf5(self, folder):
-        """The mode FUNCTIONS of every coordinate (mesh + dof vectors), what the reference keeps in
-        ``<grid>_data.h5`` (model.py:162-181) - here ``<grid>_data.npz``."""
+        """``<grid>_data.h5`` per coordinate: the mesh and the mode FUNCTIONS (dof vectors with their cell -> dof tables)
+        as ``dolfin.HDF5File`` lays them out - ``mesh``, ``MODE_0``, ``MODE_1``, ... (model.py:162-181; further attributes
+        of a coordinate, which the reference overwrites under the same names, go to ``ATT<a>_MODE_<k>``)."""
         for pm in self.mesh:
-            arrays = {"coordinates": pm.fenics_mesh.coordinates(), "cells": pm.fenics_mesh.cells()}
+            out = fem.HDF5File(fem.MPI.comm_world, os.path.join(folder, pm.name + "_data.h5"), "w")
+            out.write(pm.fenics_mesh, "mesh")
             for a, att in enumerate(pm.attributes):
                 for k in range(self.numModes):
-                    f = att.interpolationfct[k]
-                    V = f.function_space()
-                    arrays["ATT%d_MODE_%d" % (a, k)] = f.vector().host()
-                    arrays["ATT%d_META" % a] = np.array([V.ufl_element().degree(), V._ncomp])
-            np.savez(os.path.join(folder, pm.name + "_data.npz"), **arrays)
-        self.logger.info("Wrote %i data files for Mode data", self.num_pgd_var)
+                    out.write(att.interpolationfct[k], ("MODE_%d" % k) if a == 0 else "ATT%d_MODE_%d" % (a, k))
+            out.close()
+        self.logger.info("Wrote %i HDF files for Mode data", self.num_pgd_var)
 
     def _write_xdmf(self, folder):
-        """Per coordinate: ``<grid>.bin`` (raw little-endian: topology int32, geometry and one block per mode
-        float64) and a ``<grid>.xdmf`` that references it (model.py:183-196 writes .xdmf + .h5)."""
-        self._layout = {}
+        """``<grid>.xdmf`` + ``<grid>.h5`` per coordinate through ``XDMFFile``: /Mesh/0/mesh/{topology, geometry} and the
+        vertex values of every mode in /VisualisationVector/<k> (model.py:183-196)."""
         for pm in self.mesh:
-            topo = np.ascontiguousarray(pm.topology, dtype="<i4")
-            geom = np.ascontiguousarray(pm.fenics_mesh.coordinates(), dtype="<f8")
-            if geom.shape[1] == 1:                         # XDMF has no 1-D geometry: pad like dolfin does
-                geom = np.concatenate([geom, np.zeros_like(geom)], axis=1)
-            items, pos = {}, 0
-            with open(os.path.join(folder, pm.name + ".bin"), "wb") as fb:
-                for key, arr in [("topology", topo), ("geometry", geom)] + [
-                        ("%d/%d" % (a, k), np.ascontiguousarray(self._visual(att, k, False), dtype="<f8"))
-                        for a, att in enumerate(pm.attributes) for k in range(len(att.data))]:
-                    fb.write(arr.tobytes())
-                    items[key] = (pos, arr.shape)
-                    pos += arr.nbytes
-            self._layout[pm.name] = items
-            with open(os.path.join(folder, pm.name + ".xdmf"), "w") as fx:
-                fx.write('<?xml version="1.0"?>\n<Xdmf Version="3.0"><Domain>\n')
-                fx.write(self._grid_xml(pm, items, False, "  "))
-                fx.write("</Domain></Xdmf>\n")
+            out = fem.XDMFFile(os.path.join(folder, pm.name + ".xdmf"))
+            out.write(pm.fenics_mesh)
+            for att in pm.attributes:
+                for k in range(self.numModes):
+                    out.write(att.interpolationfct[k], k)
+            out.close()
 
-    @staticmethod
-    def _binary_item(name, entry, number_type, precision):
-        pos, shape = entry
-        return ('<DataItem Dimensions="%s" NumberType="%s" Precision="%d" Format="Binary" Endian="Little" Seek="%d">'
-                '%s.bin</DataItem>' % (" ".join(str(v) for v in shape), number_type, precision, pos, name))
-
-    def _grid_xml(self, pm, items, pad_vectors, ind):
+    def _grid_xml(self, pm, pad_vectors, ind, folder):
+        """One <Grid> of the pxdmf file, its data items pointing into ``<grid>.h5`` exactly as the reference writes them
+        (model.py:236-392)."""
         d = self.mesh.index(pm)
         dims, cname, unit = self._grid_info(d)
-        out = [ind + '<Grid Name="%s">' % pm.name,
-               ind + '  <Information Name="Dims" Value="%s" />' % dims,
-               ind + '  <Information Name="Dim0" Value="%s" />' % cname,
-               ind + '  <Information Name="Unit0" Value="%s" />' % unit]
-        tshape = items["topology"][1]
-        out.append(ind + '    <Topology NumberOfElements = "%d" TopologyType = "%s" NodesPerElement = "%d" >' % (
-            pm.numElements, pm.typElements, tshape[1]))
-        out.append(ind + "      " + self._binary_item(pm.name, items["topology"], "Int", 4))
-        out.append(ind + "    </Topology>")
-        gshape = items["geometry"][1]
-        out.append(ind + '    <Geometry GeometryType = "%s">' % ("XY" if gshape[1] == 2 else "XYZ"))
-        out.append(ind + "      " + self._binary_item(pm.name, items["geometry"], "Float", 8))
-        out.append(ind + "    </Geometry>")
-        for a, att in enumerate(pm.attributes):
-            for k in range(len(att.data)):
-                out.append(ind + '    <Attribute Name="%s_%d" AttributeType="%s" Center="Node">' % (att.name, k, att.field))
-                if att.field.lower() == "vector" and pad_vectors:
-                    # grids of different dimension in one file: vector attributes carry three components on
-                    # every grid, a 1-D coordinate repeating its values (model.py:321-368), written inline
-                    v = self._visual(att, k, True)
-                    if dims == 1:
-                        v = np.repeat(v[:, :1], 3, axis=1)
-                    out.append(ind + '      <DataItem Dimensions="%d 3" Format="XML" NumberType="float" >' % v.shape[0])
-                    out.extend("%.8e %.8e %.8e" % tuple(r) for r in v)
-                    out.append(ind + "      </DataItem>")
-                else:
-                    out.append(ind + "      " + self._binary_item(pm.name, items["%d/%d" % (a, k)], "Float", 8))
-                out.append(ind + "    </Attribute>")
+        with h5lite.File(os.path.join(folder, pm.name + ".h5"), "r") as hf:
+            tshape = np.array(hf.get("Mesh/0/mesh/topology")).shape
+            gshape = np.array(hf.get("Mesh/0/mesh/geometry")).shape
+            out = [ind + '<Grid Name="%s">' % pm.name,
+                   ind + '  <Information Name="Dims" Value="%s" />' % dims,
+                   ind + '  <Information Name="Dim0" Value="%s" />' % cname,
+                   ind + '  <Information Name="Unit0" Value="%s" />' % unit,
+                   ind + '    <Topology NumberOfElements = "%d" TopologyType = "%s" NodesPerElement = "%d" >' % (
+                       pm.numElements, pm.typElements, tshape[1]),
+                   ind + '      <DataItem Dimensions = "%d %d" NumberType = "UInt" Format = "HDF">%s.h5:/Mesh/0/mesh/topology</DataItem>' % (
+                       pm.numElements, tshape[1], pm.name),
+                   ind + "    </Topology>",
+                   ind + '    <Geometry GeometryType = "%s">' % ("XY" if gshape[1] == 2 else "XYZ"),
+                   ind + '      <DataItem Dimensions = "%d %d" Format = "HDF">%s.h5:/Mesh/0/mesh/geometry</DataItem>' % (
+                       gshape[0], gshape[1], pm.name),
+                   ind + "    </Geometry>"]
+            count = 0
+            for att in pm.attributes:
+                for k in range(len(att.data)):
+                    out.append(ind + '    <Attribute Name="%s_%d" AttributeType="%s" Center="Node">' % (att.name, k, att.field))
+                    if att.field.lower() == "vector" and pad_vectors:
+                        # grids of different dimension in one file: vector attributes carry three components on every grid,
+                        # a 1-D coordinate repeating its values (model.py:321-368), written inline
+                        raw = np.array(hf.get("/VisualisationVector/%d" % count))
+                        v = np.zeros((raw.shape[0], 3))
+                        if dims > 1:
+                            v[:, :raw.shape[1]] = raw
+                        else:
+                            v[:] = raw[:, :1]
+                        out.append(ind + '      <DataItem Dimensions="%d 3" Format="XML" NumberType="float" >' % v.shape[0])
+                        out.extend("%.8e %.8e %.8e" % tuple(r) for r in v)
+                        out.append(ind + "      </DataItem>")
+                    else:
+                        vshape = np.array(hf.get("/VisualisationVector/%d" % count)).shape
+                        out.append(ind + '      <DataItem Dimensions="%d %d" Format="HDF">%s.h5:/VisualisationVector/%d</DataItem>' % (
+                            vshape[0], vshape[1], pm.name, count))
+                    out.append(ind + "    </Attribute>")
+                    count += 1
         out.append(ind + "</Grid>")
         return "\n".join(out) + "\n"
 
     def write_pxdmf(self, folder, xdmf_exist=False):
         """One ``<name>.pxdmf`` with a grid per PGD coordinate and its modes as attributes - the file the
-        ParaView PGD plugin opens (model.py:198-416)."""
-        if xdmf_exist is False or not getattr(self, "_layout", None):
+        ParaView PGD plugin opens (model.py:198-416); the heavy data stay in the ``<grid>.h5`` files."""
+        if xdmf_exist is False:
             self._write_xdmf(folder)
         dims = [self._grid_info(d)[0] for d in range(self.num_pgd_var)]
         pad = max(dims) != min(dims)
@@ -261,13 +255,14 @@ class PGD:
             f.write('<Xdmf Version="3.0" xmlns:xi="http://www.w3.org/2001/XInclude">\n')
             f.write('  <Domain Name="%s.pxdmf">\n' % self.name)
             for pm in self.mesh:
-                f.write(self._grid_xml(pm, self._layout[pm.name], pad, "    "))
+                f.write(self._grid_xml(pm, pad, "    ", folder))
             f.write("  </Domain>\n</Xdmf>")
         self.logger.info("Wrote %s ", path)
 
     @staticmethod
     def _read_item(item, folder):
-        """numpy array of a <DataItem>: inline XML, raw Binary, or HDF (needs h5py)."""
+        """numpy array of a <DataItem>: inline XML, HDF (``file.h5:/path``; h5py when installed, else pgdrome_amd.h5lite)
+        or raw Binary (the files round 1 of this repository wrote)."""
         fmt = item.get("Format", "XML")
         dims = tuple(int(v) for v in item.get("Dimensions").split())
         if fmt == "XML":
@@ -280,19 +275,22 @@ class PGD:
                 fb.seek(int(item.get("Seek", "0")))
                 return np.frombuffer(fb.read(int(np.prod(dims)) * dt.itemsize), dtype=dt).reshape(dims).copy()
         if fmt == "HDF":
-            try:
-                import h5py
-            except ImportError as e:
-                raise RuntimeError("this pxdmf file keeps its data in HDF5 (%s): h5py is needed to read it"
-                                   % item.text.strip()) from e
             fname, key = item.text.strip().split(":")
-            with h5py.File(os.path.join(folder, fname), "r") as hf:
-                return np.array(hf.get(key))
+            try:
+                import h5py as h5
+            except ImportError:
+                h5 = h5lite
+            with h5.File(os.path.join(folder, fname), "r") as hf:
+                node = hf.get(key)
+                if node is None:
+                    raise RuntimeError("%s has no dataset %s" % (fname, key))
+                return np.array(node)
         raise ValueError("unknown DataItem format %r" % fmt)
 
     def load_pxdmf(self, filepath, verbose=False):
-        """Read a pxdmf file into this instance: ``sol = PGD().load_pxdmf(path)`` (model.py:418-572).  The mode
-        functions (``<grid>_data.npz``) are attached by ``create_interpolation_fcts``."""
+        """Read a pxdmf file into this instance: ``sol = PGD().load_pxdmf(path)`` (model.py:418-572) - one written here or by
+        the reference (inline XML or HDF items).  The mesh of every coordinate comes from ``<grid>_data.h5`` when that file
+        is there (``write_hdf5``); the mode functions are attached by ``create_interpolation_fcts``."""
         folder = os.path.dirname(os.path.abspath(filepath))
         root = et.parse(filepath).getroot()
         self.folder = folder
@@ -300,10 +298,13 @@ class PGD:
         self.mesh = []
         for g in root.iter("Grid"):
             pm = PGDMesh(g.get("Name"))
-            data = os.path.join(folder, pm.name + "_data.npz")
-            if os.path.exists(data):
-                with np.load(data) as z:
-                    pm.fenics_mesh = fem.Mesh(z["coordinates"], z["cells"])
+            try:
+                hdf = fem.HDF5File(fem.MPI.comm_world, os.path.join(folder, pm.name + "_data.h5"), "r")
+                pm.fenics_mesh = fem.Mesh()
+                hdf.read(pm.fenics_mesh, "mesh", False)
+                hdf.close()
+            except RuntimeError:
+                pm.fenics_mesh = None
             info = [[e.attrib.get("Name"), e.attrib.get("Value")] for e in g.iter("Information")]
             pm.info = [int(info[0][1]), info[1][1], info[2][1]] if len(info) >= 3 else [v for _, v in info]
             pm.meshdim = int(info[0][1])
@@ -336,15 +337,17 @@ class PGD:
         return self
 
     def _load_mode_functions(self, d, attri):
-        """Mode functions of coordinate d from ``<grid>_data.npz`` in the space interpolationInfo names."""
+        """Mode functions of coordinate d from ``<grid>_data.h5`` in the space interpolationInfo names (model.py:640-700)."""
         pm = self.mesh[d]
         att = pm.attributes[attri]
-        path = os.path.join(self.folder, pm.name + "_data.npz")
+        path = os.path.join(self.folder, pm.name + "_data.h5")
         if not os.path.exists(path):
             raise ValueError("mode functions of dimension %d are missing: %s not found (write_hdf5 creates it)" % (d, path))
         info = att.interpolationInfo
-        with np.load(path) as z:
-            mesh = fem.Mesh(z["coordinates"], z["cells"])
+        hdf = fem.HDF5File(fem.MPI.comm_world, path, "r")
+        try:
+            mesh = fem.Mesh()
+            hdf.read(mesh, "mesh", False)
             pm.fenics_mesh = mesh
             kind = str(info.get("_type", "scalar")).lower()
             if kind == "scalar":
@@ -355,13 +358,14 @@ class PGD:
                 raise ValueError("function space type not defined or wrong defined %s" % (kind,))
             out = []
             for k in range(self.numModes):
-                vals = z["ATT%d_MODE_%d" % (attri, k)]
-                if vals.size != V.dim():
-                    raise ValueError("stored mode has %d dofs, the space named in interpolationInfo %d" % (vals.size, V.dim()))
                 f = fem.Function(V)
-                f.vector()._host = vals.astype(np.float64)
-                f.vector().touched_host()
+                try:
+                    hdf.read(f, ("MODE_%d" % k) if attri == 0 else "ATT%d_MODE_%d" % (attri, k))
+                except RuntimeError as e:
+                    raise ValueError(str(e)) from e
                 out.append(f)
+        finally:
+            hdf.close()
         att.interpolationfct = out
 
     def save_modes_latex(self, folder, attri, prefix="_"):

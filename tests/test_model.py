@@ -98,8 +98,8 @@ def oracle_backend():
 
 def test_pxdmf_round_trip_like_the_reference_unit_test(oracle_backend, tmp_path):
     """u(x, p, E) = x^2 p / E with P1 / P1 / P2 modes, written and read back: the scenario and the assertions of
-    the reference's tests/unit/test_pgdclass_dolfin.py (there through dolfin.HDF5File / XDMFFile / h5py, absent
-    here; the heavy data go to raw binary XDMF items and .npz instead)."""
+    the reference's tests/unit/test_pgdclass_dolfin.py, in the reference's own file layout (.xdmf + .h5 per coordinate
+    through XDMFFile, <grid>_data.h5 through HDF5File, HDF items in the .pxdmf) - real HDF5 via pgdrome_amd.h5lite."""
     mx, mp_, me = fem.IntervalMesh(50, 0.0, 1.0), fem.IntervalMesh(10, 0.0, 2.0), fem.IntervalMesh(10, 0.5, 1.0)
     Vs = [fem.FunctionSpace(mx, "CG", 1), fem.FunctionSpace(mp_, "CG", 1), fem.FunctionSpace(me, "CG", 2)]
     codes = ["x[0]*x[0]", "x[0]", "1.0/x[0]"]
@@ -109,7 +109,13 @@ def test_pxdmf_round_trip_like_the_reference_unit_test(oracle_backend, tmp_path)
     folder = str(tmp_path)
     pgd.write_pxdmf(folder, False)
     pgd.write_hdf5(folder)
-    assert {"Test.pxdmf", "PGD1.xdmf", "PGD1.bin", "PGD1_data.npz", "PGD3_data.npz"} <= set(os.listdir(folder))
+    assert {"Test.pxdmf", "PGD1.xdmf", "PGD1.h5", "PGD1_data.h5", "PGD3.h5", "PGD3_data.h5"} <= set(os.listdir(folder))
+    text = open(os.path.join(folder, "Test.pxdmf")).read()
+    assert 'Format = "HDF">PGD1.h5:/Mesh/0/mesh/topology' in text and 'Format="HDF">PGD3.h5:/VisualisationVector/0' in text
+    from pgdrome_amd import h5lite
+    with h5lite.File(os.path.join(folder, "PGD3_data.h5"), "r") as hf:      # the layout dolfin.HDF5File gives a P2 function
+        assert sorted(hf.keys()) == ["MODE_0", "mesh"] and sorted(hf["MODE_0"].keys()) == ["cell_dofs", "cells", "vector_0", "x_cell_dofs"]
+        assert hf["mesh/topology"].attrs["celltype"] == "interval" and np.array(hf["MODE_0/cell_dofs"]).size == 30
     sol = PGD().load_pxdmf(os.path.join(folder, "Test.pxdmf"))
     assert sol.name == "Test.pxdmf" and sol.num_pgd_var == 3 and sol.numModes == 1
     assert [m.numNodes for m in sol.mesh] == [51, 11, 11] and [m.numElements for m in sol.mesh] == [50, 10, 10]
@@ -167,7 +173,7 @@ def test_pxdmf_vector_field_on_grids_of_different_dimension(oracle_backend, tmp_
     assert np.allclose(u((1.5, 0.5)), 1.5 * np.array([1.5, 0.75]))
 
 
-def test_load_pxdmf_reads_inline_items_and_names_the_missing_hdf5_reader(oracle_backend, tmp_path):
+def test_load_pxdmf_reads_inline_items_and_reports_a_missing_hdf5_file(oracle_backend, tmp_path):
     doc = """<?xml version="1.0"?><Xdmf Version="3.0"><Domain Name="hand.pxdmf"><Grid Name="PGD1">
 <Information Name="Dims" Value="1" /><Information Name="Dim0" Value="t" /><Information Name="Unit0" Value="s" />
 <Topology NumberOfElements = "2" TopologyType = "Polyline" NodesPerElement = "2" ><DataItem Dimensions = "2 2" NumberType = "UInt" Format = "XML">
@@ -199,11 +205,13 @@ def test_load_pxdmf_reads_inline_items_and_names_the_missing_hdf5_reader(oracle_
     with open(path, "w") as f:
         f.write(doc % '<Attribute Name="T_1" AttributeType="Scalar" Center="Node"><DataItem Dimensions="3 1" Format="HDF">'
                       'PGD1.h5:/VisualisationVector/1</DataItem></Attribute>')
-    try:
-        import h5py  # noqa: F401
-    except ImportError:
-        with pytest.raises(RuntimeError, match="h5py"):
-            PGD().load_pxdmf(path)
+    with pytest.raises((RuntimeError, OSError)):        # the item points into PGD1.h5, which is not there
+        PGD().load_pxdmf(path)
+    from pgdrome_amd import h5lite
+    with h5lite.File(os.path.join(str(tmp_path), "PGD1.h5"), "w") as hf:
+        hf.create_dataset("/VisualisationVector/1", data=np.array([[3.0], [2.0], [1.0]]))
+    sol = PGD().load_pxdmf(path)
+    assert sol.numModes == 2 and sol.mesh[0].attributes[0].data[1][:, 0].tolist() == [3.0, 2.0, 1.0]
 
 
 def test_sensor_responses_derivatives_and_reductions(oracle_backend):

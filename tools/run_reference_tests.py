@@ -43,7 +43,8 @@ def main():
         fem.set_backend(HipBackend(0))
     sys.modules["dolfin"] = fem
     sys.modules["fenics"] = fem
-    sys.modules["h5py"] = types.ModuleType("h5py")
+    from pgdrome_amd import h5lite
+    sys.modules["h5py"] = h5lite          # File(path, "r").get(name) -> array-like: what pgdrome/model.py uses of h5py
     logging.disable(logging.CRITICAL)
     warnings.filterwarnings("ignore")
     results = []
