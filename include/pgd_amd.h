@@ -275,7 +275,7 @@ enum {
                                   (symmetric half) storage from the atoms' diagonal forms; 0: converted from CSR per solve */
     PGD_TUNE_SPMV_VARIANT = 13, /* k_spmv_dia_march: 0 (default) 64 x 4 patches, 256 threads; 1: 64 x 8 patches, 512 threads */
     PGD_TUNE_SPMV_ZCHUNK = 6,   /* k_spmv_sym_grid3 (structured vertex grids, x planes in LDS): most planes per
-                                   workgroup march (default 16; fewer while that keeps 8 workgroups per CU); 0 = off */
+                                   workgroup march (default 8; fewer while that keeps 4 workgroups per CU); 0 = off */
     PGD_TUNE_SPMV_SYM = 3,   /* 1 (default): the products of the SPD solves (pgd_pcg_solve, pgd_pcg_solve_sharded,
                                 pgd_spmv_dot_slot after pgd_op_symmetrize) read the operator from its symmetric
                                 half storage when the mesh qualifies (k_spmv_sym); 0: always the CSR kernels */

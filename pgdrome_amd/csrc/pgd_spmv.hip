@@ -1005,12 +1005,14 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         int chunks = 0;
         if (c->spmv_zchunk > 0 && (!dot || w == x) && r0 % plane == 0 && r1 % plane == 0 &&
             plane * 64 >= c->spmv_grid_min_plane_bytes) {
-            // planes per march: as long as the launch still has ~8 workgroups per CU (a march of fewer than 4 planes pays
-            // its prologue too often; below that the row-order kernel is the faster one: 64^3 11 us vs 15 us)
+            // planes per march: as long as the launch still has ~4 workgroups per CU (measured on z-slabs of the 256 x 256
+            // grid, tools/bench_spmv_slab.py: 30 planes - the interior of an 8-GPU rank - 31.9 us marching 8 planes vs 41.4 us
+            // in row order; a march of fewer than 3 planes pays its prologue too often, and a single plane - the boundary
+            // launches of the sharded solve - is faster in row order: 7.1 vs 8-14 us)
             const int64_t tile_planes = (int64_t)D.tiles_x * D.tiles_y * (D.z1 - D.z0);
-            D.zchunk = (int)std::min<int64_t>(c->spmv_zchunk, tile_planes * (wy / 4) / (8 * (int64_t)c->num_cu));
+            D.zchunk = (int)std::min<int64_t>(c->spmv_zchunk, tile_planes * (wy / 4) / (4 * (int64_t)c->num_cu));
             if (c->spmv_zchunk_force > 0) D.zchunk = c->spmv_zchunk_force;       // tests: the march on any grid size
-            chunks = (D.zchunk >= 4 || c->spmv_zchunk_force > 0) ? (D.z1 - D.z0 + D.zchunk - 1) / D.zchunk : 0;
+            chunks = (D.zchunk >= 3 || c->spmv_zchunk_force > 0) ? (D.z1 - D.z0 + D.zchunk - 1) / D.zchunk : 0;
         }
         const int64_t gg = (int64_t)chunks * D.tiles_x * D.tiles_y;
         bool timed2 = false;

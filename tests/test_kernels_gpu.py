@@ -485,7 +485,7 @@ def test_grid_march_in_multi_tile_launch_shapes(ctx, shape):
 @pytest.mark.parametrize("npts", [128, 256])
 def test_products_agree_at_bench_size(ctx, npts):
     """The BENCH configuration's operator (256^3 P1 dofs, 255^3 x 6 tetrahedra; 128^3 = config 3's) through every product
-    kernel: k_spmv_dia_march with its adaptive march (16 planes at 256^3, 4 at 128^3), the row-order kernel, the
+    kernel: k_spmv_dia_march with its adaptive march (8 planes at 256^3 and 128^3), the row-order kernel, the
     dictionary CSR kernel and the plain CSR kernel give the same y bit for bit; at 128^3 the CSR arrays are downloaded
     and the oracle's C product and scipy's agree to rounding; at both sizes the size-independent properties hold
     (K annihilates linear fields, M 1 sums to the volume, symmetry x.(A w) = w.(A x))."""
@@ -516,7 +516,7 @@ def test_products_agree_at_bench_size(ctx, npts):
             ys[name] = (ctx.vec_download(yv), ctx.slots_download(30, 1)[0])
         ctx.tune(3, 1)
         assert ctx.op_symmetrize(op) is True
-        for name, knobs in (("dia_march", [(6, 16)]), ("dia_rows", [(6, 0)])):
+        for name, knobs in (("dia_march", [(6, 8)]), ("dia_rows", [(6, 0)])):
             for k, v in knobs:
                 ctx.tune(k, v)
             c0 = ctx.kernel_counts()
@@ -527,7 +527,7 @@ def test_products_agree_at_bench_size(ctx, npts):
     finally:
         ctx.tune(3, 1)
         ctx.tune(2, 1)
-        ctx.tune(6, 16)
+        ctx.tune(6, 8)
     base = ys["csr"][0]
     for name in ("csr_dict", "dia_march", "dia_rows"):
         assert np.array_equal(ys[name][0], base), (name, np.abs(ys[name][0] - base).max())

@@ -15,9 +15,9 @@ from pgdrome_amd import _lib, fem
 from pgdrome_amd import sizes as psizes
 
 MODES = [  # name, sym, dict, zchunk knob, zchunk force, variant
-    ("csr", 0, 0, 16, 0, 0), ("csr_dict16", 0, 1, 16, 0, 0), ("dia_rows", 1, 1, 0, 0, 0),
-    ("march 64x4", 1, 1, 16, 0, 0), ("march 64x8", 1, 1, 16, 0, 1), ("march 64x4 z8", 1, 1, 16, 8, 0),
-    ("march 64x4 z32", 1, 1, 16, 32, 0), ("march 64x8 z32", 1, 1, 16, 32, 1),
+    ("csr_dict16", 0, 1, 16, 0, 0), ("dia_rows", 1, 1, 0, 0, 0),
+    ("march adaptive", 1, 1, 16, 0, 0), ("march z3", 1, 1, 16, 3, 0), ("march z4", 1, 1, 16, 4, 0), ("march z8", 1, 1, 16, 8, 0),
+    ("march z16", 1, 1, 16, 16, 0), ("march 64x8 adaptive", 1, 1, 16, 0, 1),
 ]
 
 
@@ -53,7 +53,7 @@ def main():
                 print(f"  round {rnd} {name:20s}: {t*1e6:7.1f} us per product+reduce; CSR formula {alg/t/1e9:6.0f} GB/s; own minimum "
                       f"{mine/1e9:.3f} GB -> {mine/t/1e9:5.0f} GB/s = {mine/t/8e12*100:4.1f}% of 8 TB/s; p.q = {ctx.slots_download(30, 1)[0]:.12e}",
                       flush=True)
-        ctx.tune(3, 1); ctx.tune(2, 1); ctx.tune(6, 16); ctx.tune(7, 0); ctx.tune(13, 0)
+        ctx.tune(3, 1); ctx.tune(2, 1); ctx.tune(6, 8); ctx.tune(7, 0); ctx.tune(13, 0)
         for v in (x, y):
             ctx.vec_free(v)
         for a in (ak, am, op):

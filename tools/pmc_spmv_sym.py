@@ -25,7 +25,7 @@ nv = ctx.mesh_info(mesh)["nv"]
 x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, nv))
 y = ctx.vec_alloc(nv)
 ctx.tune(3, 0 if mode == "csr" else 1)
-ctx.tune(6, 16 if mode == "grid" else 0)       # the library default (0 turns the march off)
+ctx.tune(6, 8 if mode == "grid" else 0)        # the library default (0 turns the march off)
 ctx.tune(7, zchunk if mode == "grid" else 0)      # exactly this many planes per march
 ctx.tune(13, variant)
 if mode != "csr":
