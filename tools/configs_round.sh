@@ -1,0 +1,8 @@
+# every BASELINE config at full size on one GPU -> gpurun_out/${TAG}_configs_full_size_n1.jsonl   usage: bash tools/configs_round.sh TAG
+TAG=${1:-r02}
+cd $GRAFT_REPO_ROOT
+: > gpurun_out/${TAG}_configs_full_size_n1.jsonl
+for cfg in cfg1 cfg2 cfg3 cfg5; do
+  timeout -k 10 400 python tools/run_config.py $cfg 2> gpurun_out/${TAG}_$cfg.err | tail -1 >> gpurun_out/${TAG}_configs_full_size_n1.jsonl || exit 1
+  echo "$cfg done"
+done
