@@ -12,12 +12,14 @@ fem_numpy.py     P1 simplex meshes, closed-form element atoms, CSR assembly,
                  Dirichlet elimination, Jacobi-PCG - the FEM arithmetic that the
                  reference delegates to FEniCS 2019.1.0 (third-party, absent from
                  /root/reference and from this image).
-pgd_numpy.py     matrix-level restatement of the reference's enrichment and
-                 alternating-directions loops (pgdrome/solver.py:306-506, 508-881).
 backend_numpy.py the oracle as a backend of the host-side form frontend, so the
                  host logic can be exercised on CPU in ``-m "not gpu"`` tests.
 c/               plain-C (OpenMP) restatement of CSR SpMV / Jacobi-PCG used for
-                 the timed CPU baseline at BASELINE.json's full sizes.
+                 the timed CPU baseline at BASELINE.json's full sizes (c_oracle.py binds it,
+                 cpu_baseline.py is bench.py's cpu_baseline leg).
+The enrichment and fixed-point loops themselves (pgdrome/solver.py:306-506, 508-881) need no
+restatement here: the reference's own file is imported and run on backend_numpy by
+tests/golden/make_fixtures.py, and its results are the fixtures.
 
 Parity pinning: the control flow is pinned by fixtures
 captured from the reference's own ``solve_PGD`` (tests/golden/make_fixtures.py);
