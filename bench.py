@@ -51,6 +51,7 @@ def parse():
                     help="sharded runs: drive the PCG recurrence from Python over torch.distributed instead of "
                          "the in-library loop (pgd_pcg_solve_sharded over RCCL)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--spmv-variant", type=int, default=-1, help="PGD_TUNE_SPMV_VARIANT for A/B runs (-1: library default)")
     ap.add_argument("--no-pmc", action="store_true", help="do not start rocprofv3 --pmc child processes for roofline.traffic")
     ap.add_argument("--no-csr-section", action="store_true", help="skip the timed CSR products (roofline.csr_product)")
     return ap.parse_args()
@@ -94,6 +95,8 @@ def main():
         stream = tstream.cuda_stream
         assert stream, "expected a non-default HIP stream"
     be = fem.set_backend(HipBackend(local_rank, stream))
+    if args.spmv_variant >= 0:
+        be.ctx.tune(13, args.spmv_variant)
 
     n = args.n
     t_setup = time.time()
@@ -175,8 +178,9 @@ def main():
     sym = be.ctx.mesh_sym_info(space.handle())
     ran = max(("dia_march", "dia_rows", "sym_rows", "csr_dict", "csr"), key=lambda k: kc[k])
     kernel_names = {
-        "dia_march": "k_spmv_dia_march<dot,store,4> (symmetric half storage in diagonal form: 8 slot arrays of n doubles, a 64 x 4 "
-                     "patch of the %d x %d vertex grid marching along z, x planes and the plane-below couplings in LDS)" % (sym["nx"], sym["ny"]),
+        "dia_march": "k_spmv_dia_march2<dot,store> (symmetric half storage in diagonal form: 8 slot arrays of n doubles, a 64 x 8 "
+                     "patch of the %d x %d vertex grid marching along z, two rows per thread, x planes and the plane-below "
+                     "couplings in LDS)" % (sym["nx"], sym["ny"]),
         "dia_rows": "k_spmv_dia_rows<dot,store> (symmetric half storage in diagonal form, row order)",
         "sym_rows": "k_spmv_sym<dot,store,%d> (symmetric half storage, %d relative patterns)" % (sym["slots"], patterns),
         "csr_dict": "k_spmv_csr_dict16<dot,store> (CSR values, column ids from %d relative patterns)" % patterns,
@@ -312,7 +316,7 @@ def pmc_traffic(own_bytes):
                 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                     with open(f) as fh:
                         for row in csv.DictReader(fh):
-                            if row.get("Counter_Name") == counter and "k_spmv_dia_march" in row.get("Kernel_Name", ""):
+                            if row.get("Counter_Name") == counter and "k_spmv_dia_march" in row.get("Kernel_Name", ""):   # march or march2
                                 got.append(float(row["Counter_Value"]))
                 shutil.rmtree(d, ignore_errors=True)
                 if not got:

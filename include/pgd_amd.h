@@ -273,7 +273,8 @@ enum {
                                       the other ranks must come out of the solve with an error instead of waiting for it */
     PGD_TUNE_COMBINE_DIA = 14, /* 1 (default): on structured vertex grids pgd_op_combine also forms the operator's diagonal
                                   (symmetric half) storage from the atoms' diagonal forms; 0: converted from CSR per solve */
-    PGD_TUNE_SPMV_VARIANT = 13, /* k_spmv_dia_march: 0 (default) 64 x 4 patches, 256 threads; 1: 64 x 8 patches, 512 threads */
+    PGD_TUNE_SPMV_VARIANT = 13, /* the z-march: 0 (default) k_spmv_dia_march2, 64 x 8 patches, 256 threads, two rows per thread;
+                                   1: k_spmv_dia_march<8>, 64 x 8 patches, 512 threads; 2: k_spmv_dia_march<4>, 64 x 4 patches, 256 threads */
     PGD_TUNE_SPMV_ZCHUNK = 6,   /* k_spmv_sym_grid3 (structured vertex grids, x planes in LDS): most planes per
                                    workgroup march (default 8; fewer while that keeps 4 workgroups per CU); 0 = off */
     PGD_TUNE_SPMV_SYM = 3,   /* 1 (default): the products of the SPD solves (pgd_pcg_solve, pgd_pcg_solve_sharded,

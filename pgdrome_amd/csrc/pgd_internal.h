@@ -148,7 +148,7 @@ struct Ctx {
     int64_t spmv_grid_min_plane_bytes = 0;   // structured grids whose planes of values are at least this large take k_spmv_sym_grid3
     int spmv_zchunk_force = 0;    // > 0: exactly this many planes per march whatever the grid size (tests)
     int fault_iteration = -1;     // tests: pgd_pcg_solve_sharded fails on this rank in that iteration (once)
-    int spmv_variant = 0;         // k_spmv_dia_march: 0 = 64 x 4 patches (256 threads), 1 = 64 x 8 patches (512 threads)
+    int spmv_variant = 0;         // z-march: 0 = k_spmv_dia_march2 (64 x 8 patch, two rows per thread), 1 = 64 x 8 / 512 threads, 2 = 64 x 4 / 256 threads
     int spmv_zchunk = 8;          // k_spmv_dia_march: most planes a workgroup marches through (0: never use that kernel)
     int pcg_fold_reduce = 1;      // scaled recurrence: final reduction passes folded into the vector kernels (3 launches / iteration)
     int pcg_scaled = 1;           // pgd_pcg_solve on the symmetrically scaled system (no dinv / z passes) when the symmetric storage applies

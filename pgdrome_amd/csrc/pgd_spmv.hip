@@ -649,8 +649,8 @@ __global__ __launch_bounds__(64 * WY) void k_spmv_dia_march(DiaArgs A) {
     }
     __syncthreads();
     for (int z = za; z < zb; ++z) {
-        double vn[2];
-        fetch(z + 2, vn);                                   // in flight while this plane is computed
+        double vn[2] = {0.0, 0.0};
+        if (z + 2 <= zb) fetch(z + 2, vn);                  // in flight while this plane is computed (plane zb + 1 is never read)
         const int64_t row = base + P * z;
         double uv[8];
 #pragma unroll
@@ -705,6 +705,145 @@ __global__ __launch_bounds__(64 * WY) void k_spmv_dia_march(DiaArgs A) {
             for (int k = 0; k < WY; k += 4) t += (s_red[k] + s_red[k + 1]) + (s_red[k + 2] + s_red[k + 3]);
             A.partials[b] = t;
         }
+    }
+}
+
+// Two rows per thread: the same march on a 64 x 8 patch with 256 threads - thread (lane, wave) owns the rows y0 + 2 wave
+// and y0 + 2 wave + 1.  Half the barriers and patch-border rows per row of work, twice the loads in flight per wave; the
+// upper row takes its (0, -1, 0) coupling from the lower row's registers and its plane-below (0, -1, -1) coupling from the
+// thread's own LDS cell.  Same per-row arithmetic and order: bit-identical to k_spmv_dia_march.
+template <bool DOT, bool STORE>
+__global__ __launch_bounds__(256) void k_spmv_dia_march2(DiaArgs A) {
+    constexpr int NT = 256, PY = 8, HY = PY + 2, SLICE = DM_HX * HY;        // 660 cells per plane
+    __shared__ double s_x[3 * SLICE];
+    __shared__ double s_lo[2 * 4 * NT];                     // [row of the pair][slot 4..7][thread]
+    __shared__ double s_red[4];
+    if (A.flags && A.flags[0]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_chunk = A.tiles_x * A.tiles_y;
+    const int chunk = b / per_chunk, tile = b - chunk * per_chunk;
+    const int ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+    const int x0 = tx * 64, y0 = ty * PY;
+    const int x = x0 + lane, ya = y0 + 2 * wv;
+    const bool live0 = x < A.nx && ya < A.ny, live1 = x < A.nx && ya + 1 < A.ny;
+    const bool inx0 = live0 && x > 0, inx1 = live1 && x > 0;
+    const bool iny0 = live0 && ya > 0;                      // the upper row of the pair always has its y - 1 neighbour: the lower row
+    const bool ldx = lane > 0, ldy = wv > 0;
+    const int64_t nx = A.nx, P = (int64_t)A.nx * A.ny, n = A.n;
+    const int64_t base0 = live0 ? x + nx * ya : 0, base1 = live1 ? x + nx * (ya + 1) : 0;
+    const int centre = (2 * wv + 1) * DM_HX + lane + 1;     // the lower row of the pair; the upper one at + DM_HX
+    const int za = A.z0 + chunk * A.zchunk, zb = min(A.z1, za + A.zchunk);
+    int64_t goff[3];
+    bool gok[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int i = tid + q * NT;
+        const int ly = i / DM_HX, lx = i - ly * DM_HX;
+        const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+        gok[q] = i < SLICE && gx >= 0 && gx < A.nx && gy >= 0 && gy < A.ny;
+        goff[q] = gok[q] ? gx + nx * gy : 0;
+    }
+    auto fetch = [&](int z, double v[3]) {
+        const bool zok = z >= 0 && z < A.nz;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[q] = (zok && gok[q]) ? A.x[goff[q] + P * z] : 0.0;
+    };
+    auto put = [&](int z, const double v[3]) {
+        const int sl = ((z % 3) + 3) % 3;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (tid + q * NT < SLICE) s_x[sl * SLICE + tid + q * NT] = v[q];
+    };
+    double dot = 0.0;
+    if (za < zb) {
+        double v[3];
+        for (int z = za - 1; z <= za + 1; ++z) { fetch(z, v); put(z, v); }
+        if (za > 0) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                s_lo[s * NT + tid] = A.uvals[(int64_t)(4 + s) * n + base0 + P * (za - 1)];
+                s_lo[(4 + s) * NT + tid] = A.uvals[(int64_t)(4 + s) * n + base1 + P * (za - 1)];
+            }
+        }
+    }
+    __syncthreads();
+    for (int z = za; z < zb; ++z) {
+        double vn[3] = {0.0, 0.0, 0.0};
+        if (z + 2 <= zb) fetch(z + 2, vn);                  // plane zb + 1 is never read
+        const int64_t r0 = base0 + P * z, r1 = base1 + P * z;
+        double u0[8], u1[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) { u0[s] = A.uvals[(int64_t)s * n + r0]; u1[s] = A.uvals[(int64_t)s * n + r1]; }
+        // in-plane lower couplings from the neighbouring rows' slots (L1 / L2); (0, -1) of the upper row = u0[2]
+        const double t1a = A.uvals[1 * n + (inx0 ? r0 - 1 : r0)];
+        const double t2a = A.uvals[2 * n + (iny0 ? r0 - nx : r0)];
+        const double t3a = A.uvals[3 * n + ((inx0 && iny0) ? r0 - nx - 1 : r0)];
+        const double t1b = A.uvals[1 * n + (inx1 ? r1 - 1 : r1)];
+        const double t3b = A.uvals[3 * n + (inx1 ? r1 - nx - 1 : r1)];
+        double a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0, b4 = 0.0, b5 = 0.0, b6 = 0.0, b7 = 0.0;
+        if (z > 0) {                                        // uniform
+            a4 = live0 ? s_lo[tid] : 0.0;
+            b4 = live1 ? s_lo[4 * NT + tid] : 0.0;
+            if (inx0) a5 = ldx ? s_lo[NT + tid - 1] : A.uvals[5 * n + r0 - P - 1];
+            if (inx1) b5 = ldx ? s_lo[5 * NT + tid - 1] : A.uvals[5 * n + r1 - P - 1];
+            if (iny0) a6 = ldy ? s_lo[6 * NT + tid - 64] : A.uvals[6 * n + r0 - P - nx];      // row below the pair: upper row of wave - 1
+            if (live1) b6 = s_lo[2 * NT + tid];                                                // the pair's own lower row
+            if (inx0 && iny0) a7 = (ldx && ldy) ? s_lo[7 * NT + tid - 65] : A.uvals[7 * n + r0 - P - nx - 1];
+            if (inx1) b7 = ldx ? s_lo[3 * NT + tid - 1] : A.uvals[7 * n + r1 - P - nx - 1];
+        }
+        const double a1 = inx0 ? t1a : 0.0, a2 = iny0 ? t2a : 0.0, a3 = (inx0 && iny0) ? t3a : 0.0;
+        const double b1 = inx1 ? t1b : 0.0, b2 = live1 ? u0[2] : 0.0, b3 = inx1 ? t3b : 0.0;
+        const int sl0 = ((z - 1) % 3 + 3) % 3;
+        const double *xm = s_x + sl0 * SLICE + centre;
+        const double *xc = s_x + ((sl0 + 1) % 3) * SLICE + centre;
+        const double *xp = s_x + ((sl0 + 2) % 3) * SLICE + centre;
+        const double xa = xc[0], xb = xc[DM_HX];
+        double acc0 = a7 * xm[-DM_HX - 1];
+        acc0 = fma(a6, xm[-DM_HX], acc0);
+        acc0 = fma(a5, xm[-1], acc0);
+        acc0 = fma(a4, xm[0], acc0);
+        acc0 = fma(a3, xc[-DM_HX - 1], acc0);
+        acc0 = fma(a2, xc[-DM_HX], acc0);
+        acc0 = fma(a1, xc[-1], acc0);
+        acc0 = fma(u0[0], xa, acc0);
+        acc0 = fma(u0[1], xc[1], acc0);
+        acc0 = fma(u0[2], xc[DM_HX], acc0);
+        acc0 = fma(u0[3], xc[DM_HX + 1], acc0);
+        acc0 = fma(u0[4], xp[0], acc0);
+        acc0 = fma(u0[5], xp[1], acc0);
+        acc0 = fma(u0[6], xp[DM_HX], acc0);
+        acc0 = fma(u0[7], xp[DM_HX + 1], acc0);
+        double acc1 = b7 * xm[-1];
+        acc1 = fma(b6, xm[0], acc1);
+        acc1 = fma(b5, xm[DM_HX - 1], acc1);
+        acc1 = fma(b4, xm[DM_HX], acc1);
+        acc1 = fma(b3, xc[-1], acc1);
+        acc1 = fma(b2, xc[0], acc1);
+        acc1 = fma(b1, xc[DM_HX - 1], acc1);
+        acc1 = fma(u1[0], xb, acc1);
+        acc1 = fma(u1[1], xc[DM_HX + 1], acc1);
+        acc1 = fma(u1[2], xc[2 * DM_HX], acc1);
+        acc1 = fma(u1[3], xc[2 * DM_HX + 1], acc1);
+        acc1 = fma(u1[4], xp[DM_HX], acc1);
+        acc1 = fma(u1[5], xp[DM_HX + 1], acc1);
+        acc1 = fma(u1[6], xp[2 * DM_HX], acc1);
+        acc1 = fma(u1[7], xp[2 * DM_HX + 1], acc1);
+        if (STORE && live0) A.y[r0] = acc0;
+        if (STORE && live1) A.y[r1] = acc1;
+        if (DOT && live0) dot = fma(acc0, xa, dot);
+        if (DOT && live1) dot = fma(acc1, xb, dot);
+        lds_barrier();
+        put(z + 2, vn);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { s_lo[s * NT + tid] = u0[4 + s]; s_lo[(4 + s) * NT + tid] = u1[4 + s]; }
+        lds_barrier();
+    }
+    if (DOT) {
+        const double sum = wave_sum(dot);
+        if (lane == 0) s_red[wv] = sum;
+        __syncthreads();
+        if (tid == 0) A.partials[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     }
 }
 
@@ -999,7 +1138,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         D.nx = m->sym_nx; D.ny = m->sym_ny; D.nz = (int)(m->nv / plane);
         D.row_begin = (int)r0; D.row_end = (int)r1;
         D.z0 = (int)(r0 / plane); D.z1 = (int)(r1 / plane);
-        const int wy = c->spmv_variant == 1 ? 8 : 4;        // patch rows = waves per workgroup
+        const int wy = c->spmv_variant <= 1 ? 8 : 4;        // patch rows (0: 4 waves x two rows per thread; 1: 8 waves; 2: 4 waves, one row)
         D.tiles_x = (D.nx + 63) / 64; D.tiles_y = (D.ny + wy - 1) / wy; D.zchunk = 0;
         // plane-aligned row range, PCG product (w = x) or plain product, planes large enough: the LDS march
         int chunks = 0;
@@ -1028,7 +1167,11 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         else if (dot) k_spmv_dia_march<true, false, WY><<<wgs, 64 * WY, 0, c->stream>>>(D);            \
         else k_spmv_dia_march<false, true, WY><<<wgs, 64 * WY, 0, c->stream>>>(D);                     \
     } while (0)
-            if (wy == 8) PGD_MARCH(8); else PGD_MARCH(4);
+            if (c->spmv_variant == 0) {
+                if (dot && store) k_spmv_dia_march2<true, true><<<wgs, 256, 0, c->stream>>>(D);
+                else if (dot) k_spmv_dia_march2<true, false><<<wgs, 256, 0, c->stream>>>(D);
+                else k_spmv_dia_march2<false, true><<<wgs, 256, 0, c->stream>>>(D);
+            } else if (wy == 8) PGD_MARCH(8); else PGD_MARCH(4);
 #undef PGD_MARCH
             c->kcount[KC_DIA_MARCH] += 1;
         } else {
@@ -1134,7 +1277,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_SPMV_ZCHUNK && value >= 0 && value <= 65536) { c->spmv_zchunk = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_FAULT_ITERATION && value >= -1 && value <= (1 << 30)) { c->fault_iteration = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_COMBINE_DIA && value >= 0 && value <= 1) { c->spmv_combine_dia = (int)value; return PGD_OK; }
-    if (knob == PGD_TUNE_SPMV_VARIANT && value >= 0 && value <= 1) { c->spmv_variant = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_VARIANT && value >= 0 && value <= 2) { c->spmv_variant = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }
 

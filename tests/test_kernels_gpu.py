@@ -440,9 +440,9 @@ def test_grid_march_in_multi_tile_launch_shapes(ctx, shape):
     assert abs(d_rows - x @ ref) <= 1e-13 * (np.abs(x) @ rowabs)
     plane = nx * ny
     try:
-        for zc, patch in ((1, 0), (4, 0), (16, 0), (1000, 0), (1, 1), (5, 1), (1000, 1)):   # planes per march (forced), patch form
-            ctx.tune(7, zc)
-            ctx.tune(13, patch)                                      # 0: 64 x 4 patches, 1: 64 x 8 patches
+        for zc, patch in ((1, 0), (4, 0), (16, 0), (1000, 0), (1, 1), (5, 1), (1000, 1), (1, 2), (3, 2), (8, 2), (1000, 2)):
+            ctx.tune(7, zc)                                          # planes per march (forced)
+            ctx.tune(13, patch)                                      # 0: 64 x 8, two rows per thread (default), 1: 64 x 8 (512 threads), 2: 64 x 4
             ctx.vec_fill(yv, -5.0)
             ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 32)
             y = ctx.vec_download(yv)

@@ -15,9 +15,9 @@ from pgdrome_amd import _lib, fem
 from pgdrome_amd import sizes as psizes
 
 MODES = [  # name, sym, dict, zchunk knob, zchunk force, variant
-    ("csr_dict16", 0, 1, 16, 0, 0), ("dia_rows", 1, 1, 0, 0, 0),
-    ("march adaptive", 1, 1, 16, 0, 0), ("march z3", 1, 1, 16, 3, 0), ("march z4", 1, 1, 16, 4, 0), ("march z8", 1, 1, 16, 8, 0),
-    ("march z16", 1, 1, 16, 16, 0), ("march 64x8 adaptive", 1, 1, 16, 0, 1),
+    ("csr", 0, 0, 8, 0, 0), ("csr_dict16", 0, 1, 8, 0, 0), ("dia_rows", 1, 1, 0, 0, 0),
+    ("march2 adaptive", 1, 1, 8, 0, 0), ("march<8> adaptive", 1, 1, 8, 0, 1), ("march<4> adaptive", 1, 1, 8, 0, 2),
+    ("march2 z4", 1, 1, 8, 4, 0), ("march2 z16", 1, 1, 16, 16, 0),
 ]
 
 
