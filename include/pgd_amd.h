@@ -269,6 +269,9 @@ enum {
     PGD_TUNE_PCG_SCALED = 10,   /* 1 (default): pgd_pcg_solve runs CG on D^-1/2 A D^-1/2 (the same iterates as Jacobi-PCG,
                                    two vector passes per iteration fewer) when the symmetric storage applies; 0: unscaled */
     PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */
+    PGD_TUNE_PCG_DEFER_X = 16, /* 1 (default): in the scaled recurrence on systems above 2^20 rows the update x += alpha p is done by
+                                  the kernel that forms p = r + beta p (which reads p anyway): 8 vector passes per iteration instead
+                                  of 9, bit-identical iterates; 0: the x / r kernel + p kernel pair */
     PGD_TUNE_FAULT_ITERATION = 15, /* tests only: pgd_pcg_solve_sharded fails on this rank in that iteration, once (-1: never) -
                                       the other ranks must come out of the solve with an error instead of waiting for it */
     PGD_TUNE_COMBINE_DIA = 14, /* 1 (default): on structured vertex grids pgd_op_combine also forms the operator's diagonal

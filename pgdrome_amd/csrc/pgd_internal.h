@@ -151,6 +151,7 @@ struct Ctx {
     int spmv_variant = 0;         // z-march: 0 = k_spmv_dia_march2 (64 x 8 patch, two rows per thread), 1 = 64 x 8 / 512 threads, 2 = 64 x 4 / 256 threads
     int spmv_zchunk = 8;          // k_spmv_dia_march: most planes a workgroup marches through (0: never use that kernel)
     int pcg_fold_reduce = 1;      // scaled recurrence: final reduction passes folded into the vector kernels (3 launches / iteration)
+    int pcg_defer_x = 1;          // scaled recurrence, large systems: x += alpha p in the p kernel (8 vector passes per iteration, not 9)
     int pcg_scaled = 1;           // pgd_pcg_solve on the symmetrically scaled system (no dinv / z passes) when the symmetric storage applies
     int spmv_combine_dia = 1;     // structured grids: op_combine also forms the diagonal form from the atoms' diagonal forms
     int spmv_sym = 1;             // PCG products from the symmetric half storage when the mesh qualifies

@@ -1275,6 +1275,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_PCG_FOLD_REDUCE && value >= 0 && value <= 1) { c->pcg_fold_reduce = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_SCALED && value >= 0 && value <= 1) { c->pcg_scaled = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK && value >= 0 && value <= 65536) { c->spmv_zchunk = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_PCG_DEFER_X && value >= 0 && value <= 1) { c->pcg_defer_x = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_FAULT_ITERATION && value >= -1 && value <= (1 << 30)) { c->fault_iteration = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_COMBINE_DIA && value >= 0 && value <= 1) { c->spmv_combine_dia = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_VARIANT && value >= 0 && value <= 2) { c->spmv_variant = (int)value; return PGD_OK; }

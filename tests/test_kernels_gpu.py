@@ -598,6 +598,54 @@ def test_start_gram_matches_oracle(ctx, name):
     ctx.mesh_free(h)
 
 
+def test_pcg_with_the_x_update_in_the_p_kernel_is_bit_identical(ctx):
+    """Above 2^20 rows the scaled recurrence lets the p kernel apply x += alpha p (8 vector passes per iteration instead of
+    9; the last update is applied after the loop when the solve converges): same iterates, bit for bit, as the x / r
+    kernel + p kernel pair - also when the loop ends on maxit, and on a converged start."""
+    from pgdrome_amd import fem
+    npts = 104                                        # 104^3 = 1 124 864 rows > 2^20
+    mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), npts - 1, npts - 1, npts - 1)
+    coords = mesh.coordinates()
+    h = ctx.mesh_upload(coords, mesh.cells())
+    n = coords.shape[0]
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bc = np.where(np.any((coords <= 1e-12) | (coords >= 1 - 1e-12), axis=1))[0].astype(np.int32)
+    rng = np.random.default_rng(5)
+    b = rng.uniform(-1, 1, n)
+    b[bc] = 0.0
+    x0 = 0.01 * rng.uniform(-1, 1, n)
+    x0[bc] = 0.0
+    bv = ctx.vec_from(b)
+    out = {}
+    try:
+        for defer in (1, 0):
+            ctx.tune(16, defer)
+            for maxit in (10000, 37):                 # to convergence; cut off in the middle of a 16-iteration chunk
+                op = ctx.op_combine(h, [ak, am], [1.0, 3.0], bc)
+                xv = ctx.vec_from(x0)
+                try:
+                    it, rel = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, maxit)
+                except Exception:
+                    raise
+                out[(defer, maxit)] = (it, rel, ctx.vec_download(xv))
+                if maxit == 10000:
+                    it2, rel2 = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, maxit)          # converged start: nothing pending
+                    out[(defer, "again")] = (it2, rel2, ctx.vec_download(xv))
+                ctx.vec_free(xv)
+                ctx.atom_free(op)
+    finally:
+        ctx.tune(16, 1)
+    for key in (10000, 37, "again"):
+        a, c = out[(1, key)], out[(0, key)]
+        assert a[0] == c[0] and a[1] == c[1], key
+        assert np.array_equal(a[2], c[2]), (key, np.abs(a[2] - c[2]).max())
+    assert out[(1, 10000)][1] <= 1e-10 and out[(1, 37)][0] == 37 and out[(1, "again")][0] <= 1
+    ctx.vec_free(bv)
+    for a in (ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
 def test_vector_ops(ctx):
     rng = np.random.default_rng(5)
     for n in (1, 63, 64, 257, 100_003):
