@@ -269,6 +269,9 @@ enum {
     PGD_TUNE_PCG_SCALED = 10,   /* 1 (default): pgd_pcg_solve runs CG on D^-1/2 A D^-1/2 (the same iterates as Jacobi-PCG,
                                    two vector passes per iteration fewer) when the symmetric storage applies; 0: unscaled */
     PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */
+    PGD_TUNE_UNIT_DIAG = 17,   /* 1 (default): the scaled operator D^-1/2 A D^-1/2 of pgd_pcg_solve(_sharded) gets its diagonal set to
+                                  exactly 1 on structured grids and the products do not load it (7 instead of 8 slot values per row);
+                                  0: diagonal s_i^2 a_ii stored and loaded */
     PGD_TUNE_PCG_DEFER_X = 16, /* 1 (default): in the scaled recurrence on systems above 2^20 rows the update x += alpha p is done by
                                   the kernel that forms p = r + beta p (which reads p anyway): 8 vector passes per iteration instead
                                   of 9, bit-identical iterates; 0: the x / r kernel + p kernel pair */

@@ -88,6 +88,7 @@ struct Csr : Obj {
     double *uvals = nullptr;
     bool uvals_valid = false;
     bool uvals_scaled = false;  // the slot arrays hold D^-1/2 A D^-1/2 (inside pgd_pcg_solve only)
+    bool uvals_unit = false;    // ... in diagonal form, whose slot 0 is exactly 1 and is not loaded by the products
     int64_t uvals_stride = 0;  // doubles between two slot arrays (rows + padding)
     size_t vals_bytes = 0, dinv_bytes = 0, uvals_bytes = 0;
     ~Csr() override {
@@ -151,6 +152,7 @@ struct Ctx {
     int spmv_variant = 0;         // z-march: 0 = k_spmv_dia_march2 (64 x 8 patch, two rows per thread), 1 = 64 x 8 / 512 threads, 2 = 64 x 4 / 256 threads
     int spmv_zchunk = 8;          // k_spmv_dia_march: most planes a workgroup marches through (0: never use that kernel)
     int pcg_fold_reduce = 1;      // scaled recurrence: final reduction passes folded into the vector kernels (3 launches / iteration)
+    int spmv_unit_diag = 1;       // scaled recurrence on structured grids: the unit diagonal is set to exactly 1 and not loaded
     int pcg_defer_x = 1;          // scaled recurrence, large systems: x += alpha p in the p kernel (8 vector passes per iteration, not 9)
     int pcg_scaled = 1;           // pgd_pcg_solve on the symmetrically scaled system (no dinv / z passes) when the symmetric storage applies
     int spmv_combine_dia = 1;     // structured grids: op_combine also forms the diagonal form from the atoms' diagonal forms

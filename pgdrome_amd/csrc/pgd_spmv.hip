@@ -535,6 +535,7 @@ struct DiaArgs {
     int nx, ny, nz;         // vertex grid of the (local) mesh
     int row_begin, row_end; // k_spmv_dia_rows
     int z0, z1, zchunk, tiles_x, tiles_y;   // k_spmv_dia_march
+    int unit_diag;          // the operator is D^-1/2 A D^-1/2 of the scaled recurrence: its diagonal is 1 and is not loaded
 };
 
 // row order, any row range: small grids, ranges that are not whole planes, products with w != x
@@ -557,7 +558,7 @@ __global__ __launch_bounds__(64) void k_spmv_dia_rows(DiaArgs A) {
         const int64_t off = dx + (int64_t)A.nx * dy + P * dz;
         const bool up = x + dx < A.nx && y + dy < A.ny && z + dz < A.nz;
         const bool lo = s > 0 && x >= dx && y >= dy && z >= dz;
-        uv[s] = A.uvals[(int64_t)s * A.n + row];                        // 0 where the neighbour does not exist
+        uv[s] = (s == 0 && A.unit_diag) ? 1.0 : A.uvals[(int64_t)s * A.n + row];   // 0 where the neighbour does not exist
         ux[s] = A.x[up ? row + off : row];
         const double t = A.uvals[(int64_t)s * A.n + (lo ? row - off : row)];
         lv[s] = lo ? t : 0.0;
@@ -653,8 +654,10 @@ __global__ __launch_bounds__(64 * WY) void k_spmv_dia_march(DiaArgs A) {
         if (z + 2 <= zb) fetch(z + 2, vn);                  // in flight while this plane is computed (plane zb + 1 is never read)
         const int64_t row = base + P * z;
         double uv[8];
+        uv[0] = 1.0;                                        // unit diagonal of the scaled operator: 56 instead of 64 B of slots per row
+        if (!A.unit_diag) uv[0] = A.uvals[row];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) uv[s] = A.uvals[(int64_t)s * n + row];
+        for (int s = 1; s < 8; ++s) uv[s] = A.uvals[(int64_t)s * n + row];
         // in-plane lower couplings: slot s of the row s names (L1 / L2 hits, except across the patch border)
         const double t1 = A.uvals[1 * n + (inx ? row - 1 : row)];
         const double t2 = A.uvals[2 * n + (iny ? row - nx : row)];
@@ -773,8 +776,10 @@ __global__ __launch_bounds__(256) void k_spmv_dia_march2(DiaArgs A) {
         if (z + 2 <= zb) fetch(z + 2, vn);                  // plane zb + 1 is never read
         const int64_t r0 = base0 + P * z, r1 = base1 + P * z;
         double u0[8], u1[8];
+        u0[0] = u1[0] = 1.0;                                // unit diagonal of the scaled operator: 56 instead of 64 B of slots per row
+        if (!A.unit_diag) { u0[0] = A.uvals[r0]; u1[0] = A.uvals[r1]; }
 #pragma unroll
-        for (int s = 0; s < 8; ++s) { u0[s] = A.uvals[(int64_t)s * n + r0]; u1[s] = A.uvals[(int64_t)s * n + r1]; }
+        for (int s = 1; s < 8; ++s) { u0[s] = A.uvals[(int64_t)s * n + r0]; u1[s] = A.uvals[(int64_t)s * n + r1]; }
         // in-plane lower couplings from the neighbouring rows' slots (L1 / L2); (0, -1) of the upper row = u0[2]
         const double t1a = A.uvals[1 * n + (inx0 ? r0 - 1 : r0)];
         const double t2a = A.uvals[2 * n + (iny0 ? r0 - nx : r0)];
@@ -905,15 +910,18 @@ __global__ __launch_bounds__(TPB) void k_csr_to_dia(const int *__restrict__ row_
     if (asym) atomicAdd(&flags[1], 1);
 }
 
-// slot s of row i holds a(i, i + off_s): times s_i s_{i + off_s}
+// slot s of row i holds a(i, i + off_s): times s_i s_{i + off_s}.  The diagonal of D^-1/2 A D^-1/2 is 1: it is SET to exactly 1
+// (s_i^2 a_ii differs from it by the rounding of s_i, a relative perturbation of the operator at the level of the rounding of
+// every product with it), and the products of the scaled recurrence do not load it (DiaArgs::unit_diag).
 __global__ __launch_bounds__(TPB) void k_dia_scale(double *__restrict__ uvals, int64_t stride, const double *__restrict__ sc,
-                                                   int64_t nv, int nx, int ny) {
+                                                   int64_t nv, int nx, int ny, int unit) {
     const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (i >= nv) return;
     const int64_t P = (int64_t)nx * ny;
     const double si = sc[i];
+    uvals[i] = unit ? 1.0 : uvals[i] * si * si;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
+    for (int s = 1; s < 8; ++s) {
         const int64_t j = i + (s & 1) + (int64_t)nx * ((s >> 1) & 1) + P * (s >> 2);
         if (j < nv) uvals[(int64_t)s * stride + i] *= si * sc[j];      // slots without a neighbour hold 0 and keep it
     }
@@ -996,11 +1004,12 @@ __global__ __launch_bounds__(TPB) void k_sym_scale(double *__restrict__ uvals, i
 int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *sc) {
     if (!(a->uvals && a->uvals_valid) || a->uvals_scaled) return fail(c, PGD_ERR_INVALID, "sym_scale: no unscaled symmetric copy");
     const int g = (int)((m->nv + TPB - 1) / TPB);
-    if (m->sym_nx > 0) k_dia_scale<<<g, TPB, 0, c->stream>>>(a->uvals, a->uvals_stride, sc, m->nv, m->sym_nx, m->sym_ny);
+    if (m->sym_nx > 0) k_dia_scale<<<g, TPB, 0, c->stream>>>(a->uvals, a->uvals_stride, sc, m->nv, m->sym_nx, m->sym_ny, c->spmv_unit_diag);
     else if (m->sym_w == 4) k_sym_scale<4><<<g, TPB, 0, c->stream>>>(a->uvals, a->uvals_stride, m->pids, m->sym_tab, sc, m->nv);
     else k_sym_scale<8><<<g, TPB, 0, c->stream>>>(a->uvals, a->uvals_stride, m->pids, m->sym_tab, sc, m->nv);
     PGD_LAUNCH_CHECK(c);
     a->uvals_scaled = true;
+    a->uvals_unit = m->sym_nx > 0 && c->spmv_unit_diag;
     return PGD_OK;
 }
 
@@ -1140,6 +1149,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         D.z0 = (int)(r0 / plane); D.z1 = (int)(r1 / plane);
         const int wy = c->spmv_variant <= 1 ? 8 : 4;        // patch rows (0: 4 waves x two rows per thread; 1: 8 waves; 2: 4 waves, one row)
         D.tiles_x = (D.nx + 63) / 64; D.tiles_y = (D.ny + wy - 1) / wy; D.zchunk = 0;
+        D.unit_diag = (a->uvals_scaled && a->uvals_unit) ? 1 : 0;
         // plane-aligned row range, PCG product (w = x) or plain product, planes large enough: the LDS march
         int chunks = 0;
         if (c->spmv_zchunk > 0 && (!dot || w == x) && r0 % plane == 0 && r1 % plane == 0 &&
@@ -1181,7 +1191,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
             else k_spmv_dia_rows<false, true><<<nblk, 64, 0, c->stream>>>(D);
             c->kcount[KC_DIA_ROWS] += 1;
         }
-        if (timed2) PGD_TRY(prof_end(c, m, nrows, 8.0 * 8 + 16));
+        if (timed2) PGD_TRY(prof_end(c, m, nrows, 8.0 * (D.unit_diag ? 7 : 8) + 16));
         PGD_LAUNCH_CHECK(c);
         return PGD_OK;
     }
@@ -1275,6 +1285,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_PCG_FOLD_REDUCE && value >= 0 && value <= 1) { c->pcg_fold_reduce = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_SCALED && value >= 0 && value <= 1) { c->pcg_scaled = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK && value >= 0 && value <= 65536) { c->spmv_zchunk = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_UNIT_DIAG && value >= 0 && value <= 1) { c->spmv_unit_diag = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_DEFER_X && value >= 0 && value <= 1) { c->pcg_defer_x = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_FAULT_ITERATION && value >= -1 && value <= (1 << 30)) { c->fault_iteration = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_COMBINE_DIA && value >= 0 && value <= 1) { c->spmv_combine_dia = (int)value; return PGD_OK; }
