@@ -296,7 +296,8 @@ def _first_spatial_operator(prob):
 def pmc_traffic(own_bytes):
     """HBM-side bytes per launch of the dominant kernel.  bench.py cannot read PMC counters of its own process, so it
     starts `rocprofv3 --pmc` CHILD processes (one counter per pass, as MI355X_MICROARCH.md prescribes) on
-    tools/pmc_spmv_sym.py - the same kernel on the same 256^3 operator shape - and applies the calibrated factors of
+    tools/pmc_spmv_sym.py - the same kernel instance (12 iterations of pgd_pcg_solve on the same 256^3 operator shape: the product
+    of the scaled operator with the fused dot) - and applies the calibrated factors of
     profiles/r02a_pmc_calibration_and_march.json (FETCH_SIZE x 2 for 8 B/lane streaming loads, measured on a known 1 GiB
     stream; WRITE_SIZE exact).  Falls back to the committed profile when no profiler can be started."""
     import csv
@@ -322,7 +323,8 @@ def pmc_traffic(own_bytes):
                 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                     with open(f) as fh:
                         for row in csv.DictReader(fh):
-                            if row.get("Counter_Name") == counter and "k_spmv_dia_march" in row.get("Kernel_Name", ""):   # march or march2
+                            name = row.get("Kernel_Name", "")
+                            if row.get("Counter_Name") == counter and "k_spmv_dia_march" in name and "<true, true" in name:
                                 got.append(float(row["Counter_Value"]))
                 shutil.rmtree(d, ignore_errors=True)
                 if not got:

@@ -31,7 +31,13 @@ ctx.tune(13, variant)
 if mode != "csr":
     assert ctx.op_symmetrize(op)
 ctx.flags_reset()
-for _ in range(6):
-    ctx.spmv_dot_slot(op, x, y, x, 0, nv, 30)
+if mode == "grid":
+    # the PCG instance as the solves launch it: the product of the SCALED operator (unit diagonal not loaded) with the fused
+    # dot, inside pgd_pcg_solve - 12 iterations that cannot converge (rtol = atol = 0), issued eagerly (< one graph chunk)
+    b = ctx.vec_from(np.random.default_rng(99).uniform(-1, 1, nv))
+    ctx.pcg_solve(op, b, y, 0.0, 0.0, 12)
+else:
+    for _ in range(6):
+        ctx.spmv_dot_slot(op, x, y, x, 0, nv, 30)
 ctx.sync()
 print("done", n, mode, zchunk, variant, ctx.kernel_counts())

@@ -48,7 +48,7 @@ prod = {}
 for counter, kind in (("FETCH_SIZE", "load"), ("WRITE_SIZE", "store")):
     d = per_kernel("pmc_%s_march_%s" % (tag, counter), counter)
     for k, vs in d.items():
-        if "k_spmv_dia_march" in k:
+        if "k_spmv_dia_march" in k and "<true, true" in k:        # the PCG instance (fused dot, y stored)
             u = res["calibration"].get("%s_8B_per_lane" % kind, {}).get("counter_unit_bytes", 1.0)
             mean = sum(vs) / len(vs) * u
             prod[counter] = {"kernel": k[:80], "counter_bytes_per_launch": mean, "factor_8B": factors.get((kind, 8)),
