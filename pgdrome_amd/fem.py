@@ -282,7 +282,7 @@ class DofLayout:
             raise NotImplementedError("Lagrange degree %d on %s cells: P1 everywhere, P2 on intervals "
                                       "/ triangles / tetrahedra (SURVEY 8(f4))" % (self.degree, mesh.ufl_cell()))
         self.n = self.coords.shape[0]
-        self._handles, self._atoms = {}, {}
+        self._handles, self._atoms, self._atom_weights = {}, {}, {}
         self._ones = self._space = None
 
     @property
@@ -351,22 +351,37 @@ class DofLayout:
         return h
 
     def atom(self, kind, da=0, db=0, weight=None):
-        """Cached device atom; weighted atoms are keyed by the weight's identity+version."""
+        """Cached device atom; weighted atoms are keyed by the weight's identity + version, the identity checked through
+        a weak reference: an address (``id``) is reused as soon as a vector dies, and an iterate can end up as the weight
+        of a functional (``assemble(E * F * F * dx)`` with E and F equally "old")."""
         be = get_backend()
         if self.mesh.geometry().dim() == 1 and kind == DUDV:
             kind = STIFF
         wkey = None if weight is None else (id(weight), weight.version)
         key = (id(be), kind, da if kind in (DUDV, CONV) else 0, db if kind in (DUDV, CONVT) else 0, wkey)
         a = self._atoms.get(key)
+        if a is not None and weight is not None:
+            ref = self._atom_weights.get(key)
+            if ref is None or ref() is not weight:          # another vector lives at that address now
+                self._drop_atom(be, key)
+                a = None
         if a is None:
-            if weight is not None:   # drop stale versions of the same weight
-                for k in [k for k in self._atoms if k[0] == id(be) and k[1] == kind and k[4] and k[4][0] == id(weight)]:
-                    stale = self._atoms.pop(k)
-                    _purge_atom(stale)       # the library recycles handle numbers: forget everything keyed by it
-                    be.atom_free(stale)
+            if weight is not None:
+                # drop stale versions of the same weight and the atoms of weights that died (2 GB each at 256^3)
+                for k in [k for k in self._atoms if k[0] == id(be) and k[4] and
+                          ((k[1] == kind and k[4][0] == id(weight)) or self._atom_weights[k]() is None)]:
+                    self._drop_atom(be, k)
             a = be.atom(self.handle(), kind, key[2], key[3], weight.dev() if weight is not None else 0)
             self._atoms[key] = a
+            if weight is not None:
+                self._atom_weights[key] = weakref.ref(weight)
         return a
+
+    def _drop_atom(self, be, key):
+        stale = self._atoms.pop(key)
+        self._atom_weights.pop(key, None)
+        _purge_atom(stale)       # the library recycles handle numbers: forget everything keyed by it
+        be.atom_free(stale)
 
 
 def IntervalMesh(n, a, b):
@@ -1975,7 +1990,10 @@ def _weight_last(plain, lay):
     """Order undifferentiated coefficients so that the one best suited as the atom's weight comes last:
     an Expression (fixed data) before anything else, then the vector that changes least often."""
     def key(c):
-        return (1 if isinstance(c.leaf, Expression) else 0, -_coef_vec(c.leaf, lay).version)
+        # ties (equally "old" vectors): the factor that occurs once in the integrand is the weight, the repeated one
+        # (F * F) the function the functional is evaluated on
+        return (1 if isinstance(c.leaf, Expression) else 0, -_coef_vec(c.leaf, lay).version,
+                -sum(1 for o in plain if o.leaf is c.leaf))
     return sorted(plain, key=key)
 
 
