@@ -2308,8 +2308,8 @@ def _boundary_load(scalar_lay, measure):
         raise ValueError("ds(%r) without subdomain_data" % (measure.subdomain_id,))
     key = (id(get_backend()), id(scalar_lay), ids.tobytes())
     hit = _DS_CACHE.get(key)
-    if hit is not None:
-        return hit
+    if hit is not None and hit[1]() is scalar_lay:       # (an address is reused once a layout has died: check who lives there)
+        return hit[0]
     out = np.zeros(scalar_lay.n)
     tdim, deg = mesh.topology().dim(), scalar_lay.degree
     if ids.size and tdim == 1:
@@ -2375,7 +2375,7 @@ def _boundary_load(scalar_lay, measure):
         np.add.at(out, gl.ravel(), loads.ravel())
     if len(_DS_CACHE) > 64:
         _DS_CACHE.clear()
-    _DS_CACHE[key] = out
+    _DS_CACHE[key] = (out, weakref.ref(scalar_lay))
     return out
 
 
