@@ -52,6 +52,7 @@ def parse():
                          "the in-library loop (pgd_pcg_solve_sharded over RCCL)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--spmv-variant", type=int, default=-1, help="PGD_TUNE_SPMV_VARIANT for A/B runs (-1: library default)")
+    ap.add_argument("--single-sync", type=int, default=-1, help="PGD_TUNE_PCG_SINGLE_SYNC for A/B runs (-1: library default)")
     ap.add_argument("--unit-diag", type=int, default=-1, help="PGD_TUNE_UNIT_DIAG for A/B runs (-1: library default)")
     ap.add_argument("--defer-x", type=int, default=-1, help="PGD_TUNE_PCG_DEFER_X for A/B runs (-1: library default)")
     ap.add_argument("--no-pmc", action="store_true", help="do not start rocprofv3 --pmc child processes for roofline.traffic")
@@ -103,6 +104,8 @@ def main():
         be.ctx.tune(16, args.defer_x)
     if args.unit_diag >= 0:
         be.ctx.tune(17, args.unit_diag)
+    if args.single_sync >= 0:
+        be.ctx.tune(18, args.single_sync)
 
     n = args.n
     t_setup = time.time()

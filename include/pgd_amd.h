@@ -269,6 +269,10 @@ enum {
     PGD_TUNE_PCG_SCALED = 10,   /* 1 (default): pgd_pcg_solve runs CG on D^-1/2 A D^-1/2 (the same iterates as Jacobi-PCG,
                                    two vector passes per iteration fewer) when the symmetric storage applies; 0: unscaled */
     PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */
+    PGD_TUNE_PCG_SINGLE_SYNC = 18, /* 1 (default): scaled recurrence on structured grids above 2^20 rows with ONE reduction and ONE
+                                      vector kernel per iteration: the product also leaves q.q, beta comes from
+                                      r'.r' = alpha^2 q.q - r.r (exact in exact arithmetic; every alpha and the stop test use the
+                                      measured r.r); 7 vector passes and 3 launches per iteration instead of 8 and 5.  0: off */
     PGD_TUNE_UNIT_DIAG = 17,   /* 1 (default): the scaled operator D^-1/2 A D^-1/2 of pgd_pcg_solve(_sharded) gets its diagonal set to
                                   exactly 1 on structured grids and the products do not load it (7 instead of 8 slot values per row);
                                   0: diagonal s_i^2 a_ii stored and loaded */

@@ -152,6 +152,8 @@ struct Ctx {
     int spmv_variant = 0;         // z-march: 0 = k_spmv_dia_march2 (64 x 8 patch, two rows per thread), 1 = 64 x 8 / 512 threads, 2 = 64 x 4 / 256 threads
     int spmv_zchunk = 8;          // k_spmv_dia_march: most planes a workgroup marches through (0: never use that kernel)
     int pcg_fold_reduce = 1;      // scaled recurrence: final reduction passes folded into the vector kernels (3 launches / iteration)
+    int spmv_qq = 0;              // transient: the DIA products also leave y . y partial sums (pairs per workgroup)
+    int pcg_single_sync = 1;      // scaled recurrence on structured grids above 2^20 rows: one reduction + one vector kernel per iteration
     int spmv_unit_diag = 1;       // scaled recurrence on structured grids: the unit diagonal is set to exactly 1 and not loaded
     int pcg_defer_x = 1;          // scaled recurrence, large systems: x += alpha p in the p kernel (8 vector passes per iteration, not 9)
     int pcg_scaled = 1;           // pgd_pcg_solve on the symmetrically scaled system (no dinv / z passes) when the symmetric storage applies
@@ -241,6 +243,7 @@ int scan_exclusive_i32(Ctx *c, const int *in, int *out, int64_t n);   // out has
 int reduce_partials(Ctx *c, const double *partials, int nparts, int nvals, int slot0, int check_mode,
                     int slot_rr, int slot_tol2);
 int reduce_partials_to(Ctx *c, const double *partials, int nparts, int nvals, double *dest);
+int k_reduce_stage1_pub(Ctx *c, const double *partials, int nparts, int nvals, double *out);
 int vec_dot_range(Ctx *c, const double *x, const double *y, int64_t lo, int64_t hi, int slot);
 // pgd_spmv.hip
 int launch_spmv(Ctx *c, const Mesh *m, const double *vals, const double *x, double *y,

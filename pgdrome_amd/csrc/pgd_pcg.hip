@@ -11,6 +11,8 @@
 // wavefront-shuffle -> LDS -> fixed-order final pass: bitwise reproducible.
 #include "pgd_internal.h"
 
+#include <algorithm>
+
 namespace pgd {
 
 constexpr int MAXT = 8;          // atoms per combine launch
@@ -581,6 +583,109 @@ __global__ __launch_bounds__(TPB) void k_pcg_px_s(double *__restrict__ x, double
     }
 }
 
+// ---- single-sync form of the same scaled recurrence (structured grids, large systems).
+// Textbook CG has two reductions per iteration: p.q (for alpha) and r'.r' of the new residual (for beta).  With
+// alpha = r.r / p.q and r' = r - alpha q:  r'.r' = r.r - 2 alpha r.q + alpha^2 q.q = alpha^2 q.q - r.r  (r.q = p.q by the
+// conjugacy of p), so beta = r'.r' / r.r is known as soon as the product has left p.q and q.q - and ONE vector kernel can
+// apply x += alpha p, r -= alpha q, p = r + beta p (7 vector passes, 3 launches per iteration instead of 8 and 5).  Only
+// beta uses the predicted r'.r' (relative error ~ 2 eps / beta); the MEASURED r.r of every new residual, summed by the
+// same vector kernel, feeds the next alpha and the stop test, so nothing accumulates.  Iterates equal the textbook ones
+// up to rounding.  Slots: S1_RZ (measured r~.r~ of the current residual), S1_RR (its true r.r, exact phase),
+// S1_ALPHA, S1_BETA.
+enum { S1_RZ = 24, S1_RR = 25, S1_ALPHA = 26, S1_BETA = 27, S1_PQ = 28, S1_QQ = 29 };
+
+// one workgroup: sums the product's (p.q, q.q) pairs and the previous vector kernel's (r~.r~, true r.r) pairs, runs the stop
+// test on that residual and, if the solve goes on, forms alpha and beta for the update that follows
+__global__ __launch_bounds__(1024) void k_pcg1_scalars(const double *__restrict__ prod, int nprod, const double *__restrict__ vecp,
+                                                       int nvec, double *__restrict__ slots, int *__restrict__ flags) {
+    __shared__ double s_w[16];
+    if (flags[0]) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    double out[4];
+    for (int v = 0; v < 4; ++v) {
+        const double *src = v < 2 ? prod : vecp;
+        const int n = v < 2 ? nprod : nvec, off = v & 1;
+        double a4[4] = {0, 0, 0, 0};
+        int i = threadIdx.x;
+        for (; i + 3 * 1024 < n; i += 4 * 1024) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a4[u] += src[2 * (int64_t)(i + u * 1024) + off];
+        }
+        for (int u = 0; i < n; i += 1024, ++u) a4[u & 3] += src[2 * (int64_t)i + off];
+        double acc = wave_sum((a4[0] + a4[1]) + (a4[2] + a4[3]));
+        __syncthreads();
+        if (lane == 0) s_w[wv] = acc;
+        __syncthreads();
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s_w[k];
+        out[v] = t;
+    }
+    if (threadIdx.x != 0) return;
+    const double pq = out[0], qq = out[1], rz = out[2], rr = out[3], tol2 = slots[S_TOL2];
+    slots[S1_PQ] = pq; slots[S1_QQ] = qq; slots[S1_RZ] = rz; slots[S1_RR] = rr;
+    if (!(rz == rz) || !(pq == pq)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; return; }
+    if (flags[3]) { if (rr <= tol2) { flags[0] = 1; return; } }
+    else if (rz * slots[S_DMIN] <= 1e4 * tol2) flags[3] = 1;
+    const double alpha = rz / pq;
+    double rnew = alpha * alpha * qq - rz;
+    if (!(rnew > 0.0)) rnew = 0.0;                      // rounding below zero (beta at the eps level): a steepest-descent restart
+    slots[S1_ALPHA] = alpha;
+    slots[S1_BETA] = rnew / rz;
+    flags[1] += 1;
+}
+
+// x += alpha p; r -= alpha q; p = r + beta p; partial sums (r~.r~, exact phase ? sum r^2 / s^2 : r~.r~) of the new residual
+__global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
+                                                     const double *__restrict__ q, const double *__restrict__ s, int64_t n,
+                                                     const double *__restrict__ slots, double *__restrict__ partials,
+                                                     const int *__restrict__ flags) {
+    if (flags[0]) return;
+    __shared__ double s_red[4];
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const double alpha = slots[S1_ALPHA], beta = slots[S1_BETA];
+    const bool exact = flags[3] != 0;
+    double rz = 0.0, rr = 0.0;
+    const int64_t npair = n >> 1;
+    for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < npair; k += (int64_t)gridDim.x * TPB) {
+        const int64_t i = 2 * k;
+        const d2 qi = *reinterpret_cast<const d2 *>(q + i);
+        d2 pi = *reinterpret_cast<d2 *>(p + i), xi = *reinterpret_cast<d2 *>(x + i), ri = *reinterpret_cast<d2 *>(r + i);
+        xi.x = fma(alpha, pi.x, xi.x); xi.y = fma(alpha, pi.y, xi.y);
+        ri.x = fma(-alpha, qi.x, ri.x); ri.y = fma(-alpha, qi.y, ri.y);
+        pi.x = fma(beta, pi.x, ri.x); pi.y = fma(beta, pi.y, ri.y);
+        *reinterpret_cast<d2 *>(x + i) = xi;
+        *reinterpret_cast<d2 *>(r + i) = ri;
+        *reinterpret_cast<d2 *>(p + i) = pi;
+        rz = fma(ri.x, ri.x, rz); rz = fma(ri.y, ri.y, rz);
+        if (exact) {
+            const d2 si = *reinterpret_cast<const d2 *>(s + i);
+            const double tx = ri.x / si.x, ty = ri.y / si.y;
+            rr = fma(tx, tx, rr); rr = fma(ty, ty, rr);
+        }
+    }
+    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t i = n - 1;
+        x[i] = fma(alpha, p[i], x[i]);
+        const double ri = fma(-alpha, q[i], r[i]);
+        r[i] = ri;
+        p[i] = fma(beta, p[i], ri);
+        rz = fma(ri, ri, rz);
+        if (exact) { const double t = ri / s[i]; rr = fma(t, t, rr); }
+    }
+    rz = block_sum(rz, s_red);
+    rr = block_sum(rr, s_red);
+    if (threadIdx.x == 0) { partials[2 * blockIdx.x] = rz; partials[2 * blockIdx.x + 1] = exact ? rr : rz; }
+}
+
+// before the first iteration: the initial residual's (r~.r~, true r.r) as the one non-zero pair of the vector partials
+__global__ void k_pcg1_seed(double *__restrict__ partials, int npairs, const double *__restrict__ slots, int slot_rz, int slot_rr) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += gridDim.x * blockDim.x) {
+        partials[2 * i] = i == 0 ? slots[slot_rz] : 0.0;
+        partials[2 * i + 1] = i == 0 ? slots[slot_rr] : 0.0;
+    }
+}
+
 // x <- s x (back to the unscaled unknown); partial sum r^2 / s^2 (the true r.r, for the report)
 // p != nullptr: the x update of the last iteration is still pending (k_pcg_px_s was a no-op once the done flag was set):
 // x <- s (x + alpha p) with alpha = S[slot_rz] / S[slot_pq] of that iteration
@@ -922,11 +1027,36 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     double *part2 = c->work[6];
     // large systems: the x update rides in the p kernel (PGD_TUNE_PCG_DEFER_X); the folded small-system form keeps its own kernels
     const bool folded_form = scaled && c->pcg_fold_reduce && n <= ((int64_t)1 << 20);
-    const bool deferred_x = scaled && c->pcg_defer_x && !folded_form;
+    const bool single_sync = scaled && c->pcg_single_sync && !folded_form && m->sym_nx > 0;
+    const bool deferred_x = scaled && c->pcg_defer_x && !folded_form && !single_sync;
+    const int g2v = grid_for((n + 1) / 2);
+    if (single_sync) {
+        // the first look at the residual happens in the first k_pcg1_scalars: hand it the initial residual's sums
+        k_pcg1_seed<<<8, TPB, 0, c->stream>>>(part2, g2v, c->slots, S_INIT, S_INIT + 1);
+        PGD_LAUNCH_CHECK(c);
+    }
     auto enqueue = [&](int start, int count) -> int {
         for (int k = 0; k < count; ++k) {
             const int out = S_PAIR + 2 * ((start + k) & 1), rz_old = S_PAIR + 2 * ((start + k + 1) & 1);
             int nparts = 0;
+            if (single_sync) {
+                c->spmv_qq = 1;
+                const int rc = launch_spmv_op(c, m, o, p, q, p, 0, n, true, true, c->flags, &nparts);
+                c->spmv_qq = 0;
+                PGD_TRY(rc);
+                const double *prod = c->partials;
+                if (nparts > 8192) {
+                    const int nb = (nparts + 1023) / 1024;
+                    PGD_TRY(ensure_work(c, 5, (int64_t)nb * 2 > 4096 ? (int64_t)nb * 2 : 4096));
+                    PGD_TRY(k_reduce_stage1_pub(c, c->partials, nparts, 2, c->work[5]));
+                    prod = c->work[5];
+                    nparts = nb;
+                }
+                k_pcg1_scalars<<<1, 1024, 0, c->stream>>>(prod, nparts, part2, g2v, c->slots, c->flags);
+                k_pcg1_update<<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, n, c->slots, part2, c->flags);
+                PGD_LAUNCH_CHECK(c);
+                continue;
+            }
             PGD_TRY(launch_spmv_op(c, m, o, p, q, p, 0, n, true, true, c->flags, &nparts));
             // (pays only where the launches, not the bytes, set the pace: 256^2 rows +22 %, 128^3 +-0, 256^3 -2 %)
             if (scaled && c->pcg_fold_reduce && nparts > 0 && nparts <= 8192 && n <= ((int64_t)1 << 20)) {
@@ -967,7 +1097,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     hipGraphExec_t gexec = nullptr;
     if (maxit >= CHECK_EVERY) {
         // everything a chunk allocates lazily must exist before the capture starts
-        PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS > (n + 63) / 64 ? 4 * (int64_t)MAX_VEC_BLOCKS : (n + 63) / 64));
+        PGD_TRY(ensure_partials(c, std::max<int64_t>(4 * (int64_t)MAX_VEC_BLOCKS, 2 * ((n + 63) / 64) + 64)));
         PGD_TRY(ensure_work(c, 5, 4096));
         const bool prof_saved = c->prof;
         c->prof = false;

@@ -536,6 +536,7 @@ struct DiaArgs {
     int row_begin, row_end; // k_spmv_dia_rows
     int z0, z1, zchunk, tiles_x, tiles_y;   // k_spmv_dia_march
     int unit_diag;          // the operator is D^-1/2 A D^-1/2 of the scaled recurrence: its diagonal is 1 and is not loaded
+    int qq;                 // DOT launches: partial sums in pairs (w . y, y . y) per workgroup (single-sync recurrence)
 };
 
 // row order, any row range: small grids, ranges that are not whole planes, products with w != x
@@ -573,7 +574,10 @@ __global__ __launch_bounds__(64) void k_spmv_dia_rows(DiaArgs A) {
     if (DOT) {
         const double v = (tid < nr) ? acc * A.w[r0 + tid] : 0.0;
         const double sum = wave_sum(v);
-        if (tid == 0) A.partials[b] = sum;
+        if (A.qq) {
+            const double s2 = wave_sum((tid < nr) ? acc * acc : 0.0);
+            if (tid == 0) { A.partials[2 * b] = sum; A.partials[2 * b + 1] = s2; }
+        } else if (tid == 0) A.partials[b] = sum;
     }
 }
 
@@ -638,7 +642,7 @@ __global__ __launch_bounds__(64 * WY) void k_spmv_dia_march(DiaArgs A) {
         for (int q = 0; q < 2; ++q)
             if (tid + q * NT < SLICE) s_x[sl * SLICE + tid + q * NT] = v[q];
     };
-    double dot = 0.0;
+    double dot = 0.0, dot2 = 0.0;
     if (za < zb) {
         double v[2];
         for (int z = za - 1; z <= za + 1; ++z) { fetch(z, v); put(z, v); }
@@ -691,7 +695,7 @@ __global__ __launch_bounds__(64 * WY) void k_spmv_dia_march(DiaArgs A) {
         acc = fma(uv[6], xp[DM_HX], acc);
         acc = fma(uv[7], xp[DM_HX + 1], acc);
         if (STORE && live) A.y[row] = acc;
-        if (DOT && live) dot = fma(acc, x00, dot);          // the PCG product: w is x itself (checked by the launcher)
+        if (DOT && live) { dot = fma(acc, x00, dot); dot2 = fma(acc, acc, dot2); }   // the PCG product: w is x itself (checked by the launcher)
         lds_barrier();                                      // everyone is done with plane z - 1 and with s_lo
         put(z + 2, vn);                                     // ... whose slice receives plane z + 2
 #pragma unroll
@@ -699,14 +703,17 @@ __global__ __launch_bounds__(64 * WY) void k_spmv_dia_march(DiaArgs A) {
         lds_barrier();
     }
     if (DOT) {
-        const double sum = wave_sum(dot);
-        if (lane == 0) s_red[wv] = sum;
-        __syncthreads();
-        if (tid == 0) {
-            double t = 0.0;
+        for (int pass = 0; pass < (A.qq ? 2 : 1); ++pass) {
+            const double sum = wave_sum(pass ? dot2 : dot);
+            __syncthreads();
+            if (lane == 0) s_red[wv] = sum;
+            __syncthreads();
+            if (tid == 0) {
+                double t = 0.0;
 #pragma unroll
-            for (int k = 0; k < WY; k += 4) t += (s_red[k] + s_red[k + 1]) + (s_red[k + 2] + s_red[k + 3]);
-            A.partials[b] = t;
+                for (int k = 0; k < WY; k += 4) t += (s_red[k] + s_red[k + 1]) + (s_red[k + 2] + s_red[k + 3]);
+                A.partials[A.qq ? 2 * b + pass : b] = t;
+            }
         }
     }
 }
@@ -758,7 +765,7 @@ __global__ __launch_bounds__(256) void k_spmv_dia_march2(DiaArgs A) {
         for (int q = 0; q < 3; ++q)
             if (tid + q * NT < SLICE) s_x[sl * SLICE + tid + q * NT] = v[q];
     };
-    double dot = 0.0;
+    double dot = 0.0, dot2 = 0.0;
     if (za < zb) {
         double v[3];
         for (int z = za - 1; z <= za + 1; ++z) { fetch(z, v); put(z, v); }
@@ -836,8 +843,8 @@ __global__ __launch_bounds__(256) void k_spmv_dia_march2(DiaArgs A) {
         acc1 = fma(u1[7], xp[2 * DM_HX + 1], acc1);
         if (STORE && live0) A.y[r0] = acc0;
         if (STORE && live1) A.y[r1] = acc1;
-        if (DOT && live0) dot = fma(acc0, xa, dot);
-        if (DOT && live1) dot = fma(acc1, xb, dot);
+        if (DOT && live0) { dot = fma(acc0, xa, dot); dot2 = fma(acc0, acc0, dot2); }
+        if (DOT && live1) { dot = fma(acc1, xb, dot); dot2 = fma(acc1, acc1, dot2); }
         lds_barrier();
         put(z + 2, vn);
 #pragma unroll
@@ -845,10 +852,13 @@ __global__ __launch_bounds__(256) void k_spmv_dia_march2(DiaArgs A) {
         lds_barrier();
     }
     if (DOT) {
-        const double sum = wave_sum(dot);
-        if (lane == 0) s_red[wv] = sum;
-        __syncthreads();
-        if (tid == 0) A.partials[b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        for (int pass = 0; pass < (A.qq ? 2 : 1); ++pass) {
+            const double sum = wave_sum(pass ? dot2 : dot);
+            __syncthreads();
+            if (lane == 0) s_red[wv] = sum;
+            __syncthreads();
+            if (tid == 0) A.partials[A.qq ? 2 * b + pass : b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        }
     }
 }
 
@@ -1135,7 +1145,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
     const int nblk = (int)((nrows + 63) / 64);
     if (nparts_out) *nparts_out = nblk;
     if (nblk == 0) return PGD_OK;
-    if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + nblk, 4 * MAX_VEC_BLOCKS)));
+    if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + 2 * (int64_t)nblk, 4 * MAX_VEC_BLOCKS)));
     SymArgs A;
     A.uvals = a->uvals; A.x = x; A.w = w; A.y = y; A.partials = c->partials + c->partials_off; A.flags = flags;
     A.tab = m->sym_tab; A.pids = m->pids; A.n = a->uvals_stride; A.row_begin = (int)r0; A.row_end = (int)r1;
@@ -1150,6 +1160,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         const int wy = c->spmv_variant <= 1 ? 8 : 4;        // patch rows (0: 4 waves x two rows per thread; 1: 8 waves; 2: 4 waves, one row)
         D.tiles_x = (D.nx + 63) / 64; D.tiles_y = (D.ny + wy - 1) / wy; D.zchunk = 0;
         D.unit_diag = (a->uvals_scaled && a->uvals_unit) ? 1 : 0;
+        D.qq = (dot && c->spmv_qq) ? 1 : 0;                  // set by the single-sync recurrence around its product launches
         // plane-aligned row range, PCG product (w = x) or plain product, planes large enough: the LDS march
         int chunks = 0;
         if (c->spmv_zchunk > 0 && (!dot || w == x) && r0 % plane == 0 && r1 % plane == 0 &&
@@ -1168,7 +1179,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         if (gg > 0 && gg < ((int64_t)1 << 30)) {
             const int wgs = (int)gg;
             if (nparts_out) *nparts_out = wgs;
-            if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + wgs, 4 * MAX_VEC_BLOCKS)));
+            if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + (D.qq ? 2 : 1) * (int64_t)wgs, 4 * MAX_VEC_BLOCKS)));
             D.partials = c->partials + c->partials_off;
             PGD_TRY(prof_begin(c, dot, store, &timed2));
 #define PGD_MARCH(WY)                                                                                  \
@@ -1285,6 +1296,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_PCG_FOLD_REDUCE && value >= 0 && value <= 1) { c->pcg_fold_reduce = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_SCALED && value >= 0 && value <= 1) { c->pcg_scaled = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK && value >= 0 && value <= 65536) { c->spmv_zchunk = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_PCG_SINGLE_SYNC && value >= 0 && value <= 1) { c->pcg_single_sync = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_UNIT_DIAG && value >= 0 && value <= 1) { c->spmv_unit_diag = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_DEFER_X && value >= 0 && value <= 1) { c->pcg_defer_x = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_FAULT_ITERATION && value >= -1 && value <= (1 << 30)) { c->fault_iteration = (int)value; return PGD_OK; }

@@ -221,6 +221,14 @@ int reduce_partials(Ctx *c, const double *partials, int nparts, int nvals, int s
     return PGD_OK;
 }
 
+// first stage alone (long partial lists in front of a reduction kernel of the caller's own); no-op once the done flag is set
+int k_reduce_stage1_pub(Ctx *c, const double *partials, int nparts, int nvals, double *out) {
+    const int nb = (nparts + 1023) / 1024;
+    k_reduce_stage1<<<nb, TPB, 0, c->stream>>>(partials, nparts, nvals, out, c->flags, 0);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
 // the same final pass into any device array (dest[0..nvals))
 int reduce_partials_to(Ctx *c, const double *partials, int nparts, int nvals, double *dest) {
     if (nparts > 8192) {

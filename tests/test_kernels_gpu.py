@@ -618,6 +618,7 @@ def test_pcg_with_the_x_update_in_the_p_kernel_is_bit_identical(ctx):
     bv = ctx.vec_from(b)
     out = {}
     try:
+        ctx.tune(18, 0)                               # (the single-sync recurrence has its own test below)
         for defer in (1, 0):
             ctx.tune(16, defer)
             for maxit in (10000, 37):                 # to convergence; cut off in the middle of a 16-iteration chunk
@@ -635,6 +636,7 @@ def test_pcg_with_the_x_update_in_the_p_kernel_is_bit_identical(ctx):
                 ctx.atom_free(op)
     finally:
         ctx.tune(16, 1)
+        ctx.tune(18, 1)
     for key in (10000, 37, "again"):
         a, c = out[(1, key)], out[(0, key)]
         assert a[0] == c[0] and a[1] == c[1], key
@@ -643,6 +645,62 @@ def test_pcg_with_the_x_update_in_the_p_kernel_is_bit_identical(ctx):
     ctx.vec_free(bv)
     for a in (ak, am):
         ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
+def test_single_sync_recurrence_walks_the_textbook_iterates(ctx):
+    """One reduction + one vector kernel per iteration (beta from r'.r' = alpha^2 q.q - r.r; every alpha and the stop test
+    from the measured r.r): against the two-reduction recurrence on the same storage and against the oracle's textbook
+    Jacobi-PCG - same iteration counts (+-1: the rounding of beta), same solution, the TRUE residual at the tolerance, a
+    cut-off solve with the same iterate, a converged start, and run-to-run bitwise reproducibility."""
+    from pgdrome_amd import fem
+    npts = 104                                        # 1 124 864 rows > 2^20
+    mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), npts - 1, npts - 1, npts - 1)
+    coords = mesh.coordinates()
+    h = ctx.mesh_upload(coords, mesh.cells())
+    n = coords.shape[0]
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bc = np.where(np.any((coords <= 1e-12) | (coords >= 1 - 1e-12), axis=1))[0].astype(np.int32)
+    rng = np.random.default_rng(11)
+    b = rng.uniform(-1, 1, n)
+    b[bc] = 0.0
+    bv = ctx.vec_from(b)
+    res = {}
+    try:
+        for ss in (1, 0, 1):
+            ctx.tune(18, ss)
+            for maxit in (10000, 23):
+                op = ctx.op_combine(h, [ak, am], [1.0, 3.0], bc)
+                xv = ctx.vec_alloc(n)
+                k0 = ctx.kernel_counts()["dia_march"]
+                it, rel = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, maxit)
+                assert ctx.kernel_counts()["dia_march"] > k0
+                x = ctx.vec_download(xv)
+                if maxit == 10000:
+                    it2, _ = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, maxit)
+                    assert it2 <= 1
+                    # the true residual through an independent kernel (plain CSR product of the unscaled operator)
+                    yv = ctx.vec_alloc(n)
+                    ctx.tune(3, 0)
+                    ctx.spmv(op, ctx.vec_from(x), yv)
+                    ctx.tune(3, 1)
+                    r = b - ctx.vec_download(yv)
+                    assert np.linalg.norm(r) <= 1.05e-10 * np.linalg.norm(b)
+                    ctx.vec_free(yv)
+                res.setdefault((ss, maxit), []).append((it, rel, x))
+                ctx.vec_free(xv)
+                ctx.atom_free(op)
+    finally:
+        ctx.tune(18, 1)
+    a, t = res[(1, 10000)], res[(0, 10000)][0]
+    assert a[0][0] == a[1][0] and a[0][1] == a[1][1] and np.array_equal(a[0][2], a[1][2])      # reproducible run to run
+    assert abs(a[0][0] - t[0]) <= 1 and a[0][1] <= 1e-10 and t[1] <= 1e-10
+    assert np.linalg.norm(a[0][2] - t[2]) <= 1e-9 * np.linalg.norm(t[2])
+    c1, c0 = res[(1, 23)][0], res[(0, 23)][0]
+    assert c1[0] == c0[0] == 23 and np.linalg.norm(c1[2] - c0[2]) <= 1e-11 * np.linalg.norm(c0[2])   # same 23rd iterate
+    ctx.vec_free(bv)
+    for at in (ak, am):
+        ctx.atom_free(at)
     ctx.mesh_free(h)
 
 
