@@ -601,26 +601,25 @@ __global__ __launch_bounds__(1024) void k_pcg1_scalars(const double *__restrict_
     __shared__ double s_w[16];
     if (flags[0]) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    double out[4];
-    for (int v = 0; v < 4; ++v) {
+    // the four sums side by side: waves 4 v .. 4 v + 3 add value v (fixed order: 256 strided lanes, 8 accumulators each)
+    {
+        const int v = wv >> 2, t = threadIdx.x & 255;
         const double *src = v < 2 ? prod : vecp;
         const int n = v < 2 ? nprod : nvec, off = v & 1;
-        double a4[4] = {0, 0, 0, 0};
-        int i = threadIdx.x;
-        for (; i + 3 * 1024 < n; i += 4 * 1024) {
+        double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int i = t;
+        for (; i + 7 * 256 < n; i += 8 * 256) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) a4[u] += src[2 * (int64_t)(i + u * 1024) + off];
+            for (int u = 0; u < 8; ++u) a8[u] += src[2 * (int64_t)(i + u * 256) + off];
         }
-        for (int u = 0; i < n; i += 1024, ++u) a4[u & 3] += src[2 * (int64_t)i + off];
-        double acc = wave_sum((a4[0] + a4[1]) + (a4[2] + a4[3]));
-        __syncthreads();
+        for (int u = 0; i < n; i += 256, ++u) a8[u & 7] += src[2 * (int64_t)i + off];
+        const double acc = wave_sum(((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7])));
         if (lane == 0) s_w[wv] = acc;
-        __syncthreads();
-        double t = 0.0;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) t += s_w[k];
-        out[v] = t;
     }
+    __syncthreads();
+    double out[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) out[v] = (s_w[4 * v] + s_w[4 * v + 1]) + (s_w[4 * v + 2] + s_w[4 * v + 3]);
     if (threadIdx.x != 0) return;
     const double pq = out[0], qq = out[1], rz = out[2], rr = out[3], tol2 = slots[S_TOL2];
     slots[S1_PQ] = pq; slots[S1_QQ] = qq; slots[S1_RZ] = rz; slots[S1_RR] = rr;
