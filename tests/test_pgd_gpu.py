@@ -114,6 +114,49 @@ def test_properties_at_bench_like_size():
     assert np.abs(x0 - x0[::-1, ::-1, ::-1]).max() <= 2e-2 * np.abs(x0).max()
 
 
+def test_host_round_trips_around_a_pcg_solve(hip_backend):
+    """The Galerkin start of a PCG solve (previous iterate + stored modes + the same pass of the previous step) costs ONE
+    library call with one host synchronisation - its k products and all dots happen on the device (pgd_start_gram) - not
+    k products + (k + 1)(k + 4) / 2 host-synchronised dots as in round 1; nothing else in fem._rescale_start talks to the host."""
+    be = hip_backend
+    calls = {"start_gram": 0, "vec_dot": 0, "spmv": 0, "in_rescale": False, "sizes": []}
+    orig = {k: getattr(be, k) for k in ("start_gram", "vec_dot", "spmv")}
+    inner = fem._rescale_start
+
+    def rescale(lay, op, b, x):
+        calls["in_rescale"] = True
+        try:
+            return inner(lay, op, b, x)
+        finally:
+            calls["in_rescale"] = False
+
+    def counting(name):
+        def f(*a, **k):
+            if calls["in_rescale"]:
+                calls[name] += 1
+                if name == "start_gram":
+                    calls["sizes"].append(len(a[1]))
+            return orig[name](*a, **k)
+        return f
+    fem._rescale_start = rescale
+    for k in orig:
+        setattr(be, k, counting(k))
+    try:
+        spec = problems.reaction_diffusion(fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), 40, 40, 40), 17, PGD_nmax=4)
+        p = PGDProblem(**spec)
+        s0, n0 = fem.STATS.get("host_syncs_start", 0), fem.STATS["linear_solves"]
+        p.solve_PGD(_problem="linear")
+    finally:
+        fem._rescale_start = inner
+        for k in orig:
+            setattr(be, k, orig[k])
+    pcg_solves = sum(p.num_fp_it)                      # one spatial PCG solve per pass (the parameter dimension is a band solve)
+    assert calls["start_gram"] == pcg_solves and calls["vec_dot"] == 0 and calls["spmv"] == 0
+    assert fem.STATS["host_syncs_start"] - s0 == pcg_solves
+    assert max(calls["sizes"]) >= 3 and max(calls["sizes"]) <= 9       # the start space grows with the stored modes
+    print("host synchronisations of the start per PCG solve: 1 (start spaces of", sorted(set(calls["sizes"])), "vectors)")
+
+
 SETTINGS = {"linear_solver": "cg", "preconditioner": "jacobi", "relative_tolerance": 1e-10}
 # pass counts of the committed full-size runs (profiles/r01k_configs_full_size_n1.jsonl, profiles/r02*)
 FULL_SIZE = {"cfg2": [3, 2, 2, 2, 2, 2, 2], "cfg3": [3, 3, 3, 3] + [2] * 16, "cfg5_first3": [4, 6, 5]}
