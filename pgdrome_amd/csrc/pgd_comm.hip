@@ -330,7 +330,7 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     // collective, and its outcome is agreed on: a rank that fails here must not leave the others waiting in a halo
     // exchange, and a rank whose operator did not qualify for the symmetric storage must not take another branch
     // (the scaled recurrence has one more halo exchange) than its neighbours.
-    bool sym = false;
+    bool sym = false, ss_all = false;
     auto setup = [&]() -> int {
         if (!m) return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: operator without a mesh");
         if (k.work_n != n) {      // r, u, w, p, s, q, dinv as library vectors (the slot kernels take handles)
@@ -348,17 +348,20 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     const int rc_setup = setup();
     const std::string err_setup = c->err;
     {
-        const double vote[2] = {rc_setup != PGD_OK ? 1.0 : 0.0, (rc_setup == PGD_OK && sym && c->pcg_scaled) ? 0.0 : 1.0};
-        double got[2] = {1.0, 1.0};
-        int rc = pgd_slots_upload(h, vote, B, 2);
-        if (rc == PGD_OK) rc = comm_allreduce(c, B, 2);
-        if (rc == PGD_OK) rc = pgd_slots_download(h, got, B, 2);
+        const bool can_ss = rc_setup == PGD_OK && sym && c->pcg_scaled && c->pcg_single_sync && m && m->sym_nx > 0;
+        const double vote[3] = {rc_setup != PGD_OK ? 1.0 : 0.0, (rc_setup == PGD_OK && sym && c->pcg_scaled) ? 0.0 : 1.0, can_ss ? 0.0 : 1.0};
+        double got[3] = {1.0, 1.0, 1.0};
+        int rc = pgd_slots_upload(h, vote, B, 3);
+        if (rc == PGD_OK) rc = comm_allreduce(c, B, 3);
+        if (rc == PGD_OK) rc = pgd_slots_download(h, got, B, 3);
         if (rc_setup != PGD_OK) { c->err = err_setup; return rc_setup; }
         if (rc != PGD_OK) return rc;
         if (got[0] != 0.0) return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: the setup failed on another rank");
         sym = sym && got[1] == 0.0;                     // scaled only if EVERY rank can
+        ss_all = got[2] == 0.0;                         // ... and the single-sync recurrence only if every rank's slab is a grid
     }
     const bool scaled = sym && c->pcg_scaled;
+    const bool ss = scaled && ss_all;                   // single-sync recurrence: 7 (here 8: the true norm every iteration) vector passes
     const pgd_handle r = k.work[0], u = k.work[1], w = k.work[2], p = k.work[3], s = k.work[4], q = k.work[5], dinv = k.work[6];
     const double zeros[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     PGD_TRY(pgd_slots_upload(h, zeros, B, 9));
@@ -393,10 +396,22 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         const int64_t lo[3] = {own0 + glo, own0, own1 - ghi}, hi[3] = {own1 - ghi, own0 + glo, own1};
         int total = 0;
         for (int part = 0; part < 3; ++part) {
-            if (part == 1) { PGD_TRY(comm_halo_wait(c, lo_g, hi_g, async)); halo_pending = false; }
+            if (part == 1) {
+                PGD_TRY(comm_halo_wait(c, lo_g, hi_g, async));
+                halo_pending = false;
+                if (folded) {       // both boundary planes in one row-order launch where the operator is in diagonal form
+                    int np = 0;
+                    bool both = false;
+                    c->partials_off = (c->spmv_qq ? 2 : 1) * (int64_t)total;      // pairs (w.y, y.y) per workgroup in the single-sync form
+                    const int rc = launch_spmv_dia_rows2(c, m, op, ud, wdst, ud, lo[1], hi[1], lo[2], hi[2], true, c->flags, &np, &both);
+                    c->partials_off = 0;
+                    PGD_TRY(rc);
+                    if (both) { total += np; break; }
+                }
+            }
             if (folded) {
                 int np = 0;
-                c->partials_off = total;
+                c->partials_off = (c->spmv_qq ? 2 : 1) * (int64_t)total;      // pairs (w.y, y.y) per workgroup in the single-sync form
                 const int rc = launch_spmv_op(c, m, op, ud, wdst, ud, lo[part], hi[part], true, true, c->flags, &np);
                 c->partials_off = 0;
                 PGD_TRY(rc);
@@ -421,14 +436,23 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     else PGD_TRY(pgd_spmv(h, oh, xh, q, own0, own1));
     if (scaled) PGD_TRY(cg_init_s(c, b->d, qd, scp, rd, pd, sd, own0, own1, B));
     else PGD_TRY(pgd_cg_init_slot(h, bh, q, dinv, r, u, p, s, own0, own1, B));
-    const pgd_handle mv = scaled ? r : u;                            // the vector the product is applied to
+    const pgd_handle mv = ss ? p : scaled ? r : u;                   // the vector the product is applied to
     double *mvd = get_vec(c, mv)->d;
-    PGD_TRY(product(mv, mvd, wd, false, nullptr));
-    PGD_TRY(comm_allreduce(c, B, 9));
-    PGD_TRY(pgd_cg_scalars_slot(h, B, 1, rtol, atol));
-    if (scaled) {     // the folded form reads "previous alpha, previous r.r" from the slot set of its parity: seed set 0
-        PGD_HIP(c, hipMemcpyAsync(c->slots + B + 9, c->slots + B + 5, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        PGD_HIP(c, hipMemcpyAsync(c->slots + B + 10, c->slots + B + 7, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    const int gvec = grid_for((own1 - own0 + 1) / 2);                // workgroups (= partial-sum pairs) of k_pcg1_update
+    if (ss) {
+        // textbook start p = r; the local (r~.r~, true r.r) of the initial residual become the first "previous update" sums
+        if (own1 > own0) PGD_HIP(c, hipMemcpyAsync(pd + own0, rd + own0, (size_t)(own1 - own0) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        PGD_TRY(pcg1_seed(c, MAX_VEC_BLOCKS, B, B + 1));
+        PGD_TRY(comm_allreduce(c, B, 9));
+        PGD_TRY(pcg1_tol(c, B, rtol, atol));
+    } else {
+        PGD_TRY(product(mv, mvd, wd, false, nullptr));
+        PGD_TRY(comm_allreduce(c, B, 9));
+        PGD_TRY(pgd_cg_scalars_slot(h, B, 1, rtol, atol));
+        if (scaled) {     // the folded form reads "previous alpha, previous r.r" from the slot set of its parity: seed set 0
+            PGD_HIP(c, hipMemcpyAsync(c->slots + B + 9, c->slots + B + 5, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+            PGD_HIP(c, hipMemcpyAsync(c->slots + B + 10, c->slots + B + 7, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        }
     }
     int32_t done = 0, it = 0, status = 0;
     int kk = 0;
@@ -439,6 +463,21 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         if (c->fault_iteration >= 0 && kidx == c->fault_iteration) {      // tests: a rank-local failure in mid-solve
             c->fault_iteration = -1;
             return fail(c, PGD_ERR_HIP, "pcg_solve_sharded: injected fault in iteration %d (PGD_TUNE_FAULT_ITERATION)", kidx);
+        }
+        if (ss) {
+            // product (p.q and q.q partial sums) -> local sums -> ONE all-reduce -> stop test, alpha, beta -> x, r, p update
+            int np = 0, nb = 0;
+            c->spmv_qq = 1;
+            const int rc = product(mv, pd, qd, true, &np);
+            c->spmv_qq = 0;
+            did_halo = true;
+            PGD_TRY(rc);
+            PGD_TRY(pcg1_sums(c, np, gvec, B));
+            did_ar = true;
+            PGD_TRY(comm_allreduce(c, B, 5));
+            PGD_TRY(pcg1_finish_slots(c, B));
+            PGD_TRY(pcg1_update(c, xd, rd, pd, qd, scp, own0, own1, B, &nb));
+            return PGD_OK;
         }
         if (scaled && kidx > 0) {
             // 3 kernels per iteration: vector step (forms alpha / beta itself, counts, tests), product, one reduction
@@ -486,7 +525,7 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         }
     }
     if (rc_loop != PGD_OK) { c->err = err_loop; return rc_loop; }
-    if (scaled && !done && kk > 0) {
+    if (scaled && !ss && !done && kk > 0) {
         // the last enqueued iteration's scalars are still unprocessed in the folded form: count and test them
         PGD_TRY(pgd_cg_scalars_slot(h, B, 0, rtol, atol));
         PGD_TRY(pgd_flags_download(h, &done, &it, &status));

@@ -198,9 +198,17 @@ int cg_update_s(Ctx *c, double *x, double *r, const double *w, double *p, double
 int cg_update_s2(Ctx *c, double *x, double *r, const double *w, double *p, double *s, const double *sc, int64_t lo, int64_t hi,
                  int base, int parity, int *nblocks);
 int reduce_two_slots(Ctx *c, int na, int nb, int base);
+int pcg1_seed(Ctx *c, int npairs, int slot_rz, int slot_rr);          // single-sync recurrence, sharded form (pgd_pcg.hip)
+int pcg1_tol(Ctx *c, int base, double rtol, double atol);
+int pcg1_sums(Ctx *c, int nprod, int nvec, int base);
+int pcg1_finish_slots(Ctx *c, int base);
+int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const double *sc, int64_t lo, int64_t hi, int base,
+                int *nblocks);
 int vec_sqrt(Ctx *c, double *v, int64_t n);
 int vec_div_mul(Ctx *c, double *x, const double *sc, int64_t n, int mul);
 int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *s);   // pgd_spmv.hip: slot values *= s_i s_j
+int launch_spmv_dia_rows2(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0a,
+                          int64_t r1a, int64_t r0b, int64_t r1b, bool dot, const int *flags, int *nparts_out, bool *done);
 int combine_dia(Ctx *c, const Mesh *m, Csr *o, Csr *const *atoms, const double *coefs, int n, const uint8_t *mask);
 int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0,
                    int64_t r1, bool dot, bool store, const int *flags, int *nparts_out);

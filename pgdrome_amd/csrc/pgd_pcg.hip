@@ -594,6 +594,20 @@ __global__ __launch_bounds__(TPB) void k_pcg_px_s(double *__restrict__ x, double
 // S1_ALPHA, S1_BETA.
 enum { S1_RZ = 24, S1_RR = 25, S1_ALPHA = 26, S1_BETA = 27, S1_PQ = 28, S1_QQ = 29 };
 
+__device__ __forceinline__ void pcg1_finish(double *slots, int *flags, double pq, double qq, double rz, double rr, int slot_alpha,
+                                            int slot_beta) {
+    const double tol2 = slots[S_TOL2];
+    if (!(rz == rz) || !(pq == pq)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; return; }
+    if (flags[3]) { if (rr <= tol2) { flags[0] = 1; return; } }
+    else if (rz * slots[S_DMIN] <= 1e4 * tol2) flags[3] = 1;
+    const double alpha = rz / pq;
+    double rnew = alpha * alpha * qq - rz;
+    if (!(rnew > 0.0)) rnew = 0.0;                      // rounding below zero (beta at the eps level): a steepest-descent restart
+    slots[slot_alpha] = alpha;
+    slots[slot_beta] = rnew / rz;
+    flags[1] += 1;
+}
+
 // one workgroup: sums the product's (p.q, q.q) pairs and the previous vector kernel's (r~.r~, true r.r) pairs, runs the stop
 // test on that residual and, if the solve goes on, forms alpha and beta for the update that follows
 __global__ __launch_bounds__(1024) void k_pcg1_scalars(const double *__restrict__ prod, int nprod, const double *__restrict__ vecp,
@@ -621,50 +635,84 @@ __global__ __launch_bounds__(1024) void k_pcg1_scalars(const double *__restrict_
 #pragma unroll
     for (int v = 0; v < 4; ++v) out[v] = (s_w[4 * v] + s_w[4 * v + 1]) + (s_w[4 * v + 2] + s_w[4 * v + 3]);
     if (threadIdx.x != 0) return;
-    const double pq = out[0], qq = out[1], rz = out[2], rr = out[3], tol2 = slots[S_TOL2];
-    slots[S1_PQ] = pq; slots[S1_QQ] = qq; slots[S1_RZ] = rz; slots[S1_RR] = rr;
-    if (!(rz == rz) || !(pq == pq)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; return; }
-    if (flags[3]) { if (rr <= tol2) { flags[0] = 1; return; } }
-    else if (rz * slots[S_DMIN] <= 1e4 * tol2) flags[3] = 1;
-    const double alpha = rz / pq;
-    double rnew = alpha * alpha * qq - rz;
-    if (!(rnew > 0.0)) rnew = 0.0;                      // rounding below zero (beta at the eps level): a steepest-descent restart
-    slots[S1_ALPHA] = alpha;
-    slots[S1_BETA] = rnew / rz;
-    flags[1] += 1;
+    slots[S1_PQ] = out[0]; slots[S1_QQ] = out[1]; slots[S1_RZ] = out[2]; slots[S1_RR] = out[3];
+    pcg1_finish(slots, flags, out[0], out[1], out[2], out[3], S1_ALPHA, S1_BETA);
+}
+
+// the row-sharded solve splits the same step around its all-reduce: local sums -> slots[base .. base + 3] (+ a zero) ...
+__global__ __launch_bounds__(1024) void k_pcg1_sums(const double *__restrict__ prod, int nprod, const double *__restrict__ vecp,
+                                                    int nvec, double *__restrict__ slots, int base, const int *__restrict__ flags) {
+    __shared__ double s_w[16];
+    if (flags[0]) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int v = wv >> 2, t = threadIdx.x & 255;
+    const double *src = v < 2 ? prod : vecp;
+    const int n = v < 2 ? nprod : nvec, off = v & 1;
+    double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int i = t;
+    for (; i + 7 * 256 < n; i += 8 * 256) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a8[u] += src[2 * (int64_t)(i + u * 256) + off];
+    }
+    for (int u = 0; i < n; i += 256, ++u) a8[u & 7] += src[2 * (int64_t)i + off];
+    const double acc = wave_sum(((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7])));
+    if (lane == 0) s_w[wv] = acc;
+    __syncthreads();
+    if (threadIdx.x < 4) slots[base + threadIdx.x] = (s_w[4 * threadIdx.x] + s_w[4 * threadIdx.x + 1]) + (s_w[4 * threadIdx.x + 2] + s_w[4 * threadIdx.x + 3]);
+    if (threadIdx.x == 4) slots[base + 4] = 0.0;
+}
+
+// ... and, after the all-reduce of those slots, the stop test, alpha and beta (into slots[base + 5], [base + 6])
+__global__ void k_pcg1_finish(double *__restrict__ slots, int *__restrict__ flags, int base) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || flags[0]) return;
+    slots[6] = slots[base + 3];                          // the last measured true r.r, for the report
+    pcg1_finish(slots, flags, slots[base], slots[base + 1], slots[base + 2], slots[base + 3], base + 5, base + 6);
+}
+
+// initial residual of the sharded solve: tolerance from the all-reduced b.b, first stop test
+__global__ void k_pcg1_tol(double *__restrict__ slots, int *__restrict__ flags, int base, double rtol, double atol) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double t1 = rtol * rtol * slots[base + 8], t2 = atol * atol, rr = slots[base + 1];
+    slots[S_TOL2] = t1 > t2 ? t1 : t2;
+    slots[6] = rr;
+    flags[3] = 1;                                        // the sharded form measures the true r.r in every iteration
+    if (!(rr == rr)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; }
+    else if (rr <= slots[S_TOL2]) flags[0] = 1;
 }
 
 // x += alpha p; r -= alpha q; p = r + beta p; partial sums (r~.r~, exact phase ? sum r^2 / s^2 : r~.r~) of the new residual
 __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
-                                                     const double *__restrict__ q, const double *__restrict__ s, int64_t n,
-                                                     const double *__restrict__ slots, double *__restrict__ partials,
-                                                     const int *__restrict__ flags) {
+                                                     const double *__restrict__ q, const double *__restrict__ s, int64_t lo,
+                                                     int64_t hi, const double *__restrict__ slots, int slot_alpha, int slot_beta,
+                                                     double *__restrict__ partials, const int *__restrict__ flags) {
     if (flags[0]) return;
     __shared__ double s_red[4];
     typedef double d2 __attribute__((ext_vector_type(2)));
-    const double alpha = slots[S1_ALPHA], beta = slots[S1_BETA];
+    const double alpha = slots[slot_alpha], beta = slots[slot_beta];
     const bool exact = flags[3] != 0;
     double rz = 0.0, rr = 0.0;
-    const int64_t npair = n >> 1;
-    for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < npair; k += (int64_t)gridDim.x * TPB) {
-        const int64_t i = 2 * k;
-        const d2 qi = *reinterpret_cast<const d2 *>(q + i);
-        d2 pi = *reinterpret_cast<d2 *>(p + i), xi = *reinterpret_cast<d2 *>(x + i), ri = *reinterpret_cast<d2 *>(r + i);
-        xi.x = fma(alpha, pi.x, xi.x); xi.y = fma(alpha, pi.y, xi.y);
-        ri.x = fma(-alpha, qi.x, ri.x); ri.y = fma(-alpha, qi.y, ri.y);
-        pi.x = fma(beta, pi.x, ri.x); pi.y = fma(beta, pi.y, ri.y);
-        *reinterpret_cast<d2 *>(x + i) = xi;
-        *reinterpret_cast<d2 *>(r + i) = ri;
-        *reinterpret_cast<d2 *>(p + i) = pi;
-        rz = fma(ri.x, ri.x, rz); rz = fma(ri.y, ri.y, rz);
-        if (exact) {
-            const d2 si = *reinterpret_cast<const d2 *>(s + i);
-            const double tx = ri.x / si.x, ty = ri.y / si.y;
-            rr = fma(tx, tx, rr); rr = fma(ty, ty, rr);
+    if ((lo & 1) == 0) {                                  // 16-byte accesses (row ranges of the sharded solve may start odd)
+        const int64_t npair = (hi - lo) >> 1;
+        for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < npair; k += (int64_t)gridDim.x * TPB) {
+            const int64_t i = lo + 2 * k;
+            const d2 qi = *reinterpret_cast<const d2 *>(q + i);
+            d2 pi = *reinterpret_cast<d2 *>(p + i), xi = *reinterpret_cast<d2 *>(x + i), ri = *reinterpret_cast<d2 *>(r + i);
+            xi.x = fma(alpha, pi.x, xi.x); xi.y = fma(alpha, pi.y, xi.y);
+            ri.x = fma(-alpha, qi.x, ri.x); ri.y = fma(-alpha, qi.y, ri.y);
+            pi.x = fma(beta, pi.x, ri.x); pi.y = fma(beta, pi.y, ri.y);
+            *reinterpret_cast<d2 *>(x + i) = xi;
+            *reinterpret_cast<d2 *>(r + i) = ri;
+            *reinterpret_cast<d2 *>(p + i) = pi;
+            rz = fma(ri.x, ri.x, rz); rz = fma(ri.y, ri.y, rz);
+            if (exact) {
+                const d2 si = *reinterpret_cast<const d2 *>(s + i);
+                const double tx = ri.x / si.x, ty = ri.y / si.y;
+                rr = fma(tx, tx, rr); rr = fma(ty, ty, rr);
+            }
         }
     }
-    if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
-        const int64_t i = n - 1;
+    const int64_t tail0 = (lo & 1) == 0 ? lo + 2 * ((hi - lo) >> 1) : lo;      // what the pair loop left: one row, or all of them
+    for (int64_t i = tail0 + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB) {
         x[i] = fma(alpha, p[i], x[i]);
         const double ri = fma(-alpha, q[i], r[i]);
         r[i] = ri;
@@ -871,6 +919,52 @@ int vec_div_mul(Ctx *c, double *x, const double *sc, int64_t n, int mul) {
     return PGD_OK;
 }
 
+// launchers of the single-sync recurrence for the row-sharded solve (pgd_comm.hip)
+int pcg1_seed(Ctx *c, int npairs, int slot_rz, int slot_rr) {
+    PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS));
+    k_pcg1_seed<<<8, TPB, 0, c->stream>>>(c->work[6], npairs, c->slots, slot_rz, slot_rr);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pcg1_tol(Ctx *c, int base, double rtol, double atol) {
+    k_pcg1_tol<<<1, 64, 0, c->stream>>>(c->slots, c->flags, base, rtol, atol);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pcg1_sums(Ctx *c, int nprod, int nvec, int base) {
+    const double *prod = c->partials;
+    if (nprod > 8192) {
+        const int nb = (nprod + 1023) / 1024;
+        PGD_TRY(ensure_work(c, 5, (int64_t)nb * 2 > 4096 ? (int64_t)nb * 2 : 4096));
+        PGD_TRY(k_reduce_stage1_pub(c, c->partials, nprod, 2, c->work[5]));
+        prod = c->work[5];
+        nprod = nb;
+    }
+    k_pcg1_sums<<<1, 1024, 0, c->stream>>>(prod, nprod, c->work[6], nvec, c->slots, base, c->flags);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pcg1_finish_slots(Ctx *c, int base) {
+    k_pcg1_finish<<<1, 64, 0, c->stream>>>(c->slots, c->flags, base);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const double *sc, int64_t lo, int64_t hi, int base,
+                int *nblocks) {
+    *nblocks = 0;
+    if (hi == lo) return PGD_OK;
+    const int g = grid_for((hi - lo + 1) / 2);
+    PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS));
+    k_pcg1_update<<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags);
+    PGD_LAUNCH_CHECK(c);
+    *nblocks = g;
+    return PGD_OK;
+}
+
 static int pcg_xr(Ctx *c, double *x, double *r, const double *p, const double *q, const double *dinv, double *z,
                   int64_t lo, int64_t hi, int slot_rz, int slot_pq, int slot_out, int check_mode, int slot_tol2) {
     const int g = grid_for(hi - lo);
@@ -1052,7 +1146,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
                     nparts = nb;
                 }
                 k_pcg1_scalars<<<1, 1024, 0, c->stream>>>(prod, nparts, part2, g2v, c->slots, c->flags);
-                k_pcg1_update<<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, n, c->slots, part2, c->flags);
+                k_pcg1_update<<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags);
                 PGD_LAUNCH_CHECK(c);
                 continue;
             }

@@ -534,6 +534,7 @@ struct DiaArgs {
     int64_t n;              // slot stride in doubles
     int nx, ny, nz;         // vertex grid of the (local) mesh
     int row_begin, row_end; // k_spmv_dia_rows
+    int nblk1, row_begin2, row_end2;   // ... with a second row range from workgroup nblk1 on (nblk1 < 0: one range)
     int z0, z1, zchunk, tiles_x, tiles_y;   // k_spmv_dia_march
     int unit_diag;          // the operator is D^-1/2 A D^-1/2 of the scaled recurrence: its diagonal is 1 and is not loaded
     int qq;                 // DOT launches: partial sums in pairs (w . y, y . y) per workgroup (single-sync recurrence)
@@ -545,8 +546,9 @@ __global__ __launch_bounds__(64) void k_spmv_dia_rows(DiaArgs A) {
     if (A.flags && A.flags[0]) return;
     const int tid = threadIdx.x;
     const int b = xcd_remap(blockIdx.x, gridDim.x);
-    const int r0 = A.row_begin + b * 64;
-    const int nr = min(64, A.row_end - r0);
+    const bool second = A.nblk1 >= 0 && b >= A.nblk1;       // the two boundary planes of a sharded rank in one launch
+    const int r0 = second ? A.row_begin2 + (b - A.nblk1) * 64 : A.row_begin + b * 64;
+    const int nr = min(64, (second ? A.row_end2 : A.row_end) - r0);
     const int64_t row = r0 + (tid < nr ? tid : 0);
     const int64_t P = (int64_t)A.nx * A.ny;
     const int z = (int)(row / P);
@@ -1156,6 +1158,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         D.uvals = a->uvals; D.x = x; D.w = w; D.y = y; D.partials = c->partials + c->partials_off; D.flags = flags; D.n = a->uvals_stride;
         D.nx = m->sym_nx; D.ny = m->sym_ny; D.nz = (int)(m->nv / plane);
         D.row_begin = (int)r0; D.row_end = (int)r1;
+        D.nblk1 = -1; D.row_begin2 = D.row_end2 = 0;
         D.z0 = (int)(r0 / plane); D.z1 = (int)(r1 / plane);
         const int wy = c->spmv_variant <= 1 ? 8 : 4;        // patch rows (0: 4 waves x two rows per thread; 1: 8 waves; 2: 4 waves, one row)
         D.tiles_x = (D.nx + 63) / 64; D.tiles_y = (D.ny + wy - 1) / wy; D.zchunk = 0;
@@ -1255,6 +1258,33 @@ __global__ __launch_bounds__(TPB) void k_multidot(MultiDotArgs A) {
             if (threadIdx.x == 0) A.partials[(int64_t)blockIdx.x * (A.nv + 1) + (m == GRAM_MAXV ? A.nv : m)] = sum;
         }
     }
+}
+
+// Two row ranges in ONE row-order launch of the diagonal form (the low and the high boundary plane of a row-sharded
+// rank: two 7 us launches become one).  *done = false when the operator is not held in that form - the caller then
+// launches the ranges one by one.  Partial sums: the first range's workgroups, then the second's.
+int launch_spmv_dia_rows2(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0a,
+                          int64_t r1a, int64_t r0b, int64_t r1b, bool dot, const int *flags, int *nparts_out, bool *done) {
+    *done = false;
+    if (!(c->spmv_sym && m->sym_nx > 0 && a->uvals_valid && a->uvals) || r1a <= r0a || r1b <= r0b) return PGD_OK;
+    if (r0a < 0 || r1a > r0b || r1b > m->nv) return fail(c, PGD_ERR_INVALID, "spmv: bad row ranges");
+    const int n1 = (int)((r1a - r0a + 63) / 64), n2 = (int)((r1b - r0b + 63) / 64);
+    const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
+    DiaArgs D;
+    D.qq = (dot && c->spmv_qq) ? 1 : 0;
+    if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + (D.qq ? 2 : 1) * (int64_t)(n1 + n2), 4 * MAX_VEC_BLOCKS)));
+    D.uvals = a->uvals; D.x = x; D.w = w; D.y = y; D.partials = c->partials + c->partials_off; D.flags = flags; D.n = a->uvals_stride;
+    D.nx = m->sym_nx; D.ny = m->sym_ny; D.nz = (int)(m->nv / plane);
+    D.row_begin = (int)r0a; D.row_end = (int)r1a; D.nblk1 = n1; D.row_begin2 = (int)r0b; D.row_end2 = (int)r1b;
+    D.z0 = D.z1 = D.zchunk = D.tiles_x = D.tiles_y = 0;
+    D.unit_diag = (a->uvals_scaled && a->uvals_unit) ? 1 : 0;
+    if (dot) k_spmv_dia_rows<true, true><<<n1 + n2, 64, 0, c->stream>>>(D);
+    else k_spmv_dia_rows<false, true><<<n1 + n2, 64, 0, c->stream>>>(D);
+    c->kcount[KC_DIA_ROWS] += 1;
+    PGD_LAUNCH_CHECK(c);
+    if (nparts_out) *nparts_out = n1 + n2;
+    *done = true;
+    return PGD_OK;
 }
 
 int launch_spmv_multi(Ctx *c, const Mesh *m, const double *vals, const double *x, const double *const *ys,
