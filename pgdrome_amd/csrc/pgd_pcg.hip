@@ -600,6 +600,7 @@ __device__ __forceinline__ void pcg1_finish(double *slots, int *flags, double pq
     if (!(rz == rz) || !(pq == pq)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; return; }
     if (flags[3]) { if (rr <= tol2) { flags[0] = 1; return; } }
     else if (rz * slots[S_DMIN] <= 1e4 * tol2) flags[3] = 1;
+    if (!(rz > 0.0)) { flags[0] = 1; return; }          // the residual vanished exactly: nothing left to do (and no 0 / 0 below)
     const double alpha = rz / pq;
     double rnew = alpha * alpha * qq - rz;
     if (!(rnew > 0.0)) rnew = 0.0;                      // rounding below zero (beta at the eps level): a steepest-descent restart

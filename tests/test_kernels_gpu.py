@@ -692,6 +692,15 @@ def test_single_sync_recurrence_walks_the_textbook_iterates(ctx):
                 ctx.atom_free(op)
     finally:
         ctx.tune(18, 1)
+    # a residual that vanishes EXACTLY (identity operator: every row a Dirichlet row): one iteration, no 0 / 0 in beta
+    allrows = np.arange(n, dtype=np.int32)
+    op = ctx.op_combine(h, [ak, am], [1.0, 3.0], allrows)
+    xv, bv2 = ctx.vec_alloc(n), ctx.vec_from(np.arange(1, n + 1, dtype=np.float64))
+    it, rel = ctx.pcg_solve(op, bv2, xv, 1e-10, 0.0, 100)
+    assert it == 1 and rel == 0.0 and np.array_equal(ctx.vec_download(xv), np.arange(1, n + 1, dtype=np.float64))
+    ctx.vec_free(xv)
+    ctx.vec_free(bv2)
+    ctx.atom_free(op)
     a, t = res[(1, 10000)], res[(0, 10000)][0]
     assert a[0][0] == a[1][0] and a[0][1] == a[1][1] and np.array_equal(a[0][2], a[1][2])      # reproducible run to run
     assert abs(a[0][0] - t[0]) <= 1 and a[0][1] <= 1e-10 and t[1] <= 1e-10
