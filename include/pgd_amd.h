@@ -253,7 +253,7 @@ int pgd_pcg_solve_sharded(pgd_handle ctx, pgd_handle A, pgd_handle b, pgd_handle
 
 /* Gram data of the Galerkin start of a PCG solve (the warm start x0 = sum_j c_j v_j with G c = g; this library's
  * addition in front of the solve that replaces solver.py:636,716): out[i*k + j] = v_i . (A v_j) over rows
- * [r0, r1), out[k*k + j] = v_j . b, k <= 9.  k products from the operator's fastest storage form, every dot on
+ * [r0, r1), out[k*k + j] = v_j . b, k <= 17.  k products from the operator's fastest storage form, every dot on
  * the device, ONE host synchronisation; a sharded caller all-reduces `out` once.                        */
 int pgd_start_gram(pgd_handle ctx, pgd_handle A, const pgd_handle *vecs, int k, pgd_handle b, int64_t r0,
                    int64_t r1, double *out);

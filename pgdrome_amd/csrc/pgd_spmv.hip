@@ -1229,7 +1229,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
 
 // Gram matrix of the Galerkin start of a PCG solve (fem._rescale_start): column j needs w = A v_j, then the dots
 // v_i . w for i <= j and v_j . b - one pass over w and the v_i, partial sums per workgroup, fixed order.
-constexpr int GRAM_MAXV = 9;
+constexpr int GRAM_MAXV = 17;
 struct MultiDotArgs {
     const double *w, *b;
     const double *v[GRAM_MAXV];

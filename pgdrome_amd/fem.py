@@ -31,6 +31,7 @@ from __future__ import annotations
 import logging
 import math
 import numbers
+import os
 import time
 import weakref
 
@@ -2535,7 +2536,7 @@ class _Params(dict):
 
 SMALL_DIRECT_N = 20000   # systems up to this size on 1-D meshes take the banded direct path
 WARM_START_RESCALE = True  # scale the PCG start vector to its energy-optimal length (see _rescale_start)
-START_SPACE_MAX = 8        # stored modes that may join the Galerkin start of a solve (most recent ones)
+START_SPACE_MAX = int(os.environ.get("PGD_START_SPACE_MAX", "8"))   # stored modes that may join the Galerkin start of a solve (most recent ones; <= 8)
 
 
 def _rescale_start(lay, op, b, x):

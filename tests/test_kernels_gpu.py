@@ -567,7 +567,7 @@ def test_products_agree_at_bench_size(ctx, npts):
 @pytest.mark.parametrize("name", ["rect17x9", "box20"])
 def test_start_gram_matches_oracle(ctx, name):
     """pgd_start_gram (Galerkin start of a PCG solve): G[i, j] = v_i . (A v_j), g[j] = v_j . b, full and partial row
-    ranges, 1 .. 9 vectors, products from the symmetric storage (diagonal form on the box grid)."""
+    ranges, 1 .. 17 vectors, products from the symmetric storage (diagonal form on the box grid)."""
     coords, cells = MESHES[name]()
     h = ctx.mesh_upload(coords, cells)
     n = coords.shape[0]
@@ -577,10 +577,10 @@ def test_start_gram_matches_oracle(ctx, name):
     op = ctx.op_combine(h, [ak, am], [1.0, 2.0], bc)
     A, _ = F.apply_dirichlet((K + 2.0 * M).tocsr(), np.zeros(n), bc)
     rng = np.random.default_rng(77)
-    V = rng.uniform(-1, 1, (9, n))
+    V = rng.uniform(-1, 1, (17, n))
     b = rng.uniform(-1, 1, n)
     vs, bv = [ctx.vec_from(v) for v in V], ctx.vec_from(b)
-    for k, (r0, r1) in ((1, (0, n)), (4, (0, n)), (9, (0, n)), (3, (n // 4, 3 * n // 4))):
+    for k, (r0, r1) in ((1, (0, n)), (4, (0, n)), (9, (0, n)), (17, (0, n)), (3, (n // 4, 3 * n // 4))):
         G, g = ctx.start_gram(op, vs[:k], bv, r0, r1)
         W = (A @ V[:k].T)[r0:r1]                                   # columns A v_j on the row range
         G_ref = V[:k, r0:r1] @ W
@@ -590,7 +590,7 @@ def test_start_gram_matches_oracle(ctx, name):
         assert np.abs(g - V[:k, r0:r1] @ b[r0:r1]).max() <= 1e-13 * n
     from pgdrome_amd._lib import PgdError
     with pytest.raises(PgdError):
-        ctx.start_gram(op, vs + [bv], bv)                          # more than 9 vectors
+        ctx.start_gram(op, vs + [bv], bv)                          # more than 17 vectors
     for v in vs + [bv]:
         ctx.vec_free(v)
     for a in (op, ak, am):
