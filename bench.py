@@ -224,6 +224,9 @@ def main():
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                      "launches": prof["launches"], "avg_launch_us": 1e6 * avg,
                      "bytes_per_launch": own, "bytes_per_row": own / max(rows_local, 1),
+                     # for orientation: the same rate against the chip's measured streaming ceiling (float4 copy 6.29 TB/s,
+                     # MI355X_MICROARCH.md) instead of the 8 TB/s specification that `peak` / `frac` use
+                     "measured_copy_ceiling_GBps": 6290.0, "frac_of_measured_copy_ceiling": achieved / 6290.0,
                      # SURVEY 8d's CSR formula priced on the same launch time: NOT a physical rate for this kernel (it does
                      # not stream the CSR arrays) - the CSR kernels' own measurement is in csr_product below
                      "csr_formula_bytes_per_launch": alg, "csr_formula_equivalent_GBps": alg / avg / 1e9 if avg > 0 else 0.0},
