@@ -87,11 +87,14 @@ int pgd_mesh_info(pgd_handle ctx, pgd_handle mesh, int64_t *nv, int64_t *nc, int
 int pgd_mesh_pattern_download(pgd_handle ctx, pgd_handle mesh, int32_t *row_ptr, int32_t *cols);
 /* number of distinct relative column patterns held in the mesh's column dictionary
  * (0: the pattern is too irregular, SpMV streams the column ids)                   */
+int pgd_mesh_dict_count(pgd_handle ctx, pgd_handle mesh, int32_t *count);
 /* Which form of the SPD product the mesh's patterns allow: slots = 0 (CSR kernels only), 4 or 8 upper slots
  * per row of the symmetric half storage (k_spmv_sym); nx, ny > 0 when the rows also form a full structured
  * vertex grid (row = x + nx y + nx ny z): k_spmv_sym_grid3 marches along z with its x planes in LDS.          */
 int pgd_mesh_sym_info(pgd_handle ctx, pgd_handle mesh, int32_t *slots, int32_t *nx, int32_t *ny);
-int pgd_mesh_dict_count(pgd_handle ctx, pgd_handle mesh, int32_t *count);
+/* *is_lattice = 1 when the mesh is a 3-D structured vertex grid whose coordinates are origin + index * steps[axis] to within
+ * 8 ulp (see PGD_TUNE_ASM_LATTICE); steps: 3 doubles (zeros otherwise).                                       */
+int pgd_mesh_lattice(pgd_handle ctx, pgd_handle mesh, int32_t *is_lattice, double *steps);
 int pgd_mesh_free(pgd_handle ctx, pgd_handle mesh);
 
 /* ----------------------------------------------------------------- vectors --- */
@@ -182,6 +185,12 @@ int pgd_op_diag_inv(pgd_handle ctx, pgd_handle op, pgd_handle dinv);
  * (the library solves do this themselves): *used = 1 if the mesh's patterns qualify and
  * a_ij == a_ji held to rounding, else 0 and the CSR kernels stay in use.          */
 int pgd_op_symmetrize(pgd_handle ctx, pgd_handle op, int *used);
+/* Look for the lossless row-class dictionary of the operator's diagonal form (structured vertex grids, after
+ * pgd_op_symmetrize / pgd_op_combine; PGD_TUNE_SPMV_ROW_CLASSES): *classes = number of distinct 8-tuples of slot values
+ * (1..255) when every row was verified bit by bit against its class - the z-march of later products then reads one code
+ * byte per row (k_spmv_diac_march2) - or 0: none (more than 255 classes, not a grid, too few planes).  The library solves
+ * call this themselves for the scaled operator; any later change of the operator's values drops the dictionary.   */
+int pgd_op_classify(pgd_handle ctx, pgd_handle op, int *classes);
 /* y = A x on [r0,r1), slot <- sum w_i y_i (local part)                          */
 int pgd_spmv_dot_slot(pgd_handle ctx, pgd_handle A, pgd_handle x, pgd_handle y, pgd_handle w,
                       int64_t r0, int64_t r1, int slot);
@@ -269,6 +278,16 @@ enum {
     PGD_TUNE_PCG_SCALED = 10,   /* 1 (default): pgd_pcg_solve runs CG on D^-1/2 A D^-1/2 (the same iterates as Jacobi-PCG,
                                    two vector passes per iteration fewer) when the symmetric storage applies; 0: unscaled */
     PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */
+    PGD_TUNE_SPMV_ZCHUNK_CODED = 21, /* k_spmv_diac_march2: most planes per workgroup march (default 24; whole threes, fewer while that keeps
+                                ~2 launches of workgroups per slot); PGD_TUNE_SPMV_ZCHUNK_FORCE overrides it too */
+    PGD_TUNE_ASM_LATTICE = 20, /* 1 (default): on a 3-D structured vertex grid whose coordinates are origin + index * step per axis (to 8 ulp,
+                                checked at pgd_mesh_upload) the P1 assembly takes every edge component as a whole number of steps instead of
+                                the difference of two rounded coordinates: congruent cells get identical local matrices, the rows of a uniform
+                                grid repeat bit for bit (relative change of the entries ~ 1e-16); 0: coordinate differences as they are */
+    PGD_TUNE_SPMV_ROW_CLASSES = 19, /* 1 (default): after scaling, pgd_pcg_solve(_sharded) looks for a lossless ROW-CLASS dictionary of the
+                                operator's diagonal form (uniform grids repeat a few 8-tuples of slot values; every row verified bit by
+                                bit against its class, at most 255 classes, otherwise none) and the z-march then streams one code byte
+                                per row instead of 56 B of slot values (k_spmv_diac_march2): same values, same order, same bits */
     PGD_TUNE_PCG_SINGLE_SYNC = 18, /* 1 (default): scaled recurrence on structured grids above 2^20 rows with ONE reduction and ONE
                                       vector kernel per iteration: the product also leaves q.q, beta comes from
                                       r'.r' = alpha^2 q.q - r.r (exact in exact arithmetic; every alpha and the stop test use the
@@ -307,7 +326,7 @@ int pgd_prof_read(pgd_handle ctx, int64_t *launches, double *seconds, double *al
  * physical numerator of roofline.frac when the kernel does not stream the CSR arrays.              */
 int pgd_prof_read_own(pgd_handle ctx, double *own_bytes);
 /* Launch counts per product kernel family since the context was created: [0] k_spmv_csr, [1] k_spmv_csr_dict*,
- * [2] k_spmv_sym (row order), [3] k_spmv_dia_rows, [4] k_spmv_dia_march, [5] k_spmv_multi; tests use them to
+ * [2] k_spmv_sym (row order), [3] k_spmv_dia_rows, [4] k_spmv_dia_march*, [5] k_spmv_multi, [6] k_spmv_diac_march2; tests use them to
  * prove which kernel a call reached, bench.py for its per-kernel breakdown.                          */
 int pgd_kernel_counts(pgd_handle ctx, int64_t *out, int n);
 /* One HIP-event stopwatch on the context's stream (bench.py's micro-sections: N launches between start

@@ -42,6 +42,7 @@ SIGNATURES = {
     "pgd_mesh_pattern_download": (C.c_int, [H, H, PI32, PI32]),
     "pgd_mesh_sym_info": (C.c_int, [H, H, PI32, PI32, PI32]),
     "pgd_mesh_dict_count": (C.c_int, [H, H, PI32]),
+    "pgd_mesh_lattice": (C.c_int, [H, H, PI32, PD]),
     "pgd_mesh_free": (C.c_int, [H, H]),
     "pgd_vec_alloc": (C.c_int, [H, I64, PH]),
     "pgd_vec_free": (C.c_int, [H, H]),
@@ -92,6 +93,7 @@ SIGNATURES = {
     "pgd_comm_allreduce_slots": (C.c_int, [H, C.c_int, C.c_int]),
     "pgd_pcg_solve_sharded": (C.c_int, [H, H, H, H, I64, I64, I64, I64, F64, F64, C.c_int, C.POINTER(C.c_int), PD]),
     "pgd_op_symmetrize": (C.c_int, [H, H, C.POINTER(C.c_int)]),
+    "pgd_op_classify": (C.c_int, [H, H, C.POINTER(C.c_int)]),
     "pgd_tune": (C.c_int, [H, C.c_int, I64]),
     "pgd_prof_enable": (C.c_int, [H, C.c_int]),
     "pgd_prof_read": (C.c_int, [H, PI64, PD, PD]),
@@ -236,6 +238,12 @@ class Context:
         w, nx, ny = I32(), I32(), I32()
         self._ck(self.lib.pgd_mesh_sym_info(self.h, mesh, C.byref(w), C.byref(nx), C.byref(ny)))
         return {"slots": w.value, "nx": nx.value, "ny": ny.value}
+
+    def mesh_lattice(self, mesh):
+        """(is_lattice, steps[3]) of pgd_mesh_lattice."""
+        flag, steps = I32(), np.zeros(3)
+        self._ck(self.lib.pgd_mesh_lattice(self.h, mesh, C.byref(flag), dptr(steps)))
+        return bool(flag.value), steps
 
     def mesh_dict_count(self, mesh):
         n = I32()
@@ -500,6 +508,12 @@ class Context:
         self._ck(self.lib.pgd_op_symmetrize(self.h, op, C.byref(used)))
         return bool(used.value)
 
+    def op_classify(self, op):
+        """Row-class dictionary of the operator's diagonal form: number of classes, 0 = none (pgd_op_classify)."""
+        n = C.c_int(0)
+        self._ck(self.lib.pgd_op_classify(self.h, op, C.byref(n)))
+        return int(n.value)
+
     def tune(self, knob, value):
         self._ck(self.lib.pgd_tune(self.h, int(knob), int(value)))
 
@@ -514,7 +528,7 @@ class Context:
         self._ck(self.lib.pgd_prof_read_own(self.h, C.byref(own)))
         return dict(launches=n.value, seconds=s.value, bytes=b.value, own_bytes=own.value)
 
-    KERNEL_FAMILIES = ("csr", "csr_dict", "sym_rows", "dia_rows", "dia_march", "multi")
+    KERNEL_FAMILIES = ("csr", "csr_dict", "sym_rows", "dia_rows", "dia_march", "multi", "diac_march")
 
     def kernel_counts(self):
         out = (C.c_int64 * 8)()

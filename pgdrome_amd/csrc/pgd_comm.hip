@@ -428,6 +428,7 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         PGD_TRY(vec_sqrt(c, scp, n));
         PGD_TRY(comm_halo(c, dinv, scp, own0, own1, lo_g, hi_g));
         PGD_TRY(sym_scale(c, m, op, scp));
+        PGD_TRY(dia_classify(c, m, op));                             // rank-local choice of kernel, same bits either way
         PGD_TRY(vec_div_mul(c, xd, scp, n, 0));                      // x~ = x / sc on owned and ghost rows alike
         guard.active = true;
     }

@@ -181,6 +181,7 @@ int pgd_ctx_destroy(pgd_handle h) {
     c->pool.clear();
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->timer_ev) if (e) (void)hipEventDestroy(e);
+    if (c->cls_scratch) (void)hipFree(c->cls_scratch);
     for (void *p : {(void *)c->slots, (void *)c->flags, (void *)c->partials, (void *)c->mask,
                     (void *)c->ibuf})
         if (p) (void)hipFree(p);

@@ -67,6 +67,11 @@ struct Mesh : Obj {
     // 0: not one): the slot arrays are then in DIAGONAL form - slot dx + 2 dy + 4 dz of row i = a(i, i + dx + nx dy + nx ny dz)
     // - and the products are k_spmv_dia_march / k_spmv_dia_rows (pgd_spmv.hip)
     int sym_nx = 0, sym_ny = 0;
+    // the vertices sit on a uniform lattice origin + index * lat_h (checked at upload, pgd_mesh.hip): the P1 assembly takes
+    // edge vectors as whole lattice steps, so congruent cells get identical local matrices
+    bool lattice = false;
+    double lat_h[3] = {0.0, 0.0, 0.0};
+    mutable int cls_misses = 0;  // consecutive operators on this mesh without a row-class dictionary (dia_classify)
     uint16_t *pids = nullptr;    // nv
     int *dict_off = nullptr;     // dict_count x DICT_DLEN relative offsets
     int dict_count = 0;          // 0: dictionary not available (irregular pattern) -> plain CSR kernel
@@ -90,8 +95,15 @@ struct Csr : Obj {
     bool uvals_scaled = false;  // the slot arrays hold D^-1/2 A D^-1/2 (inside pgd_pcg_solve only)
     bool uvals_unit = false;    // ... in diagonal form, whose slot 0 is exactly 1 and is not loaded by the products
     int64_t uvals_stride = 0;  // doubles between two slot arrays (rows + padding)
-    size_t vals_bytes = 0, dinv_bytes = 0, uvals_bytes = 0;
+    // row-class dictionary of the CURRENT slot values in diagonal form (dia_classify, pgd_spmv.hip): a code per row and
+    // the classes' slot tuples; cls_count = 0: none (every writer of the slot arrays resets it)
+    uint8_t *cls = nullptr;
+    int *cls_same = nullptr;       // per plane: same codes, row by row, as the plane below
+    double *cls_table = nullptr;   // owns the allocation: table, then the codes
+    int cls_count = 0;
+    size_t vals_bytes = 0, dinv_bytes = 0, uvals_bytes = 0, cls_bytes = 0;
     ~Csr() override {
+        if (cls_table) dev_release(ctx, cls_table, cls_bytes);
         if (vals) dev_release(ctx, vals, vals_bytes);
         if (dinv) dev_release(ctx, dinv, dinv_bytes);
         if (uvals) dev_release(ctx, uvals, uvals_bytes);
@@ -149,6 +161,10 @@ struct Ctx {
     int64_t spmv_grid_min_plane_bytes = 0;   // structured grids whose planes of values are at least this large take k_spmv_sym_grid3
     int spmv_zchunk_force = 0;    // > 0: exactly this many planes per march whatever the grid size (tests)
     int fault_iteration = -1;     // tests: pgd_pcg_solve_sharded fails on this rank in that iteration (once)
+    int asm_lattice = 1;          // lattice meshes: edge vectors as whole lattice steps in the assembly (PGD_TUNE_ASM_LATTICE)
+    int spmv_zchunk_coded = 24;   // most planes per march of k_spmv_diac_march2 (PGD_TUNE_SPMV_ZCHUNK_CODED)
+    int spmv_classes = 1;         // row-class dictionary of the scaled diagonal form (k_spmv_diac_march2) where the operator has one
+    void *cls_scratch = nullptr;  // hash slots of dia_classify
     int spmv_variant = 0;         // z-march: 0 = k_spmv_dia_march2 (64 x 8 patch, two rows per thread), 1 = 64 x 8 / 512 threads, 2 = 64 x 4 / 256 threads
     int spmv_zchunk = 8;          // k_spmv_dia_march: most planes a workgroup marches through (0: never use that kernel)
     int pcg_fold_reduce = 1;      // scaled recurrence: final reduction passes folded into the vector kernels (3 launches / iteration)
@@ -172,7 +188,7 @@ struct Ctx {
     hipEvent_t timer_ev[2] = {nullptr, nullptr};     // pgd_timer_start / pgd_timer_stop
 };
 
-enum { KC_CSR = 0, KC_CSR_DICT = 1, KC_SYM_ROWS = 2, KC_DIA_ROWS = 3, KC_DIA_MARCH = 4, KC_MULTI = 5 };
+enum { KC_CSR = 0, KC_CSR_DICT = 1, KC_SYM_ROWS = 2, KC_DIA_ROWS = 3, KC_DIA_MARCH = 4, KC_MULTI = 5, KC_DIAC_MARCH = 6 };
 
 // ---- helpers implemented in pgd_ctx.hip
 Ctx *get_ctx(pgd_handle h);
@@ -206,6 +222,7 @@ int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const 
                 int *nblocks);
 int vec_sqrt(Ctx *c, double *v, int64_t n);
 int vec_div_mul(Ctx *c, double *x, const double *sc, int64_t n, int mul);
+int dia_classify(Ctx *c, const Mesh *m, Csr *a);                // pgd_spmv.hip: row-class dictionary of the current slot values
 int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *s);   // pgd_spmv.hip: slot values *= s_i s_j
 int launch_spmv_dia_rows2(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0a,
                           int64_t r1a, int64_t r0b, int64_t r1b, bool dot, const int *flags, int *nparts_out, bool *done);

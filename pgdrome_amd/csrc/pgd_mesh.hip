@@ -9,6 +9,8 @@
 // scatter into CSR of the north star, turned into a gather.
 #include "pgd_internal.h"
 
+#include <cstring>
+
 namespace pgd {
 
 constexpr int MAX_ROW = 64;         // max row length for int4 cell records (P1 simplices, P2 intervals)
@@ -127,6 +129,56 @@ __global__ __launch_bounds__(NT) void k_pattern(const void *__restrict__ cells, 
     }
 }
 
+// -------------------------------------------------------------------- uniform lattices
+// A structured vertex grid (Mesh::sym_nx > 0: row = x + nx y + nx ny z) whose coordinates are origin + index * step per
+// axis to within the rounding of that formula: the assembly then takes edge vectors as whole steps (p1_geometry).
+__global__ __launch_bounds__(TPB) void k_lattice_verify(const double *__restrict__ cx, const double *__restrict__ cy,
+                                                        const double *__restrict__ cz, int64_t nv, int nx, int ny, int nz,
+                                                        double *__restrict__ h_out, int *__restrict__ flag) {
+    const int64_t v = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (v >= nv) return;
+    const int64_t P = (int64_t)nx * ny;
+    const int iz = (int)(v / P), rem = (int)(v - (int64_t)iz * P), iy = rem / nx, ix = rem - iy * nx;
+    const double *cc[3] = {cx, cy, cz};
+    const int idx[3] = {ix, iy, iz}, cnt[3] = {nx, ny, nz};
+    bool ok = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double o = cc[a][0], f = cc[a][nv - 1];
+        const double h = (f - o) / (double)(cnt[a] - 1);
+        const double scale = fmax(fmax(fabs(o), fabs(f)), fabs(f - o));
+        if (!(fabs(h) > 0.0) || !(fabs(cc[a][v] - fma((double)idx[a], h, o)) <= 8.0 * 2.220446049250313e-16 * scale)) ok = false;
+        if (v == 0) h_out[a] = h;
+    }
+    if (!ok) flag[0] = 1;
+}
+
+static int detect_lattice(Ctx *c, Mesh *m) {
+    m->lattice = false;
+    if (m->sym_nx <= 0 || m->gdim != 3 || m->ncomp != 1 || !m->coords || m->cellsN) return PGD_OK;
+    const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
+    const int nz = (int)(m->nv / plane);
+    if (m->sym_nx < 2 || m->sym_ny < 2 || nz < 2) return PGD_OK;
+    void *p;
+    PGD_TRY(dev_alloc(c, &p, 4 * sizeof(double)));
+    double *buf = (double *)p;                               // h[3], then the flag
+    PGD_HIP(c, hipMemsetAsync(buf, 0, 4 * sizeof(double), c->stream));
+    k_lattice_verify<<<(int)((m->nv + TPB - 1) / TPB), TPB, 0, c->stream>>>(m->coords, m->coords + m->nv, m->coords + 2 * m->nv, m->nv,
+                                                                        m->sym_nx, m->sym_ny, nz, buf, (int *)(buf + 3));
+    double host[4] = {0, 0, 0, 0};
+    PGD_HIP(c, hipMemcpyAsync(host, buf, sizeof host, hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(buf);
+    PGD_LAUNCH_CHECK(c);
+    int bad;
+    memcpy(&bad, &host[3], sizeof bad);
+    if (bad == 0) {
+        m->lattice = true;
+        for (int k = 0; k < 3; ++k) m->lat_h[k] = host[k];
+    }
+    return PGD_OK;
+}
+
 // -------------------------------------------------------------------- assembly
 struct AsmArgs {
     const double *cx, *cy, *cz;   // SoA coordinates
@@ -136,6 +188,8 @@ struct AsmArgs {
     double *vals;
     int64_t nv;
     int kind, da, db;
+    int lattice;                  // Mesh::lattice: edge vectors are whole lattice steps
+    double lat_h[3], lat_inv[3];
 };
 
 template <int D>
@@ -157,9 +211,18 @@ __device__ __forceinline__ void p1_geometry(const AsmArgs &A, const int *u, doub
         g[0][1] = -(g[1][1] + g[2][1]);
     } else {
         const double x0 = A.cx[u[0]], y0 = A.cy[u[0]], z0 = A.cz[u[0]];
-        const double ax = A.cx[u[1]] - x0, ay = A.cy[u[1]] - y0, az = A.cz[u[1]] - z0;
-        const double bx = A.cx[u[2]] - x0, by = A.cy[u[2]] - y0, bz = A.cz[u[2]] - z0;
-        const double cx = A.cx[u[3]] - x0, cy = A.cy[u[3]] - y0, cz = A.cz[u[3]] - z0;
+        double ax = A.cx[u[1]] - x0, ay = A.cy[u[1]] - y0, az = A.cz[u[1]] - z0;
+        double bx = A.cx[u[2]] - x0, by = A.cy[u[2]] - y0, bz = A.cz[u[2]] - z0;
+        double cx = A.cx[u[3]] - x0, cy = A.cy[u[3]] - y0, cz = A.cz[u[3]] - z0;
+        if (A.lattice) {
+            // vertices on a uniform lattice (to the rounding of their coordinates, checked at upload): every edge component
+            // is a whole number of steps - taken as exactly that, so congruent cells get IDENTICAL local matrices and the
+            // assembled rows of a uniform grid repeat bit for bit (what the row-class dictionary of the products lives on).
+            // The coordinate differences carry the rounding of i * h; this removes it (relative change ~ 1e-16).
+            ax = rint(ax * A.lat_inv[0]) * A.lat_h[0]; ay = rint(ay * A.lat_inv[1]) * A.lat_h[1]; az = rint(az * A.lat_inv[2]) * A.lat_h[2];
+            bx = rint(bx * A.lat_inv[0]) * A.lat_h[0]; by = rint(by * A.lat_inv[1]) * A.lat_h[1]; bz = rint(bz * A.lat_inv[2]) * A.lat_h[2];
+            cx = rint(cx * A.lat_inv[0]) * A.lat_h[0]; cy = rint(cy * A.lat_inv[1]) * A.lat_h[1]; cz = rint(cz * A.lat_inv[2]) * A.lat_h[2];
+        }
         // cross products: b x c, c x a, a x b
         const double n1x = by * cz - bz * cy, n1y = bz * cx - bx * cz, n1z = bx * cy - by * cx;
         const double n2x = cy * az - cz * ay, n2y = cz * ax - cx * az, n2z = cx * ay - cy * ax;
@@ -668,7 +731,17 @@ int pgd_mesh_upload(pgd_handle h, const double *coords, int64_t nv, int gdim, co
     PGD_TRY(build_topology(c, m.get()));
     PGD_TRY(build_dictionary(c, m.get()));
     PGD_TRY(build_sym_tables(c, m.get()));
+    PGD_TRY(detect_lattice(c, m.get()));
     *out = put_obj(c, m.release());
+    return PGD_OK;
+}
+
+int pgd_mesh_lattice(pgd_handle h, pgd_handle mh, int32_t *is_lattice, double *steps) {
+    PGD_CTX(c, h);
+    Mesh *m = get_mesh(c, mh);
+    if (!m) return fail(c, PGD_ERR_INVALID, "mesh_lattice: invalid handle");
+    if (is_lattice) *is_lattice = m->lattice ? 1 : 0;
+    if (steps) for (int k = 0; k < 3; ++k) steps[k] = m->lattice ? m->lat_h[k] : 0.0;
     return PGD_OK;
 }
 
@@ -752,6 +825,8 @@ int pgd_atom_assemble(pgd_handle h, pgd_handle mh, int kind, int da, int db, pgd
     A.cx = m->coords; A.cy = m->coords + m->nv; A.cz = m->coords + 2 * m->nv;
     A.cells = m->cells; A.v2c_ptr = m->v2c_ptr; A.v2c = m->v2c; A.row_ptr = m->row_ptr; A.cols = m->cols;
     A.w = w; A.vals = a->vals; A.nv = m->nv; A.kind = kind; A.da = da; A.db = db;
+    A.lattice = (m->lattice && c->asm_lattice) ? 1 : 0;
+    for (int k = 0; k < 3; ++k) { A.lat_h[k] = m->lat_h[k]; A.lat_inv[k] = m->lattice ? 1.0 / m->lat_h[k] : 0.0; }
     const int gb = (int)((m->nv + TPB - 1) / TPB);
     if (m->cellsN && m->gdim == 2) k_assemble_p2_simplex<2><<<(int)((m->nv + 63) / 64), 64, 0, c->stream>>>(A, m->cellsN);
     else if (m->cellsN) k_assemble_p2_simplex<3><<<(int)((m->nv + 63) / 64), 64, 0, c->stream>>>(A, m->cellsN);

@@ -1103,6 +1103,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         PGD_LAUNCH_CHECK(c);
         guard.active = true;            // x is scaled from here on
         PGD_TRY(sym_scale(c, m, o, sc));
+        PGD_TRY(dia_classify(c, m, o));         // uniform grids: a code byte per row instead of its slot values
         PGD_TRY(launch_spmv_op(c, m, o, x->d, q, nullptr, 0, n, false, true, nullptr, nullptr));
         const int g = grid_for(n);
         PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS));

@@ -864,6 +864,356 @@ __global__ __launch_bounds__(256) void k_spmv_dia_march2(DiaArgs A) {
     }
 }
 
+// ------------------------------------------------------------------ diagonal form with a row-class dictionary
+// On a uniform grid with piecewise-constant coefficients the rows of the (scaled) operator repeat a few 8-tuples of slot
+// values: every interior row carries the same one, the rows next to a face, an edge, a corner or a Dirichlet row a few dozen
+// others.  dia_classify() (below) finds them per solve, LOSSLESSLY - the class table holds the slot values bit by bit and
+// every row is compared with its class's tuple before the code is trusted - and the product then streams ONE BYTE per row
+// instead of 56: 17 B per row (code + x + y).  The table lives in LDS; a row of it is [s1 s5 | s3 s7 | s2 s6 | s4 s0], so the
+// pairs a neighbour's row contributes - (-1, 0) gives slots 1 and 5, (-1, -1) gives 3 and 7, (0, -1) gives 2 and 6 - are
+// one ds_read_b128 each, and the second value of each pair is the coupling to the plane ABOVE the neighbour, i.e. exactly
+// what the march needs one step later for its plane below: the eight plane-below couplings of a thread's two rows are
+// carried in registers from step to step, nothing of the operator is re-read.  Class id `ncls` is the all-zero row: cells
+// outside the grid carry it, so the boundary needs no predicates (0 * x adds an exact 0, as the masked form does).
+// Same values, same order of the 15 fused multiply-adds per row: bit-identical to k_spmv_dia_march2.
+constexpr int CLS_MAX = 255;             // classes per operator (+ the zero class = 256 table rows of 64 B)
+constexpr int CLS_SLOTS = 1024;          // hash slots of the classification
+__host__ __device__ constexpr int cls_pos(int s) {      // position of slot s in a table row
+    return s == 1 ? 0 : s == 5 ? 1 : s == 3 ? 2 : s == 7 ? 3 : s == 2 ? 4 : s == 6 ? 5 : s == 4 ? 6 : 7;
+}
+
+struct DiacArgs {
+    const uint8_t *cls;
+    const int *same;        // [nz]: plane z carries, row by row, the codes of plane z - 1 (scalar loads: ints)
+    const double *table;    // [ncls + 1][8]
+    int ncls;
+    const double *x;
+    double *y, *partials;
+    const int *flags;
+    int nx, ny, nz;
+    int z0, z1, zchunk, tiles_x, tiles_y;
+    int qq;
+};
+
+// A kernel this light is paced by instruction issue and by the bytes a CU keeps in flight, so the march is built around
+// what does NOT change from plane to plane:
+// * the couplings live in registers and are looked up again only where the class codes of a plane differ from the plane
+//   before (dia_classify flags those planes: on a uniform grid the planes next to the z faces, and the first plane of a
+//   march).  In between, a step touches no code and no table, and the couplings to the plane below are the upward halves of
+//   the pairs it already holds.
+// * three plane fetches are in flight per workgroup - three register sets that rotate by name, the march being unrolled
+//   three steps at a time - and nothing touches a fetched value before it is staged (the zero of the cells outside the grid
+//   is selected then): a select or a lane predicate at the load makes the wave wait for the fetch it has just issued.
+// * x is read from LDS (22 ds_read_b64 for a thread's two rows); four slices - the planes z - 1, z, z + 1 being read and
+//   z + 2 being staged - make ONE barrier per step enough.
+using d2 = __attribute__((ext_vector_type(2))) double;
+struct DiacT { d2 A15, A37, A26, A40, B15, B37, B26, B40, L15, L37, LB15, D26, LD37; };
+constexpr int DIAC_MAXCHUNK = 1024;    // planes per march at most (the per-plane flags of a march are staged in LDS)
+
+template <bool DOT, bool STORE>
+__global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
+    constexpr int NT = 256, PY = 8, HY = PY + 2, SLICE = DM_HX * HY;        // 660 cells per plane
+    constexpr int SLOT = 3 * NT;                            // ... in slots of 768: every thread stages three cells, no predicates
+    __shared__ double s_x[4 * SLOT];
+    __shared__ __attribute__((aligned(16))) double s_t[(CLS_MAX + 1) * 8];
+    __shared__ uint8_t s_c[4 * SLOT];
+    __shared__ uint8_t s_slow[DIAC_MAXCHUNK + 16];          // [z - za + 4]: the step of plane z looks its couplings up
+    __shared__ double s_red[4];
+    if (A.flags && A.flags[0]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_chunk = A.tiles_x * A.tiles_y;
+    const int chunk = b / per_chunk, tile = b - chunk * per_chunk;
+    const int ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+    const int x0 = tx * 64, y0 = ty * PY;
+    const int x = x0 + lane, ya = y0 + 2 * wv;
+    const bool live0 = x < A.nx && ya < A.ny, live1 = x < A.nx && ya + 1 < A.ny;
+    const int64_t P = (int64_t)A.nx * A.ny;
+    const int base0 = live0 ? x + A.nx * ya : 0, base1 = live1 ? x + A.nx * (ya + 1) : 0;      // offsets within a plane (P < 2^31)
+    const int centre = (2 * wv + 1) * DM_HX + lane + 1;     // the lower row of the pair; the upper one at + DM_HX
+    const int za = A.z0 + chunk * A.zchunk, zb = min(A.z1, za + A.zchunk);
+    const unsigned zero_cls = (unsigned)A.ncls;
+    for (int i = tid; i < (A.ncls + 1) * 8; i += NT) s_t[i] = A.table[i];
+    // A.same[z] != 0: every row of plane z carries the code of the row below it (plane z - 1).  A step looks codes up where
+    // that does not hold, and at the first plane of the march.
+    for (int i = tid; i < zb - za + 12; i += NT) {
+        const int z = za - 4 + i;
+        s_slow[i] = (z == za || !(z > 0 && z < A.nz && A.same[z] != 0)) ? 1 : 0;
+    }
+    if (za >= zb) {                                         // uniform; the launcher sizes the grid so that no chunk is empty
+        if (DOT && tid == 0) { if (A.qq) { A.partials[2 * b] = 0.0; A.partials[2 * b + 1] = 0.0; } else A.partials[b] = 0.0; }
+        return;
+    }
+    int goff[3];
+    bool gok[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int i = tid + q * NT;
+        const int ly = i / DM_HX, lx = i - ly * DM_HX;
+        const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+        gok[q] = i < SLICE && gx >= 0 && gx < A.nx && gy >= 0 && gy < A.ny;
+        goff[q] = gok[q] ? gx + A.nx * gy : 0;
+    }
+    auto slow = [&](int z) -> bool { return __builtin_amdgcn_readfirstlane((int)s_slow[z - za + 4]) != 0; };
+    // Loads are unconditional (cells outside the grid read a valid address, planes outside it the nearest plane).  Planes
+    // beyond zb are never used by the march (zb itself is: the plane above the last one).
+    auto fetch = [&](int z, double (&v)[3], unsigned (&cc)[3]) {
+        const int zc = min(max(z, 0), A.nz - 1);
+        const double *xz = A.x + P * zc;                    // uniform base + 32-bit lane offset
+        const uint8_t *cz = A.cls + P * zc;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) { v[q] = xz[goff[q]]; cc[q] = cz[goff[q]]; }
+    };
+    auto put = [&](int z, const double (&v)[3], const unsigned (&cc)[3]) {
+        const bool zok = z >= 0 && z < A.nz && z <= zb;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            s_x[(z & 3) * SLOT + tid + q * NT] = (zok && gok[q]) ? v[q] : 0.0;
+            s_c[(z & 3) * SLOT + tid + q * NT] = (uint8_t)((zok && gok[q]) ? cc[q] : zero_cls);
+        }
+    };
+    auto pair = [&](int code, int k) -> d2 { return *reinterpret_cast<const d2 *>(s_t + code * 8 + 2 * k); };
+    DiacT T;
+    double dot = 0.0, dot2 = 0.0;
+    double r0[3], r1[3], r2[3];                             // the three plane fetches in flight
+    unsigned k0[3], k1[3], k2[3];
+    fetch(za - 1, r0, k0);
+    fetch(za, r1, k1);
+    fetch(za + 1, r2, k2);
+    put(za - 1, r0, k0);
+    put(za, r1, k1);
+    put(za + 1, r2, k2);
+    fetch(za + 2, r0, k0);
+    fetch(za + 3, r1, k1);
+    fetch(za + 4, r2, k2);
+    __syncthreads();
+    double a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0, b4 = 0.0, b5 = 0.0, b6 = 0.0, b7 = 0.0;      // couplings to the plane below
+    // one step: rows of plane z; `rv / rk` hold plane z + 2 (staged at the end of the step) and then take the fetch of z + 5
+    auto step = [&](int z, double (&rv)[3], unsigned (&rk)[3]) {
+        const bool look = slow(z);
+        if (look) {                                         // uniform: look the couplings up (codes of planes z - 1 and z are staged)
+            const uint8_t *cm = s_c + ((z - 1) & 3) * SLOT + centre;
+            const int mA = cm[0], mB = cm[DM_HX], mL = cm[-1], mLB = cm[DM_HX - 1], mD = cm[-DM_HX], mLD = cm[-DM_HX - 1];
+            a4 = pair(mA, 3).x; b6 = pair(mA, 2).y; b4 = pair(mB, 3).x; a5 = pair(mL, 0).y; b7 = pair(mL, 1).y;
+            b5 = pair(mLB, 0).y; a6 = pair(mD, 2).y; a7 = pair(mLD, 1).y;
+            const uint8_t *cz = s_c + (z & 3) * SLOT + centre;
+            const int cA = cz[0], cB = cz[DM_HX], cL = cz[-1], cLB = cz[DM_HX - 1], cD = cz[-DM_HX], cLD = cz[-DM_HX - 1];
+            T.A15 = pair(cA, 0); T.A37 = pair(cA, 1); T.A26 = pair(cA, 2); T.A40 = pair(cA, 3);
+            T.B15 = pair(cB, 0); T.B37 = pair(cB, 1); T.B26 = pair(cB, 2); T.B40 = pair(cB, 3);
+            T.L15 = pair(cL, 0); T.L37 = pair(cL, 1); T.LB15 = pair(cLB, 0); T.D26 = pair(cD, 2); T.LD37 = pair(cLD, 1);
+        }
+        const double *xm = s_x + ((z - 1) & 3) * SLOT + centre;
+        const double *xc = s_x + (z & 3) * SLOT + centre;
+        const double *xp = s_x + ((z + 1) & 3) * SLOT + centre;
+        const double xa = xc[0], xb = xc[DM_HX];
+        double acc0 = a7 * xm[-DM_HX - 1];
+        acc0 = fma(a6, xm[-DM_HX], acc0);
+        acc0 = fma(a5, xm[-1], acc0);
+        acc0 = fma(a4, xm[0], acc0);
+        acc0 = fma(T.LD37.x, xc[-DM_HX - 1], acc0);
+        acc0 = fma(T.D26.x, xc[-DM_HX], acc0);
+        acc0 = fma(T.L15.x, xc[-1], acc0);
+        acc0 = fma(T.A40.y, xa, acc0);
+        acc0 = fma(T.A15.x, xc[1], acc0);
+        acc0 = fma(T.A26.x, xb, acc0);
+        acc0 = fma(T.A37.x, xc[DM_HX + 1], acc0);
+        acc0 = fma(T.A40.x, xp[0], acc0);
+        acc0 = fma(T.A15.y, xp[1], acc0);
+        acc0 = fma(T.A26.y, xp[DM_HX], acc0);
+        acc0 = fma(T.A37.y, xp[DM_HX + 1], acc0);
+        double acc1 = b7 * xm[-1];
+        acc1 = fma(b6, xm[0], acc1);
+        acc1 = fma(b5, xm[DM_HX - 1], acc1);
+        acc1 = fma(b4, xm[DM_HX], acc1);
+        acc1 = fma(T.L37.x, xc[-1], acc1);
+        acc1 = fma(T.A26.x, xa, acc1);
+        acc1 = fma(T.LB15.x, xc[DM_HX - 1], acc1);
+        acc1 = fma(T.B40.y, xb, acc1);
+        acc1 = fma(T.B15.x, xc[DM_HX + 1], acc1);
+        acc1 = fma(T.B26.x, xc[2 * DM_HX], acc1);
+        acc1 = fma(T.B37.x, xc[2 * DM_HX + 1], acc1);
+        acc1 = fma(T.B40.x, xp[DM_HX], acc1);
+        acc1 = fma(T.B15.y, xp[DM_HX + 1], acc1);
+        acc1 = fma(T.B26.y, xp[2 * DM_HX], acc1);
+        acc1 = fma(T.B37.y, xp[2 * DM_HX + 1], acc1);
+        const bool on = z < zb;                             // (the march runs in threes: up to two idle steps behind the last plane)
+        double *yz = A.y + P * (on ? z : za);
+        if (STORE && live0 && on) yz[base0] = acc0;
+        if (STORE && live1 && on) yz[base1] = acc1;
+        if (DOT) {
+            const double d0 = (live0 && on) ? acc0 : 0.0, d1 = (live1 && on) ? acc1 : 0.0;      // + 0 * x: the sums are unchanged
+            dot = fma(d0, xa, dot); dot2 = fma(d0, d0, dot2);
+            dot = fma(d1, xb, dot); dot2 = fma(d1, d1, dot2);
+        }
+        // the plane below the next step is this one: its upward couplings are the second halves of the pairs just used - and
+        // stay that until the codes change again
+        if (look) { a4 = T.A40.x; b6 = T.A26.y; b4 = T.B40.x; a5 = T.L15.y; b7 = T.L37.y; b5 = T.LB15.y; a6 = T.D26.y; a7 = T.LD37.y; }
+        put(z + 2, rv, rk);                                 // slot (z + 2) & 3: the plane z - 2 that nobody reads any more
+        fetch(z + 5, rv, rk);
+        lds_barrier();
+    };
+#pragma clang loop unroll(disable)
+    for (int z = za; z < zb; z += 3) {
+        step(z, r0, k0);
+        step(z + 1, r1, k1);
+        step(z + 2, r2, k2);
+    }
+    if (DOT) {
+        for (int pass = 0; pass < (A.qq ? 2 : 1); ++pass) {
+            const double sum = wave_sum(pass ? dot2 : dot);
+            __syncthreads();
+            if (lane == 0) s_red[wv] = sum;
+            __syncthreads();
+            if (tid == 0) A.partials[A.qq ? 2 * b + pass : b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        }
+    }
+}
+
+// --- the classification (per solve, after the slot arrays got their final values)
+__device__ __forceinline__ unsigned long long cls_hash(const double *__restrict__ uvals, int64_t stride, int64_t i) {
+    unsigned long long h = 0x9e3779b97f4a7c15ull;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        unsigned long long v = (unsigned long long)__double_as_longlong(uvals[(int64_t)s * stride + i]);
+        v *= 0xff51afd7ed558ccdull; v ^= v >> 32;
+        h = (h ^ v) * 0xc4ceb9fe1a85ec53ull; h ^= h >> 29;
+    }
+    return h ? h : 1ull;
+}
+
+struct ClsScratch {
+    unsigned long long keys[CLS_SLOTS];     // 0 = empty
+    int rep[CLS_SLOTS];                     // lowest row with that key
+    int id[CLS_SLOTS];                      // class id of the slot (rank of its rep row)
+    int info[4];                            // [0] distinct keys, [1] != 0: no dictionary (too many classes / a hash collision)
+};
+
+__global__ __launch_bounds__(TPB) void k_cls_insert(const double *__restrict__ uvals, int64_t stride, int64_t nv, ClsScratch *S) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (*(volatile int *)&S->info[1]) return;
+    const bool active = i < nv;
+    const unsigned long long h = active ? cls_hash(uvals, stride, i) : 0ull;
+    const int lane = threadIdx.x & 63;
+    unsigned long long todo = __ballot(active);
+    while (todo) {                                          // one insertion per distinct key of the wavefront
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned long long h0 = __shfl(h, leader);
+        todo &= ~__ballot(active && h == h0);
+        if (lane != leader) continue;
+        int slot = (int)(h0 & (CLS_SLOTS - 1));
+        for (int probe = 0; probe < CLS_SLOTS; ++probe, slot = (slot + 1) & (CLS_SLOTS - 1)) {
+            unsigned long long k = *(volatile unsigned long long *)&S->keys[slot];
+            if (k == 0ull) {
+                k = atomicCAS(&S->keys[slot], 0ull, h0);
+                if (k == 0ull) {
+                    k = h0;
+                    if (atomicAdd(&S->info[0], 1) + 1 > CLS_MAX) atomicExch(&S->info[1], 1);
+                }
+            }
+            if (k == h0) {
+                if (*(volatile int *)&S->rep[slot] > (int)i) atomicMin(&S->rep[slot], (int)i);
+                break;
+            }
+        }
+    }
+}
+
+// class ids in the order of the representative rows (deterministic), the table in the products' layout
+__global__ __launch_bounds__(CLS_SLOTS) void k_cls_table(const double *__restrict__ uvals, int64_t stride, ClsScratch *S,
+                                                          double *__restrict__ table) {
+    __shared__ int s_rep[CLS_SLOTS];
+    const int t = threadIdx.x;
+    const bool used = S->keys[t] != 0ull;
+    s_rep[t] = used ? S->rep[t] : 0x7fffffff;
+    __syncthreads();
+    if (S->info[1]) return;
+    int rank = 0;
+    for (int k = 0; k < CLS_SLOTS; ++k) rank += (s_rep[k] < s_rep[t]) ? 1 : 0;
+    S->id[t] = used ? rank : -1;
+    if (used && rank <= CLS_MAX) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) table[rank * 8 + cls_pos(s)] = uvals[(int64_t)s * stride + s_rep[t]];
+    }
+    if (t < 8) table[min(S->info[0], CLS_MAX) * 8 + t] = 0.0;        // the zero class
+}
+
+__global__ __launch_bounds__(TPB) void k_cls_assign(const double *__restrict__ uvals, int64_t stride, int64_t nv, ClsScratch *S,
+                                                    const double *__restrict__ table, uint8_t *__restrict__ cls) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= nv || S->info[1]) return;
+    const unsigned long long h = cls_hash(uvals, stride, i);
+    int slot = (int)(h & (CLS_SLOTS - 1)), id = -1;
+    for (int probe = 0; probe < CLS_SLOTS; ++probe, slot = (slot + 1) & (CLS_SLOTS - 1)) {
+        const unsigned long long k = S->keys[slot];
+        if (k == h) { id = S->id[slot]; break; }
+        if (k == 0ull) break;
+    }
+    bool same = id >= 0 && id <= CLS_MAX;
+    if (same) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            same = same && __double_as_longlong(uvals[(int64_t)s * stride + i]) == __double_as_longlong(table[id * 8 + cls_pos(s)]);
+    }
+    if (!same) { atomicExch(&S->info[1], 2); return; }       // two tuples under one key: keep the plain diagonal form
+    cls[i] = (uint8_t)id;
+}
+
+// same[z] = 1 iff every row of plane z has the code of the row below it in plane z - 1 (same[0] = 0): the march keeps its
+// couplings across such planes without looking at a code
+__global__ __launch_bounds__(TPB) void k_cls_planes(const uint8_t *__restrict__ cls, int64_t plane, int nz, int *__restrict__ same) {
+    __shared__ int s_diff;
+    const int z = blockIdx.x;
+    if (threadIdx.x == 0) s_diff = 0;
+    __syncthreads();
+    bool diff = z == 0;
+    if (z > 0) {
+        const uint8_t *a = cls + plane * z, *b = a - plane;
+        for (int64_t i = threadIdx.x; i < plane; i += TPB) diff = diff || a[i] != b[i];
+    }
+    if (diff) s_diff = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) same[z] = s_diff ? 0 : 1;
+}
+
+// Row classes of the operator's CURRENT slot values (a->uvals, diagonal form).  a->cls_count > 0 afterwards when the
+// dictionary exists; any later change of the slot values must reset it (sym_scale, combine_dia, ensure_sym do).
+int dia_classify(Ctx *c, const Mesh *m, Csr *a) {
+    a->cls_count = 0;
+    if (!c->spmv_classes || m->sym_nx <= 0 || !(a->uvals && a->uvals_valid) || m->nv >= ((int64_t)1 << 31)) return PGD_OK;
+    if (m->cls_misses >= 2 && (m->cls_misses & 15) != 0) { ++m->cls_misses; return PGD_OK; }   // an operator without classes: look again only now and then
+    const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
+    if (m->nv / plane < 3 || plane * 64 < c->spmv_grid_min_plane_bytes) return PGD_OK;          // no march on this grid anyway
+    void *p;
+    if (!c->cls_scratch) { PGD_TRY(dev_alloc(c, &p, sizeof(ClsScratch))); c->cls_scratch = p; }
+    const int nzp = (int)(m->nv / plane);
+    const size_t same_bytes = ((size_t)nzp * sizeof(int) + 63) / 64 * 64;
+    if (!a->cls) {
+        a->cls_bytes = (size_t)m->nv + (size_t)(CLS_MAX + 1) * 8 * sizeof(double) + same_bytes + 64;
+        PGD_TRY(dev_alloc(c, &p, a->cls_bytes));
+        a->cls_table = (double *)p;                          // the table first (aligned), then the plane flags, then the codes
+        a->cls_same = (int *)((uint8_t *)p + (size_t)(CLS_MAX + 1) * 8 * sizeof(double));
+        a->cls = (uint8_t *)a->cls_same + same_bytes;
+    }
+    ClsScratch *S = (ClsScratch *)c->cls_scratch;
+    hipStream_t st = c->stream;
+    PGD_HIP(c, hipMemsetAsync(S->keys, 0, sizeof S->keys, st));
+    PGD_HIP(c, hipMemsetAsync(S->rep, 0x7f, sizeof S->rep, st));
+    PGD_HIP(c, hipMemsetAsync(S->info, 0, sizeof S->info, st));
+    const int g = (int)((m->nv + TPB - 1) / TPB);
+    k_cls_insert<<<g, TPB, 0, st>>>(a->uvals, a->uvals_stride, m->nv, S);
+    k_cls_table<<<1, CLS_SLOTS, 0, st>>>(a->uvals, a->uvals_stride, S, a->cls_table);
+    k_cls_assign<<<g, TPB, 0, st>>>(a->uvals, a->uvals_stride, m->nv, S, a->cls_table, a->cls);
+    k_cls_planes<<<nzp, TPB, 0, st>>>(a->cls, plane, nzp, a->cls_same);
+    int info[4] = {0, 1, 0, 0};
+    PGD_HIP(c, hipMemcpyAsync(info, S->info, sizeof info, hipMemcpyDeviceToHost, st));
+    PGD_HIP(c, hipStreamSynchronize(st));
+    PGD_LAUNCH_CHECK(c);
+    if (info[1] != 0 || info[0] <= 0 || info[0] > CLS_MAX) { ++m->cls_misses; return PGD_OK; }
+    m->cls_misses = 0;
+    a->cls_count = info[0];
+    return PGD_OK;
+}
+
 // every column of every row must be a grid neighbour (dx, dy, dz) in {-1, 0, 1}^3 of the row with |offset| one of the
 // eight diagonals: only then is the diagonal form lossless.  Checked once per mesh.
 __device__ __forceinline__ int dia_slot(int64_t d, int64_t nx, int64_t P, int *dx, int *dy, int *dz) {
@@ -1015,6 +1365,7 @@ __global__ __launch_bounds__(TPB) void k_sym_scale(double *__restrict__ uvals, i
 
 int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *sc) {
     if (!(a->uvals && a->uvals_valid) || a->uvals_scaled) return fail(c, PGD_ERR_INVALID, "sym_scale: no unscaled symmetric copy");
+    a->cls_count = 0;
     const int g = (int)((m->nv + TPB - 1) / TPB);
     if (m->sym_nx > 0) k_dia_scale<<<g, TPB, 0, c->stream>>>(a->uvals, a->uvals_stride, sc, m->nv, m->sym_nx, m->sym_ny, c->spmv_unit_diag);
     else if (m->sym_w == 4) k_sym_scale<4><<<g, TPB, 0, c->stream>>>(a->uvals, a->uvals_stride, m->pids, m->sym_tab, sc, m->nv);
@@ -1030,6 +1381,7 @@ int ensure_sym(Ctx *c, const Mesh *m, Csr *a, bool *usable) {
     if (!c->spmv_sym || m->sym_w == 0) return PGD_OK;
     if (a->uvals_valid && !a->uvals_scaled) { *usable = a->uvals != nullptr; return PGD_OK; }
     a->uvals_scaled = false;
+    a->cls_count = 0;
     a->uvals_valid = true;                       // decided for this set of values, whatever the outcome
     const int64_t stride = m->nv;      // (padding the arrays apart - 2^27-byte strides at 256^3 - measured no difference)
     if (a->uvals && a->uvals_stride != stride) { dev_release(c, a->uvals, a->uvals_bytes); a->uvals = nullptr; }
@@ -1097,6 +1449,7 @@ __global__ __launch_bounds__(TPB) void k_combine_dia(CombineDiaArgs A, double *_
 // mask: Dirichlet flags per row (or null) - only valid on the LAST pass, like k_combine's column mask
 int combine_dia(Ctx *c, const Mesh *m, Csr *o, Csr *const *atoms, const double *coefs, int n, const uint8_t *mask) {
     o->uvals_valid = false;
+    o->cls_count = 0;
     if (!c->spmv_sym || m->sym_nx <= 0 || !c->spmv_combine_dia) return PGD_OK;
     for (int t = 0; t < n; ++t) {
         bool usable = false;
@@ -1191,6 +1544,35 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         else if (dot) k_spmv_dia_march<true, false, WY><<<wgs, 64 * WY, 0, c->stream>>>(D);            \
         else k_spmv_dia_march<false, true, WY><<<wgs, 64 * WY, 0, c->stream>>>(D);                     \
     } while (0)
+            bool coded = c->spmv_variant == 0 && c->spmv_classes && a->cls_count > 0;
+            int wgs_c = wgs, zchunk_c = D.zchunk;
+            if (coded && c->spmv_zchunk_force <= 0) {
+                // the coded march is unrolled three planes at a time and its steps are light: longer marches (fewer halo planes
+                // and prologues per row; 256^3: 24 planes 81 us, 12 planes 89 us, 6 planes 103 us), in whole threes, while the launch
+                // still has ~2 workgroups per slot (two workgroups fit a CU)
+                const int64_t tile_planes = (int64_t)D.tiles_x * D.tiles_y * (D.z1 - D.z0);
+                zchunk_c = (int)std::min<int64_t>(c->spmv_zchunk_coded, tile_planes / (4 * (int64_t)c->num_cu));
+                zchunk_c = std::max(3, zchunk_c / 3 * 3);
+                wgs_c = (D.z1 - D.z0 + zchunk_c - 1) / zchunk_c * D.tiles_x * D.tiles_y;
+            }
+            coded = coded && zchunk_c <= DIAC_MAXCHUNK;
+            if (coded) {
+                // the operator has a row-class dictionary (dia_classify): one byte per row instead of the slot values
+                DiacArgs E;
+                E.cls = a->cls; E.same = a->cls_same; E.table = a->cls_table; E.ncls = a->cls_count; E.x = x; E.y = y; E.partials = D.partials; E.flags = flags;
+                E.nx = D.nx; E.ny = D.ny; E.nz = D.nz; E.z0 = D.z0; E.z1 = D.z1; E.zchunk = zchunk_c; E.tiles_x = D.tiles_x; E.tiles_y = D.tiles_y;
+                E.qq = D.qq;
+                if (nparts_out) *nparts_out = wgs_c;
+                if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + (D.qq ? 2 : 1) * (int64_t)wgs_c, 4 * MAX_VEC_BLOCKS)));
+                E.partials = c->partials + c->partials_off;
+                if (dot && store) k_spmv_diac_march2<true, true><<<wgs_c, 256, 0, c->stream>>>(E);
+                else if (dot) k_spmv_diac_march2<true, false><<<wgs_c, 256, 0, c->stream>>>(E);
+                else k_spmv_diac_march2<false, true><<<wgs_c, 256, 0, c->stream>>>(E);
+                c->kcount[KC_DIAC_MARCH] += 1;
+                if (timed2) PGD_TRY(prof_end(c, m, nrows, 17.0));
+                PGD_LAUNCH_CHECK(c);
+                return PGD_OK;
+            }
             if (c->spmv_variant == 0) {
                 if (dot && store) k_spmv_dia_march2<true, true><<<wgs, 256, 0, c->stream>>>(D);
                 else if (dot) k_spmv_dia_march2<true, false><<<wgs, 256, 0, c->stream>>>(D);
@@ -1332,6 +1714,9 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_FAULT_ITERATION && value >= -1 && value <= (1 << 30)) { c->fault_iteration = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_COMBINE_DIA && value >= 0 && value <= 1) { c->spmv_combine_dia = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_VARIANT && value >= 0 && value <= 2) { c->spmv_variant = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_ROW_CLASSES && value >= 0 && value <= 1) { c->spmv_classes = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_ASM_LATTICE && value >= 0 && value <= 1) { c->asm_lattice = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_ZCHUNK_CODED && value >= 3 && value <= 1024) { c->spmv_zchunk_coded = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }
 
@@ -1387,6 +1772,16 @@ int pgd_op_symmetrize(pgd_handle h, pgd_handle ah, int *used) {
     bool usable = false;
     PGD_TRY(ensure_sym(c, m, a, &usable));
     if (used) *used = usable ? 1 : 0;
+    return PGD_OK;
+}
+
+int pgd_op_classify(pgd_handle h, pgd_handle ah, int *classes) {
+    PGD_CTX(c, h);
+    Csr *a = get_csr(c, ah);
+    Mesh *m = a ? get_mesh(c, a->mesh) : nullptr;
+    if (!a || !m) return fail(c, PGD_ERR_INVALID, "op_classify: invalid handle");
+    PGD_TRY(dia_classify(c, m, a));
+    if (classes) *classes = a->cls_count;
     return PGD_OK;
 }
 

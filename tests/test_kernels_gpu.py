@@ -404,7 +404,9 @@ def test_grid_march_in_multi_tile_launch_shapes(ctx, shape):
     info = ctx.mesh_sym_info(h)
     assert (info["slots"], info["nx"], info["ny"]) == (8, nx, ny)
     K, M = F.assemble_atom(coords, cells, F.STIFF), F.assemble_atom(coords, cells, F.MASS)
+    ctx.tune(20, 0)               # entries from the coordinate differences, like the oracle's: the 4e-15 bounds below are on the PRODUCT
     ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    ctx.tune(20, 1)
     bc = boundary_dofs(coords)[::3].astype(np.int32)                 # a scattered part of the boundary is Dirichlet
     op = ctx.op_combine(h, [ak, am], [1.0, 0.37], bc)
     A, _ = F.apply_dirichlet((K + 0.37 * M).tocsr(), np.zeros(n), bc)
@@ -524,12 +526,23 @@ def test_products_agree_at_bench_size(ctx, npts):
             ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
             assert ctx.kernel_counts()[name] == c0[name] + 1
             ys[name] = (ctx.vec_download(yv), ctx.slots_download(30, 1)[0])
+        # ... and the march on the row-class dictionary (one code byte per row), several chunk lengths
+        assert 1 <= ctx.op_classify(op) <= 64
+        ctx.tune(6, 8)
+        for zc in (24, 12, 5):                        # most planes per march (whole threes: 5 -> 3)
+            ctx.tune(21, zc)
+            c0 = ctx.kernel_counts()
+            ctx.vec_fill(yv, -1.0)
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
+            assert ctx.kernel_counts()["diac_march"] == c0["diac_march"] + 1
+            ys["diac_march_%d" % zc] = (ctx.vec_download(yv), ctx.slots_download(30, 1)[0])
     finally:
         ctx.tune(3, 1)
         ctx.tune(2, 1)
         ctx.tune(6, 8)
+        ctx.tune(21, 24)
     base = ys["csr"][0]
-    for name in ("csr_dict", "dia_march", "dia_rows"):
+    for name in ("csr_dict", "dia_march", "dia_rows", "diac_march_24", "diac_march_12", "diac_march_5"):
         assert np.array_equal(ys[name][0], base), (name, np.abs(ys[name][0] - base).max())
         assert abs(ys[name][1] - ys["csr"][1]) <= 1e-12 * np.abs(x) @ np.abs(base)
     assert np.all(base[bc] == x[bc])                                   # Dirichlet rows are identity rows
@@ -672,9 +685,10 @@ def test_single_sync_recurrence_walks_the_textbook_iterates(ctx):
             for maxit in (10000, 23):
                 op = ctx.op_combine(h, [ak, am], [1.0, 3.0], bc)
                 xv = ctx.vec_alloc(n)
-                k0 = ctx.kernel_counts()["dia_march"]
+                k0 = ctx.kernel_counts()
                 it, rel = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, maxit)
-                assert ctx.kernel_counts()["dia_march"] > k0
+                k1 = ctx.kernel_counts()
+                assert k1["dia_march"] + k1["diac_march"] > k0["dia_march"] + k0["diac_march"]
                 x = ctx.vec_download(xv)
                 if maxit == 10000:
                     it2, _ = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, maxit)
@@ -710,6 +724,160 @@ def test_single_sync_recurrence_walks_the_textbook_iterates(ctx):
     ctx.vec_free(bv)
     for at in (ak, am):
         ctx.atom_free(at)
+    ctx.mesh_free(h)
+
+
+@pytest.mark.parametrize("shape", sorted(GRID_SHAPES))
+def test_row_class_dictionary_is_lossless(ctx, shape):
+    """k_spmv_diac_march2: the z-march that reads one class code per row and the classes' slot tuples from LDS.  On
+    uniform grids with constant coefficients (all-Dirichlet, all-Neumann, one Dirichlet face) the operator has a few dozen
+    row classes; the product must be bit-identical to the march that streams the slot values (several tiles, partial
+    tiles, chunk prologues at za > 0, plane-aligned slabs), dots included.  A variable coefficient gives no dictionary
+    and the plain march; new operator values drop the dictionary."""
+    nx, ny, nz = GRID_SHAPES[shape]
+    coords, cells = F.box_mesh((0, 0, 0), (1.0, 0.7, 1.3), nx - 1, ny - 1, nz - 1)
+    h = ctx.mesh_upload(coords, cells)
+    n = coords.shape[0]
+    plane = nx * ny
+    # the vertices sit on a uniform lattice: the assembly takes edge vectors as whole steps, congruent cells get identical
+    # local matrices (entries within the oracle's own rounding noise - it differences the rounded coordinates)
+    lat, steps = ctx.mesh_lattice(h)
+    assert lat and np.allclose(steps, [1.0 / (nx - 1), 0.7 / (ny - 1), 1.3 / (nz - 1)], rtol=1e-14)
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    for atom, kind in ((ak, F.STIFF), (am, F.MASS)):
+        ref = F.assemble_atom(coords, cells, kind)
+        # (a difference of two rounded coordinates of size ~1 carries ulp(1) / h = n * eps of relative error: the oracle's noise)
+        assert np.abs(ctx.atom_download(atom, ref.nnz) - ref.data).max() <= 16 * max(nx, ny, nz) * 2.3e-16 * np.abs(ref.data).max()
+    bnd = boundary_dofs(coords).astype(np.int32)
+    face = np.where(coords[:, 2] <= 1e-12)[0].astype(np.int32)
+    rng = np.random.default_rng(99)
+    x = rng.uniform(-1, 1, n)
+    xv, yv = ctx.vec_from(x), ctx.vec_alloc(n)
+    ctx.flags_reset()
+    try:
+        for bc in (bnd, np.zeros(0, dtype=np.int32), face):
+            op = ctx.op_combine(h, [ak, am], [1.0, 0.37], bc)
+            assert ctx.op_symmetrize(op) is True
+            ctx.tune(7, 4)
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)                  # the march over the slot values
+            y_ref, d_ref = ctx.vec_download(yv), ctx.slots_download(30, 1)[0]
+            ncls = ctx.op_classify(op)
+            assert 1 <= ncls <= 255, ncls
+            for zc in (1, 3, 4, 16, 1000):
+                ctx.tune(7, zc)
+                k0 = ctx.kernel_counts()
+                ctx.vec_fill(yv, -5.0)
+                ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 31)
+                k1 = ctx.kernel_counts()
+                assert k1["diac_march"] == k0["diac_march"] + 1 and k1["dia_march"] == k0["dia_march"]
+                y = ctx.vec_download(yv)
+                assert np.array_equal(y, y_ref), (shape, zc, np.abs(y - y_ref).max())
+                if zc == 4:
+                    assert ctx.slots_download(31, 1)[0] == d_ref      # same partial sums in the same order
+                z0, z1 = 1, nz - 1
+                ctx.vec_fill(yv, -7.0)
+                ctx.spmv_dot_slot(op, xv, yv, xv, z0 * plane, z1 * plane, 32)
+                y2 = ctx.vec_download(yv)
+                assert np.array_equal(y2[z0 * plane:z1 * plane], y_ref[z0 * plane:z1 * plane])
+                assert np.all(y2[:z0 * plane] == -7.0) and np.all(y2[z1 * plane:] == -7.0)
+            # switched off: the plain march again
+            ctx.tune(19, 0)
+            k0 = ctx.kernel_counts()
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 31)
+            ctx.tune(19, 1)
+            k1 = ctx.kernel_counts()
+            assert k1["diac_march"] == k0["diac_march"] and k1["dia_march"] == k0["dia_march"] + 1
+            # new values through the same handle: no stale dictionary
+            op = ctx.op_combine(h, [ak, am], [2.0, 0.1], bc, op=op)
+            k0 = ctx.kernel_counts()
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 31)
+            k1 = ctx.kernel_counts()
+            assert k1["diac_march"] == k0["diac_march"] and k1["dia_march"] == k0["dia_march"] + 1
+            y_new = ctx.vec_download(yv)
+            assert 1 <= ctx.op_classify(op) <= 255
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 31)
+            assert np.array_equal(ctx.vec_download(yv), y_new)
+            ctx.atom_free(op)
+        # a coefficient that varies from vertex to vertex: more than 255 classes (or none that verify) -> no dictionary
+        wv = ctx.vec_from(1.0 + coords[:, 0] ** 2 + 0.5 * np.sin(coords.sum(axis=1)))
+        aw = ctx.atom_assemble(h, F.KIND_NAMES.index("wmass"), 0, 0, wv)
+        opw = ctx.op_combine(h, [ak, aw], [1.0, 0.5], bnd)
+        assert ctx.op_symmetrize(opw) is True
+        ctx.tune(7, 4)
+        assert ctx.op_classify(opw) == 0
+        k0 = ctx.kernel_counts()
+        ctx.spmv_dot_slot(opw, xv, yv, xv, 0, n, 31)
+        k1 = ctx.kernel_counts()
+        assert k1["diac_march"] == k0["diac_march"] and k1["dia_march"] == k0["dia_march"] + 1
+        ctx.atom_free(opw)
+        ctx.atom_free(aw)
+        ctx.vec_free(wv)
+        # a grid whose planes are not equally spaced is no lattice: coordinate differences as they are, and (here) no classes
+        c2 = coords.copy()
+        c2[:, 2] = c2[:, 2] ** 1.5
+        h2 = ctx.mesh_upload(c2, cells)
+        assert ctx.mesh_lattice(h2)[0] is False and ctx.mesh_sym_info(h2)["nx"] == nx
+        ctx.mesh_free(h2)
+    finally:
+        ctx.tune(7, 0)
+        ctx.tune(19, 1)
+    for v in (xv, yv):
+        ctx.vec_free(v)
+    for a in (ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
+def test_pcg_on_row_classes_is_bit_identical(ctx):
+    """The library's PCG classifies the scaled operator per solve: with and without the dictionary the solve walks the same
+    iterates bit for bit (single-sync recurrence and the two-reduction one) when both kernels march equally far - y is
+    bit-identical anyway, the fused dots are summed per workgroup - and it really ran on the coded kernel."""
+    from pgdrome_amd import fem
+    npts = 104
+    mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), npts - 1, npts - 1, npts - 1)
+    coords = mesh.coordinates()
+    h = ctx.mesh_upload(coords, mesh.cells())
+    n = coords.shape[0]
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bc = np.where(np.any((coords <= 1e-12) | (coords >= 1 - 1e-12), axis=1))[0].astype(np.int32)
+    rng = np.random.default_rng(21)
+    b = rng.uniform(-1, 1, n)
+    b[bc] = 0.0
+    bv = ctx.vec_from(b)
+    out = {}
+    try:
+        ctx.tune(7, 6)        # the same march length for both kernels: the same workgroups, the same partial sums of the fused dots
+        for ss in (1, 0):
+            ctx.tune(18, ss)
+            for classes in (1, 0):
+                ctx.tune(19, classes)
+                op = ctx.op_combine(h, [ak, am], [1.0, 3.0], bc)
+                xv = ctx.vec_alloc(n)
+                k0 = ctx.kernel_counts()
+                it, rel = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, 10000)
+                k1 = ctx.kernel_counts()
+                coded, plain = k1["diac_march"] - k0["diac_march"], k1["dia_march"] - k0["dia_march"]
+                assert (coded > 0 and plain == 0) if classes else (coded == 0 and plain > 0)
+                out[(ss, classes)] = (it, rel, ctx.vec_download(xv))
+                # afterwards the operator is usable as before: products of the UNSCALED operator through the plain kernels
+                yv = ctx.vec_alloc(n)
+                ctx.flags_reset()
+                ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
+                r = b - ctx.vec_download(yv)
+                assert np.linalg.norm(r) <= 1.05e-10 * np.linalg.norm(b)
+                ctx.vec_free(yv)
+                ctx.vec_free(xv)
+                ctx.atom_free(op)
+    finally:
+        ctx.tune(7, 0)
+        ctx.tune(18, 1)
+        ctx.tune(19, 1)
+    for ss in (1, 0):
+        a, c = out[(ss, 1)], out[(ss, 0)]
+        assert a[0] == c[0] and a[1] == c[1] and np.array_equal(a[2], c[2]), (ss, a[0], c[0])
+    ctx.vec_free(bv)
+    for a in (ak, am):
+        ctx.atom_free(a)
     ctx.mesh_free(h)
 
 

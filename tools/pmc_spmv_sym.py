@@ -31,7 +31,14 @@ ctx.tune(13, variant)
 if mode != "csr":
     assert ctx.op_symmetrize(op)
 ctx.flags_reset()
-if mode == "grid":
+if mode == "coded":
+    # the march on the row-class dictionary as a plain product with the fused dot (k_spmv_diac_march2), 12 launches
+    ctx.tune(6, 8)
+    ctx.tune(7, zchunk)
+    assert ctx.op_classify(op) > 0
+    for _ in range(12):
+        ctx.spmv_dot_slot(op, x, y, x, 0, nv, 30)
+elif mode == "grid":
     # the PCG instance as the solves launch it: the product of the SCALED operator (unit diagonal not loaded) with the fused
     # dot, inside pgd_pcg_solve - 12 iterations that cannot converge (rtol = atol = 0), issued eagerly (< one graph chunk)
     b = ctx.vec_from(np.random.default_rng(99).uniform(-1, 1, nv))
