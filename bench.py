@@ -185,8 +185,11 @@ def main():
     kc = {k: kc1[k] - kc0[k] for k in kc1}
     patterns = be.ctx.mesh_dict_count(space.handle())
     sym = be.ctx.mesh_sym_info(space.handle())
-    ran = max(("dia_march", "dia_rows", "sym_rows", "csr_dict", "csr"), key=lambda k: kc[k])
+    ran = max(("diac_march", "dia_march", "dia_rows", "sym_rows", "csr_dict", "csr"), key=lambda k: kc[k])
     kernel_names = {
+        "diac_march": "k_spmv_diac_march2<dot,store> (symmetric half storage in diagonal form behind a lossless row-class dictionary: "
+                      "one code byte per row, the classes' 8-tuples of slot values in LDS / registers; a 64 x 8 patch of the %d x %d "
+                      "vertex grid marching along z, two rows per thread, x planes in LDS)" % (sym["nx"], sym["ny"]),
         "dia_march": "k_spmv_dia_march2<dot,store> (symmetric half storage in diagonal form: 8 slot arrays of n doubles, a 64 x 8 "
                      "patch of the %d x %d vertex grid marching along z, two rows per thread, x planes and the plane-below "
                      "couplings in LDS)" % (sym["nx"], sym["ny"]),
@@ -198,6 +201,12 @@ def main():
     own = prof["own_bytes"] / launches                       # least bytes that kernel must move, per launch
     alg = prof["bytes"] / launches                           # 12 nnz + 20 n for the rows covered
     achieved = own / avg / 1e9 if avg > 0 else 0.0
+    # the vector update of the single-sync recurrence (x, r, p in one kernel: 4 vectors read, 3 written = 56 B per row)
+    upd_n = prof.get("update_launches", 0)
+    upd_avg = prof["update_seconds"] / upd_n if upd_n else 0.0
+    upd_bytes = prof["update_bytes"] / upd_n if upd_n else 0.0
+    upd_achieved = upd_bytes / upd_avg / 1e9 if upd_avg > 0 else 0.0
+    it_us = 1e6 * pcg_seconds / max(pcg_its, 1)
     out = {
         "metric": "PGD fixed-point iters/sec + SpMV HBM GB/s, 256^3 P1 space x 1D param",
         "value": K / elapsed, "unit": "fixed-point iterations/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -213,8 +222,9 @@ def main():
                                   (dist.get_world_size() if sharded else None)),
                    "pcg_iterations_per_step": pcg_its / K, "modes_completed": len(prob.num_fp_it),
                    "us_per_pcg_iteration": 1e6 * pcg_seconds / max(pcg_its, 1),
-                   "pcg_iteration_breakdown_us": {"product": 1e6 * avg, "vector_kernels_reductions_and_solve_setup":
-                                                  1e6 * (pcg_seconds / max(pcg_its, 1) - avg)},
+                   "pcg_iteration_breakdown_us": ({"product": 1e6 * avg, "vector_update": 1e6 * upd_avg,
+                                                   "scalars_kernel_launch_gaps_and_solve_setup": it_us - 1e6 * (avg + upd_avg)} if upd_n else
+                                                  {"product": 1e6 * avg, "vector_kernels_reductions_and_solve_setup": it_us - 1e6 * avg}),
                    "seconds_in_pcg_solves": pcg_seconds, "seconds_timed": elapsed,
                    "product_launches_by_kernel": kc,
                    "setup_seconds_untimed": t_setup},
@@ -233,8 +243,27 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_csr_section:
         out["roofline"]["csr_product"] = csr_section(be, prob, n_sp, nnz)
-    if rank == 0 and world == 1 and n == 256 and sym["nx"] and not args.no_pmc:
-        out["roofline"].update(pmc_traffic(own))
+    pmc = pmc_traffic(own, upd_bytes) if rank == 0 and world == 1 and n == 256 and sym["nx"] and not args.no_pmc else {}
+    out["roofline"].update(pmc.get("product", {}))
+    if upd_n and upd_avg > avg:
+        # The product no longer takes most of an iteration: `roofline` is the DOMINANT kernel's - the vector update - and the
+        # product's keeps its fields, unchanged, under roofline.spmv.
+        spmv = out["roofline"]
+        out["roofline"] = {"bound": "hbm",
+                           "kernel": "k_pcg1_update (single-sync recurrence: x += alpha p, r -= alpha q, p = r + beta p, partial sums of r.r; "
+                                     "16-byte accesses, 4 vectors read + 3 written)",
+                           "achieved": upd_achieved, "peak": 8000.0, "unit": "GB/s", "frac": upd_achieved / 8000.0, "traffic": None,
+                           "launches": upd_n, "avg_launch_us": 1e6 * upd_avg, "bytes_per_launch": upd_bytes,
+                           "bytes_per_row": upd_bytes / max(rows_local, 1),
+                           "measured_copy_ceiling_GBps": 6290.0, "frac_of_measured_copy_ceiling": upd_achieved / 6290.0,
+                           "share_of_pcg_iteration": 1e6 * upd_avg / it_us if it_us > 0 else None}
+        out["roofline"].update(pmc.get("update", {}))
+        spmv["share_of_pcg_iteration"] = 1e6 * avg / it_us if it_us > 0 else None
+        if ran == "diac_march":
+            # the same product in the plain diagonal form streams 72 B per row (k_spmv_dia_march2, r02u: 262-275 us at 256^3)
+            spmv["plain_diagonal_form_bytes_per_row"] = 72.0
+            spmv["speedup_over_plain_diagonal_form_r02u"] = 268.0e-6 / avg if avg > 0 else None
+        out["roofline"]["spmv"] = spmv
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(prob, spec, be, pcg_its / K, args)
     if rank == 0:
@@ -299,58 +328,71 @@ def _first_spatial_operator(prob):
     return A.op()
 
 
-def pmc_traffic(own_bytes):
-    """HBM-side bytes per launch of the dominant kernel.  bench.py cannot read PMC counters of its own process, so it
-    starts `rocprofv3 --pmc` CHILD processes (one counter per pass, as MI355X_MICROARCH.md prescribes) on
-    tools/pmc_spmv_sym.py - the same kernel instance (12 iterations of pgd_pcg_solve on the same 256^3 operator shape: the product
-    of the scaled operator with the fused dot) - and applies the calibrated factors of
-    profiles/r02a_pmc_calibration_and_march.json (FETCH_SIZE x 2 for 8 B/lane streaming loads, measured on a known 1 GiB
-    stream; WRITE_SIZE exact).  Falls back to the committed profile when no profiler can be started."""
+def pmc_traffic(own_bytes, upd_bytes):
+    """HBM-side bytes per launch of the PCG product and of the vector update.  bench.py cannot read PMC counters of its own
+    process, so it starts `rocprofv3 --pmc` CHILD processes (one counter per pass, as MI355X_MICROARCH.md prescribes) on
+    tools/pmc_spmv_sym.py - the same kernel instances (12 iterations of pgd_pcg_solve on the same 256^3 operator shape) - and
+    applies the calibrated factors of profiles/r02a_pmc_calibration_and_march.json (FETCH_SIZE x 2 for 8 and 16 B/lane
+    streaming loads, measured on a known 1 GiB stream; WRITE_SIZE exact).  Falls back to the committed profile when no
+    profiler can be started.  Returns {"product": {...}, "update": {...}} with `traffic`, `traffic_source`,
+    `traffic_over_kernel_min`."""
     import csv
     import glob
     import shutil
     import subprocess
     import tempfile
     fallback = os.path.join(ROOT, "profiles", "pmc_spmv_latest.json")
-    res = {"traffic": None, "traffic_source": None}
+    kernels = {"product": (lambda name: "k_spmv_dia" in name and "<true, true" in name, own_bytes),
+               "update": (lambda name: "k_pcg1_update" in name, upd_bytes)}
+    res = {k: {"traffic": None, "traffic_source": None} for k in kernels}
     rp = shutil.which("rocprofv3")
     nested = any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if rp and not nested:
         env = {k: v for k, v in os.environ.items() if not k.startswith(("ROCPROF", "ROCP_", "HSA_TOOLS")) and k != "LD_PRELOAD"}
         env["TMPDIR"] = "/tmp"
-        vals = {}
+        vals = {k: {} for k in kernels}
         try:
             for counter in ("FETCH_SIZE", "WRITE_SIZE"):
                 d = tempfile.mkdtemp(prefix="pgd_pmc_", dir="/tmp")
                 subprocess.run([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                                 os.path.join(ROOT, "tools", "pmc_spmv_sym.py"), "256", "grid", "0"],
                                check=True, timeout=180, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-                got = []
+                got = {k: [] for k in kernels}
                 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                     with open(f) as fh:
                         for row in csv.DictReader(fh):
-                            name = row.get("Kernel_Name", "")
-                            if row.get("Counter_Name") == counter and "k_spmv_dia_march" in name and "<true, true" in name:
-                                got.append(float(row["Counter_Value"]))
+                            if row.get("Counter_Name") != counter:
+                                continue
+                            for k, (match, _) in kernels.items():
+                                if match(row.get("Kernel_Name", "")):
+                                    got[k].append(float(row["Counter_Value"]))
                 shutil.rmtree(d, ignore_errors=True)
-                if not got:
-                    raise RuntimeError("no %s rows for the product" % counter)
-                v = sum(got) / len(got)
-                if v * 1024.0 < 64.0 * own_bytes:           # the counter is reported in KiB on ROCm 7.x
-                    v *= 1024.0
-                vals[counter] = v
-            res["traffic"] = 2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]
-            res["traffic_source"] = ("rocprofv3 --pmc child processes of this run (tools/pmc_spmv_sym.py 256 grid): FETCH_SIZE x 2 "
-                                     "(calibrated, profiles/r02a_pmc_calibration_and_march.json) + WRITE_SIZE; counts Infinity-Cache hits")
-            res["traffic_over_kernel_min"] = res["traffic"] / own_bytes
-            return res
+                for k, (_, least) in kernels.items():
+                    if not got[k]:
+                        continue
+                    v = sum(got[k]) / len(got[k])
+                    if least > 0 and v * 1024.0 < 64.0 * least:       # the counter is reported in KiB on ROCm 7.x
+                        v *= 1024.0
+                    vals[k][counter] = v
+            for k, (_, least) in kernels.items():
+                if len(vals[k]) == 2 and least > 0:
+                    res[k]["traffic"] = 2.0 * vals[k]["FETCH_SIZE"] + vals[k]["WRITE_SIZE"]
+                    res[k]["traffic_source"] = ("rocprofv3 --pmc child processes of this run (tools/pmc_spmv_sym.py 256 grid): FETCH_SIZE x 2 "
+                                                "(calibrated, profiles/r02a_pmc_calibration_and_march.json) + WRITE_SIZE; counts Infinity-Cache hits")
+                    res[k]["traffic_over_kernel_min"] = res[k]["traffic"] / least
+            if res["product"]["traffic"] is not None:
+                return res
         except Exception as e:      # noqa: BLE001 - the bench line must still be printed
-            res["traffic_error"] = repr(e)[:200]
+            res["product"]["traffic_error"] = repr(e)[:200]
     if os.path.exists(fallback):
         with open(fallback) as f:
-            res["traffic"] = json.load(f)["hbm_bytes_per_launch"]
-        res["traffic_source"] = "profiles/pmc_spmv_latest.json (separate rocprofv3 --pmc passes, not this run)"
-        res["traffic_over_kernel_min"] = res["traffic"] / own_bytes
+            saved = json.load(f)
+        for k, (_, least) in kernels.items():
+            key = "hbm_bytes_per_launch" if k == "product" else "update_hbm_bytes_per_launch"
+            if saved.get(key) and least > 0:
+                res[k]["traffic"] = saved[key]
+                res[k]["traffic_source"] = "profiles/pmc_spmv_latest.json (separate rocprofv3 --pmc passes, not this run)"
+                res[k]["traffic_over_kernel_min"] = res[k]["traffic"] / least
     return res
 
 

@@ -325,6 +325,10 @@ int pgd_prof_read(pgd_handle ctx, int64_t *launches, double *seconds, double *al
  * symmetric half storage: 8 W + 16..18 B per row; CSR forms: 12 or 8 B per entry + 20..22 B per row): the
  * physical numerator of roofline.frac when the kernel does not stream the CSR arrays.              */
 int pgd_prof_read_own(pgd_handle ctx, double *own_bytes);
+/* ... and the same for the vector update of the single-sync recurrence (k_pcg1_update: x += alpha p, r -= alpha q,
+ * p = r + beta p and the partial sums of r.r in ONE kernel): launches timed, their seconds, and 56 B per row (4 vectors
+ * read, 3 written) - the kernel that takes most of a PCG iteration once the product reads a code byte per row.   */
+int pgd_prof_read_update(pgd_handle ctx, int64_t *launches, double *seconds, double *bytes);
 /* Launch counts per product kernel family since the context was created: [0] k_spmv_csr, [1] k_spmv_csr_dict*,
  * [2] k_spmv_sym (row order), [3] k_spmv_dia_rows, [4] k_spmv_dia_march*, [5] k_spmv_multi, [6] k_spmv_diac_march2; tests use them to
  * prove which kernel a call reached, bench.py for its per-kernel breakdown.                          */

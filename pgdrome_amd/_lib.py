@@ -98,6 +98,7 @@ SIGNATURES = {
     "pgd_prof_enable": (C.c_int, [H, C.c_int]),
     "pgd_prof_read": (C.c_int, [H, PI64, PD, PD]),
     "pgd_prof_read_own": (C.c_int, [H, PD]),
+    "pgd_prof_read_update": (C.c_int, [H, PI64, PD, PD]),
     "pgd_kernel_counts": (C.c_int, [H, PI64, C.c_int]),
     "pgd_calib_stream": (C.c_int, [H, H, C.c_int, C.c_int]),
     "pgd_timer_start": (C.c_int, [H]),
@@ -526,7 +527,10 @@ class Context:
         self._ck(self.lib.pgd_prof_read(self.h, C.byref(n), C.byref(s), C.byref(b)))
         own = F64()
         self._ck(self.lib.pgd_prof_read_own(self.h, C.byref(own)))
-        return dict(launches=n.value, seconds=s.value, bytes=b.value, own_bytes=own.value)
+        un, us, ub = I64(), F64(), F64()
+        self._ck(self.lib.pgd_prof_read_update(self.h, C.byref(un), C.byref(us), C.byref(ub)))
+        return dict(launches=n.value, seconds=s.value, bytes=b.value, own_bytes=own.value,
+                    update_launches=un.value, update_seconds=us.value, update_bytes=ub.value)
 
     KERNEL_FAMILIES = ("csr", "csr_dict", "sym_rows", "dia_rows", "dia_march", "multi", "diac_march")
 

@@ -114,7 +114,8 @@ void prof_flush(Ctx *c) {
     (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess) c->prof_seconds += 1e-3 * ms;
+        if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess)
+            (c->ev_kind[i / 2] ? c->prof_upd_seconds : c->prof_seconds) += 1e-3 * ms;
     }
     c->ev_used = 0;
 }
@@ -325,7 +326,10 @@ int pgd_prof_enable(pgd_handle h, int on) {
         c->prof_seconds = 0.0;
         c->prof_bytes = 0.0;
         c->prof_own_bytes = 0.0;
+        c->prof_upd_launches = 0;
+        c->prof_upd_seconds = c->prof_upd_bytes = 0.0;
         if (c->ev.empty()) {
+            c->ev_kind.assign(1024, 0);
             c->ev.resize(2048);
             for (auto &e : c->ev) PGD_HIP(c, hipEventCreate(&e));
         }
@@ -339,6 +343,15 @@ int pgd_prof_read(pgd_handle h, int64_t *launches, double *seconds, double *byte
     if (launches) *launches = c->prof_launches;
     if (seconds) *seconds = c->prof_seconds;
     if (bytes) *bytes = c->prof_bytes;
+    return PGD_OK;
+}
+
+int pgd_prof_read_update(pgd_handle h, int64_t *launches, double *seconds, double *bytes) {
+    PGD_CTX(c, h);
+    prof_flush(c);
+    if (launches) *launches = c->prof_upd_launches;
+    if (seconds) *seconds = c->prof_upd_seconds;
+    if (bytes) *bytes = c->prof_upd_bytes;
     return PGD_OK;
 }
 

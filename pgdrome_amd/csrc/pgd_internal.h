@@ -180,7 +180,10 @@ struct Ctx {
     bool prof = false;
     bool prof_pcg_only = false;   // time only the PCG instance k_spmv_csr<dot,store>
     std::vector<hipEvent_t> ev;   // pairs
+    std::vector<uint8_t> ev_kind; // per pair: 0 = a product launch, 1 = the vector update of the single-sync recurrence
     size_t ev_used = 0;
+    int64_t prof_upd_launches = 0, prof_upd_seen = 0;   // k_pcg1_update, timed like the products (one launch in four)
+    double prof_upd_seconds = 0.0, prof_upd_bytes = 0.0;
     int64_t prof_launches = 0, prof_seen = 0;
     double prof_seconds = 0.0, prof_bytes = 0.0;
     double prof_own_bytes = 0.0;  // least bytes the kernels that were timed must move in their own storage form

@@ -1148,7 +1148,20 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
                     nparts = nb;
                 }
                 k_pcg1_scalars<<<1, 1024, 0, c->stream>>>(prod, nparts, part2, g2v, c->slots, c->flags);
+                // launch timing on: one update in four between HIP events, like the products (7 vector passes = 56 B per row)
+                const bool timed_u = c->prof && ((c->prof_upd_seen++ & 3) == 0);
+                if (timed_u) {
+                    if (c->ev_used + 2 > c->ev.size()) prof_flush(c);
+                    c->ev_kind[c->ev_used / 2] = 1;
+                    PGD_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+                }
                 k_pcg1_update<<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags);
+                if (timed_u) {
+                    PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+                    c->ev_used += 2;
+                    c->prof_upd_launches += 1;
+                    c->prof_upd_bytes += 56.0 * (double)n;
+                }
                 PGD_LAUNCH_CHECK(c);
                 continue;
             }

@@ -299,6 +299,7 @@ static int prof_begin(Ctx *c, bool dot, bool store, bool *timed) {
     *timed = candidate && ((c->prof_seen++ & 3) == 0);
     if (*timed) {
         if (c->ev_used + 2 > c->ev.size()) prof_flush(c);
+        c->ev_kind[c->ev_used / 2] = 0;
         PGD_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
     }
     return PGD_OK;
