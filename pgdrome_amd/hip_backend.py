@@ -16,6 +16,12 @@ class HipBackend:
         self.ctx = _lib.Context(device, stream)
         self.device = device
         self.stream = stream          # external HIP stream handle (None: the library's own stream)
+        # PGD_TUNE="knob=value,knob=value": pgd_tune() calls on every context (A/B runs of whole solves without code
+        # changes; the knobs select kernels and summation groupings, never a different result beyond rounding)
+        import os
+        for item in filter(None, os.environ.get("PGD_TUNE", "").split(",")):
+            knob, value = item.split("=")
+            self.ctx.tune(int(knob), int(value))
 
     # ---- meshes
     def mesh(self, coords, cells):
