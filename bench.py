@@ -201,7 +201,7 @@ def main():
     own = prof["own_bytes"] / launches                       # least bytes that kernel must move, per launch
     alg = prof["bytes"] / launches                           # 12 nnz + 20 n for the rows covered
     achieved = own / avg / 1e9 if avg > 0 else 0.0
-    # the vector update of the single-sync recurrence (x, r, p in one kernel: 4 vectors read, 3 written = 56 B per row)
+    # the vector update of the single-sync recurrence (r, p and - every other launch - x in one kernel: 40 / 56 B per row)
     upd_n = prof.get("update_launches", 0)
     upd_avg = prof["update_seconds"] / upd_n if upd_n else 0.0
     upd_bytes = prof["update_bytes"] / upd_n if upd_n else 0.0
@@ -250,8 +250,9 @@ def main():
         # product's keeps its fields, unchanged, under roofline.spmv.
         spmv = out["roofline"]
         out["roofline"] = {"bound": "hbm",
-                           "kernel": "k_pcg1_update (single-sync recurrence: x += alpha p, r -= alpha q, p = r + beta p, partial sums of r.r; "
-                                     "16-byte accesses, 4 vectors read + 3 written)",
+                           "kernel": "k_pcg1_update (single-sync recurrence: r -= alpha q, p = r + beta p, partial sums of r.r, and x += alpha p "
+                                     "as a two-term update in every other launch; 16-byte accesses; 3 vectors read + 2 written, or 4 + 3: "
+                                     "averages over both kinds of launch)",
                            "achieved": upd_achieved, "peak": 8000.0, "unit": "GB/s", "frac": upd_achieved / 8000.0, "traffic": None,
                            "launches": upd_n, "avg_launch_us": 1e6 * upd_avg, "bytes_per_launch": upd_bytes,
                            "bytes_per_row": upd_bytes / max(rows_local, 1),

@@ -278,6 +278,10 @@ enum {
     PGD_TUNE_PCG_SCALED = 10,   /* 1 (default): pgd_pcg_solve runs CG on D^-1/2 A D^-1/2 (the same iterates as Jacobi-PCG,
                                    two vector passes per iteration fewer) when the symmetric storage applies; 0: unscaled */
     PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */
+    PGD_TUNE_PCG_LAG_X = 22,   /* 1 (default): in the single-sync recurrence of pgd_pcg_solve x - an output accumulator that nothing of the
+                                recurrence reads - is updated every OTHER iteration with two terms, the earlier direction taken back out of
+                                p = r + beta' p' (5 + 7 instead of 7 + 7 vector passes per two iterations); residuals, directions, alpha, beta and
+                                iteration counts are bit-identical to 0, x agrees to the rounding of its own updates */
     PGD_TUNE_SPMV_ZCHUNK_CODED = 21, /* k_spmv_diac_march2: most planes per workgroup march (default 24; whole threes, fewer while that keeps
                                 ~2 launches of workgroups per slot); PGD_TUNE_SPMV_ZCHUNK_FORCE overrides it too */
     PGD_TUNE_ASM_LATTICE = 20, /* 1 (default): on a 3-D structured vertex grid whose coordinates are origin + index * step per axis (to 8 ulp,

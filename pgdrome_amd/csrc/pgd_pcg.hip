@@ -592,10 +592,12 @@ __global__ __launch_bounds__(TPB) void k_pcg_px_s(double *__restrict__ x, double
 // same vector kernel, feeds the next alpha and the stop test, so nothing accumulates.  Iterates equal the textbook ones
 // up to rounding.  Slots: S1_RZ (measured r~.r~ of the current residual), S1_RR (its true r.r, exact phase),
 // S1_ALPHA, S1_BETA.
-enum { S1_RZ = 24, S1_RR = 25, S1_ALPHA = 26, S1_BETA = 27, S1_PQ = 28, S1_QQ = 29 };
+enum { S1_RZ = 24, S1_RR = 25, S1_ALPHA = 26, S1_BETA = 27, S1_PQ = 28, S1_QQ = 29,
+       S1_ALPHA_PREV = 40, S1_BETA_PREV = 41, S1_PEND = 42 };      // the lagged x update (below)
+constexpr double LAG_MIN_BETA = 0.01;
 
 __device__ __forceinline__ void pcg1_finish(double *slots, int *flags, double pq, double qq, double rz, double rr, int slot_alpha,
-                                            int slot_beta) {
+                                            int slot_beta, bool keep_prev = false) {
     const double tol2 = slots[S_TOL2];
     if (!(rz == rz) || !(pq == pq)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; return; }
     if (flags[3]) { if (rr <= tol2) { flags[0] = 1; return; } }
@@ -604,6 +606,7 @@ __device__ __forceinline__ void pcg1_finish(double *slots, int *flags, double pq
     const double alpha = rz / pq;
     double rnew = alpha * alpha * qq - rz;
     if (!(rnew > 0.0)) rnew = 0.0;                      // rounding below zero (beta at the eps level): a steepest-descent restart
+    if (keep_prev) { slots[S1_ALPHA_PREV] = slots[slot_alpha]; slots[S1_BETA_PREV] = slots[slot_beta]; }   // the lagged x update needs them
     slots[slot_alpha] = alpha;
     slots[slot_beta] = rnew / rz;
     flags[1] += 1;
@@ -637,7 +640,7 @@ __global__ __launch_bounds__(1024) void k_pcg1_scalars(const double *__restrict_
     for (int v = 0; v < 4; ++v) out[v] = (s_w[4 * v] + s_w[4 * v + 1]) + (s_w[4 * v + 2] + s_w[4 * v + 3]);
     if (threadIdx.x != 0) return;
     slots[S1_PQ] = out[0]; slots[S1_QQ] = out[1]; slots[S1_RZ] = out[2]; slots[S1_RR] = out[3];
-    pcg1_finish(slots, flags, out[0], out[1], out[2], out[3], S1_ALPHA, S1_BETA);
+    pcg1_finish(slots, flags, out[0], out[1], out[2], out[3], S1_ALPHA, S1_BETA, true);
 }
 
 // the row-sharded solve splits the same step around its all-reduce: local sums -> slots[base .. base + 3] (+ a zero) ...
@@ -681,27 +684,42 @@ __global__ void k_pcg1_tol(double *__restrict__ slots, int *__restrict__ flags, 
     else if (rr <= slots[S_TOL2]) flags[0] = 1;
 }
 
-// x += alpha p; r -= alpha q; p = r + beta p; partial sums (r~.r~, exact phase ? sum r^2 / s^2 : r~.r~) of the new residual
+// x += alpha p; r -= alpha q; p = r + beta p; partial sums (r~.r~, exact phase ? sum r^2 / s^2 : r~.r~) of the new residual.
+// LAGGED x UPDATE (lag = 1 / 2, pgd_pcg_solve on large structured systems): x is an output accumulator - nothing of the
+// recurrence (r, p, q, alpha, beta, the stop test) reads it - so it need not be touched in every iteration.  Iterations with an
+// even index (lag = 1) leave x alone when beta >= LAG_MIN_BETA: 5 vector passes instead of 7; the next iteration (lag = 2) adds
+// both terms, x += alpha' p' + alpha p, with the previous direction taken back out of the recurrence that formed the present
+// one: p = r + beta' p'  =>  p' = (p - r) / beta' (r and p being what this kernel reads anyway, alpha' and beta' kept by
+// k_pcg1_scalars).  The rounding of p' is eps |p| / beta' <= 100 eps |p|: the two-term update differs from two single ones at
+// the level of the rounding of x itself.  slots[S1_PEND] (written by workgroup 0 of the lag = 1 launches, read by the lag = 2
+// ones and by k_scale_out when the solve ends between the two) says whether a term is outstanding.  lag = 0: every iteration.
 __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
                                                      const double *__restrict__ q, const double *__restrict__ s, int64_t lo,
-                                                     int64_t hi, const double *__restrict__ slots, int slot_alpha, int slot_beta,
-                                                     double *__restrict__ partials, const int *__restrict__ flags) {
+                                                     int64_t hi, double *__restrict__ slots, int slot_alpha, int slot_beta,
+                                                     double *__restrict__ partials, const int *__restrict__ flags, int lag) {
     if (flags[0]) return;
     __shared__ double s_red[4];
     typedef double d2 __attribute__((ext_vector_type(2)));
     const double alpha = slots[slot_alpha], beta = slots[slot_beta];
     const bool exact = flags[3] != 0;
+    const bool skip_x = lag == 1 && beta >= LAG_MIN_BETA;
+    const bool two = lag == 2 && slots[S1_PEND] != 0.0;
+    const double alpha_p = two ? slots[S1_ALPHA_PREV] : 0.0, ibeta_p = two ? 1.0 / slots[S1_BETA_PREV] : 0.0;
     double rz = 0.0, rr = 0.0;
     if ((lo & 1) == 0) {                                  // 16-byte accesses (row ranges of the sharded solve may start odd)
         const int64_t npair = (hi - lo) >> 1;
         for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < npair; k += (int64_t)gridDim.x * TPB) {
             const int64_t i = lo + 2 * k;
             const d2 qi = *reinterpret_cast<const d2 *>(q + i);
-            d2 pi = *reinterpret_cast<d2 *>(p + i), xi = *reinterpret_cast<d2 *>(x + i), ri = *reinterpret_cast<d2 *>(r + i);
-            xi.x = fma(alpha, pi.x, xi.x); xi.y = fma(alpha, pi.y, xi.y);
+            d2 pi = *reinterpret_cast<d2 *>(p + i), ri = *reinterpret_cast<d2 *>(r + i);
+            if (!skip_x) {                                // uniform
+                d2 xi = *reinterpret_cast<d2 *>(x + i);
+                if (two) { xi.x = fma(alpha_p, (pi.x - ri.x) * ibeta_p, xi.x); xi.y = fma(alpha_p, (pi.y - ri.y) * ibeta_p, xi.y); }
+                xi.x = fma(alpha, pi.x, xi.x); xi.y = fma(alpha, pi.y, xi.y);
+                *reinterpret_cast<d2 *>(x + i) = xi;
+            }
             ri.x = fma(-alpha, qi.x, ri.x); ri.y = fma(-alpha, qi.y, ri.y);
             pi.x = fma(beta, pi.x, ri.x); pi.y = fma(beta, pi.y, ri.y);
-            *reinterpret_cast<d2 *>(x + i) = xi;
             *reinterpret_cast<d2 *>(r + i) = ri;
             *reinterpret_cast<d2 *>(p + i) = pi;
             rz = fma(ri.x, ri.x, rz); rz = fma(ri.y, ri.y, rz);
@@ -714,16 +732,22 @@ __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, dou
     }
     const int64_t tail0 = (lo & 1) == 0 ? lo + 2 * ((hi - lo) >> 1) : lo;      // what the pair loop left: one row, or all of them
     for (int64_t i = tail0 + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB) {
-        x[i] = fma(alpha, p[i], x[i]);
-        const double ri = fma(-alpha, q[i], r[i]);
+        const double pi = p[i], r0 = r[i];
+        if (!skip_x) {
+            double xi = x[i];
+            if (two) xi = fma(alpha_p, (pi - r0) * ibeta_p, xi);
+            x[i] = fma(alpha, pi, xi);
+        }
+        const double ri = fma(-alpha, q[i], r0);
         r[i] = ri;
-        p[i] = fma(beta, p[i], ri);
+        p[i] = fma(beta, pi, ri);
         rz = fma(ri, ri, rz);
         if (exact) { const double t = ri / s[i]; rr = fma(t, t, rr); }
     }
     rz = block_sum(rz, s_red);
     rr = block_sum(rr, s_red);
     if (threadIdx.x == 0) { partials[2 * blockIdx.x] = rz; partials[2 * blockIdx.x + 1] = exact ? rr : rz; }
+    if (lag == 1 && blockIdx.x == 0 && threadIdx.x == 0) slots[S1_PEND] = skip_x ? 1.0 : 0.0;
 }
 
 // before the first iteration: the initial residual's (r~.r~, true r.r) as the one non-zero pair of the vector partials
@@ -737,15 +761,21 @@ __global__ void k_pcg1_seed(double *__restrict__ partials, int npairs, const dou
 // x <- s x (back to the unscaled unknown); partial sum r^2 / s^2 (the true r.r, for the report)
 // p != nullptr: the x update of the last iteration is still pending (k_pcg_px_s was a no-op once the done flag was set):
 // x <- s (x + alpha p) with alpha = S[slot_rz] / S[slot_pq] of that iteration
+// lagged != 0 (with p): the solve ended after a k_pcg1_update that left x alone (slots[S1_PEND] says whether it did): the
+// outstanding term is alpha p' with p' = (p - r) / beta of that iteration, whose alpha and beta are still in their slots
 __global__ __launch_bounds__(TPB) void k_scale_out(double *__restrict__ x, const double *__restrict__ r, const double *__restrict__ s,
                                                    int64_t n, double *__restrict__ partials, const double *__restrict__ p,
-                                                   const double *__restrict__ slots, int slot_rz, int slot_pq) {
+                                                   const double *__restrict__ slots, int slot_rz, int slot_pq, int lagged) {
     __shared__ double s_red[4];
     double rr = 0.0;
-    const double alpha = p ? slots[slot_rz] / slots[slot_pq] : 0.0;
+    const bool lag_term = lagged && p && slots[S1_PEND] != 0.0;
+    const double alpha = lagged ? (lag_term ? slots[S1_ALPHA] : 0.0) : p ? slots[slot_rz] / slots[slot_pq] : 0.0;
+    const double ibeta = lag_term ? 1.0 / slots[S1_BETA] : 0.0;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
-        const double si = s[i], t = r[i] / si;
-        const double xi = p ? fma(alpha, p[i], x[i]) : x[i];
+        const double si = s[i], ri = r[i], t = ri / si;
+        double xi = x[i];
+        if (lag_term) xi = fma(alpha, (p[i] - ri) * ibeta, xi);
+        else if (p && !lagged) xi = fma(alpha, p[i], xi);
         x[i] = xi * si;
         rr = fma(t, t, rr);
     }
@@ -960,7 +990,7 @@ int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const 
     if (hi == lo) return PGD_OK;
     const int g = grid_for((hi - lo + 1) / 2);
     PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS));
-    k_pcg1_update<<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags);
+    k_pcg1_update<<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, 0);
     PGD_LAUNCH_CHECK(c);
     *nblocks = g;
     return PGD_OK;
@@ -1124,6 +1154,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     const bool folded_form = scaled && c->pcg_fold_reduce && n <= ((int64_t)1 << 20);
     const bool single_sync = scaled && c->pcg_single_sync && !folded_form && m->sym_nx > 0;
     const bool deferred_x = scaled && c->pcg_defer_x && !folded_form && !single_sync;
+    const bool lag_x = single_sync && c->pcg_lag_x;
     const int g2v = grid_for((n + 1) / 2);
     if (single_sync) {
         // the first look at the residual happens in the first k_pcg1_scalars: hand it the initial residual's sums
@@ -1148,19 +1179,21 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
                     nparts = nb;
                 }
                 k_pcg1_scalars<<<1, 1024, 0, c->stream>>>(prod, nparts, part2, g2v, c->slots, c->flags);
-                // launch timing on: one update in four between HIP events, like the products (7 vector passes = 56 B per row)
-                const bool timed_u = c->prof && ((c->prof_upd_seen++ & 3) == 0);
+                // launch timing on: every third update between HIP events (5 or 7 vector passes = 40 or 56 B per row)
+                const bool timed_u = c->prof && ((c->prof_upd_seen++ % 3) == 0);        // one in three: both halves of the x-update pairs get sampled
                 if (timed_u) {
                     if (c->ev_used + 2 > c->ev.size()) prof_flush(c);
                     c->ev_kind[c->ev_used / 2] = 1;
                     PGD_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
                 }
-                k_pcg1_update<<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags);
+                // the x update lags behind by one iteration in every other one (chunks start at even iteration indices)
+                const int lag = lag_x ? 1 + ((start + k) & 1) : 0;
+                k_pcg1_update<<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags, lag);
                 if (timed_u) {
                     PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
                     c->ev_used += 2;
                     c->prof_upd_launches += 1;
-                    c->prof_upd_bytes += 56.0 * (double)n;
+                    c->prof_upd_bytes += (lag == 1 ? 40.0 : 56.0) * (double)n;      // (a lag = 1 launch that meets beta < 0.01 moves 56)
                 }
                 PGD_LAUNCH_CHECK(c);
                 continue;
@@ -1244,8 +1277,10 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         guard.active = false;
         // converged (or broke down) inside an iteration whose p kernel was a no-op: its x update is still to come
         const bool pending = deferred_x && f[0] != 0 && f[1] > 0;
-        k_scale_out<<<g, TPB, 0, c->stream>>>(x->d, r, sc, n, c->partials, pending ? p : nullptr, c->slots,
-                                              S_PAIR + 2 * (f[1] & 1), S_PQ);
+        // lagged x update: f[1] update kernels ran; if the last one had an even index it may have left its term outstanding
+        const bool lag_pending = lag_x && f[1] > 0 && ((f[1] - 1) & 1) == 0;
+        k_scale_out<<<g, TPB, 0, c->stream>>>(x->d, r, sc, n, c->partials, (pending || lag_pending) ? p : nullptr, c->slots,
+                                              S_PAIR + 2 * (f[1] & 1), S_PQ, lag_pending ? 1 : 0);
         PGD_LAUNCH_CHECK(c);
         PGD_TRY(reduce_partials(c, c->partials, g, 1, S_TMP, -1, 0, 0));
         o->uvals_valid = false;        // the slot arrays hold the scaled operator: nobody else may take them for A

@@ -881,6 +881,62 @@ def test_pcg_on_row_classes_is_bit_identical(ctx):
     ctx.mesh_free(h)
 
 
+def test_lagged_x_update_leaves_the_recurrence_alone(ctx):
+    """Single-sync recurrence with x updated every other iteration (two terms, the earlier direction reconstructed from
+    p = r + beta' p'): iteration counts and reported residuals are IDENTICAL to the every-iteration update - nothing of the
+    recurrence reads x - and x agrees to rounding; also when the solve stops between the two halves of a pair (odd maxit:
+    the outstanding term is applied on the way out), on an even maxit, and on a converged start."""
+    from pgdrome_amd import fem
+    npts = 104
+    mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), npts - 1, npts - 1, npts - 1)
+    coords = mesh.coordinates()
+    h = ctx.mesh_upload(coords, mesh.cells())
+    n = coords.shape[0]
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bc = np.where(np.any((coords <= 1e-12) | (coords >= 1 - 1e-12), axis=1))[0].astype(np.int32)
+    rng = np.random.default_rng(31)
+    b = rng.uniform(-1, 1, n)
+    b[bc] = 0.0
+    x0 = 0.01 * rng.uniform(-1, 1, n)
+    x0[bc] = 0.0
+    bv = ctx.vec_from(b)
+    out = {}
+    try:
+        for lag in (1, 0):
+            ctx.tune(22, lag)
+            for maxit in (10000, 23, 24, 1, 2):
+                op = ctx.op_combine(h, [ak, am], [1.0, 3.0], bc)
+                xv = ctx.vec_from(x0)
+                it, rel = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, maxit)
+                out[(lag, maxit)] = (it, rel, ctx.vec_download(xv))
+                if maxit == 10000:
+                    it2, rel2 = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, maxit)
+                    out[(lag, "again")] = (it2, rel2, ctx.vec_download(xv))
+                    if lag:          # the true residual of the lagged solve through an independent kernel
+                        yv = ctx.vec_alloc(n)
+                        ctx.tune(3, 0)
+                        ctx.spmv(op, xv, yv)
+                        ctx.tune(3, 1)
+                        assert np.linalg.norm(b - ctx.vec_download(yv)) <= 1.05e-10 * np.linalg.norm(b)
+                        ctx.vec_free(yv)
+                ctx.vec_free(xv)
+                ctx.atom_free(op)
+    finally:
+        ctx.tune(22, 1)
+    for key in (10000, 23, 24, 1, 2, "again"):
+        a, c = out[(1, key)], out[(0, key)]
+        if key == "again":       # starts from the solution of the run before, which differs in the last bits
+            assert a[0] == c[0] and abs(a[1] - c[1]) <= 1e-6 * c[1], (key, a[:2], c[:2])
+        else:
+            assert a[0] == c[0] and a[1] == c[1], (key, a[:2], c[:2])
+        assert np.linalg.norm(a[2] - c[2]) <= 1e-13 * np.linalg.norm(c[2]), (key, np.linalg.norm(a[2] - c[2]) / np.linalg.norm(c[2]))
+    assert out[(1, 23)][0] == 23 and out[(1, 24)][0] == 24 and out[(1, "again")][0] <= 1 and out[(1, 10000)][1] <= 1e-10
+    ctx.vec_free(bv)
+    for a in (ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
 def test_vector_ops(ctx):
     rng = np.random.default_rng(5)
     for n in (1, 63, 64, 257, 100_003):
