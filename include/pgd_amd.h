@@ -278,6 +278,9 @@ enum {
     PGD_TUNE_PCG_SCALED = 10,   /* 1 (default): pgd_pcg_solve runs CG on D^-1/2 A D^-1/2 (the same iterates as Jacobi-PCG,
                                    two vector passes per iteration fewer) when the symmetric storage applies; 0: unscaled */
     PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */
+    PGD_TUNE_PCG_STREAM_HINTS = 23, /* 1 (default): in the single-sync recurrence q, r and x - vectors no other kernel of the iteration touches -
+                                are read and written with non-temporal hints, p (read by the product next) keeps the default policy and so its
+                                place in the Infinity Cache; same arithmetic, bit-identical results */
     PGD_TUNE_PCG_LAG_X = 22,   /* 1 (default): in the single-sync recurrence of pgd_pcg_solve x - an output accumulator that nothing of the
                                 recurrence reads - is updated every OTHER iteration with two terms, the earlier direction taken back out of
                                 p = r + beta' p' (5 + 7 instead of 7 + 7 vector passes per two iterations); residuals, directions, alpha, beta and

@@ -894,6 +894,7 @@ struct DiacArgs {
     int nx, ny, nz;
     int z0, z1, zchunk, tiles_x, tiles_y;
     int qq;
+    int nt_y;               // y is stored with the non-temporal hint
 };
 
 // A kernel this light is paced by instruction issue and by the bytes a CU keeps in flight, so the march is built around
@@ -1039,8 +1040,13 @@ __global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
         acc1 = fma(T.B37.y, xp[2 * DM_HX + 1], acc1);
         const bool on = z < zb;                             // (the march runs in threes: up to two idle steps behind the last plane)
         double *yz = A.y + P * (on ? z : za);
-        if (STORE && live0 && on) yz[base0] = acc0;
-        if (STORE && live1 && on) yz[base1] = acc1;
+        if (A.nt_y) {
+            if (STORE && live0 && on) __builtin_nontemporal_store(acc0, yz + base0);
+            if (STORE && live1 && on) __builtin_nontemporal_store(acc1, yz + base1);
+        } else {
+            if (STORE && live0 && on) yz[base0] = acc0;
+            if (STORE && live1 && on) yz[base1] = acc1;
+        }
         if (DOT) {
             const double d0 = (live0 && on) ? acc0 : 0.0, d1 = (live1 && on) ? acc1 : 0.0;      // + 0 * x: the sums are unchanged
             dot = fma(d0, xa, dot); dot2 = fma(d0, d0, dot2);
@@ -1563,6 +1569,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
                 E.cls = a->cls; E.same = a->cls_same; E.table = a->cls_table; E.ncls = a->cls_count; E.x = x; E.y = y; E.partials = D.partials; E.flags = flags;
                 E.nx = D.nx; E.ny = D.ny; E.nz = D.nz; E.z0 = D.z0; E.z1 = D.z1; E.zchunk = zchunk_c; E.tiles_x = D.tiles_x; E.tiles_y = D.tiles_y;
                 E.qq = D.qq;
+                E.nt_y = (D.qq && c->pcg_stream_hints) ? 1 : 0;      // the PCG's q: read once, by the vector update (+ 1 %)
                 if (nparts_out) *nparts_out = wgs_c;
                 if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + (D.qq ? 2 : 1) * (int64_t)wgs_c, 4 * MAX_VEC_BLOCKS)));
                 E.partials = c->partials + c->partials_off;
@@ -1718,6 +1725,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_SPMV_ROW_CLASSES && value >= 0 && value <= 1) { c->spmv_classes = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_ASM_LATTICE && value >= 0 && value <= 1) { c->asm_lattice = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_LAG_X && value >= 0 && value <= 1) { c->pcg_lag_x = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_PCG_STREAM_HINTS && value >= 0 && value <= 1) { c->pcg_stream_hints = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK_CODED && value >= 3 && value <= 1024) { c->spmv_zchunk_coded = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }

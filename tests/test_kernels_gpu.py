@@ -921,8 +921,19 @@ def test_lagged_x_update_leaves_the_recurrence_alone(ctx):
                         ctx.vec_free(yv)
                 ctx.vec_free(xv)
                 ctx.atom_free(op)
+        # the cache hints of the recurrence (q, r, x streamed, p cached) change no bit
+        ctx.tune(22, 1)
+        ctx.tune(23, 0)
+        op = ctx.op_combine(h, [ak, am], [1.0, 3.0], bc)
+        xv = ctx.vec_from(x0)
+        it, rel = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, 10000)
+        a = out[(1, 10000)]
+        assert it == a[0] and rel == a[1] and np.array_equal(ctx.vec_download(xv), a[2])
+        ctx.vec_free(xv)
+        ctx.atom_free(op)
     finally:
         ctx.tune(22, 1)
+        ctx.tune(23, 1)
     for key in (10000, 23, 24, 1, 2, "again"):
         a, c = out[(1, key)], out[(0, key)]
         if key == "again":       # starts from the solution of the run before, which differs in the last bits
