@@ -90,7 +90,7 @@ int pgd_mesh_pattern_download(pgd_handle ctx, pgd_handle mesh, int32_t *row_ptr,
 int pgd_mesh_dict_count(pgd_handle ctx, pgd_handle mesh, int32_t *count);
 /* Which form of the SPD product the mesh's patterns allow: slots = 0 (CSR kernels only), 4 or 8 upper slots
  * per row of the symmetric half storage (k_spmv_sym); nx, ny > 0 when the rows also form a full structured
- * vertex grid (row = x + nx y + nx ny z): k_spmv_sym_grid3 marches along z with its x planes in LDS.          */
+ * vertex grid (row = x + nx y + nx ny z): k_spmv_dia_march2 / k_spmv_diac_march2 march along z with x planes in LDS. */
 int pgd_mesh_sym_info(pgd_handle ctx, pgd_handle mesh, int32_t *slots, int32_t *nx, int32_t *ny);
 /* *is_lattice = 1 when the mesh is a 3-D structured vertex grid whose coordinates are origin + index * steps[axis] to within
  * 8 ulp (see PGD_TUNE_ASM_LATTICE); steps: 3 doubles (zeros otherwise).                                       */
@@ -311,7 +311,7 @@ enum {
                                   (symmetric half) storage from the atoms' diagonal forms; 0: converted from CSR per solve */
     PGD_TUNE_SPMV_VARIANT = 13, /* the z-march: 0 (default) k_spmv_dia_march2, 64 x 8 patches, 256 threads, two rows per thread;
                                    1: k_spmv_dia_march<8>, 64 x 8 patches, 512 threads; 2: k_spmv_dia_march<4>, 64 x 4 patches, 256 threads */
-    PGD_TUNE_SPMV_ZCHUNK = 6,   /* k_spmv_sym_grid3 (structured vertex grids, x planes in LDS): most planes per
+    PGD_TUNE_SPMV_ZCHUNK = 6,   /* k_spmv_dia_march* (structured vertex grids, x planes in LDS): most planes per
                                    workgroup march (default 8; fewer while that keeps 4 workgroups per CU); 0 = off */
     PGD_TUNE_SPMV_SYM = 3,   /* 1 (default): the products of the SPD solves (pgd_pcg_solve, pgd_pcg_solve_sharded,
                                 pgd_spmv_dot_slot after pgd_op_symmetrize) read the operator from its symmetric

@@ -158,7 +158,7 @@ struct Ctx {
     int num_cu = 256;
     int spmv_dict = 1;            // use the column dictionary when the mesh has one
     int spmv_rows = 64;           // rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256
-    int64_t spmv_grid_min_plane_bytes = 0;   // structured grids whose planes of values are at least this large take k_spmv_sym_grid3
+    int64_t spmv_grid_min_plane_bytes = 0;   // structured grids whose planes of values are at least this large take the z-march (k_spmv_dia_march*)
     int spmv_zchunk_force = 0;    // > 0: exactly this many planes per march whatever the grid size (tests)
     int fault_iteration = -1;     // tests: pgd_pcg_solve_sharded fails on this rank in that iteration (once)
     int pcg_stream_hints = 1;     // single-sync recurrence: q, r, x non-temporal, p cached (PGD_TUNE_PCG_STREAM_HINTS)
