@@ -477,7 +477,8 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
             did_ar = true;
             PGD_TRY(comm_allreduce(c, B, 5));
             PGD_TRY(pcg1_finish_slots(c, B));
-            PGD_TRY(pcg1_update(c, xd, rd, pd, qd, scp, own0, own1, B, &nb));
+            // (x is updated every other iteration, two terms at a time: k_pcg1_update; every rank reads the same beta)
+            PGD_TRY(pcg1_update(c, xd, rd, pd, qd, scp, own0, own1, B, &nb, c->pcg_lag_x ? 1 + (kidx & 1) : 0));
             return PGD_OK;
         }
         if (scaled && kidx > 0) {
@@ -532,6 +533,8 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         PGD_TRY(pgd_flags_download(h, &done, &it, &status));
     }
     if (status != 0) return fail(c, PGD_ERR_SINGULAR, "sharded PCG breakdown (NaN) after %d iterations", it);
+    if (ss && c->pcg_lag_x && it > 0 && ((it - 1) & 1) == 0)          // the last update had an even index: its term of x may be outstanding
+        PGD_TRY(pcg1_flush_x(c, xd, pd, rd, own0, own1, B));
     if (scaled) {
         guard.active = false;
         PGD_TRY(vec_div_mul(c, xd, scp, n, 1));                      // back to x = sc x~ (ghosts too; refreshed below)

@@ -224,7 +224,8 @@ int pcg1_tol(Ctx *c, int base, double rtol, double atol);
 int pcg1_sums(Ctx *c, int nprod, int nvec, int base);
 int pcg1_finish_slots(Ctx *c, int base);
 int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const double *sc, int64_t lo, int64_t hi, int base,
-                int *nblocks);
+                int *nblocks, int lag);
+int pcg1_flush_x(Ctx *c, double *x, const double *p, const double *r, int64_t lo, int64_t hi, int base);
 int vec_sqrt(Ctx *c, double *v, int64_t n);
 int vec_div_mul(Ctx *c, double *x, const double *sc, int64_t n, int mul);
 int dia_classify(Ctx *c, const Mesh *m, Csr *a);                // pgd_spmv.hip: row-class dictionary of the current slot values

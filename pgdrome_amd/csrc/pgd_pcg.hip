@@ -670,7 +670,7 @@ __global__ __launch_bounds__(1024) void k_pcg1_sums(const double *__restrict__ p
 __global__ void k_pcg1_finish(double *__restrict__ slots, int *__restrict__ flags, int base) {
     if (threadIdx.x != 0 || blockIdx.x != 0 || flags[0]) return;
     slots[6] = slots[base + 3];                          // the last measured true r.r, for the report
-    pcg1_finish(slots, flags, slots[base], slots[base + 1], slots[base + 2], slots[base + 3], base + 5, base + 6);
+    pcg1_finish(slots, flags, slots[base], slots[base + 1], slots[base + 2], slots[base + 3], base + 5, base + 6, true);
 }
 
 // initial residual of the sharded solve: tolerance from the all-reduced b.b, first stop test
@@ -991,15 +991,33 @@ int pcg1_finish_slots(Ctx *c, int base) {
 }
 
 int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const double *sc, int64_t lo, int64_t hi, int base,
-                int *nblocks) {
+                int *nblocks, int lag) {
     *nblocks = 0;
     if (hi == lo) return PGD_OK;
     const int g = grid_for((hi - lo + 1) / 2);
     PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS));
-    if (c->pcg_stream_hints) k_pcg1_update<true><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, 0);
-    else k_pcg1_update<false><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, 0);
+    if (c->pcg_stream_hints) k_pcg1_update<true><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, lag);
+    else k_pcg1_update<false><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, lag);
     PGD_LAUNCH_CHECK(c);
     *nblocks = g;
+    return PGD_OK;
+}
+
+// the sharded solve's way out when its last update left a term of x outstanding (lagged x update): x += alpha (p - r) / beta on
+// the owned rows, alpha and beta of that iteration still in their slots; a no-op when slots[S1_PEND] is 0
+__global__ __launch_bounds__(TPB) void k_pcg1_flush_x(double *__restrict__ x, const double *__restrict__ p, const double *__restrict__ r,
+                                                      int64_t lo, int64_t hi, const double *__restrict__ slots, int slot_alpha,
+                                                      int slot_beta) {
+    if (slots[S1_PEND] == 0.0) return;
+    const double alpha = slots[slot_alpha], ibeta = 1.0 / slots[slot_beta];
+    for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB)
+        x[i] = fma(alpha, (p[i] - r[i]) * ibeta, x[i]);
+}
+
+int pcg1_flush_x(Ctx *c, double *x, const double *p, const double *r, int64_t lo, int64_t hi, int base) {
+    if (hi == lo) return PGD_OK;
+    k_pcg1_flush_x<<<grid_for(hi - lo), TPB, 0, c->stream>>>(x, p, r, lo, hi, c->slots, base + 5, base + 6);
+    PGD_LAUNCH_CHECK(c);
     return PGD_OK;
 }
 
