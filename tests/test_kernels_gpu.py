@@ -1106,6 +1106,14 @@ def test_error_paths(ctx):
     bad[0, 0] = 77
     with pytest.raises(PgdError):
         ctx.mesh_upload(coords, bad)
+    # tetrahedra are validated on the device, before any kernel follows a vertex id
+    c3, t3 = F.box_mesh((0, 0, 0), (1, 1, 1), 3, 2, 2)
+    for wrong in (c3.shape[0], -1):
+        bad3 = t3.copy()
+        bad3[5, 2] = wrong
+        with pytest.raises(PgdError, match="out of range"):
+            ctx.mesh_upload(c3, bad3)
+    ctx.mesh_free(ctx.mesh_upload(c3, t3))
     h = ctx.mesh_upload(coords, cells)
     v = ctx.vec_alloc(3)
     a = ctx.atom_assemble(h, F.MASS)
