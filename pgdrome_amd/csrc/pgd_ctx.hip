@@ -183,6 +183,7 @@ int pgd_ctx_destroy(pgd_handle h) {
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->timer_ev) if (e) (void)hipEventDestroy(e);
     if (c->cls_scratch) (void)hipFree(c->cls_scratch);
+    if (c->gram_w) (void)hipFree(c->gram_w);
     for (void *p : {(void *)c->slots, (void *)c->flags, (void *)c->partials, (void *)c->mask,
                     (void *)c->ibuf})
         if (p) (void)hipFree(p);
