@@ -164,6 +164,7 @@ struct Ctx {
     int pcg_stream_hints = 1;     // single-sync recurrence: q, r, x non-temporal, p cached (PGD_TUNE_PCG_STREAM_HINTS)
     int pcg_lag_x = 1;            // single-sync recurrence: x is updated every other iteration, two terms at a time (PGD_TUNE_PCG_LAG_X)
     int asm_lattice = 1;          // lattice meshes: edge vectors as whole lattice steps in the assembly (PGD_TUNE_ASM_LATTICE)
+    int spmv_fetch_depth = 6;     // plane fetches in flight per workgroup of k_spmv_diac_march2 (3 or 6; PGD_TUNE_SPMV_FETCH_DEPTH)
     int spmv_zchunk_coded = 24;   // most planes per march of k_spmv_diac_march2 (PGD_TUNE_SPMV_ZCHUNK_CODED)
     int spmv_classes = 1;         // row-class dictionary of the scaled diagonal form (k_spmv_diac_march2) where the operator has one
     void *cls_scratch = nullptr;  // hash slots of dia_classify

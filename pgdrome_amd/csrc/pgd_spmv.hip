@@ -912,7 +912,7 @@ using d2 = __attribute__((ext_vector_type(2))) double;
 struct DiacT { d2 A15, A37, A26, A40, B15, B37, B26, B40, L15, L37, LB15, D26, LD37; };
 constexpr int DIAC_MAXCHUNK = 1024;    // planes per march at most (the per-plane flags of a march are staged in LDS)
 
-template <bool DOT, bool STORE>
+template <bool DOT, bool STORE, int D>
 __global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
     constexpr int NT = 256, PY = 8, HY = PY + 2, SLICE = DM_HX * HY;        // 660 cells per plane
     constexpr int SLOT = 3 * NT;                            // ... in slots of 768: every thread stages three cells, no predicates
@@ -977,20 +977,19 @@ __global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
     auto pair = [&](int code, int k) -> d2 { return *reinterpret_cast<const d2 *>(s_t + code * 8 + 2 * k); };
     DiacT T;
     double dot = 0.0, dot2 = 0.0;
-    double r0[3], r1[3], r2[3];                             // the three plane fetches in flight
-    unsigned k0[3], k1[3], k2[3];
-    fetch(za - 1, r0, k0);
-    fetch(za, r1, k1);
-    fetch(za + 1, r2, k2);
-    put(za - 1, r0, k0);
-    put(za, r1, k1);
-    put(za + 1, r2, k2);
-    fetch(za + 2, r0, k0);
-    fetch(za + 3, r1, k1);
-    fetch(za + 4, r2, k2);
+    double rr[D][3];                                        // the D plane fetches in flight (D = 3 or 6 register sets, rotating by name)
+    unsigned kk[D][3];
+    fetch(za - 1, rr[0], kk[0]);
+    fetch(za, rr[1], kk[1]);
+    fetch(za + 1, rr[2], kk[2]);
+    put(za - 1, rr[0], kk[0]);
+    put(za, rr[1], kk[1]);
+    put(za + 1, rr[2], kk[2]);
+#pragma unroll
+    for (int s = 0; s < D; ++s) fetch(za + 2 + s, rr[s], kk[s]);
     __syncthreads();
     double a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0, b4 = 0.0, b5 = 0.0, b6 = 0.0, b7 = 0.0;      // couplings to the plane below
-    // one step: rows of plane z; `rv / rk` hold plane z + 2 (staged at the end of the step) and then take the fetch of z + 5
+    // one step: rows of plane z; `rv / rk` hold plane z + 2 (staged at the end of the step) and then take the fetch of z + 2 + D
     auto step = [&](int z, double (&rv)[3], unsigned (&rk)[3]) {
         const bool look = slow(z);
         if (look) {                                         // uniform: look the couplings up (codes of planes z - 1 and z are staged)
@@ -1038,7 +1037,7 @@ __global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
         acc1 = fma(T.B15.y, xp[DM_HX + 1], acc1);
         acc1 = fma(T.B26.y, xp[2 * DM_HX], acc1);
         acc1 = fma(T.B37.y, xp[2 * DM_HX + 1], acc1);
-        const bool on = z < zb;                             // (the march runs in threes: up to two idle steps behind the last plane)
+        const bool on = z < zb;                             // (the march runs in groups of D steps: idle steps behind the last plane)
         double *yz = A.y + P * (on ? z : za);
         if (A.nt_y) {
             if (STORE && live0 && on) __builtin_nontemporal_store(acc0, yz + base0);
@@ -1056,14 +1055,13 @@ __global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
         // stay that until the codes change again
         if (look) { a4 = T.A40.x; b6 = T.A26.y; b4 = T.B40.x; a5 = T.L15.y; b7 = T.L37.y; b5 = T.LB15.y; a6 = T.D26.y; a7 = T.LD37.y; }
         put(z + 2, rv, rk);                                 // slot (z + 2) & 3: the plane z - 2 that nobody reads any more
-        fetch(z + 5, rv, rk);
+        fetch(z + 2 + D, rv, rk);
         lds_barrier();
     };
 #pragma clang loop unroll(disable)
-    for (int z = za; z < zb; z += 3) {
-        step(z, r0, k0);
-        step(z + 1, r1, k1);
-        step(z + 2, r2, k2);
+    for (int z = za; z < zb; z += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) step(z + s, rr[s], kk[s]);
     }
     if (DOT) {
         for (int pass = 0; pass < (A.qq ? 2 : 1); ++pass) {
@@ -1559,7 +1557,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
                 // still has ~2 workgroups per slot (two workgroups fit a CU)
                 const int64_t tile_planes = (int64_t)D.tiles_x * D.tiles_y * (D.z1 - D.z0);
                 zchunk_c = (int)std::min<int64_t>(c->spmv_zchunk_coded, tile_planes / (4 * (int64_t)c->num_cu));
-                zchunk_c = std::max(3, zchunk_c / 3 * 3);
+                zchunk_c = zchunk_c >= 12 ? zchunk_c / 6 * 6 : std::max(3, zchunk_c / 3 * 3);
                 wgs_c = (D.z1 - D.z0 + zchunk_c - 1) / zchunk_c * D.tiles_x * D.tiles_y;
             }
             coded = coded && zchunk_c <= DIAC_MAXCHUNK;
@@ -1573,9 +1571,17 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
                 if (nparts_out) *nparts_out = wgs_c;
                 if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + (D.qq ? 2 : 1) * (int64_t)wgs_c, 4 * MAX_VEC_BLOCKS)));
                 E.partials = c->partials + c->partials_off;
-                if (dot && store) k_spmv_diac_march2<true, true><<<wgs_c, 256, 0, c->stream>>>(E);
-                else if (dot) k_spmv_diac_march2<true, false><<<wgs_c, 256, 0, c->stream>>>(E);
-                else k_spmv_diac_march2<false, true><<<wgs_c, 256, 0, c->stream>>>(E);
+                // six plane fetches in flight where the march is long enough to run in sixes (a light kernel is paced by the bytes
+                // a CU keeps in flight), three otherwise
+                const bool six = zchunk_c >= 12 && zchunk_c % 6 == 0 && c->spmv_fetch_depth != 3;
+#define PGD_DIAC(DD)                                                                                       \
+    do {                                                                                                   \
+        if (dot && store) k_spmv_diac_march2<true, true, DD><<<wgs_c, 256, 0, c->stream>>>(E);            \
+        else if (dot) k_spmv_diac_march2<true, false, DD><<<wgs_c, 256, 0, c->stream>>>(E);               \
+        else k_spmv_diac_march2<false, true, DD><<<wgs_c, 256, 0, c->stream>>>(E);                        \
+    } while (0)
+                if (six) PGD_DIAC(6); else PGD_DIAC(3);
+#undef PGD_DIAC
                 c->kcount[KC_DIAC_MARCH] += 1;
                 if (timed2) PGD_TRY(prof_end(c, m, nrows, 17.0));
                 PGD_LAUNCH_CHECK(c);
@@ -1767,6 +1773,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_ASM_LATTICE && value >= 0 && value <= 1) { c->asm_lattice = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_LAG_X && value >= 0 && value <= 1) { c->pcg_lag_x = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_STREAM_HINTS && value >= 0 && value <= 1) { c->pcg_stream_hints = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_FETCH_DEPTH && (value == 3 || value == 6)) { c->spmv_fetch_depth = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK_CODED && value >= 3 && value <= 1024) { c->spmv_zchunk_coded = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }
