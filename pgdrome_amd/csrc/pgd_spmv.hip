@@ -912,14 +912,13 @@ using d2 = __attribute__((ext_vector_type(2))) double;
 struct DiacT { d2 A15, A37, A26, A40, B15, B37, B26, B40, L15, L37, LB15, D26, LD37; };
 constexpr int DIAC_MAXCHUNK = 1024;    // planes per march at most (the per-plane flags of a march are staged in LDS)
 
-template <bool DOT, bool STORE, int D>
+template <bool DOT, bool STORE, int D, bool NTY>
 __global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
     constexpr int NT = 256, PY = 8, HY = PY + 2, SLICE = DM_HX * HY;        // 660 cells per plane
     constexpr int SLOT = 3 * NT;                            // ... in slots of 768: every thread stages three cells, no predicates
     __shared__ double s_x[4 * SLOT];
     __shared__ __attribute__((aligned(16))) double s_t[(CLS_MAX + 1) * 8];
     __shared__ uint8_t s_c[4 * SLOT];
-    __shared__ uint8_t s_slow[DIAC_MAXCHUNK + 16];          // [z - za + 4]: the step of plane z looks its couplings up
     __shared__ double s_red[4];
     if (A.flags && A.flags[0]) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -937,11 +936,13 @@ __global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
     const unsigned zero_cls = (unsigned)A.ncls;
     for (int i = tid; i < (A.ncls + 1) * 8; i += NT) s_t[i] = A.table[i];
     // A.same[z] != 0: every row of plane z carries the code of the row below it (plane z - 1).  A step looks codes up where
-    // that does not hold, and at the first plane of the march.
-    for (int i = tid; i < zb - za + 12; i += NT) {
-        const int z = za - 4 + i;
-        s_slow[i] = (z == za || !(z > 0 && z < A.nz && A.same[z] != 0)) ? 1 : 0;
-    }
+    // that does not hold, and at the first plane of the march: one bit per step, 64 steps per (wave-uniform) mask - no memory
+    // access and no wait in the steps themselves.
+    auto slow_mask = [&](int zbase) -> unsigned long long {
+        const int z = zbase + lane;
+        return __ballot(z == za || !(z > 0 && z < A.nz && A.same[z] != 0));
+    };
+    unsigned long long look_mask = slow_mask(za);
     if (za >= zb) {                                         // uniform; the launcher sizes the grid so that no chunk is empty
         if (DOT && tid == 0) { if (A.qq) { A.partials[2 * b] = 0.0; A.partials[2 * b + 1] = 0.0; } else A.partials[b] = 0.0; }
         return;
@@ -956,7 +957,6 @@ __global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
         gok[q] = i < SLICE && gx >= 0 && gx < A.nx && gy >= 0 && gy < A.ny;
         goff[q] = gok[q] ? gx + A.nx * gy : 0;
     }
-    auto slow = [&](int z) -> bool { return __builtin_amdgcn_readfirstlane((int)s_slow[z - za + 4]) != 0; };
     // Loads are unconditional (cells outside the grid read a valid address, planes outside it the nearest plane).  Planes
     // beyond zb are never used by the march (zb itself is: the plane above the last one).
     auto fetch = [&](int z, double (&v)[3], unsigned (&cc)[3]) {
@@ -991,8 +991,10 @@ __global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
     double a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0, b4 = 0.0, b5 = 0.0, b6 = 0.0, b7 = 0.0;      // couplings to the plane below
     // one step: rows of plane z; `rv / rk` hold plane z + 2 (staged at the end of the step) and then take the fetch of z + 2 + D
     auto step = [&](int z, double (&rv)[3], unsigned (&rk)[3]) {
-        const bool look = slow(z);
-        if (look) {                                         // uniform: look the couplings up (codes of planes z - 1 and z are staged)
+        const int zi = z - za;
+        if (zi > 0 && (zi & 63) == 0) look_mask = slow_mask(z);       // uniform; marches longer than 64 planes
+        const bool look = (look_mask >> (zi & 63)) & 1ull;
+        if (__builtin_expect(look, 0)) {                                         // uniform: look the couplings up (codes of planes z - 1 and z are staged)
             const uint8_t *cm = s_c + ((z - 1) & 3) * SLOT + centre;
             const int mA = cm[0], mB = cm[DM_HX], mL = cm[-1], mLB = cm[DM_HX - 1], mD = cm[-DM_HX], mLD = cm[-DM_HX - 1];
             a4 = pair(mA, 3).x; b6 = pair(mA, 2).y; b4 = pair(mB, 3).x; a5 = pair(mL, 0).y; b7 = pair(mL, 1).y;
@@ -1039,7 +1041,7 @@ __global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
         acc1 = fma(T.B37.y, xp[2 * DM_HX + 1], acc1);
         const bool on = z < zb;                             // (the march runs in groups of D steps: idle steps behind the last plane)
         double *yz = A.y + P * (on ? z : za);
-        if (A.nt_y) {
+        if (NTY) {
             if (STORE && live0 && on) __builtin_nontemporal_store(acc0, yz + base0);
             if (STORE && live1 && on) __builtin_nontemporal_store(acc1, yz + base1);
         } else {
@@ -1576,9 +1578,10 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
                 const bool six = zchunk_c >= 12 && zchunk_c % 6 == 0 && c->spmv_fetch_depth != 3;
 #define PGD_DIAC(DD)                                                                                       \
     do {                                                                                                   \
-        if (dot && store) k_spmv_diac_march2<true, true, DD><<<wgs_c, 256, 0, c->stream>>>(E);            \
-        else if (dot) k_spmv_diac_march2<true, false, DD><<<wgs_c, 256, 0, c->stream>>>(E);               \
-        else k_spmv_diac_march2<false, true, DD><<<wgs_c, 256, 0, c->stream>>>(E);                        \
+        if (dot && store && E.nt_y) k_spmv_diac_march2<true, true, DD, true><<<wgs_c, 256, 0, c->stream>>>(E);   \
+        else if (dot && store) k_spmv_diac_march2<true, true, DD, false><<<wgs_c, 256, 0, c->stream>>>(E);       \
+        else if (dot) k_spmv_diac_march2<true, false, DD, false><<<wgs_c, 256, 0, c->stream>>>(E);               \
+        else k_spmv_diac_march2<false, true, DD, false><<<wgs_c, 256, 0, c->stream>>>(E);                        \
     } while (0)
                 if (six) PGD_DIAC(6); else PGD_DIAC(3);
 #undef PGD_DIAC
