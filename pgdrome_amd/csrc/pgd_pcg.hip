@@ -996,8 +996,20 @@ int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const 
     if (hi == lo) return PGD_OK;
     const int g = grid_for((hi - lo + 1) / 2);
     PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS));
+    const bool timed_u = c->prof && ((c->prof_upd_seen++ % 3) == 0);      // launch timing, as in pgd_pcg_solve
+    if (timed_u) {
+        if (c->ev_used + 2 > c->ev.size()) prof_flush(c);
+        c->ev_kind[c->ev_used / 2] = 1;
+        PGD_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
+    }
     if (c->pcg_stream_hints) k_pcg1_update<true><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, lag);
     else k_pcg1_update<false><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, lag);
+    if (timed_u) {
+        PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+        c->ev_used += 2;
+        c->prof_upd_launches += 1;
+        c->prof_upd_bytes += (lag == 1 ? 48.0 : 64.0) * (double)(hi - lo);      // the sharded form measures the true r.r in every iteration: + s
+    }
     PGD_LAUNCH_CHECK(c);
     *nblocks = g;
     return PGD_OK;
