@@ -894,7 +894,7 @@ struct DiacArgs {
     int nx, ny, nz;
     int z0, z1, zchunk, tiles_x, tiles_y;
     int qq;
-    int nt_y;               // y is stored with the non-temporal hint
+    int nt_y;               // y is stored with the non-temporal hint (the launcher picks the NTY instantiation)
 };
 
 // A kernel this light is paced by instruction issue and by the bytes a CU keeps in flight, so the march is built around
@@ -903,14 +903,16 @@ struct DiacArgs {
 //   before (dia_classify flags those planes: on a uniform grid the planes next to the z faces, and the first plane of a
 //   march).  In between, a step touches no code and no table, and the couplings to the plane below are the upward halves of
 //   the pairs it already holds.
-// * three plane fetches are in flight per workgroup - three register sets that rotate by name, the march being unrolled
-//   three steps at a time - and nothing touches a fetched value before it is staged (the zero of the cells outside the grid
+// * D = 6 (or 3) plane fetches are in flight per workgroup - D register sets that rotate by name, the march being unrolled
+//   D steps at a time - and nothing touches a fetched value before it is staged (the zero of the cells outside the grid
 //   is selected then): a select or a lane predicate at the load makes the wave wait for the fetch it has just issued.
+// * run-time switches cost taken branches in every step: the non-temporal y store is a template parameter (NTY), the
+//   "this step looks its couplings up" flags are one wave-uniform 64-bit mask per 64 steps.
 // * x is read from LDS (22 ds_read_b64 for a thread's two rows); four slices - the planes z - 1, z, z + 1 being read and
 //   z + 2 being staged - make ONE barrier per step enough.
 using d2 = __attribute__((ext_vector_type(2))) double;
 struct DiacT { d2 A15, A37, A26, A40, B15, B37, B26, B40, L15, L37, LB15, D26, LD37; };
-constexpr int DIAC_MAXCHUNK = 1024;    // planes per march at most (the per-plane flags of a march are staged in LDS)
+constexpr int DIAC_MAXCHUNK = 1024;    // planes per march at most
 
 template <bool DOT, bool STORE, int D, bool NTY>
 __global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
