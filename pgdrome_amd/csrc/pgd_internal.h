@@ -71,7 +71,6 @@ struct Mesh : Obj {
     // edge vectors as whole lattice steps, so congruent cells get identical local matrices
     bool lattice = false;
     double lat_h[3] = {0.0, 0.0, 0.0};
-    mutable int cls_misses = 0;  // consecutive operators on this mesh without a row-class dictionary (dia_classify)
     uint16_t *pids = nullptr;    // nv
     int *dict_off = nullptr;     // dict_count x DICT_DLEN relative offsets
     int dict_count = 0;          // 0: dictionary not available (irregular pattern) -> plain CSR kernel
