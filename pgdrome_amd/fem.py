@@ -1221,13 +1221,6 @@ class Measure:
             self.mesh = subdomain_data.mesh()
 
     def __call__(self, *args, **kw):
-        if not kw and len(args) == 1 and self.subdomain_id is None and self.subdomain_data is None and type(args[0]) is Mesh:
-            # dx(mesh), asked for per functional by the callbacks: one (immutable) Measure per mesh
-            cache = self.__dict__.setdefault("_per_mesh", {})
-            hit = cache.get(id(args[0]))
-            if hit is None or hit.mesh is not args[0]:
-                hit = cache[id(args[0])] = Measure(self.kind, args[0])
-            return hit
         mesh, sid = kw.get("domain", self.mesh), kw.get("subdomain_id", self.subdomain_id)
         data = kw.get("subdomain_data", self.subdomain_data)
         for a in args:
@@ -1413,13 +1406,11 @@ class Function(Expr):
         self.assign(other)
 
     def _poly(self):
-        p = self.__dict__.get("_poly_cache")
-        if p is None:
-            if self._V._ncomp > 1:
-                raise TypeError("vector-valued Function in a scalar expression: index it (u[i]) or use dot()")
-            # (read-only by convention: every consumer builds new lists; callbacks multiply the same modes thousands of times)
-            p = self.__dict__["_poly_cache"] = [Term(1.0, (Factor(self),))]
-        return p
+        if self._V._ncomp > 1:
+            raise TypeError("vector-valued Function in a scalar expression: index it (u[i]) or use dot()")
+        # (not cached on the Function: the term refers back to it, and a reference cycle would keep iterates - 134 MB of HBM each at
+        # 256^3 - alive until the cycle collector runs)
+        return [Term(1.0, (Factor(self),))]
 
     def __call__(self, *x):
         if len(x) == 1 and hasattr(x[0], "__len__"):
