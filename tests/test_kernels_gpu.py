@@ -798,6 +798,21 @@ def test_row_class_dictionary_is_lossless(ctx, shape):
             ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 31)
             assert np.array_equal(ctx.vec_download(yv), y_new)
             ctx.atom_free(op)
+        # a scattered Dirichlet set (every third boundary vertex): many more classes, or none - either way the same y
+        op = ctx.op_combine(h, [ak, am], [1.0, 0.37], bnd[::3])
+        assert ctx.op_symmetrize(op) is True
+        ctx.tune(7, 4)
+        ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
+        y_ref = ctx.vec_download(yv)
+        ncls = ctx.op_classify(op)
+        assert 0 <= ncls <= 255
+        k0 = ctx.kernel_counts()
+        ctx.vec_fill(yv, -3.0)
+        ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 31)
+        k1 = ctx.kernel_counts()
+        assert (k1["diac_march"] - k0["diac_march"], k1["dia_march"] - k0["dia_march"]) == ((1, 0) if ncls else (0, 1))
+        assert np.array_equal(ctx.vec_download(yv), y_ref)
+        ctx.atom_free(op)
         # a coefficient that varies from vertex to vertex: more than 255 classes (or none that verify) -> no dictionary
         wv = ctx.vec_from(1.0 + coords[:, 0] ** 2 + 0.5 * np.sin(coords.sum(axis=1)))
         aw = ctx.atom_assemble(h, F.KIND_NAMES.index("wmass"), 0, 0, wv)
