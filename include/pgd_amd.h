@@ -278,6 +278,10 @@ enum {
     PGD_TUNE_PCG_SCALED = 10,   /* 1 (default): pgd_pcg_solve runs CG on D^-1/2 A D^-1/2 (the same iterates as Jacobi-PCG,
                                    two vector passes per iteration fewer) when the symmetric storage applies; 0: unscaled */
     PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */
+    PGD_TUNE_PCG_SMALL_SINGLE_SYNC = 25, /* 1 (default): systems of up to 2^20 rows - where the launches, not the bytes, set the pace - run the
+                                single-sync recurrence in TWO launches per iteration: the product, and an update kernel whose every workgroup sums
+                                the partial sums and forms alpha, beta and the stop decision itself (k_pcg1_step); 0: the two-reduction
+                                recurrence in three launches (k_pcg_xr_s2 / k_pcg_p_s2) */
     PGD_TUNE_SPMV_FETCH_DEPTH = 24, /* k_spmv_diac_march2: plane fetches in flight per workgroup, 6 (default, marches of 12+ planes in whole sixes) or 3 */
     PGD_TUNE_PCG_STREAM_HINTS = 23, /* 1 (default): in the single-sync recurrence q, r and x - vectors no other kernel of the iteration touches -
                                 are read and written with non-temporal hints, p (read by the product next) keeps the default policy and so its

@@ -756,6 +756,122 @@ __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, dou
     if (lag == 1 && blockIdx.x == 0 && threadIdx.x == 0) slots[S1_PEND] = skip_x ? 1.0 : 0.0;
 }
 
+// ---- small systems (up to 2^20 rows): the scalar step folded into the vector update, 2 launches per iteration.
+// Where launches and not bytes set the pace (256^2 rows: three 3 us kernels and their gaps per iteration) EVERY workgroup of
+// the update sums the product's (p.q, q.q) pairs and the previous update's (r~.r~, r.r) pairs itself - in one fixed order
+// (256 strided lanes, wave sums, the four waves), so every workgroup holds the
+// same alpha, beta and stop decision bit for bit - and workgroup 0 keeps the scalar bank and the flags for the host and the
+// kernels that follow.  Nothing a workgroup reads is written by another workgroup of the same launch: the update's own partial
+// sums, alpha / beta (the lagged x update reads the previous pair) and the "exact phase" bit alternate between two buffers with
+// the parity of the iteration; a workgroup that starts late and finds the done flag already set by workgroup 0 returns, which
+// is what its own test would have told it.  (Measured on larger systems too: at 128^3 a wash, at 256^3 the redundant sums cost
+// more than the launch they save - those keep k_pcg1_scalars + k_pcg1_update.)
+enum { S1F_ALPHA = 44 /* +parity */, S1F_BETA = 46 /* +parity */, S1F_EXACT = 48 /* +parity */ };
+
+struct Pcg1Scalars { double alpha, beta; int exact, done, status; double pq, qq, rz, rr; };
+
+__device__ __forceinline__ Pcg1Scalars pcg1_wg_scalars(const double *__restrict__ prod, int nprod, const double *__restrict__ vecp, int nvec,
+                                                       const double *__restrict__ slots, int exact_cur, double *s_w /* >= 16 */) {
+    // all four sums in one sweep (16-byte loads of the pairs, every load independent), one exchange through LDS: a fixed
+    // order - lane t adds the pairs t, t + 256, ... - so every workgroup, and every run, gets the same bits
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    double a[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = t; i < nprod; i += 256) { const d2 v = *reinterpret_cast<const d2 *>(prod + 2 * (int64_t)i); a[0] += v.x; a[1] += v.y; }
+    for (int i = t; i < nvec; i += 256) { const d2 v = *reinterpret_cast<const d2 *>(vecp + 2 * (int64_t)i); a[2] += v.x; a[3] += v.y; }
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a[v] = wave_sum(a[v]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v) s_w[4 * v + wv] = a[v];
+    }
+    __syncthreads();
+    double out[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) out[v] = (s_w[4 * v] + s_w[4 * v + 1]) + (s_w[4 * v + 2] + s_w[4 * v + 3]);
+    __syncthreads();                                     // s_w is the caller's reduction scratch as well
+    Pcg1Scalars S;
+    S.pq = out[0]; S.qq = out[1]; S.rz = out[2]; S.rr = out[3];
+    S.alpha = S.beta = 0.0; S.exact = exact_cur; S.done = 0; S.status = 0;
+    // (pcg1_finish, on local values)
+    const double tol2 = slots[S_TOL2];
+    if (!(S.rz == S.rz) || !(S.pq == S.pq)) { S.done = 1; S.status = PGD_ERR_SINGULAR; return S; }
+    if (exact_cur) { if (S.rr <= tol2) { S.done = 1; return S; } }
+    else if (S.rz * slots[S_DMIN] <= 1e4 * tol2) S.exact = 1;
+    if (!(S.rz > 0.0)) { S.done = 1; return S; }
+    S.alpha = S.rz / S.pq;
+    double rnew = S.alpha * S.alpha * S.qq - S.rz;
+    if (!(rnew > 0.0)) rnew = 0.0;
+    S.beta = rnew / S.rz;
+    return S;
+}
+
+// par = parity of the iteration; vec_in / vec_out: the previous / this update's partial-sum pairs
+__global__ __launch_bounds__(TPB) void k_pcg1_step(double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
+                                                   const double *__restrict__ q, const double *__restrict__ s, int64_t n,
+                                                   const double *__restrict__ prod, int nprod, const double *__restrict__ vec_in, int nvec,
+                                                   double *__restrict__ vec_out, double *__restrict__ slots, int *__restrict__ flags,
+                                                   int par, int lag) {
+    if (flags[0]) return;
+    __shared__ double s_red[16];
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const Pcg1Scalars S = pcg1_wg_scalars(prod, nprod, vec_in, nvec, slots, slots[S1F_EXACT + (par ^ 1)] != 0.0, s_red);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        slots[S1_PQ] = S.pq; slots[S1_QQ] = S.qq; slots[S1_RZ] = S.rz; slots[S1_RR] = S.rr;
+        slots[S1F_EXACT + par] = S.exact ? 1.0 : 0.0;
+        flags[3] = S.exact;
+        if (S.done) { if (S.status) flags[2] = S.status; flags[0] = 1; }
+        else { slots[S1F_ALPHA + par] = S.alpha; slots[S1F_BETA + par] = S.beta; flags[1] += 1; }
+    }
+    if (S.done) return;                                  // uniform over the whole launch
+    const double alpha = S.alpha, beta = S.beta;
+    const bool exact = S.exact != 0;
+    const bool skip_x = lag == 1 && beta >= LAG_MIN_BETA;
+    const bool two = lag == 2 && slots[S1_PEND] != 0.0;
+    const double alpha_p = two ? slots[S1F_ALPHA + (par ^ 1)] : 0.0, ibeta_p = two ? 1.0 / slots[S1F_BETA + (par ^ 1)] : 0.0;
+    double rz = 0.0, rr = 0.0;
+    const int64_t npair = n >> 1;
+    for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < npair; k += (int64_t)gridDim.x * TPB) {
+        const int64_t i = 2 * k;
+        const d2 qi = *reinterpret_cast<const d2 *>(q + i);
+        d2 pi = *reinterpret_cast<d2 *>(p + i), ri = *reinterpret_cast<d2 *>(r + i);
+        if (!skip_x) {                                    // uniform
+            d2 xi = *reinterpret_cast<d2 *>(x + i);
+            if (two) { xi.x = fma(alpha_p, (pi.x - ri.x) * ibeta_p, xi.x); xi.y = fma(alpha_p, (pi.y - ri.y) * ibeta_p, xi.y); }
+            xi.x = fma(alpha, pi.x, xi.x); xi.y = fma(alpha, pi.y, xi.y);
+            *reinterpret_cast<d2 *>(x + i) = xi;
+        }
+        ri.x = fma(-alpha, qi.x, ri.x); ri.y = fma(-alpha, qi.y, ri.y);
+        pi.x = fma(beta, pi.x, ri.x); pi.y = fma(beta, pi.y, ri.y);
+        *reinterpret_cast<d2 *>(r + i) = ri;
+        *reinterpret_cast<d2 *>(p + i) = pi;
+        rz = fma(ri.x, ri.x, rz); rz = fma(ri.y, ri.y, rz);
+        if (exact) {
+            const d2 si = *reinterpret_cast<const d2 *>(s + i);
+            const double tx = ri.x / si.x, ty = ri.y / si.y;
+            rr = fma(tx, tx, rr); rr = fma(ty, ty, rr);
+        }
+    }
+    for (int64_t i = 2 * npair + (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
+        const double pi = p[i], r0 = r[i];
+        if (!skip_x) {
+            double xi = x[i];
+            if (two) xi = fma(alpha_p, (pi - r0) * ibeta_p, xi);
+            x[i] = fma(alpha, pi, xi);
+        }
+        const double ri = fma(-alpha, q[i], r0);
+        r[i] = ri;
+        p[i] = fma(beta, pi, ri);
+        rz = fma(ri, ri, rz);
+        if (exact) { const double t = ri / s[i]; rr = fma(t, t, rr); }
+    }
+    rz = block_sum(rz, s_red);
+    rr = block_sum(rr, s_red);
+    if (threadIdx.x == 0) { vec_out[2 * blockIdx.x] = rz; vec_out[2 * blockIdx.x + 1] = exact ? rr : rz; }
+    if (lag == 1 && blockIdx.x == 0 && threadIdx.x == 0) slots[S1_PEND] = skip_x ? 1.0 : 0.0;
+}
+
 // before the first iteration: the initial residual's (r~.r~, true r.r) as the one non-zero pair of the vector partials
 __global__ void k_pcg1_seed(double *__restrict__ partials, int npairs, const double *__restrict__ slots, int slot_rz, int slot_rr) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < npairs; i += gridDim.x * blockDim.x) {
@@ -771,12 +887,13 @@ __global__ void k_pcg1_seed(double *__restrict__ partials, int npairs, const dou
 // outstanding term is alpha p' with p' = (p - r) / beta of that iteration, whose alpha and beta are still in their slots
 __global__ __launch_bounds__(TPB) void k_scale_out(double *__restrict__ x, const double *__restrict__ r, const double *__restrict__ s,
                                                    int64_t n, double *__restrict__ partials, const double *__restrict__ p,
-                                                   const double *__restrict__ slots, int slot_rz, int slot_pq, int lagged) {
+                                                   const double *__restrict__ slots, int slot_rz, int slot_pq, int lagged,
+                                                   int slot_alpha, int slot_beta) {
     __shared__ double s_red[4];
     double rr = 0.0;
     const bool lag_term = lagged && p && slots[S1_PEND] != 0.0;
-    const double alpha = lagged ? (lag_term ? slots[S1_ALPHA] : 0.0) : p ? slots[slot_rz] / slots[slot_pq] : 0.0;
-    const double ibeta = lag_term ? 1.0 / slots[S1_BETA] : 0.0;
+    const double alpha = lagged ? (lag_term ? slots[slot_alpha] : 0.0) : p ? slots[slot_rz] / slots[slot_pq] : 0.0;
+    const double ibeta = lag_term ? 1.0 / slots[slot_beta] : 0.0;
     for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) {
         const double si = s[i], ri = r[i], t = ri / si;
         double xi = x[i];
@@ -1185,17 +1302,23 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     PGD_LAUNCH_CHECK(c);
 
     // second partials buffer for the folded reductions (the x / r update reads the product's partials while writing its own)
-    PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS));
-    double *part2 = c->work[6];
+    PGD_TRY(ensure_work(c, 6, 4 * (int64_t)MAX_VEC_BLOCKS));
+    double *part2 = c->work[6];                         // (the two-launch form of small systems alternates between this half and the next)
     // large systems: the x update rides in the p kernel (PGD_TUNE_PCG_DEFER_X); the folded small-system form keeps its own kernels
-    const bool folded_form = scaled && c->pcg_fold_reduce && n <= ((int64_t)1 << 20);
-    const bool single_sync = scaled && c->pcg_single_sync && !folded_form && m->sym_nx > 0;
+    // systems of up to 2^20 rows: single-sync recurrence in two launches per iteration (k_pcg1_step) ...
+    const bool fold = scaled && c->pcg_single_sync && c->pcg_small_ss && n <= ((int64_t)1 << 20);
+    // ... or the two-reduction recurrence with its final reduction passes folded into their consumers (three launches)
+    const bool folded_form = scaled && c->pcg_fold_reduce && n <= ((int64_t)1 << 20) && !fold;
+    const bool single_sync = fold || (scaled && c->pcg_single_sync && !folded_form && m->sym_nx > 0);
+    double *part2b = part2 + 2 * (int64_t)MAX_VEC_BLOCKS;
     const bool deferred_x = scaled && c->pcg_defer_x && !folded_form && !single_sync;
     const bool lag_x = single_sync && c->pcg_lag_x;
     const int g2v = grid_for((n + 1) / 2);
     if (single_sync) {
         // the first look at the residual happens in the first k_pcg1_scalars: hand it the initial residual's sums
-        k_pcg1_seed<<<8, TPB, 0, c->stream>>>(part2, g2v, c->slots, S_INIT, S_INIT + 1);
+        // (two-launch form: iteration k reads the pairs of parity (k - 1) & 1, so the seed goes to the second half)
+        k_pcg1_seed<<<8, TPB, 0, c->stream>>>(fold ? part2b : part2, g2v, c->slots, S_INIT, S_INIT + 1);
+        if (fold) PGD_HIP(c, hipMemsetAsync(c->slots + S1F_ALPHA, 0, 6 * sizeof(double), c->stream));     // alpha, beta, exact-phase bit x 2 parities
         PGD_LAUNCH_CHECK(c);
     }
     auto enqueue = [&](int start, int count) -> int {
@@ -1215,7 +1338,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
                     prod = c->work[5];
                     nparts = nb;
                 }
-                k_pcg1_scalars<<<1, 1024, 0, c->stream>>>(prod, nparts, part2, g2v, c->slots, c->flags);
+                if (!fold) k_pcg1_scalars<<<1, 1024, 0, c->stream>>>(prod, nparts, part2, g2v, c->slots, c->flags);
                 // launch timing on: every third update between HIP events (5 or 7 vector passes = 40 or 56 B per row)
                 const bool timed_u = c->prof && ((c->prof_upd_seen++ % 3) == 0);        // one in three: both halves of the x-update pairs get sampled
                 if (timed_u) {
@@ -1225,7 +1348,11 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
                 }
                 // the x update lags behind by one iteration in every other one (chunks start at even iteration indices)
                 const int lag = lag_x ? 1 + ((start + k) & 1) : 0;
-                if (c->pcg_stream_hints) k_pcg1_update<true><<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags, lag);
+                if (fold) {
+                    const int par = (start + k) & 1;
+                    k_pcg1_step<<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, n, prod, nparts, par ? part2 : part2b, g2v, par ? part2b : part2,
+                                                            c->slots, c->flags, par, lag);
+                } else if (c->pcg_stream_hints) k_pcg1_update<true><<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags, lag);
                 else k_pcg1_update<false><<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags, lag);
                 if (timed_u) {
                     PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
@@ -1317,8 +1444,11 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         const bool pending = deferred_x && f[0] != 0 && f[1] > 0;
         // lagged x update: f[1] update kernels ran; if the last one had an even index it may have left its term outstanding
         const bool lag_pending = lag_x && f[1] > 0 && ((f[1] - 1) & 1) == 0;
+        // (alpha and beta of that last update: in the two-launch form they sit in the slots of its parity)
+        const int last_par = f[1] > 0 ? (f[1] - 1) & 1 : 0;
         k_scale_out<<<g, TPB, 0, c->stream>>>(x->d, r, sc, n, c->partials, (pending || lag_pending) ? p : nullptr, c->slots,
-                                              S_PAIR + 2 * (f[1] & 1), S_PQ, lag_pending ? 1 : 0);
+                                              S_PAIR + 2 * (f[1] & 1), S_PQ, lag_pending ? 1 : 0,
+                                              fold ? S1F_ALPHA + last_par : S1_ALPHA, fold ? S1F_BETA + last_par : S1_BETA);
         PGD_LAUNCH_CHECK(c);
         PGD_TRY(reduce_partials(c, c->partials, g, 1, S_TMP, -1, 0, 0));
         o->uvals_valid = false;        // the slot arrays hold the scaled operator: nobody else may take them for A

@@ -373,6 +373,7 @@ struct SymArgs {
     const uint16_t *pids;
     int64_t n;              // slot stride in doubles (rows + padding)
     int row_begin, row_end;
+    int qq;                 // DOT launches: partial sums in pairs (w . y, y . y) per workgroup (single-sync recurrence)
 };
 
 struct SymRec { int v[16]; };
@@ -515,7 +516,10 @@ __global__ __launch_bounds__(64) void k_spmv_sym(SymArgs A) {
     if (DOT) {
         const double v = (tid < nr) ? acc * A.w[r0 + tid] : 0.0;
         const double sum = wave_sum(v);
-        if (tid == 0) A.partials[b] = sum;
+        if (A.qq) {
+            const double s2 = wave_sum((tid < nr) ? acc * acc : 0.0);
+            if (tid == 0) { A.partials[2 * b] = sum; A.partials[2 * b + 1] = s2; }
+        } else if (tid == 0) A.partials[b] = sum;
     }
 }
 
@@ -1514,6 +1518,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
     SymArgs A;
     A.uvals = a->uvals; A.x = x; A.w = w; A.y = y; A.partials = c->partials + c->partials_off; A.flags = flags;
     A.tab = m->sym_tab; A.pids = m->pids; A.n = a->uvals_stride; A.row_begin = (int)r0; A.row_end = (int)r1;
+    A.qq = (dot && c->spmv_qq) ? 1 : 0;
     if (m->sym_nx > 0) {
         // structured vertex grid: the operator is held in diagonal form
         const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
@@ -1779,6 +1784,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_ASM_LATTICE && value >= 0 && value <= 1) { c->asm_lattice = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_LAG_X && value >= 0 && value <= 1) { c->pcg_lag_x = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_STREAM_HINTS && value >= 0 && value <= 1) { c->pcg_stream_hints = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_PCG_SMALL_SINGLE_SYNC && value >= 0 && value <= 1) { c->pcg_small_ss = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_FETCH_DEPTH && (value == 3 || value == 6)) { c->spmv_fetch_depth = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK_CODED && value >= 3 && value <= 1024) { c->spmv_zchunk_coded = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);

@@ -963,6 +963,61 @@ def test_lagged_x_update_leaves_the_recurrence_alone(ctx):
     ctx.mesh_free(h)
 
 
+@pytest.mark.parametrize("name", ["rect129", "box40"])
+def test_two_launch_recurrence_of_small_systems(ctx, name):
+    """Systems of up to 2^20 rows: single-sync recurrence in TWO launches per iteration - the product, and k_pcg1_step, whose
+    every workgroup sums the partial sums and forms alpha, beta and the stop decision itself (alternating buffers).  Against
+    the two-reduction recurrence in three launches (PGD_TUNE_PCG_SMALL_SINGLE_SYNC = 0): iteration counts +0 .. +2 (the stop
+    test sees a residual one iteration later), the same solution, the TRUE residual at the tolerance through the CSR kernel,
+    the same iterate when cut off at an odd and an even count, a converged start, bitwise reproducible."""
+    if name == "rect129":
+        coords, cells = F.rectangle_mesh((0, 0), (1.0, 0.8), 128, 128)
+    else:
+        coords, cells = F.box_mesh((0, 0, 0), (1.0, 0.7, 1.3), 39, 39, 39)
+    h = ctx.mesh_upload(coords, cells)
+    n = coords.shape[0]
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bc = boundary_dofs(coords).astype(np.int32)
+    rng = np.random.default_rng(3)
+    b = rng.uniform(-1, 1, n)
+    b[bc] = 0.0
+    bv = ctx.vec_from(b)
+    res = {}
+    try:
+        for two in (1, 0, 1):
+            ctx.tune(25, two)
+            for maxit in (10000, 23, 24):
+                op = ctx.op_combine(h, [ak, am], [1.0, 3.0], bc)
+                xv = ctx.vec_alloc(n)
+                it, rel = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, maxit)
+                x = ctx.vec_download(xv)
+                if maxit == 10000:
+                    it2, _ = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, maxit)
+                    assert it2 <= 1
+                    yv = ctx.vec_alloc(n)
+                    ctx.tune(3, 0)
+                    ctx.spmv(op, ctx.vec_from(x), yv)
+                    ctx.tune(3, 1)
+                    assert np.linalg.norm(b - ctx.vec_download(yv)) <= 1.05e-10 * np.linalg.norm(b)
+                    ctx.vec_free(yv)
+                res.setdefault((two, maxit), []).append((it, rel, x))
+                ctx.vec_free(xv)
+                ctx.atom_free(op)
+    finally:
+        ctx.tune(25, 1)
+    a, t = res[(1, 10000)], res[(0, 10000)][0]
+    assert a[0][0] == a[1][0] and a[0][1] == a[1][1] and np.array_equal(a[0][2], a[1][2])      # reproducible run to run
+    assert 0 <= a[0][0] - t[0] <= 2 and a[0][1] <= 1e-10 and t[1] <= 1e-10
+    assert np.linalg.norm(a[0][2] - t[2]) <= 1e-9 * np.linalg.norm(t[2])
+    for maxit in (23, 24):
+        c1, c0 = res[(1, maxit)][0], res[(0, maxit)][0]
+        assert c1[0] == c0[0] == maxit and np.linalg.norm(c1[2] - c0[2]) <= 1e-10 * np.linalg.norm(c0[2])
+    ctx.vec_free(bv)
+    for at in (ak, am):
+        ctx.atom_free(at)
+    ctx.mesh_free(h)
+
+
 def test_vector_ops(ctx):
     rng = np.random.default_rng(5)
     for n in (1, 63, 64, 257, 100_003):
