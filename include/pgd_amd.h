@@ -278,6 +278,7 @@ enum {
     PGD_TUNE_PCG_SCALED = 10,   /* 1 (default): pgd_pcg_solve runs CG on D^-1/2 A D^-1/2 (the same iterates as Jacobi-PCG,
                                    two vector passes per iteration fewer) when the symmetric storage applies; 0: unscaled */
     PGD_TUNE_SPMV_ZCHUNK_FORCE = 7, /* > 0: exactly this many planes per march on any grid size (0: adaptive) */
+    PGD_TUNE_PCG_SMALL_ROWS = 26, /* structured grids of up to this many rows take the two-launch form as well (default 2^22: +2 % at 128^3; at 256^3 the redundant sums cost more than the launch they save) */
     PGD_TUNE_PCG_SMALL_SINGLE_SYNC = 25, /* 1 (default): systems of up to 2^20 rows - where the launches, not the bytes, set the pace - run the
                                 single-sync recurrence in TWO launches per iteration: the product, and an update kernel whose every workgroup sums
                                 the partial sums and forms alpha, beta and the stop decision itself (k_pcg1_step); 0: the two-reduction

@@ -160,6 +160,7 @@ struct Ctx {
     int64_t spmv_grid_min_plane_bytes = 0;   // structured grids whose planes of values are at least this large take the z-march (k_spmv_dia_march*)
     int spmv_zchunk_force = 0;    // > 0: exactly this many planes per march whatever the grid size (tests)
     int fault_iteration = -1;     // tests: pgd_pcg_solve_sharded fails on this rank in that iteration (once)
+    int64_t pcg_small_ss_rows = (int64_t)1 << 22;   // ... structured grids up to this many rows as well (PGD_TUNE_PCG_SMALL_ROWS; 128^3: +2 %, 256^3: a loss)
     int pcg_small_ss = 1;         // systems up to 2^20 rows: single-sync recurrence with the scalar step inside the update kernel (2 launches)
     int pcg_stream_hints = 1;     // single-sync recurrence: q, r, x non-temporal, p cached (PGD_TUNE_PCG_STREAM_HINTS)
     int pcg_lag_x = 1;            // single-sync recurrence: x is updated every other iteration, two terms at a time (PGD_TUNE_PCG_LAG_X)

@@ -1306,14 +1306,15 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     double *part2 = c->work[6];                         // (the two-launch form of small systems alternates between this half and the next)
     // large systems: the x update rides in the p kernel (PGD_TUNE_PCG_DEFER_X); the folded small-system form keeps its own kernels
     // systems of up to 2^20 rows: single-sync recurrence in two launches per iteration (k_pcg1_step) ...
-    const bool fold = scaled && c->pcg_single_sync && c->pcg_small_ss && n <= ((int64_t)1 << 20);
+    const bool fold = scaled && c->pcg_single_sync && c->pcg_small_ss && (n <= ((int64_t)1 << 20) || (n <= c->pcg_small_ss_rows && m->sym_nx > 0));
     // ... or the two-reduction recurrence with its final reduction passes folded into their consumers (three launches)
     const bool folded_form = scaled && c->pcg_fold_reduce && n <= ((int64_t)1 << 20) && !fold;
     const bool single_sync = fold || (scaled && c->pcg_single_sync && !folded_form && m->sym_nx > 0);
     double *part2b = part2 + 2 * (int64_t)MAX_VEC_BLOCKS;
     const bool deferred_x = scaled && c->pcg_defer_x && !folded_form && !single_sync;
     const bool lag_x = single_sync && c->pcg_lag_x;
-    const int g2v = grid_for((n + 1) / 2);
+    // (two-launch form above 2^20 rows: 512 workgroups in the update, every one of which sums all partial sums)
+    const int g2v = grid_for((n + 1) / 2, TPB, (n > ((int64_t)1 << 20) && n <= c->pcg_small_ss_rows && c->pcg_small_ss) ? 512 : MAX_VEC_BLOCKS);
     if (single_sync) {
         // the first look at the residual happens in the first k_pcg1_scalars: hand it the initial residual's sums
         // (two-launch form: iteration k reads the pairs of parity (k - 1) & 1, so the seed goes to the second half)

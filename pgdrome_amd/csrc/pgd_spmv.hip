@@ -1785,6 +1785,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_PCG_LAG_X && value >= 0 && value <= 1) { c->pcg_lag_x = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_STREAM_HINTS && value >= 0 && value <= 1) { c->pcg_stream_hints = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_SMALL_SINGLE_SYNC && value >= 0 && value <= 1) { c->pcg_small_ss = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_PCG_SMALL_ROWS && value >= 0) { c->pcg_small_ss_rows = value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_FETCH_DEPTH && (value == 3 || value == 6)) { c->spmv_fetch_depth = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK_CODED && value >= 3 && value <= 1024) { c->spmv_zchunk_coded = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
