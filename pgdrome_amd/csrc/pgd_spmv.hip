@@ -1562,12 +1562,13 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
             bool coded = c->spmv_variant == 0 && c->spmv_classes && a->cls_count > 0;
             int wgs_c = wgs, zchunk_c = D.zchunk;
             if (coded && c->spmv_zchunk_force <= 0) {
-                // the coded march is unrolled three planes at a time and its steps are light: longer marches (fewer halo planes
-                // and prologues per row; 256^3: 24 planes 81 us, 12 planes 89 us, 6 planes 103 us), in whole threes, while the launch
-                // still has ~2 workgroups per slot (two workgroups fit a CU)
+                // the coded march is unrolled six (three) planes at a time and its steps are light: longer marches (fewer halo planes
+                // and prologues per row; 256^3: 24 planes 81 us, 12 planes 89 us, 6 planes 103 us), in whole sixes (threes)
                 const int64_t tile_planes = (int64_t)D.tiles_x * D.tiles_y * (D.z1 - D.z0);
-                zchunk_c = (int)std::min<int64_t>(c->spmv_zchunk_coded, tile_planes / (4 * (int64_t)c->num_cu));
-                zchunk_c = zchunk_c >= 12 ? zchunk_c / 6 * 6 : std::max(3, zchunk_c / 3 * 3);
+                // (about one workgroup per CU is enough for this kernel - 128^3: marches of 18 planes = 256 workgroups 61.6 passes/s of
+                // cfg3, 12 planes 59.9, 3 planes (four workgroups per CU, the rule of the plain march) 55.7, 24 planes 58.4)
+                zchunk_c = (int)std::min<int64_t>(c->spmv_zchunk_coded, (tile_planes + c->num_cu / 2) / (int64_t)c->num_cu);
+                zchunk_c = zchunk_c >= 9 ? std::max(12, (zchunk_c + 3) / 6 * 6) : std::max(3, zchunk_c / 3 * 3);
                 wgs_c = (D.z1 - D.z0 + zchunk_c - 1) / zchunk_c * D.tiles_x * D.tiles_y;
             }
             coded = coded && zchunk_c <= DIAC_MAXCHUNK;
