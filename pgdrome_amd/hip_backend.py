@@ -20,8 +20,11 @@ class HipBackend:
         # changes; the knobs select kernels and summation groupings, never a different result beyond rounding)
         import os
         for item in filter(None, os.environ.get("PGD_TUNE", "").split(",")):
-            knob, value = item.split("=")
-            self.ctx.tune(int(knob), int(value))
+            try:
+                knob, value = (int(t) for t in item.split("="))
+            except ValueError:
+                raise ValueError("PGD_TUNE: expected knob=value pairs of integers (include/pgd_amd.h: pgd_tune_knob), got %r" % item) from None
+            self.ctx.tune(knob, value)
 
     # ---- meshes
     def mesh(self, coords, cells):
