@@ -113,7 +113,8 @@ def _shared_gpu_worker(rank, world, port, shape, q, in_library):
         p.solve_PGD(_problem="linear")
         modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values()) for f in p.PGD_func[0]]
         if rank == 0:
-            q.put(dict(num_fp_it=p.num_fp_it, amplitude=p.amplitude, modes_x=modes_x, stats=dict(comm.stats)))
+            q.put(dict(num_fp_it=p.num_fp_it, amplitude=p.amplitude, modes_x=modes_x, stats=dict(comm.stats),
+                       kernels=be.ctx.kernel_counts()))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -155,6 +156,43 @@ def test_sharded_solve_with_real_halos_on_one_gpu(world, in_library):
     for m in range(ref.PGD_modes):
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
     assert out["stats"]["halo"] > 100
+
+
+def test_sharded_solve_marches_on_row_classes():
+    """Two ranks whose slabs are large enough for the z-march (128 x 128 planes, 50 owned planes each): the interior rows'
+    product of the in-library sharded loop runs on the row-class dictionary of each rank's LOCAL scaled operator
+    (k_spmv_diac_march2), the boundary planes in row order, the x update lags; the run must reproduce the unsharded one."""
+    import torch.multiprocessing as mp
+    from pgdrome_amd import fem, problems
+    from pgdrome_amd.hip_backend import HipBackend
+    from pgdrome_amd.solver import PGDProblem
+    shape = (127, 127, 99)
+    old = fem._backend
+    fem.set_backend(HipBackend(0))
+    fem.clear_caches()
+    try:
+        P = fem.Point
+        ref = PGDProblem(**problems.reaction_diffusion(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape), 17, PGD_nmax=3))
+        ref.solve_PGD(_problem="linear")
+        ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
+    finally:
+        fem.set_backend(old)
+        fem.clear_caches()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, 2, port, shape, q, True)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    out = q.get(timeout=600)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert out["kernels"]["diac_march"] > 100 and out["kernels"]["dia_rows"] > 100
+    assert out["num_fp_it"] == ref.num_fp_it
+    np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
+    for m in range(ref.PGD_modes):
+        assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
 
 
 def _faulty_worker(rank, world, port, shape, q):
