@@ -267,6 +267,12 @@ int pgd_pcg_solve_sharded(pgd_handle ctx, pgd_handle A, pgd_handle b, pgd_handle
 int pgd_start_gram(pgd_handle ctx, pgd_handle A, const pgd_handle *vecs, int k, pgd_handle b, int64_t r0,
                    int64_t r1, double *out);
 
+/* out[j] = x . y_j over entries [lo, hi) for k <= 256 vectors: ceil(k / 17) passes over x and ONE host
+ * synchronisation.  Serves the functionals of one iterate against all stored modes of its dimension
+ * (the scalar assemble() calls inside solver.py:568-612 when the products A y_j are already stored). */
+int pgd_vec_multidot(pgd_handle ctx, pgd_handle x, const pgd_handle *ys, int k, int64_t lo, int64_t hi,
+                     double *out);
+
 /* ------------------------------------------------------------------ tuning --- */
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */

@@ -133,6 +133,9 @@ class NumpyBackend:
         hi = a.size if hi < 0 else hi
         return float(a[lo:hi] @ b[lo:hi])
 
+    def vec_multidot(self, x, ys, lo=0, hi=-1):
+        return np.array([self.vec_dot(x, y, lo, hi) for y in ys])
+
     # ---- atoms and operators
     def atom(self, mh, kind, da, db, w):
         m = self._obj[mh]

@@ -66,6 +66,7 @@ SIGNATURES = {
     "pgd_bilinear": (C.c_int, [H, H, H, H, I64, I64, PD]),
     "pgd_bilinear_many": (C.c_int, [H, H, H, PH, C.c_int, I64, I64, PD]),
     "pgd_start_gram": (C.c_int, [H, H, PH, C.c_int, H, I64, I64, PD]),
+    "pgd_vec_multidot": (C.c_int, [H, H, PH, C.c_int, I64, I64, PD]),
     "pgd_pcg_solve": (C.c_int, [H, H, H, H, F64, F64, C.c_int, C.POINTER(C.c_int), PD]),
     "pgd_band_solve": (C.c_int, [H, H, H, H]),
     "pgd_slots_ptr": (C.c_int, [H, C.POINTER(VP)]),
@@ -317,6 +318,14 @@ class Context:
         out = F64()
         self._ck(self.lib.pgd_vec_dot(self.h, x, y, int(lo), int(hi), C.byref(out)))
         return out.value
+
+    def vec_multidot(self, x, ys, lo=0, hi=-1):
+        """[x . y for y in ys] over [lo, hi): one host synchronisation for up to 256 vectors."""
+        k = len(ys)
+        arr = (H * k)(*[int(v) for v in ys])
+        out = np.zeros(k, dtype=np.float64)
+        self._ck(self.lib.pgd_vec_multidot(self.h, x, arr, k, int(lo), int(hi), dptr(out)))
+        return out
 
     # ---- atoms / operators
     def atom_assemble(self, mesh, kind, da=0, db=0, w=0):

@@ -1875,6 +1875,49 @@ int pgd_spmv_dot_slot(pgd_handle h, pgd_handle ah, pgd_handle xh, pgd_handle yh,
     return reduce_partials(c, c->partials, nparts, 1, slot, 0, 0, 0);
 }
 
+// x . y_j for up to 256 vectors y_j at once: ceil(k / 17) passes over x, one host synchronisation.  The driver's
+// functionals of one iterate against all stored modes of its dimension (fem._bilinear_scalar) come through here.
+int pgd_vec_multidot(pgd_handle h, pgd_handle xh, const pgd_handle *yhs, int k, int64_t lo, int64_t hi, double *out) {
+    PGD_CTX(c, h);
+    Vec *x = get_vec(c, xh);
+    if (!x || !yhs || !out || k < 1 || k > 256) return fail(c, PGD_ERR_INVALID, "vec_multidot: invalid handles or count (1..256)");
+    if (hi < 0) hi = x->n;
+    if (lo < 0 || lo > hi || hi > x->n) return fail(c, PGD_ERR_INVALID, "vec_multidot: bad range");
+    std::vector<const double *> y((size_t)k);
+    for (int j = 0; j < k; ++j) {
+        Vec *v = get_vec(c, yhs[j]);
+        if (!v || v->n != x->n) return fail(c, PGD_ERR_INVALID, "vec_multidot: invalid vector %d", j);
+        y[(size_t)j] = v->d;
+    }
+    for (int j = 0; j < k; ++j) out[j] = 0.0;
+    if (hi == lo) return PGD_OK;
+    PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS > 512 ? 2 * (int64_t)MAX_VEC_BLOCKS : 512));
+    double *res = c->work[6];
+    const int g = grid_for(hi - lo);
+    PGD_TRY(ensure_partials(c, (int64_t)g * (GRAM_MAXV + 1) > 4 * MAX_VEC_BLOCKS ? (int64_t)g * (GRAM_MAXV + 1) : 4 * MAX_VEC_BLOCKS));
+    int off = 0;
+    for (int j0 = 0; j0 < k; j0 += GRAM_MAXV) {
+        const int nv = std::min(GRAM_MAXV, k - j0);
+        MultiDotArgs A;
+        A.w = x->d; A.b = x->d; A.nv = nv; A.lo = lo; A.hi = hi; A.partials = c->partials;
+        for (int q = 0; q < GRAM_MAXV; ++q) A.v[q] = y[(size_t)(j0 + std::min(q, nv - 1))];
+        k_multidot<<<g, TPB, 0, c->stream>>>(A);
+        PGD_LAUNCH_CHECK(c);
+        PGD_TRY(reduce_partials_to(c, c->partials, g, nv + 1, res + off));     // nv dots, then y_last . x again (unused)
+        off += nv + 1;
+    }
+    std::vector<double> host((size_t)off);
+    PGD_HIP(c, hipMemcpyAsync(host.data(), res, (size_t)off * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    off = 0;
+    for (int j0 = 0; j0 < k; j0 += GRAM_MAXV) {
+        const int nv = std::min(GRAM_MAXV, k - j0);
+        for (int q = 0; q < nv; ++q) out[j0 + q] = host[(size_t)(off + q)];
+        off += nv + 1;
+    }
+    return PGD_OK;
+}
+
 int pgd_start_gram(pgd_handle h, pgd_handle ah, const pgd_handle *vhs, int k, pgd_handle bh, int64_t r0, int64_t r1,
                    double *out) {
     PGD_CTX(c, h);

@@ -2075,6 +2075,45 @@ def _cached_product(atom, v):
     return None
 
 
+_MULTIDOT_MAX = max(1, min(256, int(os.environ.get("PGD_BATCH_FUNCTIONALS", "256"))))   # 1: one dot per request (A/B)
+
+
+def _dots_with_stored_products(be, atom, other, Ag, swapped, lo, hi):
+    """other . Ag, and in the same device pass other . (A v) for every other stored product of this atom.
+
+    The driver asks for the functionals of one iterate against ALL stored modes of its dimension, one
+    assemble() at a time (solver.py:568-612), and each answer costs a host synchronisation; the products A v
+    of the stored modes are cached by the right-hand-side assembly, so the first request computes all of them
+    in one launch sequence with one synchronisation and memoises the rest (same keys _bilinear_scalar looks up).
+    Only on an unsharded dimension: the ranks of a sharded one would have to agree on the candidate list."""
+    outs, keys, refs = [Ag], [None], [None]
+    oid, over = id(other), other.version
+    for (a, _vid), (ver, out, ref) in _MV_CACHE.items():
+        if a != atom or out is Ag:
+            continue
+        v = ref()
+        if v is None or v.version != ver or v is other:
+            continue
+        key = (atom, id(v), ver, oid, over) if swapped else (atom, oid, over, id(v), ver)
+        if key in _SCALAR_MEMO:
+            continue
+        outs.append(out)
+        keys.append(key)
+        refs.append(v)
+        if len(outs) == _MULTIDOT_MAX:
+            break
+    if len(outs) == 1:
+        return be.vec_dot(other.dev(), Ag.dev(), lo, hi)
+    vals = be.vec_multidot(other.dev(), [o.dev() for o in outs], lo, hi)
+    if len(_SCALAR_MEMO) + len(outs) > _SCALAR_MEMO_MAX:
+        _SCALAR_MEMO.clear()
+    wo = weakref.ref(other)
+    for key, v, val in zip(keys[1:], refs[1:], vals[1:]):
+        wv = weakref.ref(v)
+        _SCALAR_MEMO[key] = (float(val), wv, wo) if swapped else (float(val), wo, wv)
+    return float(vals[0])
+
+
 def _bilinear_scalar(lay, atom, f, g, symmetric=False):
     """f^T A g with memoisation on (atom, vector identity, vector version).
 
@@ -2088,10 +2127,12 @@ def _bilinear_scalar(lay, atom, f, g, symmetric=False):
     be = get_backend()
     lo, hi = lay.owned_range()
     Ag = _cached_product(atom, g)
-    other = f
+    other, swapped = f, False
     if Ag is None and symmetric and f is not g:
-        Ag, other = _cached_product(atom, f), g
-    if Ag is not None and not (Ag._small() and lay.part is None):
+        Ag, other, swapped = _cached_product(atom, f), g, True
+    if Ag is not None and lay.part is None and not Ag._small():
+        val = _dots_with_stored_products(be, atom, other, Ag, swapped, lo, hi)
+    elif Ag is not None and not (Ag._small() and lay.part is None):
         val = _allreduce_sum(lay.mesh, be.vec_dot(other.dev(), Ag.dev(), lo, hi))
     elif Ag is not None:
         val = float(other.host() @ Ag.host())

@@ -82,6 +82,9 @@ class HipBackend:
     def vec_dot(self, x, y, lo=0, hi=-1):
         return self.ctx.vec_dot(x, y, lo, hi)
 
+    def vec_multidot(self, x, ys, lo=0, hi=-1):
+        return self.ctx.vec_multidot(x, ys, lo, hi)
+
     # ---- atoms and operators
     def atom(self, mh, kind, da, db, w):
         return self.ctx.atom_assemble(mh, kind, da, db, w)

@@ -1040,6 +1040,33 @@ def test_vector_ops(ctx):
         ctx.vec_free(yv)
 
 
+def test_multidot_matches_single_dots(ctx):
+    """pgd_vec_multidot: x . y_j for 1 .. 40 vectors (chunks of 17) and a partial range, against numpy and against
+    pgd_vec_dot (the functionals of one iterate against all stored modes go through it, fem._dots_with_stored_products)."""
+    from pgdrome_amd._lib import PgdError
+    rng = np.random.default_rng(77)
+    for n, lo, hi in ((1, 0, -1), (257, 3, 200), (100_003, 0, -1), (100_003, 999, 54_321)):
+        x = rng.standard_normal(n)
+        ys = [rng.standard_normal(n) for _ in range(40)]
+        xv, yv = ctx.vec_from(x), [ctx.vec_from(y) for y in ys]
+        stop = n if hi < 0 else hi
+        for k in (1, 2, 16, 17, 18, 34, 35, 40):
+            got = ctx.vec_multidot(xv, yv[:k], lo, hi)
+            want = np.array([x[lo:stop] @ y[lo:stop] for y in ys[:k]])
+            scale = np.array([np.abs(x[lo:stop]) @ np.abs(y[lo:stop]) for y in ys[:k]])
+            assert np.all(np.abs(got - want) <= 4e-16 * np.sqrt(max(stop - lo, 1)) * scale + 1e-300), (n, k)
+            one = np.array([ctx.vec_dot(xv, v, lo, hi) for v in yv[:k]])
+            assert np.all(np.abs(got - one) <= 1e-14 * scale + 1e-300)
+            assert np.array_equal(got, ctx.vec_multidot(xv, yv[:k], lo, hi))          # fixed summation order
+        assert np.array_equal(ctx.vec_multidot(xv, yv[:3], 0, 0), np.zeros(3))
+        with pytest.raises(PgdError):
+            ctx.vec_multidot(xv, [yv[0], 999999], lo, hi)
+        with pytest.raises(PgdError):
+            ctx.vec_multidot(xv, yv[:2], 5, n + 1)
+        for v in [xv] + yv:
+            ctx.vec_free(v)
+
+
 @pytest.mark.parametrize("kind", ["mass", "stiff", "conv", "convt", "wmass", "wstiff"])
 def test_p2_interval_atoms_match_oracle(ctx, kind):
     """Quadratic elements on a non-uniform interval mesh: pattern bit-exact, values to rounding."""
