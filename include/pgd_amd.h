@@ -185,6 +185,13 @@ int pgd_op_diag_inv(pgd_handle ctx, pgd_handle op, pgd_handle dinv);
  * (the library solves do this themselves): *used = 1 if the mesh's patterns qualify and
  * a_ij == a_ji held to rounding, else 0 and the CSR kernels stay in use.          */
 int pgd_op_symmetrize(pgd_handle ctx, pgd_handle op, int *used);
+/* Which storage form a product with this ATOM reads right now: 0 = the CSR kernels, 1 = the z-march over its diagonal form,
+ * 2 = the z-march over its row-class dictionary (one code byte per row).  Forms 1 / 2 exist on structured vertex grids once
+ * pgd_op_combine has put the atom into an operator; the first call looks for the atom's row classes (once: atoms do not
+ * change).  The frontend asks before it trades a fused product-dot (fem._bilinear_scalar, the functionals of
+ * solver.py:547-569) for product + dot with the product kept.  y is bit-identical in all three forms. */
+int pgd_atom_product_form(pgd_handle ctx, pgd_handle A, int *form);
+
 /* Look for the lossless row-class dictionary of the operator's diagonal form (structured vertex grids, after
  * pgd_op_symmetrize / pgd_op_combine; PGD_TUNE_SPMV_ROW_CLASSES): *classes = number of distinct 8-tuples of slot values
  * (1..255) when every row was verified bit by bit against its class - the z-march of later products then reads one code
@@ -277,6 +284,11 @@ int pgd_vec_multidot(pgd_handle ctx, pgd_handle x, const pgd_handle *ys, int k, 
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
+    PGD_TUNE_LAZY_CSR = 28,  /* 1 (default): where pgd_op_combine can form the operator's diagonal form (structured grids, symmetric atoms) it
+                                leaves the CSR values to the first reader that asks for them - the solve, its start and its products read
+                                the diagonal form only (1.5 ms less per solve at 256^3); 0: both forms at once */
+    PGD_TUNE_ATOM_FAST = 27, /* 1 (default): pgd_spmv with an atom whose diagonal form exists takes the z-march, over the atom's own row
+                                classes where it has them (looked for once per atom); 0: always the CSR kernels.  Bit-identical y */
     PGD_TUNE_SPMV_ROWS = 1,  /* rows (= threads) per k_spmv_csr workgroup: 64 (default), 128 or 256 */
     PGD_TUNE_SPMV_GRID_MIN_BYTES = 8, /* ... used when a grid plane of values has at least this many bytes (default 0) */
     PGD_TUNE_PCG_FOLD_REDUCE = 12, /* 1 (default): the scaled recurrence sums its reduction partials inside the vector kernels

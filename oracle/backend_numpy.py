@@ -137,6 +137,9 @@ class NumpyBackend:
         return np.array([self.vec_dot(x, y, lo, hi) for y in ys])
 
     # ---- atoms and operators
+    def atom_product_form(self, atom):
+        return 0
+
     def atom(self, mh, kind, da, db, w):
         m = self._obj[mh]
         A = F.assemble_atom(m.coords, m.cells, kind, da, db, self._obj[w] if w else None)

@@ -66,6 +66,7 @@ SIGNATURES = {
     "pgd_bilinear": (C.c_int, [H, H, H, H, I64, I64, PD]),
     "pgd_bilinear_many": (C.c_int, [H, H, H, PH, C.c_int, I64, I64, PD]),
     "pgd_start_gram": (C.c_int, [H, H, PH, C.c_int, H, I64, I64, PD]),
+    "pgd_atom_product_form": (C.c_int, [H, H, C.POINTER(C.c_int)]),
     "pgd_vec_multidot": (C.c_int, [H, H, PH, C.c_int, I64, I64, PD]),
     "pgd_pcg_solve": (C.c_int, [H, H, H, H, F64, F64, C.c_int, C.POINTER(C.c_int), PD]),
     "pgd_band_solve": (C.c_int, [H, H, H, H]),
@@ -328,6 +329,12 @@ class Context:
         return out
 
     # ---- atoms / operators
+    def atom_product_form(self, atom):
+        """0: CSR kernels, 1: z-march over the diagonal form, 2: z-march over the atom's row classes."""
+        f = C.c_int(0)
+        self._ck(self.lib.pgd_atom_product_form(self.h, atom, C.byref(f)))
+        return f.value
+
     def atom_assemble(self, mesh, kind, da=0, db=0, w=0):
         a = H(0)
         self._ck(self.lib.pgd_atom_assemble(self.h, mesh, int(kind), int(da), int(db), int(w), C.byref(a)))

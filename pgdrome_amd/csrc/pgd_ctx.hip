@@ -29,6 +29,7 @@ int fail(Ctx *c, int code, const char *fmt, ...) {
 
 pgd_handle put_obj(Ctx *c, Obj *o) {
     o->ctx = c;
+    o->serial = c->next_serial++;
     if (!c->free_list.empty()) {
         int64_t i = c->free_list.back();
         c->free_list.pop_back();

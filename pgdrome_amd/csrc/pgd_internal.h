@@ -32,6 +32,7 @@ void dev_release(Ctx *c, void *p, size_t bytes);   // back to the context's buff
 struct Obj {
     enum Kind { FREE = 0, VEC, MESH, CSR } kind = FREE;
     Ctx *ctx = nullptr;
+    uint64_t serial = 0;        // unique per object of a context (handles are recycled, serials are not): put_obj
     virtual ~Obj() {}
 };
 
@@ -100,8 +101,21 @@ struct Csr : Obj {
     int *cls_same = nullptr;       // per plane: same codes, row by row, as the plane below
     double *cls_table = nullptr;   // owns the allocation: table, then the codes
     int cls_count = 0;
+    bool cls_tried = false;        // atoms: the dictionary was looked for once for the current slot values (atom_fast_form)
+    bool immutable = false;        // an ATOM (assembled / uploaded / embedded): its values change only through pgd_atom_embed(dst)
+    uint64_t version = 0;          // bumped by every writer of `vals` after creation
+    // pgd_op_combine on a structured grid forms the diagonal form only; the CSR values follow on first use (ensure_vals)
+    // from this recipe: atoms by handle + serial + version (a freed or rewritten atom is an error, not a wrong product)
+    bool vals_pending = false;
+    std::vector<pgd_handle> rec_atoms;
+    std::vector<uint64_t> rec_serials, rec_versions;
+    std::vector<double> rec_coefs;
+    int *rec_bc = nullptr;         // Dirichlet dofs of the combine (device copy)
+    int64_t rec_nbc = 0;
+    size_t rec_bc_bytes = 0;
     size_t vals_bytes = 0, dinv_bytes = 0, uvals_bytes = 0, cls_bytes = 0;
     ~Csr() override {
+        if (rec_bc) dev_release(ctx, rec_bc, rec_bc_bytes);
         if (cls_table) dev_release(ctx, cls_table, cls_bytes);
         if (vals) dev_release(ctx, vals, vals_bytes);
         if (dinv) dev_release(ctx, dinv, dinv_bytes);
@@ -167,6 +181,9 @@ struct Ctx {
     int asm_lattice = 1;          // lattice meshes: edge vectors as whole lattice steps in the assembly (PGD_TUNE_ASM_LATTICE)
     int spmv_fetch_depth = 6;     // plane fetches in flight per workgroup of k_spmv_diac_march2 (3 or 6; PGD_TUNE_SPMV_FETCH_DEPTH)
     int spmv_zchunk_coded = 24;   // most planes per march of k_spmv_diac_march2 (PGD_TUNE_SPMV_ZCHUNK_CODED)
+    int atom_fast = 1;            // products with an atom whose diagonal form exists take the z-march (+ its own row classes, looked for once)
+    int lazy_csr = 1;             // pgd_op_combine forms only the diagonal form where it can; CSR values on first use
+    uint64_t next_serial = 1;
     int spmv_classes = 1;         // row-class dictionary of the scaled diagonal form (k_spmv_diac_march2) where the operator has one
     void *cls_scratch = nullptr;  // hash slots of dia_classify
     double *gram_w = nullptr;     // pgd_start_gram: the products A v_j, one vector each
@@ -232,6 +249,8 @@ int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const 
 int pcg1_flush_x(Ctx *c, double *x, const double *p, const double *r, int64_t lo, int64_t hi, int base);
 int vec_sqrt(Ctx *c, double *v, int64_t n);
 int vec_div_mul(Ctx *c, double *x, const double *sc, int64_t n, int mul);
+int ensure_vals(Ctx *c, const Mesh *m, Csr *a);                 // pgd_pcg.hip: CSR values of an operator whose combine was deferred
+bool atom_fast_form(Ctx *c, const Mesh *m, Csr *a, int64_t r0, int64_t r1);   // pgd_spmv.hip
 int dia_classify(Ctx *c, const Mesh *m, Csr *a);                // pgd_spmv.hip: row-class dictionary of the current slot values
 int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *s);   // pgd_spmv.hip: slot values *= s_i s_j
 int launch_spmv_dia_rows2(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0a,

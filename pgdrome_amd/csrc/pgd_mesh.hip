@@ -830,6 +830,7 @@ static int new_csr(Ctx *c, pgd_handle mh, Mesh *m, pgd_handle *out, Csr **res) {
     PGD_TRY(dev_alloc(c, &p, a->vals_bytes));
     a->vals = (double *)p;
     PGD_HIP(c, hipMemsetAsync(a->vals, 0, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(double) + PAD_BYTES, c->stream));
+    a->immutable = true;       // an atom: written once, here or by its caller (pgd_atom_embed(dst) accumulates and says so)
     *res = a.get();
     *out = put_obj(c, a.release());
     return PGD_OK;
@@ -909,6 +910,9 @@ int pgd_atom_embed(pgd_handle h, pgd_handle bmh, pgd_handle src, int cv, int cu,
     } else {
         PGD_TRY(new_csr(c, bmh, b, out, &d));      // zero-filled
     }
+    PGD_TRY(ensure_vals(c, m, a));
+    d->version += 1;           // new values: forms derived from the old ones are gone
+    d->uvals_valid = false; d->uvals_scaled = false; d->cls_count = 0; d->cls_tried = false; d->dinv_valid = false;
     k_block_embed<<<(int)((m->nv + TPB - 1) / TPB), TPB, 0, c->stream>>>(m->row_ptr, a->vals, m->nv, b->ncomp, cv, cu, coef, b->row_ptr, d->vals);
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
@@ -930,6 +934,7 @@ int pgd_atom_download(pgd_handle h, pgd_handle ah, double *vals) {
     Csr *a = get_csr(c, ah);
     Mesh *m = a ? get_mesh(c, a->mesh) : nullptr;
     if (!a || !m || !vals) return fail(c, PGD_ERR_INVALID, "atom_download: invalid handle");
+    PGD_TRY(ensure_vals(c, m, a));
     if (m->nnz) PGD_HIP(c, hipMemcpyAsync(vals, a->vals, (size_t)m->nnz * sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PGD_HIP(c, hipStreamSynchronize(c->stream));
     return PGD_OK;

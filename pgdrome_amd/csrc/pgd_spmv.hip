@@ -1406,6 +1406,8 @@ int ensure_sym(Ctx *c, const Mesh *m, Csr *a, bool *usable) {
         a->uvals = (double *)p;
         a->uvals_stride = stride;
     }
+    PGD_TRY(ensure_vals(c, m, a));
+    a->cls_tried = false;
     PGD_HIP(c, hipMemsetAsync(c->flags + 4, 0, 4 * sizeof(int), c->stream));
     const int g = (int)((m->nv + TPB - 1) / TPB);
     if (m->sym_nx > 0) k_csr_to_dia<<<g, TPB, 0, c->stream>>>(m->row_ptr, m->cols, a->vals, m->nv, m->sym_nx, m->sym_ny, stride, a->uvals, c->flags + 4);
@@ -1464,6 +1466,7 @@ __global__ __launch_bounds__(TPB) void k_combine_dia(CombineDiaArgs A, double *_
 int combine_dia(Ctx *c, const Mesh *m, Csr *o, Csr *const *atoms, const double *coefs, int n, const uint8_t *mask) {
     o->uvals_valid = false;
     o->cls_count = 0;
+    o->cls_tried = false;
     if (!c->spmv_sym || m->sym_nx <= 0 || !c->spmv_combine_dia) return PGD_OK;
     for (int t = 0; t < n; ++t) {
         bool usable = false;
@@ -1504,10 +1507,29 @@ int combine_dia(Ctx *c, const Mesh *m, Csr *o, Csr *const *atoms, const double *
     return PGD_OK;
 }
 
+// Products with an ATOM (immutable values) on a structured grid: once its diagonal form exists - pgd_op_combine converted
+// it for the first operator it went into - plane-aligned products take the z-march instead of the CSR kernels (bit-identical
+// y), and the atom's own row classes are looked for ONCE (0.65 ms at 256^3): mass and stiffness of a uniform grid have them, so
+// the functionals and right-hand-side products of the fixed-point loop read one code byte per row like the PCG product.
+bool atom_fast_form(Ctx *c, const Mesh *m, Csr *a, int64_t r0, int64_t r1) {
+    if (!c->atom_fast || !c->spmv_sym || m->sym_nx <= 0 || !a->immutable || !(a->uvals && a->uvals_valid) || a->uvals_scaled) return false;
+    const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
+    if (r1 < 0) r1 = m->nv;
+    if (r0 < 0 || r0 > r1 || r1 > m->nv || r0 % plane != 0 || r1 % plane != 0 || (r1 - r0) / plane < 3) return false;
+    if (plane * 64 < c->spmv_grid_min_plane_bytes || c->spmv_zchunk <= 0) return false;
+    if (!a->cls_tried) {
+        a->cls_tried = true;
+        if (dia_classify(c, m, a) != PGD_OK) { a->cls_count = 0; return false; }
+    }
+    return true;
+}
+
 int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0,
                    int64_t r1, bool dot, bool store, const int *flags, int *nparts_out) {
-    if (!(c->spmv_sym && m->sym_w && a->uvals_valid && a->uvals))
+    if (!(c->spmv_sym && m->sym_w && a->uvals_valid && a->uvals)) {
+        PGD_TRY(ensure_vals(c, m, const_cast<Csr *>(a)));
         return launch_spmv(c, m, a->vals, x, y, w, r0, r1, dot, store, flags, nparts_out);
+    }
     if (r1 < 0) r1 = m->nv;
     if (r0 < 0 || r0 > r1 || r1 > m->nv) return fail(c, PGD_ERR_INVALID, "spmv: bad row range");
     const int64_t nrows = r1 - r0;
@@ -1788,6 +1810,8 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_PCG_SMALL_SINGLE_SYNC && value >= 0 && value <= 1) { c->pcg_small_ss = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_SMALL_ROWS && value >= 0) { c->pcg_small_ss_rows = value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_FETCH_DEPTH && (value == 3 || value == 6)) { c->spmv_fetch_depth = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_ATOM_FAST && value >= 0 && value <= 1) { c->atom_fast = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_LAZY_CSR && value >= 0 && value <= 1) { c->lazy_csr = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK_CODED && value >= 3 && value <= 1024) { c->spmv_zchunk_coded = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }
@@ -1799,6 +1823,8 @@ int pgd_spmv(pgd_handle h, pgd_handle ah, pgd_handle xh, pgd_handle yh, int64_t 
     Vec *x = get_vec(c, xh), *y = get_vec(c, yh);
     if (!a || !m || !x || !y || x->n != m->nv || y->n != m->nv || x == y)
         return fail(c, PGD_ERR_INVALID, "spmv: invalid handles, size mismatch or x aliases y");
+    if (atom_fast_form(c, m, a, r0, r1)) return launch_spmv_op(c, m, a, x->d, y->d, nullptr, r0, r1, false, true, nullptr, nullptr);
+    PGD_TRY(ensure_vals(c, m, a));
     return launch_spmv(c, m, a->vals, x->d, y->d, nullptr, r0, r1, false, true, nullptr, nullptr);
 }
 
@@ -1810,6 +1836,7 @@ int pgd_bilinear(pgd_handle h, pgd_handle ah, pgd_handle xh, pgd_handle yh, int6
     if (!a || !m || !x || !y || !out || x->n != m->nv || y->n != m->nv)
         return fail(c, PGD_ERR_INVALID, "bilinear: invalid handles or size mismatch");
     int nparts = 0;
+    PGD_TRY(ensure_vals(c, m, a));
     PGD_TRY(launch_spmv(c, m, a->vals, y->d, nullptr, x->d, r0, r1, true, false, nullptr, &nparts));
     if (nparts == 0) { *out = 0.0; return PGD_OK; }
     PGD_TRY(reduce_partials(c, c->partials, nparts, 1, S_TMP, -1, 0, 0));
@@ -1833,6 +1860,7 @@ int pgd_bilinear_many(pgd_handle h, pgd_handle ah, pgd_handle xh, const pgd_hand
         ys[k] = y->d;
     }
     if (ny == 0) return PGD_OK;
+    PGD_TRY(ensure_vals(c, m, a));
     return launch_spmv_multi(c, m, a->vals, x->d, ys.data(), ny, r0, r1, out);
 }
 
@@ -1844,6 +1872,16 @@ int pgd_op_symmetrize(pgd_handle h, pgd_handle ah, int *used) {
     bool usable = false;
     PGD_TRY(ensure_sym(c, m, a, &usable));
     if (used) *used = usable ? 1 : 0;
+    return PGD_OK;
+}
+
+int pgd_atom_product_form(pgd_handle h, pgd_handle ah, int *form) {
+    PGD_CTX(c, h);
+    Csr *a = get_csr(c, ah);
+    Mesh *m = a ? get_mesh(c, a->mesh) : nullptr;
+    if (!a || !m || !form) return fail(c, PGD_ERR_INVALID, "atom_product_form: invalid handle");
+    *form = 0;
+    if (atom_fast_form(c, m, a, 0, m->nv)) *form = a->cls_count > 0 ? 2 : 1;
     return PGD_OK;
 }
 

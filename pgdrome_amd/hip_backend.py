@@ -86,6 +86,9 @@ class HipBackend:
         return self.ctx.vec_multidot(x, ys, lo, hi)
 
     # ---- atoms and operators
+    def atom_product_form(self, atom):
+        return self.ctx.atom_product_form(atom)
+
     def atom(self, mh, kind, da, db, w):
         return self.ctx.atom_assemble(mh, kind, da, db, w)
 

@@ -843,6 +843,104 @@ def test_row_class_dictionary_is_lossless(ctx, shape):
     ctx.mesh_free(h)
 
 
+def test_deferred_csr_values_and_atom_products(ctx):
+    """pgd_op_combine on a structured grid forms the operator's diagonal form and leaves the CSR values to the first reader
+    (PGD_TUNE_LAZY_CSR): whoever asks later - a download, a CSR product after the solve has scaled the slot arrays, the
+    band / diagonal helpers - gets exactly what the eager combine gives, and an operator whose atoms have gone says so.
+    Products with an ATOM whose diagonal form exists take the z-march over the atom's own row classes
+    (PGD_TUNE_ATOM_FAST, pgd_atom_product_form): bit-identical y, plane-aligned ranges only."""
+    from pgdrome_amd._lib import PgdError
+    nx, ny, nz = 70, 19, 23
+    coords, cells = F.box_mesh((0, 0, 0), (1.0, 0.7, 1.3), nx - 1, ny - 1, nz - 1)
+    h = ctx.mesh_upload(coords, cells)
+    n, plane = coords.shape[0], nx * ny
+    nnz = ctx.mesh_info(h)["nnz"]
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bnd = boundary_dofs(coords).astype(np.int32)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, n)
+    xv, yv, bv = ctx.vec_from(x), ctx.vec_alloc(n), ctx.vec_from(rng.uniform(-1, 1, n))
+    try:
+        # before any operator: the atoms have no diagonal form yet, products read the CSR values
+        assert ctx.atom_product_form(ak) == 0
+        ctx.spmv(ak, xv, yv)
+        yk_csr = ctx.vec_download(yv)
+        ctx.spmv(am, xv, yv, 2 * plane, 9 * plane)
+        ym_csr = ctx.vec_download(yv, 2 * plane, 7 * plane)
+        for bc in (bnd, np.zeros(0, dtype=np.int32)):
+            ctx.tune(28, 0)
+            eager = ctx.op_combine(h, [ak, am], [1.3, 0.37], bc)
+            v_eager = ctx.atom_download(eager, nnz)
+            ctx.tune(28, 1)
+            k0 = ctx.kernel_counts()
+            lazy = ctx.op_combine(h, [ak, am], [1.3, 0.37], bc)
+            # the solve reads the diagonal form only ...
+            xs = ctx.vec_alloc(n)
+            ctx.vec_fill(xs, 0.0)
+            ctx.vec_set(bv, bc, np.zeros(bc.size)) if bc.size else None
+            it, rel = ctx.pcg_solve(lazy, bv, xs, 1e-10, 0.0, 4000)
+            k1 = ctx.kernel_counts()
+            assert rel <= 1e-10 and k1["csr"] == k0["csr"] and k1["csr_dict"] == k0["csr_dict"]
+            # ... and afterwards (slot arrays scaled and given up) the CSR values appear on request, bit for bit
+            assert np.array_equal(ctx.atom_download(lazy, nnz), v_eager)
+            ctx.spmv(lazy, xs, yv)
+            r = ctx.vec_download(yv) - ctx.vec_download(bv)
+            assert np.linalg.norm(r) <= 2e-10 * np.linalg.norm(ctx.vec_download(bv))
+            ctx.vec_free(xs)
+            # new values through the same handle, read through the diagonal helper
+            lazy = ctx.op_combine(h, [ak, am], [0.5, 2.0], bc, op=lazy)
+            eager = ctx.op_combine(h, [ak, am], [0.5, 2.0], bc, op=eager)
+            dv = ctx.vec_alloc(n)
+            ctx.op_diag_inv(lazy, dv)
+            d_lazy = ctx.vec_download(dv)
+            ctx.op_diag_inv(eager, dv)
+            assert np.array_equal(d_lazy, ctx.vec_download(dv))
+            ctx.vec_free(dv)
+            ctx.atom_free(lazy)
+            ctx.atom_free(eager)
+        # the atoms went through combine_dia: they have their diagonal form now, and on this uniform grid row classes
+        assert ctx.atom_product_form(ak) == 2 and ctx.atom_product_form(am) == 2
+        ctx.tune(7, 4)            # (a grid this small would take the row-order kernel over the slot values otherwise)
+        k0 = ctx.kernel_counts()
+        ctx.vec_fill(yv, -1.0)
+        ctx.spmv(ak, xv, yv)
+        assert np.array_equal(ctx.vec_download(yv), yk_csr)
+        ctx.vec_fill(yv, -1.0)
+        ctx.spmv(am, xv, yv, 2 * plane, 9 * plane)
+        y = ctx.vec_download(yv)
+        assert np.array_equal(y[2 * plane:9 * plane], ym_csr) and np.all(y[:2 * plane] == -1.0) and np.all(y[9 * plane:] == -1.0)
+        k1 = ctx.kernel_counts()
+        assert k1["diac_march"] == k0["diac_march"] + 2 and k1["csr"] == k0["csr"] and k1["csr_dict"] == k0["csr_dict"]
+        # a range that is not plane-aligned, and the knob switched off: the CSR kernels, same bits
+        ctx.spmv(ak, xv, yv, 5, n - 3)
+        assert np.array_equal(ctx.vec_download(yv, 5, n - 8), yk_csr[5:n - 3])
+        ctx.tune(27, 0)
+        assert ctx.atom_product_form(ak) == 0
+        k0 = ctx.kernel_counts()
+        ctx.spmv(ak, xv, yv)
+        k1 = ctx.kernel_counts()
+        assert k1["diac_march"] == k0["diac_march"] and np.array_equal(ctx.vec_download(yv), yk_csr)
+        ctx.tune(27, 1)
+        # an operator left pending whose atom is freed (its handle taken by another atom): an error, not a wrong product
+        a2 = ctx.atom_assemble(h, F.MASS)
+        op = ctx.op_combine(h, [ak, a2], [1.0, 1.0], bnd)
+        ctx.atom_free(a2)
+        a3 = ctx.atom_assemble(h, F.STIFF)
+        with pytest.raises(PgdError):
+            ctx.atom_download(op, nnz)
+        ctx.atom_free(a3)
+        ctx.atom_free(op)
+    finally:
+        ctx.tune(7, 0)
+        ctx.tune(27, 1)
+        ctx.tune(28, 1)
+    for v in (xv, yv, bv):
+        ctx.vec_free(v)
+    for a in (ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
 def test_pcg_on_row_classes_is_bit_identical(ctx):
     """The library's PCG classifies the scaled operator per solve: with and without the dictionary the solve walks the same
     iterates bit for bit (single-sync recurrence and the two-reduction one) when both kernels march equally far - y is
