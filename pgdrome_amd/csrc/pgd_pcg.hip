@@ -999,6 +999,16 @@ __global__ __launch_bounds__(TPB) void k_pcg_p_s2(double *__restrict__ p, const 
 int ensure_vals(Ctx *c, const Mesh *m, Csr *o) {
     if (!o->vals_pending) return PGD_OK;
     const int n = (int)o->rec_atoms.size();
+    if (!o->vals) {
+        void *p;
+        const size_t cnt = (size_t)(m->nnz > 0 ? m->nnz : 1);
+        o->vals_bytes = cnt * sizeof(double);
+        PGD_TRY(dev_alloc(c, &p, o->vals_bytes));
+        o->vals = (double *)p;
+        // k_combine writes every entry; the padding behind them (16-byte loads of the CSR kernels read past the end) is zero
+        const size_t used = (size_t)(m->nnz > 0 ? m->nnz : 0);
+        PGD_HIP(c, hipMemsetAsync(o->vals + used, 0, (cnt - used) * sizeof(double) + PAD_BYTES, c->stream));
+    }
     std::vector<const double *> in((size_t)n);
     for (int t = 0; t < n; ++t) {
         Csr *a = get_csr(c, o->rec_atoms[(size_t)t]);
@@ -1229,14 +1239,9 @@ int pgd_op_combine(pgd_handle h, pgd_handle mh, const pgd_handle *atoms, const d
         o = get_csr(c, *op);
         if (!o || o->mesh != mh) return fail(c, PGD_ERR_INVALID, "op_combine: *op is not an operator on this mesh");
     } else {
-        std::unique_ptr<Csr> a(new Csr);
+        std::unique_ptr<Csr> a(new Csr);       // (its CSR array - 2 GB at 256^3 - is allocated by ensure_vals, i.e. usually never)
         a->kind = Obj::CSR;
         a->mesh = mh;
-        void *p;
-        a->vals_bytes = (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(double);
-        PGD_TRY(dev_alloc(c, &p, a->vals_bytes));
-        a->vals = (double *)p;
-        PGD_HIP(c, hipMemsetAsync(a->vals, 0, (size_t)(m->nnz > 0 ? m->nnz : 1) * sizeof(double) + PAD_BYTES, c->stream));
         o = a.get();
         *op = put_obj(c, a.release());
     }
