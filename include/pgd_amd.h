@@ -284,6 +284,9 @@ int pgd_vec_multidot(pgd_handle ctx, pgd_handle x, const pgd_handle *ys, int k, 
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
+    PGD_TUNE_PCG_FOLD_FINISH = 29, /* 1 (default): in the single-sync recurrence of pgd_pcg_solve_sharded every workgroup of the vector update
+                                forms the stop decision, alpha and beta itself from the five all-reduced sums (workgroup 0 keeps the books):
+                                one launch less per iteration, bit-identical iterates; 0: k_pcg1_finish in a launch of its own */
     PGD_TUNE_LAZY_CSR = 28,  /* 1 (default): where pgd_op_combine can form the operator's diagonal form (structured grids, symmetric atoms) it
                                 leaves the CSR values to the first reader that asks for them - the solve, its start and its products read
                                 the diagonal form only (1.5 ms less per solve at 256^3); 0: both forms at once */

@@ -457,6 +457,9 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     }
     int32_t done = 0, it = 0, status = 0;
     int kk = 0;
+    // an empty slab has no update launch to fold the scalar step into; every rank must take the same form (collective-free: the
+    // decision depends on nothing rank-local but that, and a rank without rows runs k_pcg1_finish for its own books instead)
+    const bool fold = ss && c->pcg_fold_finish != 0 && own1 > own0;
     // One iteration; did_halo / did_ar say which of its two collectives were issued when it fails half way.
     bool did_halo = false, did_ar = false;
     auto iterate = [&](int kidx) -> int {
@@ -476,9 +479,10 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
             PGD_TRY(pcg1_sums(c, np, gvec, B));
             did_ar = true;
             PGD_TRY(comm_allreduce(c, B, 5));
-            PGD_TRY(pcg1_finish_slots(c, B));
+            // stop test, alpha, beta: by every workgroup of the update (fold), or by k_pcg1_finish in a launch of its own
+            if (!fold) PGD_TRY(pcg1_finish_slots(c, B));
             // (x is updated every other iteration, two terms at a time: k_pcg1_update; every rank reads the same beta)
-            PGD_TRY(pcg1_update(c, xd, rd, pd, qd, scp, own0, own1, B, &nb, c->pcg_lag_x ? 1 + (kidx & 1) : 0));
+            PGD_TRY(pcg1_update(c, xd, rd, pd, qd, scp, own0, own1, B, &nb, c->pcg_lag_x ? 1 + (kidx & 1) : 0, fold ? (kidx & 1) : -1));
             return PGD_OK;
         }
         if (scaled && kidx > 0) {
@@ -534,7 +538,7 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     }
     if (status != 0) return fail(c, PGD_ERR_SINGULAR, "sharded PCG breakdown (NaN) after %d iterations", it);
     if (ss && c->pcg_lag_x && it > 0 && ((it - 1) & 1) == 0)          // the last update had an even index: its term of x may be outstanding
-        PGD_TRY(pcg1_flush_x(c, xd, pd, rd, own0, own1, B));
+        PGD_TRY(pcg1_flush_x(c, xd, pd, rd, own0, own1, B, fold ? ((it - 1) & 1) : -1));
     if (scaled) {
         guard.active = false;
         PGD_TRY(vec_div_mul(c, xd, scp, n, 1));                      // back to x = sc x~ (ghosts too; refreshed below)

@@ -181,6 +181,7 @@ struct Ctx {
     int asm_lattice = 1;          // lattice meshes: edge vectors as whole lattice steps in the assembly (PGD_TUNE_ASM_LATTICE)
     int spmv_fetch_depth = 6;     // plane fetches in flight per workgroup of k_spmv_diac_march2 (3 or 6; PGD_TUNE_SPMV_FETCH_DEPTH)
     int spmv_zchunk_coded = 24;   // most planes per march of k_spmv_diac_march2 (PGD_TUNE_SPMV_ZCHUNK_CODED)
+    int pcg_fold_finish = 1;      // sharded single-sync loop: the scalar step inside the update kernel (one launch less per iteration)
     int atom_fast = 1;            // products with an atom whose diagonal form exists take the z-march (+ its own row classes, looked for once)
     int lazy_csr = 1;             // pgd_op_combine forms only the diagonal form where it can; CSR values on first use
     uint64_t next_serial = 1;
@@ -245,8 +246,8 @@ int pcg1_tol(Ctx *c, int base, double rtol, double atol);
 int pcg1_sums(Ctx *c, int nprod, int nvec, int base);
 int pcg1_finish_slots(Ctx *c, int base);
 int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const double *sc, int64_t lo, int64_t hi, int base,
-                int *nblocks, int lag);
-int pcg1_flush_x(Ctx *c, double *x, const double *p, const double *r, int64_t lo, int64_t hi, int base);
+                int *nblocks, int lag, int fold_par);
+int pcg1_flush_x(Ctx *c, double *x, const double *p, const double *r, int64_t lo, int64_t hi, int base, int fold_par);
 int vec_sqrt(Ctx *c, double *v, int64_t n);
 int vec_div_mul(Ctx *c, double *x, const double *sc, int64_t n, int mul);
 int ensure_vals(Ctx *c, const Mesh *m, Csr *a);                 // pgd_pcg.hip: CSR values of an operator whose combine was deferred

@@ -697,19 +697,52 @@ __global__ void k_pcg1_tol(double *__restrict__ slots, int *__restrict__ flags, 
 // 145 -> 124 us for this kernel AND 88 -> 81 us for the product behind it (7.4 -> 8.3 passes/s; loads alone + 5 %, stores alone 0,
 // p streamed as well - 3 %).  slots[S1_PEND] (written by workgroup 0 of the lag = 1 launches, read by the lag = 2
 // ones and by k_scale_out when the solve ends between the two) says whether a term is outstanding.  lag = 0: every iteration.
-template <bool NT>
+// FOLD (the row-sharded loop, whose sums arrive all-reduced in slots[fold_base .. + 3]: p.q, q.q, r~.r~ and the true r.r of the
+// residual this launch starts from): EVERY workgroup runs the scalar step itself - stop test, alpha, beta from those four
+// numbers, bit for bit the same in all of them - and workgroup 0 keeps the books (iteration count, flags, the report's r.r):
+// k_pcg1_finish and its launch are gone from the iteration.  Nothing a workgroup reads is written by another one of the same
+// launch: alpha / beta alternate between two slot pairs with the parity `par` of the iteration (the two-term x update reads the
+// previous pair), the sums are rewritten by the NEXT iteration's k_pcg1_sums, and the sharded form is in its exact phase
+// (flags[3] = 1, the true r.r in every iteration) from the start.  A workgroup that starts late and finds the done flag set by
+// workgroup 0 returns - what its own test would have told it.
+enum { S1F_ALPHA = 44 /* +parity */, S1F_BETA = 46 /* +parity */, S1F_EXACT = 48 /* +parity */ };
+
+template <bool NT, bool FOLD>
 __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
                                                      const double *__restrict__ q, const double *__restrict__ s, int64_t lo,
                                                      int64_t hi, double *__restrict__ slots, int slot_alpha, int slot_beta,
-                                                     double *__restrict__ partials, const int *__restrict__ flags, int lag) {
+                                                     double *__restrict__ partials, int *__restrict__ flags, int lag,
+                                                     int fold_base, int par) {
     if (flags[0]) return;
     __shared__ double s_red[4];
     typedef double d2 __attribute__((ext_vector_type(2)));
-    const double alpha = slots[slot_alpha], beta = slots[slot_beta];
-    const bool exact = flags[3] != 0;
+    double alpha, beta;
+    if (FOLD) {
+        const double pq = slots[fold_base], qq = slots[fold_base + 1], rz0 = slots[fold_base + 2], rr0 = slots[fold_base + 3];
+        const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
+        if (lead) slots[6] = rr0;                                  // the last measured true r.r, for the report
+        int done = 0, status = 0;
+        if (!(rz0 == rz0) || !(pq == pq)) { done = 1; status = PGD_ERR_SINGULAR; }
+        else if (rr0 <= slots[S_TOL2]) done = 1;
+        else if (!(rz0 > 0.0)) done = 1;
+        if (done) {
+            if (lead) { if (status) flags[2] = status; flags[0] = 1; }
+            return;                                                // uniform over the whole launch
+        }
+        alpha = rz0 / pq;
+        double rnew = alpha * alpha * qq - rz0;
+        if (!(rnew > 0.0)) rnew = 0.0;
+        beta = rnew / rz0;
+        if (lead) { slots[S1F_ALPHA + par] = alpha; slots[S1F_BETA + par] = beta; flags[1] += 1; }
+    } else {
+        alpha = slots[slot_alpha];
+        beta = slots[slot_beta];
+    }
+    const bool exact = FOLD ? true : flags[3] != 0;
     const bool skip_x = lag == 1 && beta >= LAG_MIN_BETA;
     const bool two = lag == 2 && slots[S1_PEND] != 0.0;
-    const double alpha_p = two ? slots[S1_ALPHA_PREV] : 0.0, ibeta_p = two ? 1.0 / slots[S1_BETA_PREV] : 0.0;
+    const double alpha_p = two ? slots[FOLD ? S1F_ALPHA + (par ^ 1) : S1_ALPHA_PREV] : 0.0;
+    const double ibeta_p = two ? 1.0 / slots[FOLD ? S1F_BETA + (par ^ 1) : S1_BETA_PREV] : 0.0;
     double rz = 0.0, rr = 0.0;
     if ((lo & 1) == 0) {                                  // 16-byte accesses (row ranges of the sharded solve may start odd)
         const int64_t npair = (hi - lo) >> 1;
@@ -766,8 +799,6 @@ __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, dou
 // the parity of the iteration; a workgroup that starts late and finds the done flag already set by workgroup 0 returns, which
 // is what its own test would have told it.  (Measured on larger systems too: at 128^3 a wash, at 256^3 the redundant sums cost
 // more than the launch they save - those keep k_pcg1_scalars + k_pcg1_update.)
-enum { S1F_ALPHA = 44 /* +parity */, S1F_BETA = 46 /* +parity */, S1F_EXACT = 48 /* +parity */ };
-
 struct Pcg1Scalars { double alpha, beta; int exact, done, status; double pq, qq, rz, rr; };
 
 __device__ __forceinline__ Pcg1Scalars pcg1_wg_scalars(const double *__restrict__ prod, int nprod, const double *__restrict__ vecp, int nvec,
@@ -1156,7 +1187,7 @@ int pcg1_finish_slots(Ctx *c, int base) {
 }
 
 int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const double *sc, int64_t lo, int64_t hi, int base,
-                int *nblocks, int lag) {
+                int *nblocks, int lag, int fold_par) {       // fold_par >= 0: the scalar step in every workgroup (parity of the iteration)
     *nblocks = 0;
     if (hi == lo) return PGD_OK;
     const int g = grid_for((hi - lo + 1) / 2);
@@ -1167,8 +1198,11 @@ int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const 
         c->ev_kind[c->ev_used / 2] = 1;
         PGD_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
     }
-    if (c->pcg_stream_hints) k_pcg1_update<true><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, lag);
-    else k_pcg1_update<false><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, lag);
+    if (fold_par >= 0) {
+        if (c->pcg_stream_hints) k_pcg1_update<true, true><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, 0, 0, c->work[6], c->flags, lag, base, fold_par);
+        else k_pcg1_update<false, true><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, 0, 0, c->work[6], c->flags, lag, base, fold_par);
+    } else if (c->pcg_stream_hints) k_pcg1_update<true, false><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, lag, 0, 0);
+    else k_pcg1_update<false, false><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, lag, 0, 0);
     if (timed_u) {
         PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
         c->ev_used += 2;
@@ -1191,9 +1225,10 @@ __global__ __launch_bounds__(TPB) void k_pcg1_flush_x(double *__restrict__ x, co
         x[i] = fma(alpha, (p[i] - r[i]) * ibeta, x[i]);
 }
 
-int pcg1_flush_x(Ctx *c, double *x, const double *p, const double *r, int64_t lo, int64_t hi, int base) {
+int pcg1_flush_x(Ctx *c, double *x, const double *p, const double *r, int64_t lo, int64_t hi, int base, int fold_par) {
     if (hi == lo) return PGD_OK;
-    k_pcg1_flush_x<<<grid_for(hi - lo), TPB, 0, c->stream>>>(x, p, r, lo, hi, c->slots, base + 5, base + 6);
+    const int sa = fold_par >= 0 ? S1F_ALPHA + fold_par : base + 5, sb = fold_par >= 0 ? S1F_BETA + fold_par : base + 6;
+    k_pcg1_flush_x<<<grid_for(hi - lo), TPB, 0, c->stream>>>(x, p, r, lo, hi, c->slots, sa, sb);
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
 }
@@ -1401,8 +1436,8 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
                     const int par = (start + k) & 1;
                     k_pcg1_step<<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, n, prod, nparts, par ? part2 : part2b, g2v, par ? part2b : part2,
                                                             c->slots, c->flags, par, lag);
-                } else if (c->pcg_stream_hints) k_pcg1_update<true><<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags, lag);
-                else k_pcg1_update<false><<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags, lag);
+                } else if (c->pcg_stream_hints) k_pcg1_update<true, false><<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags, lag, 0, 0);
+                else k_pcg1_update<false, false><<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags, lag, 0, 0);
                 if (timed_u) {
                     PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
                     c->ev_used += 2;

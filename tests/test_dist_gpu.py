@@ -179,20 +179,34 @@ def test_sharded_solve_marches_on_row_classes():
         fem.set_backend(old)
         fem.clear_caches()
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, 2, port, shape, q, True)) for r in range(2)]
-    for pr in procs:
-        pr.start()
-    out = q.get(timeout=600)
-    for pr in procs:
-        pr.join(timeout=120)
-        assert pr.exitcode == 0
-    assert out["kernels"]["diac_march"] > 100 and out["kernels"]["dia_rows"] > 100
-    assert out["num_fp_it"] == ref.num_fp_it
-    np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
+    outs = {}
+    saved = os.environ.get("PGD_TUNE")
+    try:
+        # the scalar step of an iteration inside the update kernel (default) and as a launch of its own: the same bits
+        for fold in (1, 0):
+            os.environ["PGD_TUNE"] = "29=%d" % fold
+            q = ctx.Queue()
+            port = _free_port()
+            procs = [ctx.Process(target=_shared_gpu_worker, args=(r, 2, port, shape, q, True)) for r in range(2)]
+            for pr in procs:
+                pr.start()
+            out = outs[fold] = q.get(timeout=600)
+            for pr in procs:
+                pr.join(timeout=120)
+                assert pr.exitcode == 0
+            assert out["kernels"]["diac_march"] > 100 and out["kernels"]["dia_rows"] > 100
+            assert out["num_fp_it"] == ref.num_fp_it
+            np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
+            for m in range(ref.PGD_modes):
+                assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
+    finally:
+        if saved is None:
+            os.environ.pop("PGD_TUNE", None)
+        else:
+            os.environ["PGD_TUNE"] = saved
+    assert outs[0]["amplitude"] == outs[1]["amplitude"]
     for m in range(ref.PGD_modes):
-        assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
+        assert np.array_equal(outs[0]["modes_x"][m], outs[1]["modes_x"][m])
 
 
 def _faulty_worker(rank, world, port, shape, q):
