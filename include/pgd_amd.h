@@ -284,6 +284,10 @@ int pgd_vec_multidot(pgd_handle ctx, pgd_handle x, const pgd_handle *ys, int k, 
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
+    PGD_TUNE_PCG_EXACT_PHASE = 30, /* 1 (default): the single-sync recurrence of pgd_pcg_solve_sharded measures the true residual norm (one more
+                                vector read per row in the update) only near the end, like pgd_pcg_solve: once d_lb r~.r~ comes within 10^4 of
+                                the tolerance, d_lb = (all-reduced sum of d_i^-8)^(-1/8) <= d_min, the same number on every rank; the stop test
+                                is the true norm either way.  0: the true norm in every iteration */
     PGD_TUNE_PCG_FOLD_FINISH = 29, /* 1 (default): in the single-sync recurrence of pgd_pcg_solve_sharded every workgroup of the vector update
                                 forms the stop decision, alpha and beta itself from the five all-reduced sums (workgroup 0 keeps the books):
                                 one launch less per iteration, bit-identical iterates; 0: k_pcg1_finish in a launch of its own */

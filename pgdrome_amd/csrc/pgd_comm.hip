@@ -444,8 +444,11 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         // textbook start p = r; the local (r~.r~, true r.r) of the initial residual become the first "previous update" sums
         if (own1 > own0) PGD_HIP(c, hipMemcpyAsync(pd + own0, rd + own0, (size_t)(own1 - own0) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
         PGD_TRY(pcg1_seed(c, MAX_VEC_BLOCKS, B, B + 1));
+        // (slot B + 7 rides along: the sum of s_i^16 over the owned rows, from which every rank forms the same lower bound of the
+        // smallest diagonal entry - k_pcg1_tol - for the switch into the exact phase)
+        if (c->pcg_exact_phase) PGD_TRY(pcg1_aux(c, scp, nullptr, own0, own1, B + 7));
         PGD_TRY(comm_allreduce(c, B, 9));
-        PGD_TRY(pcg1_tol(c, B, rtol, atol));
+        PGD_TRY(pcg1_tol(c, B, rtol, atol, c->pcg_exact_phase ? B + 7 : -1));
     } else {
         PGD_TRY(product(mv, mvd, wd, false, nullptr));
         PGD_TRY(comm_allreduce(c, B, 9));
@@ -537,6 +540,13 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         PGD_TRY(pgd_flags_download(h, &done, &it, &status));
     }
     if (status != 0) return fail(c, PGD_ERR_SINGULAR, "sharded PCG breakdown (NaN) after %d iterations", it);
+    if (ss && c->pcg_exact_phase) {
+        // the report: the true r.r of the final residual (a solve that stops at maxit may never have entered its exact phase).
+        // Every rank does this, whatever its own flags say: one more all-reduce per solve.
+        PGD_TRY(pcg1_aux(c, scp, rd, own0, own1, B));
+        PGD_TRY(comm_allreduce(c, B, 1));
+        PGD_HIP(c, hipMemcpyAsync(c->slots + 6, c->slots + B, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
     if (ss && c->pcg_lag_x && it > 0 && ((it - 1) & 1) == 0)          // the last update had an even index: its term of x may be outstanding
         PGD_TRY(pcg1_flush_x(c, xd, pd, rd, own0, own1, B, fold ? ((it - 1) & 1) : -1));
     if (scaled) {

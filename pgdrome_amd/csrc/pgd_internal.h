@@ -181,6 +181,7 @@ struct Ctx {
     int asm_lattice = 1;          // lattice meshes: edge vectors as whole lattice steps in the assembly (PGD_TUNE_ASM_LATTICE)
     int spmv_fetch_depth = 6;     // plane fetches in flight per workgroup of k_spmv_diac_march2 (3 or 6; PGD_TUNE_SPMV_FETCH_DEPTH)
     int spmv_zchunk_coded = 24;   // most planes per march of k_spmv_diac_march2 (PGD_TUNE_SPMV_ZCHUNK_CODED)
+    int pcg_exact_phase = 1;      // sharded single-sync loop: the true r.r only near the end (one vector read per row less in the update)
     int pcg_fold_finish = 1;      // sharded single-sync loop: the scalar step inside the update kernel (one launch less per iteration)
     int atom_fast = 1;            // products with an atom whose diagonal form exists take the z-march (+ its own row classes, looked for once)
     int lazy_csr = 1;             // pgd_op_combine forms only the diagonal form where it can; CSR values on first use
@@ -242,7 +243,8 @@ int cg_update_s2(Ctx *c, double *x, double *r, const double *w, double *p, doubl
                  int base, int parity, int *nblocks);
 int reduce_two_slots(Ctx *c, int na, int nb, int base);
 int pcg1_seed(Ctx *c, int npairs, int slot_rz, int slot_rr);          // single-sync recurrence, sharded form (pgd_pcg.hip)
-int pcg1_tol(Ctx *c, int base, double rtol, double atol);
+int pcg1_tol(Ctx *c, int base, double rtol, double atol, int slot_p8);
+int pcg1_aux(Ctx *c, const double *s, const double *r, int64_t lo, int64_t hi, int slot);
 int pcg1_sums(Ctx *c, int nprod, int nvec, int base);
 int pcg1_finish_slots(Ctx *c, int base);
 int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const double *sc, int64_t lo, int64_t hi, int base,

@@ -595,6 +595,7 @@ __global__ __launch_bounds__(TPB) void k_pcg_px_s(double *__restrict__ x, double
 enum { S1_RZ = 24, S1_RR = 25, S1_ALPHA = 26, S1_BETA = 27, S1_PQ = 28, S1_QQ = 29,
        S1_ALPHA_PREV = 40, S1_BETA_PREV = 41, S1_PEND = 42 };      // the lagged x update (below)
 constexpr double LAG_MIN_BETA = 0.01;
+enum { S1F_ALPHA = 44 /* +parity */, S1F_BETA = 46 /* +parity */, S1F_EXACT = 48 /* +parity */ };   // scalar step inside the update kernel
 
 __device__ __forceinline__ void pcg1_finish(double *slots, int *flags, double pq, double qq, double rz, double rr, int slot_alpha,
                                             int slot_beta, bool keep_prev = false) {
@@ -673,15 +674,42 @@ __global__ void k_pcg1_finish(double *__restrict__ slots, int *__restrict__ flag
     pcg1_finish(slots, flags, slots[base], slots[base + 1], slots[base + 2], slots[base + 3], base + 5, base + 6, true);
 }
 
-// initial residual of the sharded solve: tolerance from the all-reduced b.b, first stop test
-__global__ void k_pcg1_tol(double *__restrict__ slots, int *__restrict__ flags, int base, double rtol, double atol) {
+// initial residual of the sharded solve: tolerance from the all-reduced b.b, first stop test.
+// EXACT PHASE (slot_p8 >= 0): like pgd_pcg_solve the sharded single-sync loop measures the TRUE r.r = sum r~_i^2 / s_i^2 (one more
+// vector read per row in the update) only near the end - once d_min r~.r~, a lower bound of it, comes within 10^4 of the
+// tolerance.  d_min must be the same number on every rank and the bindings all-reduce SUMS: slots[slot_p8] holds the
+// all-reduced sum of s_i^16 = (1 / d_i)^8 over all owned rows, and 1 / d_min = max 1 / d_i <= (sum (1 / d_i)^8)^(1/8), so
+// (sum)^(-1/8) is a lower bound of d_min (at most n^(1/8) below it: the exact phase starts a few dozen iterations early).  A
+// sum that is not a positive finite number means "exact from the start", which is also what slot_p8 < 0 asks for.
+__global__ void k_pcg1_tol(double *__restrict__ slots, int *__restrict__ flags, int base, double rtol, double atol, int slot_p8) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const double t1 = rtol * rtol * slots[base + 8], t2 = atol * atol, rr = slots[base + 1];
     slots[S_TOL2] = t1 > t2 ? t1 : t2;
     slots[6] = rr;
-    flags[3] = 1;                                        // the sharded form measures the true r.r in every iteration
+    int exact = 1;
+    if (slot_p8 >= 0) {
+        const double p8 = slots[slot_p8];
+        if (p8 > 0.0 && p8 < 1e300) { slots[S_DMIN] = 1.0 / sqrt(sqrt(sqrt(p8))); exact = 0; }
+        slots[slot_p8] = 0.0;                            // the slot is a zero in the loop's all-reduces
+    }
+    flags[3] = exact;
+    slots[S1F_EXACT] = slots[S1F_EXACT + 1] = exact ? 1.0 : 0.0;
     if (!(rr == rr)) { flags[0] = 1; flags[2] = PGD_ERR_SINGULAR; }
     else if (rr <= slots[S_TOL2]) flags[0] = 1;
+}
+
+// partial sums of s_i^16 over [lo, hi) (s = d^-1/2: the 8-norm of 1 / d, k_pcg1_tol) and of r~_i^2 / s_i^2 (the true r.r of
+// the final residual, for the report of a solve that ended outside its exact phase)
+__global__ __launch_bounds__(TPB) void k_pcg1_aux(const double *__restrict__ s, const double *__restrict__ r, int64_t lo, int64_t hi,
+                                                  double *__restrict__ partials) {
+    __shared__ double s_red[4];
+    double acc = 0.0;
+    for (int64_t i = lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < hi; i += (int64_t)gridDim.x * TPB) {
+        if (r) { const double t = r[i] / s[i]; acc = fma(t, t, acc); }
+        else { double t = s[i] * s[i]; t *= t; t *= t; acc += t * t; }
+    }
+    acc = block_sum(acc, s_red);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
 }
 
 // x += alpha p; r -= alpha q; p = r + beta p; partial sums (r~.r~, exact phase ? sum r^2 / s^2 : r~.r~) of the new residual.
@@ -705,8 +733,6 @@ __global__ void k_pcg1_tol(double *__restrict__ slots, int *__restrict__ flags, 
 // previous pair), the sums are rewritten by the NEXT iteration's k_pcg1_sums, and the sharded form is in its exact phase
 // (flags[3] = 1, the true r.r in every iteration) from the start.  A workgroup that starts late and finds the done flag set by
 // workgroup 0 returns - what its own test would have told it.
-enum { S1F_ALPHA = 44 /* +parity */, S1F_BETA = 46 /* +parity */, S1F_EXACT = 48 /* +parity */ };
-
 template <bool NT, bool FOLD>
 __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
                                                      const double *__restrict__ q, const double *__restrict__ s, int64_t lo,
@@ -717,14 +743,21 @@ __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, dou
     __shared__ double s_red[4];
     typedef double d2 __attribute__((ext_vector_type(2)));
     double alpha, beta;
+    bool fold_exact = true;
     if (FOLD) {
         const double pq = slots[fold_base], qq = slots[fold_base + 1], rz0 = slots[fold_base + 2], rr0 = slots[fold_base + 3];
         const bool lead = blockIdx.x == 0 && threadIdx.x == 0;
         if (lead) slots[6] = rr0;                                  // the last measured true r.r, for the report
         int done = 0, status = 0;
+        const double tol2 = slots[S_TOL2];
+        fold_exact = slots[S1F_EXACT + (par ^ 1)] != 0.0;         // (pcg1_finish, on values every workgroup holds)
         if (!(rz0 == rz0) || !(pq == pq)) { done = 1; status = PGD_ERR_SINGULAR; }
-        else if (rr0 <= slots[S_TOL2]) done = 1;
-        else if (!(rz0 > 0.0)) done = 1;
+        else if (fold_exact && rr0 <= tol2) done = 1;
+        else {
+            if (!fold_exact && rz0 * slots[S_DMIN] <= 1e4 * tol2) fold_exact = true;
+            if (!(rz0 > 0.0)) done = 1;
+        }
+        if (lead) { slots[S1F_EXACT + par] = fold_exact ? 1.0 : 0.0; flags[3] = fold_exact ? 1 : 0; }
         if (done) {
             if (lead) { if (status) flags[2] = status; flags[0] = 1; }
             return;                                                // uniform over the whole launch
@@ -738,7 +771,7 @@ __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, dou
         alpha = slots[slot_alpha];
         beta = slots[slot_beta];
     }
-    const bool exact = FOLD ? true : flags[3] != 0;
+    const bool exact = FOLD ? fold_exact : flags[3] != 0;
     const bool skip_x = lag == 1 && beta >= LAG_MIN_BETA;
     const bool two = lag == 2 && slots[S1_PEND] != 0.0;
     const double alpha_p = two ? slots[FOLD ? S1F_ALPHA + (par ^ 1) : S1_ALPHA_PREV] : 0.0;
@@ -1160,10 +1193,23 @@ int pcg1_seed(Ctx *c, int npairs, int slot_rz, int slot_rr) {
     return PGD_OK;
 }
 
-int pcg1_tol(Ctx *c, int base, double rtol, double atol) {
-    k_pcg1_tol<<<1, 64, 0, c->stream>>>(c->slots, c->flags, base, rtol, atol);
+int pcg1_tol(Ctx *c, int base, double rtol, double atol, int slot_p8) {
+    k_pcg1_tol<<<1, 64, 0, c->stream>>>(c->slots, c->flags, base, rtol, atol, slot_p8);
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
+}
+
+// slots[slot] <- sum over [lo, hi) of s_i^16 (r == nullptr) or of r_i^2 / s_i^2 (k_pcg1_aux); 0 for an empty range
+int pcg1_aux(Ctx *c, const double *s, const double *r, int64_t lo, int64_t hi, int slot) {
+    if (hi == lo) {
+        PGD_HIP(c, hipMemsetAsync(c->slots + slot, 0, sizeof(double), c->stream));
+        return PGD_OK;
+    }
+    const int g = grid_for(hi - lo);
+    PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS));
+    k_pcg1_aux<<<g, TPB, 0, c->stream>>>(s, r, lo, hi, c->partials);
+    PGD_LAUNCH_CHECK(c);
+    return reduce_partials(c, c->partials, g, 1, slot, -1, 0, 0);
 }
 
 int pcg1_sums(Ctx *c, int nprod, int nvec, int base) {
@@ -1207,7 +1253,8 @@ int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const 
         PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
         c->ev_used += 2;
         c->prof_upd_launches += 1;
-        c->prof_upd_bytes += (lag == 1 ? 48.0 : 64.0) * (double)(hi - lo);      // the sharded form measures the true r.r in every iteration: + s
+        // (outside the exact phase - all but the last few dozen iterations - the kernel does not read s; the host cannot see the flag)
+        c->prof_upd_bytes += ((lag == 1 ? 40.0 : 56.0) + (c->pcg_exact_phase ? 0.0 : 8.0)) * (double)(hi - lo);
     }
     PGD_LAUNCH_CHECK(c);
     *nblocks = g;
@@ -1322,6 +1369,10 @@ int pgd_op_diag_inv(pgd_handle h, pgd_handle oh, pgd_handle dh) {
     Mesh *m = o ? get_mesh(c, o->mesh) : nullptr;
     Vec *d = get_vec(c, dh);
     if (!o || !m || !d || d->n != m->nv) return fail(c, PGD_ERR_INVALID, "op_diag_inv: invalid handles");
+    if (o->dinv_valid && o->dinv) {      // combine_dia formed it with the diagonal form (the same quotient): no pass over the CSR values
+        PGD_HIP(c, hipMemcpyAsync(d->d, o->dinv, (size_t)m->nv * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        return PGD_OK;
+    }
     PGD_TRY(ensure_vals(c, m, o));
     k_diag_inv<<<grid_for(m->nv), TPB, 0, c->stream>>>(m->row_ptr, m->cols, o->vals, d->d, m->nv);
     PGD_LAUNCH_CHECK(c);

@@ -182,9 +182,10 @@ def test_sharded_solve_marches_on_row_classes():
     outs = {}
     saved = os.environ.get("PGD_TUNE")
     try:
-        # the scalar step of an iteration inside the update kernel (default) and as a launch of its own: the same bits
-        for fold in (1, 0):
-            os.environ["PGD_TUNE"] = "29=%d" % fold
+        # the scalar step of an iteration inside the update kernel (default) and as a launch of its own; the true residual norm
+        # measured only near the end (default) and in every iteration: the same iterates, the same bits
+        for fold, tune in ((1, "29=1"), (0, "29=0"), (2, "29=1,30=0"), (3, "29=0,30=0")):
+            os.environ["PGD_TUNE"] = tune
             q = ctx.Queue()
             port = _free_port()
             procs = [ctx.Process(target=_shared_gpu_worker, args=(r, 2, port, shape, q, True)) for r in range(2)]
@@ -204,9 +205,10 @@ def test_sharded_solve_marches_on_row_classes():
             os.environ.pop("PGD_TUNE", None)
         else:
             os.environ["PGD_TUNE"] = saved
-    assert outs[0]["amplitude"] == outs[1]["amplitude"]
-    for m in range(ref.PGD_modes):
-        assert np.array_equal(outs[0]["modes_x"][m], outs[1]["modes_x"][m])
+    for other in (0, 2, 3):
+        assert outs[other]["amplitude"] == outs[1]["amplitude"]
+        for m in range(ref.PGD_modes):
+            assert np.array_equal(outs[other]["modes_x"][m], outs[1]["modes_x"][m])
 
 
 def _faulty_worker(rank, world, port, shape, q):
