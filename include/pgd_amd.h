@@ -284,6 +284,10 @@ int pgd_vec_multidot(pgd_handle ctx, pgd_handle x, const pgd_handle *ys, int k, 
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
+    PGD_TUNE_PCG_PIPELINE = 31, /* 1 (default): pgd_pcg_solve and pgd_pcg_solve_sharded queue the next 16-iteration chunk before the host looks at the
+                                flags of the previous one (snapshots into pinned memory, one event each): the GPU does not wait for the
+                                host's round trip; a chunk queued behind the iteration that converged consists of no-op launches.  Same
+                                iterates, same iteration count.  0: look, then queue */
     PGD_TUNE_PCG_EXACT_PHASE = 30, /* 1 (default): the single-sync recurrence of pgd_pcg_solve_sharded measures the true residual norm (one more
                                 vector read per row in the update) only near the end, like pgd_pcg_solve: once d_lb r~.r~ comes within 10^4 of
                                 the tolerance, d_lb = (all-reduced sum of d_i^-8)^(-1/8) <= d_min, the same number on every rank; the stop test

@@ -107,6 +107,17 @@ static int ensure_buf(Ctx *c, T **p, int64_t *cap, int64_t n) {
 
 int ensure_partials(Ctx *c, int64_t n) { return ensure_buf(c, &c->partials, &c->partials_cap, n); }
 int ensure_work(Ctx *c, int i, int64_t n) { return ensure_buf(c, &c->work[i], &c->work_cap[i], n); }
+int pcg_flag_snapshots(Ctx *c) {
+    if (!c->flags_host) {
+        void *p = nullptr;
+        PGD_HIP(c, hipHostMalloc(&p, 8 * sizeof(int), hipHostMallocDefault));
+        c->flags_host = (int *)p;
+    }
+    for (hipEvent_t &e : c->flag_ev)
+        if (!e) PGD_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    return PGD_OK;
+}
+
 int ensure_mask(Ctx *c, int64_t n) { return ensure_buf(c, &c->mask, &c->mask_cap, n); }
 int ensure_ibuf(Ctx *c, int64_t n) { return ensure_buf(c, &c->ibuf, &c->ibuf_cap, n); }
 
@@ -183,6 +194,8 @@ int pgd_ctx_destroy(pgd_handle h) {
     c->pool.clear();
     for (hipEvent_t e : c->ev) (void)hipEventDestroy(e);
     for (hipEvent_t e : c->timer_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : c->flag_ev) if (e) (void)hipEventDestroy(e);
+    if (c->flags_host) (void)hipHostFree(c->flags_host);
     if (c->cls_scratch) (void)hipFree(c->cls_scratch);
     if (c->gram_w) (void)hipFree(c->gram_w);
     for (void *p : {(void *)c->slots, (void *)c->flags, (void *)c->partials, (void *)c->mask,

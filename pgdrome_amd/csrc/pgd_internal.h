@@ -214,6 +214,9 @@ struct Ctx {
     double prof_own_bytes = 0.0;  // least bytes the kernels that were timed must move in their own storage form
     int64_t kcount[8] = {0, 0, 0, 0, 0, 0, 0, 0};     // launches per product kernel family (KC_*)
     hipEvent_t timer_ev[2] = {nullptr, nullptr};     // pgd_timer_start / pgd_timer_stop
+    int *flags_host = nullptr;                       // pinned: two snapshots of the device flags (the PCG loops look at one chunk's
+    hipEvent_t flag_ev[2] = {nullptr, nullptr};      //   flags while the next chunk is already queued: pcg_flag_snapshots)
+    int pcg_pipeline = 1;                            // 1: the next 16-iteration chunk is queued before the host looks at the flags of the last
 };
 
 enum { KC_CSR = 0, KC_CSR_DICT = 1, KC_SYM_ROWS = 2, KC_DIA_ROWS = 3, KC_DIA_MARCH = 4, KC_MULTI = 5, KC_DIAC_MARCH = 6 };
@@ -228,6 +231,7 @@ int dev_alloc(Ctx *c, void **p, size_t bytes);
 int ensure_partials(Ctx *c, int64_t n);
 int ensure_work(Ctx *c, int i, int64_t n);
 int ensure_mask(Ctx *c, int64_t n);
+int pcg_flag_snapshots(Ctx *c);                      // pgd_ctx.hip: the pinned flag buffers and their events exist
 int ensure_ibuf(Ctx *c, int64_t n);
 void prof_flush(Ctx *c);
 void comm_release(Ctx *c);          // pgd_comm.hip

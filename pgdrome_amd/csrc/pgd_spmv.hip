@@ -1810,6 +1810,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_PCG_SMALL_SINGLE_SYNC && value >= 0 && value <= 1) { c->pcg_small_ss = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_SMALL_ROWS && value >= 0) { c->pcg_small_ss_rows = value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_FETCH_DEPTH && (value == 3 || value == 6)) { c->spmv_fetch_depth = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_PCG_PIPELINE && value >= 0 && value <= 1) { c->pcg_pipeline = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_EXACT_PHASE && value >= 0 && value <= 1) { c->pcg_exact_phase = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_FOLD_FINISH && value >= 0 && value <= 1) { c->pcg_fold_finish = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_ATOM_FAST && value >= 0 && value <= 1) { c->atom_fast = (int)value; return PGD_OK; }
