@@ -18,6 +18,7 @@ ap.add_argument("config")
 ap.add_argument("--modes", type=int, default=0)
 ap.add_argument("--problem", default="linear")
 ap.add_argument("--rtol", type=float, default=1e-10)
+ap.add_argument("--trace", action="store_true", help="one line per enrichment step on stderr: seconds, passes, PCG iterations")
 args = ap.parse_args()
 
 be = fem.set_backend(HipBackend(0))
@@ -29,6 +30,20 @@ if args.modes:
 p = PGDProblem(**spec)
 be.sync()
 t1 = time.time()
+if args.trace:
+    _fp = p.FP_solve
+
+    def _timed(*a, **k):
+        t, it0, s0, n0 = time.time(), fem.STATS["pcg_iterations"], fem.STATS["pcg_seconds"], len(p.num_fp_it)
+        out = _fp(*a, **k)
+        be.sync()
+        dt, its = time.time() - t, fem.STATS["pcg_iterations"] - it0
+        passes = p.num_fp_it[-1] if len(p.num_fp_it) > n0 else 0
+        print("mode %d: %.2f s, %d passes, %d PCG iterations, %.1f us per iteration inside the solves, %.1f ms per pass outside them"
+              % (len(p.num_fp_it), dt, passes, its, 1e6 * (fem.STATS["pcg_seconds"] - s0) / max(its, 1),
+                 1e3 * (dt - (fem.STATS["pcg_seconds"] - s0)) / max(passes, 1)), file=sys.stderr, flush=True)
+        return out
+    p.FP_solve = _timed
 p.solve_PGD(_problem=args.problem, settings={"linear_solver": "cg", "preconditioner": "jacobi",
                                              "relative_tolerance": args.rtol})
 be.sync()
@@ -39,4 +54,5 @@ print(json.dumps({
     "fp_passes": p.fp_passes, "fp_it_per_s": p.fp_passes / (t2 - t1),
     "amplitude": p.amplitude, "err_fp_it": [float(e) for e in p.err_fp_it],
     "linear_solves": fem.STATS["linear_solves"], "pcg_iterations": fem.STATS["pcg_iterations"],
-    "not_converged": p.simulation_info.count("NOT converged")}))
+    "not_converged": p.simulation_info.count("NOT converged"), "pcg_seconds": fem.STATS["pcg_seconds"],
+    "product_launches_by_kernel": be.ctx.kernel_counts()}))
