@@ -2109,14 +2109,20 @@ KEEP_FUNCTIONAL_PRODUCTS = os.environ.get("PGD_KEEP_FUNCTIONAL_PRODUCTS", "1") !
 _MULTIDOT_MAX = max(1, min(256, int(os.environ.get("PGD_BATCH_FUNCTIONALS", "256"))))   # 1: one dot per request (A/B)
 
 
-def _dots_with_stored_products(be, atom, other, Ag, swapped, lo, hi):
+def _dots_with_stored_products(be, atom, other, Ag, swapped, lo, hi, lay=None):
     """other . Ag, and in the same device pass other . (A v) for every other stored product of this atom.
 
     The driver asks for the functionals of one iterate against ALL stored modes of its dimension, one
     assemble() at a time (solver.py:568-612), and each answer costs a host synchronisation; the products A v
     of the stored modes are cached by the right-hand-side assembly, so the first request computes all of them
     in one launch sequence with one synchronisation and memoises the rest (same keys _bilinear_scalar looks up).
-    Only on an unsharded dimension: the ranks of a sharded one would have to agree on the candidate list."""
+
+    Row-sharded dimension (``lay.part``): the local dots of the whole batch travel in ONE all-reduce of fixed length
+    instead of one collective per functional.  The ranks run the same program on the same cache history, so they
+    hold the same candidate list; the message still carries (count, count^2) so that every rank sees - from the same
+    all-reduced numbers - whether all counts were equal (world * sum count^2 == (sum count)^2), and if they were not
+    all of them fall back to the single all-reduced dot together."""
+    part = lay.part if lay is not None else None
     outs, keys, refs = [Ag], [None], [None]
     oid, over = id(other), other.version
     for (a, _vid), (ver, out, ref) in _MV_CACHE.items():
@@ -2133,9 +2139,26 @@ def _dots_with_stored_products(be, atom, other, Ag, swapped, lo, hi):
         refs.append(v)
         if len(outs) == _MULTIDOT_MAX:
             break
-    if len(outs) == 1:
-        return be.vec_dot(other.dev(), Ag.dev(), lo, hi)
-    vals = be.vec_multidot(other.dev(), [o.dev() for o in outs], lo, hi)
+    if part is None:
+        if len(outs) == 1:
+            return be.vec_dot(other.dev(), Ag.dev(), lo, hi)
+        vals = be.vec_multidot(other.dev(), [o.dev() for o in outs], lo, hi)
+    else:
+        if _MULTIDOT_MAX == 1:
+            return part.comm.allreduce_sum(be.vec_dot(other.dev(), Ag.dev(), lo, hi))
+        k = len(outs)
+        local = be.vec_multidot(other.dev(), [o.dev() for o in outs], lo, hi) if k > 1 else \
+            np.array([be.vec_dot(other.dev(), Ag.dev(), lo, hi)])
+        msg = np.zeros(_MULTIDOT_MAX + 2)
+        msg[0], msg[1], msg[2:2 + k] = k, k * k, local
+        msg = part.comm.allreduce_array(msg)
+        world = part.comm.world
+        if world * msg[1] != msg[0] * msg[0]:          # the ranks' candidate lists differ in length: the one dot, together
+            LOG.warning("batched functionals: the ranks hold different product caches; single dot")
+            return part.comm.allreduce_sum(float(local[0]))
+        vals = msg[2:2 + k]
+        if k == 1:
+            return float(vals[0])
     _memo_make_room(len(outs))
     wo = weakref.ref(other)
     for key, v, val in zip(keys[1:], refs[1:], vals[1:]):
@@ -2160,10 +2183,8 @@ def _bilinear_scalar(lay, atom, f, g, symmetric=False):
     other, swapped = f, False
     if Ag is None and symmetric and f is not g:
         Ag, other, swapped = _cached_product(atom, f), g, True
-    if Ag is not None and lay.part is None and not Ag._small():
-        val = _dots_with_stored_products(be, atom, other, Ag, swapped, lo, hi)
-    elif Ag is not None and not (Ag._small() and lay.part is None):
-        val = _allreduce_sum(lay.mesh, be.vec_dot(other.dev(), Ag.dev(), lo, hi))
+    if Ag is not None and (lay.part is not None or not Ag._small()):
+        val = _dots_with_stored_products(be, atom, other, Ag, swapped, lo, hi, lay)
     elif Ag is not None:
         val = float(other.host() @ Ag.host())
     elif lay.part is None and KEEP_FUNCTIONAL_PRODUCTS and not g._small() and be.atom_product_form(atom) > 0:

@@ -100,6 +100,37 @@ def test_sharded_solve_equals_single_process(world, shape, single_reduction, sto
     assert out["stats"]["halo"] > 0 and out["stats"]["allreduce"] > 0
 
 
+def test_batched_functionals_on_a_sharded_dimension_use_one_allreduce():
+    """The functionals of one iterate against the stored modes of a row-sharded dimension travel in ONE fixed-length
+    all-reduce (fem._dots_with_stored_products) instead of one collective each: fewer collectives, the same run."""
+    ctx = mp.get_context("spawn")
+    outs = {}
+    saved = os.environ.get("PGD_BATCH_FUNCTIONALS")
+    try:
+        for batch in ("256", "1"):
+            os.environ["PGD_BATCH_FUNCTIONALS"] = batch
+            q = ctx.Queue()
+            port = _free_port()
+            procs = [ctx.Process(target=_worker, args=(r, 2, port, (4, 3, 5), q, True, "norm")) for r in range(2)]
+            for pr in procs:
+                pr.start()
+            outs[batch] = q.get(timeout=240)
+            for pr in procs:
+                pr.join(timeout=120)
+                assert pr.exitcode == 0
+    finally:
+        if saved is None:
+            os.environ.pop("PGD_BATCH_FUNCTIONALS", None)
+        else:
+            os.environ["PGD_BATCH_FUNCTIONALS"] = saved
+    a, b = outs["256"], outs["1"]
+    assert a["num_fp_it"] == b["num_fp_it"]
+    np.testing.assert_allclose(a["amplitude"], b["amplitude"], rtol=1e-12)
+    for m in range(len(a["modes_x"])):
+        assert np.linalg.norm(a["modes_x"][m] - b["modes_x"][m]) <= 1e-10 * np.linalg.norm(b["modes_x"][m])
+    assert a["stats"]["allreduce"] < b["stats"]["allreduce"], (a["stats"], b["stats"])
+
+
 def test_slab_ranges_cover_all_planes():
     from pgdrome_amd.dist import slab_ranges
     for n, w in ((256, 8), (256, 3), (7, 7), (10, 4)):
