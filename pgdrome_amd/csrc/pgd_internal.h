@@ -180,6 +180,7 @@ struct Ctx {
     int pcg_lag_x = 1;            // single-sync recurrence: x is updated every other iteration, two terms at a time (PGD_TUNE_PCG_LAG_X)
     int asm_lattice = 1;          // lattice meshes: edge vectors as whole lattice steps in the assembly (PGD_TUNE_ASM_LATTICE)
     int spmv_fetch_depth = 6;     // plane fetches in flight per workgroup of k_spmv_diac_march2 (3 or 6; PGD_TUNE_SPMV_FETCH_DEPTH)
+    int spmv_zchunk_coded2 = 96;  // ... and where every slot (two workgroups per CU) gets at least 24 planes: marches that fill the slots exactly once, at most this long (0: off)
     int spmv_zchunk_coded = 24;   // most planes per march of k_spmv_diac_march2 (PGD_TUNE_SPMV_ZCHUNK_CODED)
     int pcg_exact_phase = 1;      // sharded single-sync loop: the true r.r only near the end (one vector read per row less in the update)
     int pcg_fold_finish = 1;      // sharded single-sync loop: the scalar step inside the update kernel (one launch less per iteration)

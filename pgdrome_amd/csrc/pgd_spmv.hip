@@ -1591,6 +1591,14 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
                 // cfg3, 12 planes 59.9, 3 planes (four workgroups per CU, the rule of the plain march) 55.7, 24 planes 58.4)
                 zchunk_c = (int)std::min<int64_t>(c->spmv_zchunk_coded, (tile_planes + c->num_cu / 2) / (int64_t)c->num_cu);
                 zchunk_c = zchunk_c >= 9 ? std::max(12, (zchunk_c + 3) / 6 * 6) : std::max(3, zchunk_c / 3 * 3);
+                // Large grids: a CU holds TWO of these workgroups (246 VGPRs), so with marches of 24 planes 256^3 is 1408 workgroups on
+                // 512 slots - 2.75 rounds, the last one three quarters empty, and eleven prologues per column.  Where there is work for
+                // at least 24 planes per slot the march is as long as it takes to fill every slot exactly once: 256^3 = 4 marches of 66
+                // planes = 512 workgroups, 71 -> 63 us per product (8.87 -> 9.15 passes/s; one workgroup per CU - marches of 126 planes -
+                // 102 us; 36 planes 68 us, 48 planes 72 us: `PGD_TUNE=21=...` before this rule)
+                const int64_t per_slot2 = (tile_planes + c->num_cu) / (2 * (int64_t)c->num_cu);
+                if (c->spmv_zchunk_coded2 > 0 && per_slot2 >= 24)
+                    zchunk_c = (int)std::min<int64_t>(c->spmv_zchunk_coded2, (per_slot2 + 5) / 6 * 6);
                 wgs_c = (D.z1 - D.z0 + zchunk_c - 1) / zchunk_c * D.tiles_x * D.tiles_y;
             }
             coded = coded && zchunk_c <= DIAC_MAXCHUNK;
@@ -1810,6 +1818,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_PCG_SMALL_SINGLE_SYNC && value >= 0 && value <= 1) { c->pcg_small_ss = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_SMALL_ROWS && value >= 0) { c->pcg_small_ss_rows = value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_FETCH_DEPTH && (value == 3 || value == 6)) { c->spmv_fetch_depth = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_ZCHUNK_CODED2 && value >= 0 && value <= 1020) { c->spmv_zchunk_coded2 = (int)value / 6 * 6; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_PIPELINE && value >= 0 && value <= 1) { c->pcg_pipeline = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_EXACT_PHASE && value >= 0 && value <= 1) { c->pcg_exact_phase = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_FOLD_FINISH && value >= 0 && value <= 1) { c->pcg_fold_finish = (int)value; return PGD_OK; }
