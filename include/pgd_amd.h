@@ -284,7 +284,7 @@ int pgd_vec_multidot(pgd_handle ctx, pgd_handle x, const pgd_handle *ys, int k, 
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
-    PGD_TUNE_SPMV_ZCHUNK_CODED2 = 32, /* k_spmv_diac_march2 on grids with at least 24 planes of work per resident workgroup slot (two per CU): marches long
+    PGD_TUNE_SPMV_ZCHUNK_CODED2 = 32, /* k_spmv_diac_march2 on grids with at least 8 planes of work per resident workgroup slot (two per CU): marches long
                                 enough that the launch fills every slot exactly once, at most this many planes (default 96, whole sixes; 0: the
                                 PGD_TUNE_SPMV_ZCHUNK_CODED rule everywhere) */
     PGD_TUNE_PCG_PIPELINE = 31, /* 1 (default): pgd_pcg_solve and pgd_pcg_solve_sharded queue the next 16-iteration chunk before the host looks at the

@@ -1596,9 +1596,12 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
                 // at least 24 planes per slot the march is as long as it takes to fill every slot exactly once: 256^3 = 4 marches of 66
                 // planes = 512 workgroups, 71 -> 63 us per product (8.87 -> 9.15 passes/s; one workgroup per CU - marches of 126 planes -
                 // 102 us; 36 planes 68 us, 48 planes 72 us: `PGD_TUNE=21=...` before this rule)
+                // (slabs of the sharded solve, tools/bench_coded_march.py 256x256xNZ: 32 planes 21.0 -> 17.9 us with 4 marches of 9,
+                // 64 planes 29.9 -> 25.5 us with 4 of 18, 128 planes 41 us with 4 of 36 against 45-46 us with 18 or 24: the rule holds
+                // from about 8 planes per slot on; marches under 12 planes run three steps at a time)
                 const int64_t per_slot2 = (tile_planes + c->num_cu) / (2 * (int64_t)c->num_cu);
-                if (c->spmv_zchunk_coded2 > 0 && per_slot2 >= 24)
-                    zchunk_c = (int)std::min<int64_t>(c->spmv_zchunk_coded2, (per_slot2 + 5) / 6 * 6);
+                if (c->spmv_zchunk_coded2 > 0 && per_slot2 >= 8)
+                    zchunk_c = (int)std::min<int64_t>(c->spmv_zchunk_coded2, per_slot2 >= 12 ? (per_slot2 + 5) / 6 * 6 : (per_slot2 + 2) / 3 * 3);
                 wgs_c = (D.z1 - D.z0 + zchunk_c - 1) / zchunk_c * D.tiles_x * D.tiles_y;
             }
             coded = coded && zchunk_c <= DIAC_MAXCHUNK;

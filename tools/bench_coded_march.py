@@ -1,5 +1,6 @@
 """March length of the coded product (k_spmv_diac_march2) on an n^3 grid: HIP-event time per launch for forced lengths,
-interleaved rounds in one process.    python tools/bench_coded_march.py 256 16 24 32 64"""
+interleaved rounds in one process.    python tools/bench_coded_march.py 256 16 24 32 64
+A grid nx x ny x nz (the slab of a rank of the sharded solve): python tools/bench_coded_march.py 256x256x32 0 6 12 18"""
 import os
 import sys
 
@@ -10,10 +11,12 @@ from pgdrome_amd import _lib, fem
 
 
 def main():
-    n = int(sys.argv[1])
+    dims = [int(a) for a in sys.argv[1].split("x")]
+    nx, ny, nz = dims if len(dims) == 3 else (dims[0],) * 3
+    n = sys.argv[1]
     lengths = [int(a) for a in sys.argv[2:]]
     ctx = _lib.Context(0)
-    coords, cells = fem.box_mesh_arrays((0, 0, 0), (1, 1, 1), n - 1, n - 1, n - 1)
+    coords, cells = fem.box_mesh_arrays((0, 0, 0), (1, 1, 1), nx - 1, ny - 1, nz - 1)
     mesh = ctx.mesh_upload(coords, cells)
     nv = ctx.mesh_info(mesh)["nv"]
     bnd = np.where(np.any((coords <= 1e-12) | (coords >= 1 - 1e-12), axis=1))[0].astype(np.int32)
@@ -41,7 +44,7 @@ def main():
             if ref is None:
                 ref = yy
             assert np.array_equal(yy, ref)
-            print("round %d  n=%d  march of %4d planes (0 = adaptive): %7.1f us per product+reduce = %5.0f GB/s on 17 B/row"
+            print("round %d  n=%s  march of %4d planes (0 = adaptive): %7.1f us per product+reduce = %5.0f GB/s on 17 B/row"
                   % (rnd, n, L, t * 1e6, 17 * nv / t / 1e9), flush=True)
     ctx.tune(7, 0)
 
