@@ -2058,7 +2058,7 @@ def _memo_make_room(extra=1):
             dead.append(key)
     for key in dead:
         del _SCALAR_MEMO[key]
-    if len(_SCALAR_MEMO) + extra > _SCALAR_MEMO_MAX // 2:
+    if len(_SCALAR_MEMO) + extra > (3 * _SCALAR_MEMO_MAX) // 4:       # still three quarters full of live entries: the oldest go, down to half
         for key in list(_SCALAR_MEMO)[:len(_SCALAR_MEMO) + extra - _SCALAR_MEMO_MAX // 2]:
             del _SCALAR_MEMO[key]
 _MV_CACHE = {}        # (atom handle, id(vec)) -> (version, result Vector)   A @ g for immutable g

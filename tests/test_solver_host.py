@@ -327,3 +327,57 @@ def test_galerkin_start_of_the_pcg_solves_changes_only_the_iteration_counts():
     for a, b, c in zip(m0, m1, m2):
         assert np.linalg.norm(b - a) <= 1e-6 * np.linalg.norm(a) and np.linalg.norm(c - a) <= 1e-6 * np.linalg.norm(a)
     assert its2 < its1 < its0
+
+
+def test_functional_memo_is_purged_not_cleared(monkeypatch):
+    """A full memo drops the entries that can never hit again (dead vectors, superseded versions) and, if need be, the oldest
+    half - never everything: a wholesale clear in mid-pass had every functional of the pass recomputed on the device
+    (cfg5, 50 modes)."""
+    V = fem.FunctionSpace(fem.IntervalMesh(7, 0.0, 1.0), "CG", 1)
+    live = [fem.Function(V) for _ in range(6)]
+    for i, f in enumerate(live):
+        f.vector()[:] = 1.0 + i
+    monkeypatch.setattr(fem, "_SCALAR_MEMO_MAX", 80)
+    fem._SCALAR_MEMO.clear()
+    want = {}
+    for f in live:
+        for g in live:
+            want[(id(f), id(g))] = fem.assemble(f * g * fem.dx)
+    n_live = len(fem._SCALAR_MEMO)
+    assert 0 < n_live <= 36
+    # iterates that move on: every new version leaves a stale entry behind
+    it = fem.Function(V)
+    for k in range(120):
+        it.vector()[:] = float(k)
+        fem.assemble(it * live[0] * fem.dx)
+    assert len(fem._SCALAR_MEMO) <= 80
+    # the live pairs survived the purges: still answered from the memo (same object identity of the stored tuples)
+    keys_live = [k for k in fem._SCALAR_MEMO if k[1] != id(it.vector()) and k[3] != id(it.vector())]
+    assert len(keys_live) == n_live
+    for f in live:
+        for g in live:
+            assert fem.assemble(f * g * fem.dx) == want[(id(f), id(g))]
+
+
+def test_kept_functional_products_and_batched_dots_give_the_same_functionals(monkeypatch):
+    """fem._bilinear_scalar with an atom whose backend reports a fast product form: the product is kept and the functional is a
+    dot; the functionals of one vector against all stored products come from one multidot.  Same numbers as the fused path."""
+    be = fem.get_backend()
+    mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), 17, 17, 17)       # 5832 dofs: not "small"
+    V = fem.FunctionSpace(mesh, "CG", 1)
+    rng = np.random.default_rng(3)
+    fs = [fem.Function(V) for _ in range(5)]
+    for f in fs:
+        f.vector()[:] = rng.standard_normal(V.dim())
+    forms = lambda: [[fem.assemble(a * b * fem.dx) for b in fs] + [fem.assemble(fem.inner(fem.grad(a), fem.grad(b)) * fem.dx) for b in fs]
+                     for a in fs]
+    ref = np.array(forms())
+    fem.clear_caches()
+    calls = {"multidot": 0, "bilinear": 0}
+    monkeypatch.setattr(be, "atom_product_form", lambda atom: 2)
+    orig_md, orig_bl = be.vec_multidot, be.bilinear
+    monkeypatch.setattr(be, "vec_multidot", lambda *a, **k: (calls.__setitem__("multidot", calls["multidot"] + 1), orig_md(*a, **k))[1])
+    monkeypatch.setattr(be, "bilinear", lambda *a, **k: (calls.__setitem__("bilinear", calls["bilinear"] + 1), orig_bl(*a, **k))[1])
+    got = np.array(forms())
+    assert calls["bilinear"] == 0 and calls["multidot"] > 0
+    np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-14)
