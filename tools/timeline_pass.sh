@@ -2,7 +2,7 @@
 # usage: bash tools/timeline_pass.sh TAG ; then python tools/timeline_pass.py gpurun_out/TAG_trace.csv
 TAG=${1:-tl}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl_${TAG} -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-pmc --no-csr-section > gpurun_out/${TAG}_tl_bench.json 2> gpurun_out/${TAG}_tl.err || exit 1
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl_${TAG} -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-pmc --no-csr-section ${BENCH_ARGS:-} > gpurun_out/${TAG}_tl_bench.json 2> gpurun_out/${TAG}_tl.err || exit 1
 F=$(find gpurun_out/tl_${TAG} -name '*kernel_trace.csv' | head -1)
 python3 - "$F" gpurun_out/${TAG}_trace.csv <<'PY'
 import csv, sys
