@@ -211,6 +211,44 @@ def test_sharded_solve_marches_on_row_classes():
             assert np.array_equal(outs[other]["modes_x"][m], outs[1]["modes_x"][m])
 
 
+def test_sharded_solve_on_slabs_of_the_bench_plane():
+    """Two ranks with 34 planes of 256 x 256 vertices each - the plane of the bench grid, a slab like the ranks of a multi-GPU
+    run own: here the interior product takes the coded march under the fill-every-workgroup-slot-once rule (marches of 9
+    planes, three steps at a time), the boundary planes go in row order, the scalar step sits in the update kernel and the
+    true residual norm is measured only in the exact phase.  Must reproduce the unsharded run."""
+    import torch.multiprocessing as mp
+    from pgdrome_amd import fem, problems
+    from pgdrome_amd.hip_backend import HipBackend
+    from pgdrome_amd.solver import PGDProblem
+    shape = (255, 255, 67)
+    old = fem._backend
+    fem.set_backend(HipBackend(0))
+    fem.clear_caches()
+    try:
+        P = fem.Point
+        ref = PGDProblem(**problems.reaction_diffusion(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape), 17, PGD_nmax=3))
+        ref.solve_PGD(_problem="linear")
+        ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
+    finally:
+        fem.set_backend(old)
+        fem.clear_caches()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, 2, port, shape, q, True)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    out = q.get(timeout=600)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert out["kernels"]["diac_march"] > 100 and out["kernels"]["dia_rows"] > 100
+    assert out["num_fp_it"] == ref.num_fp_it
+    np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
+    for m in range(ref.PGD_modes):
+        assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
+
+
 def _faulty_worker(rank, world, port, shape, q):
     """Rank 1 fails (rank-locally, injected) in iteration 7 of its first sharded solve."""
     import torch
