@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(TPB) void k_pcg_p_s2(double *__restrict__ p, const 
 // CSR values of an operator whose combine was deferred (pgd_op_combine with the diagonal form in place): A = sum_t c_t A_t,
 // Dirichlet columns zeroed, identity rows - from the recorded atoms, which must still be the objects they were.
 int ensure_vals(Ctx *c, const Mesh *m, Csr *o) {
-    if (!o->vals_pending) return PGD_OK;
+    if (!o->vals_pending) return o->vals ? PGD_OK : fail(c, PGD_ERR_INVALID, "operator without values (its pgd_op_combine failed?)");
     const int n = (int)o->rec_atoms.size();
     if (!o->vals) {
         void *p;
@@ -1358,11 +1358,11 @@ int pgd_op_combine(pgd_handle h, pgd_handle mh, const pgd_handle *atoms, const d
         k_mask_set<<<grid_for(nbc), TPB, 0, c->stream>>>(c->mask, o->rec_bc, nbc);
         mask = c->mask;
     }
+    o->vals_pending = true;      // from here on the recipe is complete: whatever fails below, a later reader can still form the values
     // structured grids: the diagonal form of the same operator from the atoms' diagonal forms (no per-solve conversion)
     PGD_TRY(combine_dia(c, m, o, atom_objs.data(), coefs, n, mask));
     // ... and where that form exists the solve, its start and its products read nothing else: the CSR values (8 nnz (T + 1)
     // bytes of streaming, 1.5 ms at 256^3) are formed by the first reader that asks for them, usually nobody
-    o->vals_pending = true;
     if (!(c->lazy_csr && o->uvals_valid)) PGD_TRY(ensure_vals(c, m, o));
     PGD_HIP(c, hipStreamSynchronize(c->stream));   // bc_dofs is caller-owned
     return PGD_OK;
