@@ -220,7 +220,8 @@ def test_sharded_solve_on_slabs_of_the_bench_plane():
     from pgdrome_amd import fem, problems
     from pgdrome_amd.hip_backend import HipBackend
     from pgdrome_amd.solver import PGDProblem
-    shape = (255, 255, 67)
+    # (PGD_TEST_SLAB_SHAPE=255,255,255 runs the same check on the whole bench grid split in two - a one-off, minutes not seconds)
+    shape = tuple(int(t) for t in os.environ.get("PGD_TEST_SLAB_SHAPE", "255,255,67").split(","))
     old = fem._backend
     fem.set_backend(HipBackend(0))
     fem.clear_caches()
