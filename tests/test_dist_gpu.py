@@ -236,7 +236,8 @@ def test_sharded_solve_on_slabs_of_the_bench_plane():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, 2, port, shape, q, True)) for r in range(2)]
+    world = int(os.environ.get("PGD_TEST_SLAB_WORLD", "2"))      # (at most 5: the GPU box allows six processes on the card)
+    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, shape, q, True)) for r in range(world)]
     for pr in procs:
         pr.start()
     out = q.get(timeout=600)
