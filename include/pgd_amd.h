@@ -39,7 +39,9 @@ enum {
     PGD_ERR_NOMEM = -3,
     PGD_ERR_LIMIT = -4,     /* a structural limit was exceeded (row too long...) */
     PGD_ERR_SINGULAR = -5,  /* zero pivot / PCG breakdown                        */
-    PGD_ERR_NODEVICE = -6
+    PGD_ERR_NODEVICE = -6,
+    PGD_ERR_TIMEOUT = -7,   /* sharded solve: no progress on the stream within the deadline (pgd_comm_timeout)  */
+    PGD_ERR_PEER = -8       /* sharded solve: another rank reported a rank-local failure; every rank leaves with an error */
 };
 
 /* element-matrix kinds ("atoms"); row = test, col = trial */
@@ -256,6 +258,18 @@ int pgd_comm_bind_rccl(pgd_handle ctx, const uint8_t *id128, int rank, int world
  * mode -1: query.  *state: 1 = the sharded solve overlaps, 0 = the exchange stays on the compute stream.   */
 int pgd_comm_overlap(pgd_handle ctx, int mode, int *state);
 int pgd_comm_unbind(pgd_handle ctx);
+/* Deadline of the host-side waits inside pgd_pcg_solve_sharded (the look at the flags after every chunk of iterations, the
+ * closing agreement): the stream is polled with hipEventQuery, and after `seconds` without completion the call returns
+ * PGD_ERR_TIMEOUT with "rank r/w: iteration i, last collective <name> #n" in pgd_last_error (also written to stderr) - a
+ * neighbour that died, a collective nobody matches.  The stream is then stuck for good: the caller ends the PROCESS
+ * (pgdrome_amd/dist.py exits non-zero).  Default 60 s, or PGD_COMM_TIMEOUT_S from the environment at bind time; <= 0: wait for ever. */
+int pgd_comm_timeout(pgd_handle ctx, double seconds);
+/* Phase timing of the sharded loop (bench.py's N > 1 line): mode 1 = on + reset, 0 = off, -1 = read only.  One iteration per
+ * chunk of 16 is bracketed with HIP events on the compute stream.  out[0..7] = samples, then SECONDS summed over the samples:
+ * [1] compute stream waiting for the ghost planes after the interior rows' product (exposed halo time), [2] interior product,
+ * [3] boundary rows' product, [4] local sums, [5] the all-reduce (incl. waiting for the slowest rank), [6] vector update,
+ * [7] host time spent waiting at the chunk boundaries (all chunks, not sampled).  out may be NULL.        */
+int pgd_comm_prof(pgd_handle ctx, int mode, double *out8);
 int pgd_comm_info(pgd_handle ctx, int *kind /* 0 none, 1 callbacks, 2 rccl */, int *rank, int *world);
 int pgd_comm_halo(pgd_handle ctx, pgd_handle vec, int64_t own0, int64_t own1, int64_t lo_ghost,
                   int64_t hi_ghost);
@@ -284,6 +298,12 @@ int pgd_vec_multidot(pgd_handle ctx, pgd_handle x, const pgd_handle *ys, int k, 
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
+    PGD_TUNE_FAULT_STALL_MS = 34, /* tests only: the next pgd_pcg_solve_sharded queues, once, a kernel that spins for this many
+                                milliseconds (bounded: at most 20 000) in front of its first chunk - a stream that makes no progress,
+                                for the deadline of pgd_comm_timeout */
+    PGD_TUNE_FAULT_STAGE = 33, /* tests only: where the NEXT pgd_pcg_solve_sharded fails on this rank, once: 1 = right after the setup
+                                vote, 2 = between the setup's halo exchanges, 3 = between the setup all-reduce and the loop, 4 = after the
+                                loop, before the closing agreement (0: nowhere; PGD_TUNE_FAULT_ITERATION: inside the loop) */
     PGD_TUNE_SPMV_ZCHUNK_CODED2 = 32, /* k_spmv_diac_march2 on grids with at least 8 planes of work per resident workgroup slot (two per CU): marches long
                                 enough that the launch fills every slot exactly once, at most this many planes (default 96, whole sixes; 0: the
                                 PGD_TUNE_SPMV_ZCHUNK_CODED rule everywhere) */
@@ -374,6 +394,9 @@ int pgd_prof_read_own(pgd_handle ctx, double *own_bytes);
  * p = r + beta p and the partial sums of r.r in ONE kernel): launches timed, their seconds, and 56 B per row (4 vectors
  * read, 3 written) - the kernel that takes most of a PCG iteration once the product reads a code byte per row.   */
 int pgd_prof_read_update(pgd_handle ctx, int64_t *launches, double *seconds, double *bytes);
+/* Timed launches that were NOT counted: queued behind the iteration in which their solve converged, every kernel of them returned
+ * on the done flag (full bytes, no time - they would bias the averages).  The counts above are the samples that were kept.   */
+int pgd_prof_read_dropped(pgd_handle ctx, int64_t *dropped);
 /* Launch counts per product kernel family since the context was created: [0] k_spmv_csr, [1] k_spmv_csr_dict*,
  * [2] k_spmv_sym (row order), [3] k_spmv_dia_rows, [4] k_spmv_dia_march*, [5] k_spmv_multi, [6] k_spmv_diac_march2; tests use them to
  * prove which kernel a call reached, bench.py for its per-kernel breakdown.                          */

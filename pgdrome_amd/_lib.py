@@ -90,6 +90,8 @@ SIGNATURES = {
     "pgd_comm_bind_rccl": (C.c_int, [H, PU8, C.c_int, C.c_int]),
     "pgd_comm_overlap": (C.c_int, [H, C.c_int, C.POINTER(C.c_int)]),
     "pgd_comm_unbind": (C.c_int, [H]),
+    "pgd_comm_timeout": (C.c_int, [H, F64]),
+    "pgd_comm_prof": (C.c_int, [H, C.c_int, PD]),
     "pgd_comm_info": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pgd_comm_halo": (C.c_int, [H, H, I64, I64, I64, I64]),
     "pgd_comm_allreduce_slots": (C.c_int, [H, C.c_int, C.c_int]),
@@ -101,6 +103,7 @@ SIGNATURES = {
     "pgd_prof_read": (C.c_int, [H, PI64, PD, PD]),
     "pgd_prof_read_own": (C.c_int, [H, PD]),
     "pgd_prof_read_update": (C.c_int, [H, PI64, PD, PD]),
+    "pgd_prof_read_dropped": (C.c_int, [H, PI64]),
     "pgd_kernel_counts": (C.c_int, [H, PI64, C.c_int]),
     "pgd_calib_stream": (C.c_int, [H, H, C.c_int, C.c_int]),
     "pgd_timer_start": (C.c_int, [H]),
@@ -108,6 +111,9 @@ SIGNATURES = {
 }
 
 NSLOTS = 64
+
+
+ERR_TIMEOUT, ERR_PEER = -7, -8          # PGD_ERR_TIMEOUT, PGD_ERR_PEER (include/pgd_amd.h)
 
 
 class PgdError(RuntimeError):
@@ -496,6 +502,19 @@ class Context:
         self._ck(self.lib.pgd_comm_unbind(self.h))
         self._cbs = None
 
+    def comm_timeout(self, seconds):
+        """Deadline of the host-side waits of the sharded solve (PGD_ERR_TIMEOUT after that long without progress)."""
+        self._ck(self.lib.pgd_comm_timeout(self.h, float(seconds)))
+
+    COMM_PHASES = ("samples", "halo_wait", "product_interior", "product_boundary", "local_sums", "allreduce", "update",
+                   "host_boundary_wait")
+
+    def comm_prof(self, mode=-1):
+        """Phase timing of the sharded loop: mode 1 = on + reset, 0 = off, -1 = read.  Seconds summed over the samples."""
+        out = np.zeros(8)
+        self._ck(self.lib.pgd_comm_prof(self.h, int(mode), dptr(out)))
+        return dict(zip(self.COMM_PHASES, out.tolist()))
+
     def comm_info(self):
         k, r, w = C.c_int(), C.c_int(), C.c_int()
         self._ck(self.lib.pgd_comm_info(self.h, C.byref(k), C.byref(r), C.byref(w)))
@@ -545,8 +564,10 @@ class Context:
         self._ck(self.lib.pgd_prof_read_own(self.h, C.byref(own)))
         un, us, ub = I64(), F64(), F64()
         self._ck(self.lib.pgd_prof_read_update(self.h, C.byref(un), C.byref(us), C.byref(ub)))
+        dr = I64()
+        self._ck(self.lib.pgd_prof_read_dropped(self.h, C.byref(dr)))
         return dict(launches=n.value, seconds=s.value, bytes=b.value, own_bytes=own.value,
-                    update_launches=un.value, update_seconds=us.value, update_bytes=ub.value)
+                    update_launches=un.value, update_seconds=us.value, update_bytes=ub.value, dropped_noop_samples=dr.value)
 
     KERNEL_FAMILIES = ("csr", "csr_dict", "sym_rows", "dia_rows", "dia_march", "multi", "diac_march")
 

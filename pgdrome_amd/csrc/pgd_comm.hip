@@ -18,6 +18,8 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
+#include <thread>
 
 namespace pgd {
 
@@ -86,13 +88,27 @@ void comm_release(Ctx *c) {
     if (k.ev_ready) (void)hipEventDestroy(k.ev_ready);
     if (k.ev_halo) (void)hipEventDestroy(k.ev_halo);
     if (k.halo_stream) (void)hipStreamDestroy(k.halo_stream);
+    for (hipEvent_t e : k.snap_ev) if (e) (void)hipEventDestroy(e);
+    for (auto &set : k.mark) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
+    if (k.snap_flags) (void)hipHostFree(k.snap_flags);
+    for (pgd_handle &wh : k.work) if (wh) { (void)free_obj(c, wh, Obj::VEC); wh = 0; }
     k = Comm();
+}
+
+static void comm_env_defaults(Comm &k) {
+    if (const char *env = getenv("PGD_COMM_TIMEOUT_S")) {
+        char *end = nullptr;
+        const double v = strtod(env, &end);
+        if (end != env) k.timeout_s = v;
+    }
 }
 
 // neighbour planes -> ghost planes of v (local numbering: [0, lo_g) ghost below, [own0, own1) owned,
 // [own1, own1 + hi_g) ghost above).  `async` (RCCL binding with a halo communicator only): the exchange runs on the
 // halo stream behind an event of the compute stream, and comm_halo_wait makes the compute stream wait for it - rows
 // that read no ghost entry can be multiplied in between.  Otherwise stream-ordered on the compute stream.
+// WHICH communicator carries an exchange must be the same on both ends: callers pass an `async` that depends on nothing
+// rank-local (inside a solve: every exchange of a product async, every other one not; k.overlap is agreed on at bind time).
 static int comm_halo_begin(Ctx *c, pgd_handle vh, double *v, int64_t own0, int64_t own1, int64_t lo_g, int64_t hi_g, bool async) {
     Comm &k = c->comm;
     if (k.kind == 1) {
@@ -232,6 +248,7 @@ int pgd_comm_bind_callbacks(pgd_handle h, pgd_halo_fn halo, pgd_allreduce_fn all
     if (!halo || !allreduce || world < 1 || rank < 0 || rank >= world) return fail(c, PGD_ERR_INVALID, "comm_bind_callbacks: invalid arguments");
     comm_release(c);
     c->comm.kind = 1; c->comm.rank = rank; c->comm.world = world;
+    comm_env_defaults(c->comm);
     c->comm.halo_cb = halo; c->comm.allreduce_cb = allreduce; c->comm.user = user;
     return PGD_OK;
 }
@@ -259,6 +276,7 @@ int pgd_comm_bind_rccl(pgd_handle h, const uint8_t *id128, int rank, int world) 
     void *comm = nullptr;
     PGD_NCCL(c, api, api->CommInitRank(&comm, world, id, rank));
     c->comm.kind = 2; c->comm.rank = rank; c->comm.world = world; c->comm.nccl = comm;
+    comm_env_defaults(c->comm);
     const int rc = comm_selftest(c);
     if (rc != PGD_OK) { const std::string keep = c->err; comm_release(c); c->err = keep; return rc; }
     return rc;
@@ -310,6 +328,149 @@ int pgd_comm_allreduce_slots(pgd_handle h, int first, int count) {
     return comm_allreduce(c, first, count);
 }
 
+}  // extern "C"
+
+// ---- collective discipline of one sharded solve ------------------------------------------------------------------
+// After the setup vote EVERY rank issues the same sequence of collectives whatever happens to it locally:
+//   * a rank-local failure (an allocation, a launch, a copy) POISONS the rank: it stops launching local work, but keeps
+//     issuing every collective of the protocol - all-reduces with NaN payloads, halo planes with whatever the buffers hold;
+//   * every look at the flags (before the first chunk, after every chunk of 16 iterations) and the end of the solve is an
+//     AGREEMENT: a one-slot all-reduce of the "vote" (0 from a healthy rank, NaN from a poisoned one) in front of the
+//     snapshot the host reads.  A non-zero vote takes every rank out of the solve at that very point with an error
+//     (PGD_ERR_PEER on the healthy ones, its own error on the poisoned one); decisions from the flags themselves are
+//     functions of all-reduced numbers and identical everywhere;
+//   * what cannot be handled cooperatively - a failing RCCL call, a failing snapshot, a stream that makes no progress - ends
+//     the call at once (`fatal`), and the OTHER ranks come out through their deadline (pgd_comm_timeout).
+namespace pgd {
+
+constexpr int SH_VOTE = 23;      // slot in front of the recurrence's bank B = 24 .. 32
+
+struct Shard {
+    Ctx *c;
+    int rc = PGD_OK;             // first rank-local failure
+    std::string err;
+    const char *last = "none";   // last collective issued, for the deadline's report
+    int64_t ncoll = 0;
+    int iter = -1;               // iteration being queued
+    bool poisoned() const { return rc != PGD_OK; }
+    void local(int r) {
+        if (rc == PGD_OK && r != PGD_OK) { rc = r; err = c->err; }
+    }
+};
+
+#define SH_LOCAL(S, expr)                           \
+    do {                                            \
+        if (!(S).poisoned()) (S).local((expr));     \
+    } while (0)
+
+static int sh_allreduce(Shard &S, int first, int count, const char *what) {
+    Ctx *c = S.c;
+    if (S.poisoned()) (void)hipMemsetAsync(c->slots + first, 0xFF, (size_t)count * sizeof(double), c->stream);     // NaNs
+    S.last = what;
+    S.ncoll += 1;
+    return comm_allreduce(c, first, count);
+}
+
+static int sh_halo_begin(Shard &S, pgd_handle vh, double *v, int64_t own0, int64_t own1, int64_t lo_g, int64_t hi_g, bool async,
+                         const char *what) {
+    S.last = what;
+    S.ncoll += 1;
+    return comm_halo_begin(S.c, vh, v, own0, own1, lo_g, hi_g, async);
+}
+
+// kernel that keeps the stream busy for `ms` milliseconds (tests of the deadline; bounded)
+__global__ void k_comm_stall(long long ticks) {
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+// wait for an event with the communication deadline: hipEventQuery polling (busy for the first 2 ms, then 50 us naps)
+static int wait_deadline(Shard &S, hipEvent_t ev, const char *what) {
+    Ctx *c = S.c;
+    Comm &k = c->comm;
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    for (;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) break;
+        if (e != hipErrorNotReady) return fail(c, PGD_ERR_HIP, "pcg_solve_sharded: %s: %s", what, hipGetErrorString(e));
+        const double el = std::chrono::duration<double>(clk::now() - t0).count();
+        if (k.timeout_s > 0.0 && el > k.timeout_s) {
+            const int rc = fail(c, PGD_ERR_TIMEOUT,
+                                "pcg_solve_sharded: rank %d/%d: no progress for %.1f s waiting for %s; iteration %d queued, last "
+                                "collective issued: %s (#%lld of this solve)%s",
+                                k.rank, k.world, el, what, S.iter, S.last, (long long)S.ncoll,
+                                S.poisoned() ? "; this rank had failed locally before" : "");
+            fprintf(stderr, "[pgd_amd] %s\n", c->err.c_str());
+            fflush(stderr);
+            return rc;
+        }
+        if (el > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(50));
+    }
+    k.prof_sum[7] += std::chrono::duration<double>(clk::now() - t0).count();
+    return PGD_OK;
+}
+
+static int shard_resources(Ctx *c) {
+    Comm &k = c->comm;
+    if (!k.snap_flags) {
+        void *p = nullptr;
+        PGD_HIP(c, hipHostMalloc(&p, 8 * sizeof(int) + 2 * sizeof(double), hipHostMallocDefault));
+        k.snap_flags = (int *)p;
+        k.snap_vote = reinterpret_cast<double *>(k.snap_flags + 8);
+    }
+    for (hipEvent_t &e : k.snap_ev)
+        if (!e) PGD_HIP(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    if (k.prof)
+        for (auto &set : k.mark)
+            for (hipEvent_t &e : set)
+                if (!e) PGD_HIP(c, hipEventCreate(&e));
+    return PGD_OK;
+}
+
+static void prof_collect(Ctx *c, int set) {
+    Comm &k = c->comm;
+    if (!k.mark_set[set]) return;
+    k.mark_set[set] = false;
+    float ms[6];
+    for (int i = 0; i < 6; ++i)
+        if (hipEventElapsedTime(&ms[i], k.mark[set][i], k.mark[set][i + 1]) != hipSuccess) { (void)hipGetLastError(); return; }
+    k.prof_sum[0] += 1.0;
+    k.prof_sum[2] += 1e-3 * ms[0];      // interior product
+    k.prof_sum[1] += 1e-3 * ms[1];      // waiting for the ghost planes
+    k.prof_sum[3] += 1e-3 * ms[2];      // boundary rows
+    k.prof_sum[4] += 1e-3 * ms[3];      // local sums
+    k.prof_sum[5] += 1e-3 * ms[4];      // all-reduce
+    k.prof_sum[6] += 1e-3 * ms[5];      // update
+}
+
+}  // namespace pgd
+
+extern "C" {
+
+int pgd_comm_timeout(pgd_handle h, double seconds) {
+    PGD_CTX(c, h);
+    if (!(seconds == seconds)) return fail(c, PGD_ERR_INVALID, "comm_timeout: not a number");
+    c->comm.timeout_s = seconds;
+    return PGD_OK;
+}
+
+int pgd_comm_prof(pgd_handle h, int mode, double *out8) {
+    PGD_CTX(c, h);
+    Comm &k = c->comm;
+    if (mode == 1) {
+        k.prof = true;
+        for (double &v : k.prof_sum) v = 0.0;
+    } else if (mode == 0) {
+        k.prof = false;
+    } else if (mode != -1) {
+        return fail(c, PGD_ERR_INVALID, "comm_prof: mode must be 1 (on + reset), 0 (off) or -1 (read)");
+    }
+    if (out8)
+        for (int i = 0; i < 8; ++i) out8[i] = k.prof_sum[i];
+    return PGD_OK;
+}
+
 int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, int64_t own0, int64_t own1,
                           int64_t lo_g, int64_t hi_g, double rtol, double atol, int maxit, int *iters, double *rel) {
     PGD_CTX(c, h);
@@ -323,13 +484,13 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     if (k.kind == 0) return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: no communication binding");
     if ((lo_g > 0) != (k.rank > 0) || (hi_g > 0) != (k.rank < k.world - 1))
         return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: ghost planes do not match the rank's position");
-    constexpr int B = 24, CHECK = 16;       // slot base of the recurrence (pgdrome_amd/dist.py uses the same)
+    constexpr int B = 24, CHECK = 16, V = SH_VOTE;       // slot base of the recurrence (pgdrome_amd/dist.py uses the same)
+    static_assert(V == B - 1, "the vote rides in front of the recurrence's slots");
     Mesh *m = get_mesh(c, op->mesh);
 
-    // ---- phase A: everything that can fail on ONE rank (allocations, the symmetric copy) happens before the first
-    // collective, and its outcome is agreed on: a rank that fails here must not leave the others waiting in a halo
-    // exchange, and a rank whose operator did not qualify for the symmetric storage must not take another branch
-    // (the scaled recurrence has one more halo exchange) than its neighbours.
+    // ---- phase A: everything that can fail on ONE rank before the first collective (allocations, the symmetric copy), and
+    // the choice of recurrence, are agreed on with one all-reduce: a rank whose operator did not qualify for the symmetric
+    // storage must not take another branch (the scaled recurrence has one more halo exchange) than its neighbours.
     bool sym = false, ss_all = false;
     auto setup = [&]() -> int {
         if (!m) return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: operator without a mesh");
@@ -339,8 +500,11 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
             for (pgd_handle &wh : k.work) PGD_TRY(pgd_vec_alloc(h, n, &wh));
             k.work_n = n;
         }
+        PGD_TRY(shard_resources(c));
         PGD_TRY(ensure_sym(c, m, op, &sym));
-        PGD_TRY(ensure_partials(c, std::max<int64_t>((own1 - own0) / 64 + 64, 4 * (int64_t)MAX_VEC_BLOCKS)));
+        // the product's partial sums of ALL its row ranges lie side by side, in pairs in the single-sync form: room for the worst
+        // case (row-order launches: one workgroup per 64 rows) now, so that no launch inside the loop has to move the buffer
+        PGD_TRY(ensure_partials(c, std::max<int64_t>(2 * ((own1 - own0 + 63) / 64 + 8) + 64, 4 * (int64_t)MAX_VEC_BLOCKS)));
         PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS));
         PGD_TRY(pgd_flags_reset(h));
         return PGD_OK;
@@ -356,120 +520,158 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         if (rc == PGD_OK) rc = pgd_slots_download(h, got, B, 3);
         if (rc_setup != PGD_OK) { c->err = err_setup; return rc_setup; }
         if (rc != PGD_OK) return rc;
-        if (got[0] != 0.0) return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: the setup failed on another rank");
+        if (got[0] != 0.0) return fail(c, PGD_ERR_PEER, "pcg_solve_sharded: the setup failed on another rank");
         sym = sym && got[1] == 0.0;                     // scaled only if EVERY rank can
         ss_all = got[2] == 0.0;                         // ... and the single-sync recurrence only if every rank's slab is a grid
     }
     const bool scaled = sym && c->pcg_scaled;
     const bool ss = scaled && ss_all;                   // single-sync recurrence: 7 (here 8: the true norm every iteration) vector passes
     const pgd_handle r = k.work[0], u = k.work[1], w = k.work[2], p = k.work[3], s = k.work[4], q = k.work[5], dinv = k.work[6];
-    const double zeros[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    PGD_TRY(pgd_slots_upload(h, zeros, B, 9));
-    PGD_TRY(pgd_op_diag_inv(h, oh, dinv));
+
+    // ---- from here on: the collective discipline described above
+    Shard S{c};
+    struct ProfIterGuard { Ctx *c; ~ProfIterGuard() { c->prof_iter = -1; } } prof_iter_guard{c};
+    c->prof_pend.clear();
+    auto fault_at = [&](int stage) {                    // tests (PGD_TUNE_FAULT_STAGE)
+        if (c->fault_stage == stage && !S.poisoned()) {
+            c->fault_stage = 0;
+            S.local(fail(c, PGD_ERR_HIP, "pcg_solve_sharded: injected fault at stage %d (PGD_TUNE_FAULT_STAGE)", stage));
+        }
+    };
+    fault_at(1);
+    const double zeros[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    SH_LOCAL(S, pgd_slots_upload(h, zeros, V, 10));
+    SH_LOCAL(S, pgd_op_diag_inv(h, oh, dinv));
     double *scp = get_vec(c, dinv)->d;
     double *xd = x->d, *rd = get_vec(c, r)->d, *wd = get_vec(c, w)->d, *pd = get_vec(c, p)->d, *sd = get_vec(c, s)->d,
            *qd = get_vec(c, q)->d;
 
     // On every exit after the operator and x were scaled: x back to sc x~, the slot arrays no longer taken for A.
     struct ScaleGuard {
-        Ctx *c; Csr *op; double *x; const double *sc; int64_t n; bool active;
+        Ctx *c; Csr *op; double *x; const double *sc; int64_t n; bool x_scaled, op_scaled;
         ~ScaleGuard() {
-            if (!active) return;
-            (void)vec_div_mul(c, x, sc, n, 1);
-            op->uvals_valid = false;
-            op->uvals_scaled = false;
+            if (x_scaled) (void)vec_div_mul(c, x, sc, n, 1);
+            if (op_scaled) { op->uvals_valid = false; op->uvals_scaled = false; }
         }
-    } guard{c, op, xd, scp, n, false};
+    } guard{c, op, xd, scp, n, false, false};
+
+    // one agreement: vote -> all-reduce -> snapshot of (flags, vote) into pinned slot `sn` + its event
+    auto agree_begin = [&](int sn, const char *what) -> int {
+        PGD_TRY(sh_allreduce(S, V, 1, what));
+        PGD_HIP(c, hipMemcpyAsync(k.snap_flags + 4 * sn, c->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+        PGD_HIP(c, hipMemcpyAsync(k.snap_vote + sn, c->slots + V, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+        PGD_HIP(c, hipEventRecord(k.snap_ev[sn], c->stream));
+        return PGD_OK;
+    };
+    // ... and its outcome: PGD_OK = everybody healthy (flags in f), else the error this rank leaves with
+    auto agree_end = [&](int sn, const char *what, int f[4]) -> int {
+        PGD_TRY(wait_deadline(S, k.snap_ev[sn], what));
+        for (int i = 0; i < 4; ++i) f[i] = k.snap_flags[4 * sn + i];
+        const double vote = k.snap_vote[sn];
+        if (S.poisoned()) { c->err = S.err; return S.rc; }
+        if (!(vote == 0.0)) return fail(c, PGD_ERR_PEER, "pcg_solve_sharded: another rank failed locally (%s); every rank leaves the solve", what);
+        return PGD_OK;
+    };
 
     // w = A u on the owned rows, S[B + 2] (+ S[B + 3], S[B + 4]) <- local w.u: the rows that read no ghost entry first,
     // while the boundary planes travel (overlap binding) - the same three launches in the same order either way, so the
     // overlapped and the stream-ordered solve are bit-identical.  `folded`: partial sums of all three ranges side by
     // side in the scratch, one later reduction (k_reduce_two); else one reduction per range into its own slot.
+    // Returns an error only for what ends the protocol (a failing collective); local failures poison S.
     int64_t glo = lo_g, ghi = hi_g;
     if (own1 - own0 < glo + ghi) { glo = own1 - own0; ghi = 0; }     // a rank that owns a single plane: nothing to overlap
-    bool halo_pending = false;
+    const bool async = k.overlap;                                    // the SAME choice on every rank (agreed on at bind time)
+    hipEvent_t *marks = nullptr;                                     // phase timing of the iteration being queued (or none)
+    auto mark = [&](int i) { if (marks) (void)hipEventRecord(marks[i], c->stream); };
     auto product = [&](pgd_handle uh, double *ud, double *wdst, bool folded, int *np_total) -> int {
-        const bool async = k.overlap && own1 - ghi > own0 + glo;
-        halo_pending = false;
-        PGD_TRY(comm_halo_begin(c, uh, ud, own0, own1, lo_g, hi_g, async));
-        halo_pending = async;
+        mark(0);
+        PGD_TRY(sh_halo_begin(S, uh, ud, own0, own1, lo_g, hi_g, async, "halo exchange of the product"));
         const int64_t lo[3] = {own0 + glo, own0, own1 - ghi}, hi[3] = {own1 - ghi, own0 + glo, own1};
+        const int mult = c->spmv_qq ? 2 : 1;      // pairs (w.y, y.y) per workgroup in the single-sync form
         int total = 0;
-        for (int part = 0; part < 3; ++part) {
-            if (part == 1) {
-                PGD_TRY(comm_halo_wait(c, lo_g, hi_g, async));
-                halo_pending = false;
-                if (folded) {       // both boundary planes in one row-order launch where the operator is in diagonal form
-                    int np = 0;
-                    bool both = false;
-                    c->partials_off = (c->spmv_qq ? 2 : 1) * (int64_t)total;      // pairs (w.y, y.y) per workgroup in the single-sync form
-                    const int rc = launch_spmv_dia_rows2(c, m, op, ud, wdst, ud, lo[1], hi[1], lo[2], hi[2], true, c->flags, &np, &both);
-                    c->partials_off = 0;
-                    PGD_TRY(rc);
-                    if (both) { total += np; break; }
-                }
-            }
-            if (folded) {
+        auto range = [&](int part) -> int {
+            if (!folded) return pgd_spmv_dot_slot(h, oh, uh, (wdst == wd) ? w : q, uh, lo[part], hi[part], B + 2 + part);
+            int np = 0;
+            c->partials_off = mult * (int64_t)total;
+            const int rc = launch_spmv_op(c, m, op, ud, wdst, ud, lo[part], hi[part], true, true, c->flags, &np);
+            c->partials_off = 0;
+            PGD_TRY(rc);
+            total += np;
+            return PGD_OK;
+        };
+        SH_LOCAL(S, range(0));
+        mark(1);
+        PGD_TRY(comm_halo_wait(c, lo_g, hi_g, async));
+        mark(2);
+        bool both = false;
+        if (folded) {       // both boundary planes in one row-order launch where the operator is in diagonal form
+            auto both_planes = [&]() -> int {
                 int np = 0;
-                c->partials_off = (c->spmv_qq ? 2 : 1) * (int64_t)total;      // pairs (w.y, y.y) per workgroup in the single-sync form
-                const int rc = launch_spmv_op(c, m, op, ud, wdst, ud, lo[part], hi[part], true, true, c->flags, &np);
+                c->partials_off = mult * (int64_t)total;
+                const int rc = launch_spmv_dia_rows2(c, m, op, ud, wdst, ud, lo[1], hi[1], lo[2], hi[2], true, c->flags, &np, &both);
                 c->partials_off = 0;
                 PGD_TRY(rc);
-                total += np;
-            } else {
-                PGD_TRY(pgd_spmv_dot_slot(h, oh, uh, (wdst == wd) ? w : q, uh, lo[part], hi[part], B + 2 + part));
-            }
+                if (both) total += np;
+                return PGD_OK;
+            };
+            SH_LOCAL(S, both_planes());
         }
+        if (!both) { SH_LOCAL(S, range(1)); SH_LOCAL(S, range(2)); }
+        mark(3);
         if (np_total) *np_total = total;
         return PGD_OK;
     };
 
     if (scaled) {
-        PGD_TRY(vec_sqrt(c, scp, n));
-        PGD_TRY(comm_halo(c, dinv, scp, own0, own1, lo_g, hi_g));
-        PGD_TRY(sym_scale(c, m, op, scp));
-        PGD_TRY(dia_classify(c, m, op));                             // rank-local choice of kernel, same bits either way
-        PGD_TRY(vec_div_mul(c, xd, scp, n, 0));                      // x~ = x / sc on owned and ghost rows alike
-        guard.active = true;
+        SH_LOCAL(S, vec_sqrt(c, scp, n));
+        PGD_TRY(sh_halo_begin(S, dinv, scp, own0, own1, lo_g, hi_g, false, "halo exchange of d^-1/2"));
+        fault_at(2);
+        if (!S.poisoned()) guard.op_scaled = true;
+        SH_LOCAL(S, sym_scale(c, m, op, scp));
+        SH_LOCAL(S, dia_classify(c, m, op));                             // rank-local choice of kernel, same bits either way
+        if (!S.poisoned()) guard.x_scaled = true;
+        SH_LOCAL(S, vec_div_mul(c, xd, scp, n, 0));                      // x~ = x / sc on owned and ghost rows alike
     }
-    PGD_TRY(comm_halo(c, xh, xd, own0, own1, lo_g, hi_g));
-    if (scaled) PGD_TRY(launch_spmv_op(c, m, op, xd, qd, nullptr, own0, own1, false, true, nullptr, nullptr));   // the scaled slots
-    else PGD_TRY(pgd_spmv(h, oh, xh, q, own0, own1));
-    if (scaled) PGD_TRY(cg_init_s(c, b->d, qd, scp, rd, pd, sd, own0, own1, B));
-    else PGD_TRY(pgd_cg_init_slot(h, bh, q, dinv, r, u, p, s, own0, own1, B));
+    PGD_TRY(sh_halo_begin(S, xh, xd, own0, own1, lo_g, hi_g, false, "halo exchange of the start vector"));
+    if (scaled) SH_LOCAL(S, launch_spmv_op(c, m, op, xd, qd, nullptr, own0, own1, false, true, nullptr, nullptr));   // the scaled slots
+    else SH_LOCAL(S, pgd_spmv(h, oh, xh, q, own0, own1));
+    if (scaled) SH_LOCAL(S, cg_init_s(c, b->d, qd, scp, rd, pd, sd, own0, own1, B));
+    else SH_LOCAL(S, pgd_cg_init_slot(h, bh, q, dinv, r, u, p, s, own0, own1, B));
     const pgd_handle mv = ss ? p : scaled ? r : u;                   // the vector the product is applied to
     double *mvd = get_vec(c, mv)->d;
     const int gvec = grid_for((own1 - own0 + 1) / 2);                // workgroups (= partial-sum pairs) of k_pcg1_update
     if (ss) {
         // textbook start p = r; the local (r~.r~, true r.r) of the initial residual become the first "previous update" sums
-        if (own1 > own0) PGD_HIP(c, hipMemcpyAsync(pd + own0, rd + own0, (size_t)(own1 - own0) * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-        PGD_TRY(pcg1_seed(c, MAX_VEC_BLOCKS, B, B + 1));
+        if (own1 > own0 && !S.poisoned())
+            S.local(hipMemcpyAsync(pd + own0, rd + own0, (size_t)(own1 - own0) * sizeof(double), hipMemcpyDeviceToDevice, c->stream) == hipSuccess
+                        ? PGD_OK : fail(c, PGD_ERR_HIP, "pcg_solve_sharded: copy of the start direction failed"));
+        SH_LOCAL(S, pcg1_seed(c, MAX_VEC_BLOCKS, B, B + 1));
         // (slot B + 7 rides along: the sum of s_i^16 over the owned rows, from which every rank forms the same lower bound of the
         // smallest diagonal entry - k_pcg1_tol - for the switch into the exact phase)
-        if (c->pcg_exact_phase) PGD_TRY(pcg1_aux(c, scp, nullptr, own0, own1, B + 7));
-        PGD_TRY(comm_allreduce(c, B, 9));
-        PGD_TRY(pcg1_tol(c, B, rtol, atol, c->pcg_exact_phase ? B + 7 : -1));
+        if (c->pcg_exact_phase) SH_LOCAL(S, pcg1_aux(c, scp, nullptr, own0, own1, B + 7));
+        PGD_TRY(sh_allreduce(S, B, 9, "all-reduce of the initial residual"));
+        fault_at(3);
+        SH_LOCAL(S, pcg1_tol(c, B, rtol, atol, c->pcg_exact_phase ? B + 7 : -1));
     } else {
         PGD_TRY(product(mv, mvd, wd, false, nullptr));
-        PGD_TRY(comm_allreduce(c, B, 9));
-        PGD_TRY(pgd_cg_scalars_slot(h, B, 1, rtol, atol));
-        if (scaled) {     // the folded form reads "previous alpha, previous r.r" from the slot set of its parity: seed set 0
-            PGD_HIP(c, hipMemcpyAsync(c->slots + B + 9, c->slots + B + 5, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-            PGD_HIP(c, hipMemcpyAsync(c->slots + B + 10, c->slots + B + 7, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        PGD_TRY(sh_allreduce(S, B, 9, "all-reduce of the initial residual"));
+        fault_at(3);
+        SH_LOCAL(S, pgd_cg_scalars_slot(h, B, 1, rtol, atol));
+        if (scaled && !S.poisoned()) {     // the folded form reads "previous alpha, previous r.r" from the slot set of its parity: seed set 0
+            (void)hipMemcpyAsync(c->slots + B + 9, c->slots + B + 5, sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+            (void)hipMemcpyAsync(c->slots + B + 10, c->slots + B + 7, sizeof(double), hipMemcpyDeviceToDevice, c->stream);
         }
     }
-    int32_t done = 0, it = 0, status = 0;
-    int kk = 0;
     // an empty slab has no update launch to fold the scalar step into; every rank must take the same form (collective-free: the
     // decision depends on nothing rank-local but that, and a rank without rows runs k_pcg1_finish for its own books instead)
     const bool fold = ss && c->pcg_fold_finish != 0 && own1 > own0;
-    // One iteration; did_halo / did_ar say which of its two collectives were issued when it fails half way.
-    bool did_halo = false, did_ar = false;
+    // One iteration.  Returns an error only for what ends the protocol.
     auto iterate = [&](int kidx) -> int {
-        did_halo = did_ar = false;
-        if (c->fault_iteration >= 0 && kidx == c->fault_iteration) {      // tests: a rank-local failure in mid-solve
+        S.iter = kidx;
+        c->prof_iter = kidx;
+        if (c->fault_iteration >= 0 && kidx == c->fault_iteration && !S.poisoned()) {      // tests: a rank-local failure in mid-solve
             c->fault_iteration = -1;
-            return fail(c, PGD_ERR_HIP, "pcg_solve_sharded: injected fault in iteration %d (PGD_TUNE_FAULT_ITERATION)", kidx);
+            S.local(fail(c, PGD_ERR_HIP, "pcg_solve_sharded: injected fault in iteration %d (PGD_TUNE_FAULT_ITERATION)", kidx));
         }
         if (ss) {
             // product (p.q and q.q partial sums) -> local sums -> ONE all-reduce -> stop test, alpha, beta -> x, r, p update
@@ -477,88 +679,104 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
             c->spmv_qq = 1;
             const int rc = product(mv, pd, qd, true, &np);
             c->spmv_qq = 0;
-            did_halo = true;
             PGD_TRY(rc);
-            PGD_TRY(pcg1_sums(c, np, gvec, B));
-            did_ar = true;
-            PGD_TRY(comm_allreduce(c, B, 5));
+            SH_LOCAL(S, pcg1_sums(c, np, gvec, B));
+            mark(4);
+            PGD_TRY(sh_allreduce(S, B, 5, "all-reduce of the iteration"));
+            mark(5);
             // stop test, alpha, beta: by every workgroup of the update (fold), or by k_pcg1_finish in a launch of its own
-            if (!fold) PGD_TRY(pcg1_finish_slots(c, B));
+            if (!fold) SH_LOCAL(S, pcg1_finish_slots(c, B));
             // (x is updated every other iteration, two terms at a time: k_pcg1_update; every rank reads the same beta)
-            PGD_TRY(pcg1_update(c, xd, rd, pd, qd, scp, own0, own1, B, &nb, c->pcg_lag_x ? 1 + (kidx & 1) : 0, fold ? (kidx & 1) : -1));
+            SH_LOCAL(S, pcg1_update(c, xd, rd, pd, qd, scp, own0, own1, B, &nb, c->pcg_lag_x ? 1 + (kidx & 1) : 0, fold ? (kidx & 1) : -1));
+            mark(6);
             return PGD_OK;
         }
         if (scaled && kidx > 0) {
             // 3 kernels per iteration: vector step (forms alpha / beta itself, counts, tests), product, one reduction
             int nb = 0, np = 0;
-            PGD_TRY(cg_update_s2(c, xd, rd, wd, pd, sd, scp, own0, own1, B, (kidx - 1) & 1, &nb));
-            const int rc = product(mv, rd, wd, true, &np);
-            did_halo = true;                                         // the exchange is the first thing product() issues
-            PGD_TRY(rc);
-            PGD_TRY(reduce_two_slots(c, nb, np, B));
+            SH_LOCAL(S, cg_update_s2(c, xd, rd, wd, pd, sd, scp, own0, own1, B, (kidx - 1) & 1, &nb));
+            PGD_TRY(product(mv, rd, wd, true, &np));
+            SH_LOCAL(S, reduce_two_slots(c, nb, np, B));
         } else {
-            if (scaled) PGD_TRY(cg_update_s(c, xd, rd, wd, pd, sd, scp, own0, own1, B));
-            else PGD_TRY(pgd_cg_update_slot(h, xh, r, u, w, p, s, dinv, own0, own1, B));
-            const int rc = product(mv, mvd, wd, false, nullptr);
-            did_halo = true;
-            PGD_TRY(rc);
+            if (scaled) SH_LOCAL(S, cg_update_s(c, xd, rd, wd, pd, sd, scp, own0, own1, B));
+            else SH_LOCAL(S, pgd_cg_update_slot(h, xh, r, u, w, p, s, dinv, own0, own1, B));
+            PGD_TRY(product(mv, mvd, wd, false, nullptr));
         }
-        did_ar = true;
-        PGD_TRY(comm_allreduce(c, B, 5));
-        if (!(scaled && kidx > 0) && !scaled) PGD_TRY(pgd_cg_scalars_slot(h, B, 0, rtol, atol));
+        mark(4);
+        PGD_TRY(sh_allreduce(S, B, 5, "all-reduce of the iteration"));
+        mark(5);
+        if (!(scaled && kidx > 0) && !scaled) SH_LOCAL(S, pgd_cg_scalars_slot(h, B, 0, rtol, atol));
+        mark(6);
         return PGD_OK;
     };
-    int rc_loop = PGD_OK;
-    std::string err_loop;
+
+    // ---- the loop, PIPELINED: the next chunk is queued before the host waits for the agreement behind the previous one (the GPU
+    // does not idle through the host's round trip).  Every rank queues exactly the same chunks: what is read at a boundary is
+    // either all-reduced (the vote) or a function of all-reduced numbers (the flags), and a chunk queued behind the converged
+    // iteration consists of no-op launches and matched collectives.
+    int f[4] = {0, 0, 0, 0};
+    int enq = 0, cur = 0, nchunks = 0;
+    if (c->fault_stall_ms > 0) {      // tests: a stream that stops making progress
+        const long long ticks = (long long)std::min(c->fault_stall_ms, 20000) * 100000LL;      // wall_clock64 ticks at 100 MHz
+        c->fault_stall_ms = 0;
+        k_comm_stall<<<1, 1, 0, c->stream>>>(ticks);
+    }
+    PGD_TRY(agree_begin(0, "agreement before the first chunk"));
     for (;;) {
-        if (rc_loop == PGD_OK) PGD_TRY(pgd_flags_download(h, &done, &it, &status));     // the only host synchronisation of the loop
-        if (done || kk >= maxit || rc_loop != PGD_OK) break;
-        const int chunk = std::min(CHECK, maxit - kk);
-        for (int j = 0; j < chunk; ++j, ++kk) {
-            if (rc_loop == PGD_OK) {
-                rc_loop = iterate(kk);
-                if (rc_loop == PGD_OK) continue;
-                err_loop = c->err;
-            } else {
-                did_halo = did_ar = false;
+        const int chunk = std::min(CHECK, maxit - enq);
+        if (chunk > 0) {
+            const int set = nchunks & 1;
+            for (int j = 0; j < chunk; ++j) {
+                const bool sample = k.prof && j == 5 && !S.poisoned();
+                marks = sample ? k.mark[set] : nullptr;
+                PGD_TRY(iterate(enq + j));
+                if (sample) k.mark_set[set] = true;
+                marks = nullptr;
             }
-            // POISONED: this rank failed in the middle of the chunk.  It keeps issuing the chunk's collectives - with
-            // NaN in its partial sums, so that every rank's convergence test trips on the all-reduced values and all of
-            // them leave at the next look at the flags - instead of dropping out and leaving its neighbours waiting.
-            if (halo_pending) { (void)comm_halo_wait(c, lo_g, hi_g, true); halo_pending = false; }
-            if (!did_halo) (void)comm_halo(c, mv, mvd, own0, own1, lo_g, hi_g);
-            if (!did_ar) {
-                (void)hipMemsetAsync(c->slots + B, 0xFF, 5 * sizeof(double), c->stream);       // five NaNs
-                (void)comm_allreduce(c, B, 5);
-            }
+            enq += chunk;
+            nchunks += 1;
+            PGD_TRY(agree_begin(cur ^ 1, "agreement after a chunk of iterations"));
         }
+        PGD_TRY(agree_end(cur, cur == 0 && nchunks <= 1 ? "the agreement before the first chunk" : "the agreement after a chunk", f));
+        if (chunk > 0 && nchunks >= 2) prof_collect(c, nchunks & 1);      // the chunk before the one just queued has drained
+        if (f[0] || chunk <= 0) break;                // converged (what is queued behind it does nothing), or nothing more to queue
+        cur ^= 1;
     }
-    if (rc_loop != PGD_OK) { c->err = err_loop; return rc_loop; }
-    if (scaled && !ss && !done && kk > 0) {
-        // the last enqueued iteration's scalars are still unprocessed in the folded form: count and test them
-        PGD_TRY(pgd_cg_scalars_slot(h, B, 0, rtol, atol));
-        PGD_TRY(pgd_flags_download(h, &done, &it, &status));
+    c->prof_iter = -1;
+    if (c->prof) prof_commit(c, f[1] + (ss ? 1 : 0), f[1]);      // samples of launches behind the converged iteration are dropped
+    const int32_t done = f[0], it = f[1], status = f[2];
+    if (scaled && !ss && !done && enq > 0) {
+        // the last queued iteration's scalars are still unprocessed in the folded form: count and test them (same on every rank)
+        SH_LOCAL(S, pgd_cg_scalars_slot(h, B, 0, rtol, atol));
     }
-    if (status != 0) return fail(c, PGD_ERR_SINGULAR, "sharded PCG breakdown (NaN) after %d iterations", it);
-    if (ss && c->pcg_exact_phase) {
-        // the report: the true r.r of the final residual (a solve that stops at maxit may never have entered its exact phase).
-        // Every rank does this, whatever its own flags say: one more all-reduce per solve.
-        PGD_TRY(pcg1_aux(c, scp, rd, own0, own1, B));
-        PGD_TRY(comm_allreduce(c, B, 1));
-        PGD_HIP(c, hipMemcpyAsync(c->slots + 6, c->slots + B, sizeof(double), hipMemcpyDeviceToDevice, c->stream));
-    }
-    if (ss && c->pcg_lag_x && it > 0 && ((it - 1) & 1) == 0)          // the last update had an even index: its term of x may be outstanding
-        PGD_TRY(pcg1_flush_x(c, xd, pd, rd, own0, own1, B, fold ? ((it - 1) & 1) : -1));
+    fault_at(4);
+    // ---- closing agreement: the true r.r of the final residual for the report (a solve that stops at maxit may never have
+    // entered its exact phase) rides with the vote; whatever failed locally since the last boundary comes out here
+    if (ss && c->pcg_exact_phase) SH_LOCAL(S, pcg1_aux(c, scp, rd, own0, own1, B));
+    PGD_TRY(sh_allreduce(S, V, 2, "closing agreement"));
+    if (ss && c->pcg_exact_phase && !S.poisoned())
+        (void)hipMemcpyAsync(c->slots + 6, c->slots + B, sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+    PGD_HIP(c, hipMemcpyAsync(k.snap_flags, c->flags, 4 * sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipMemcpyAsync(k.snap_vote, c->slots + V, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipEventRecord(k.snap_ev[0], c->stream));
+    int f2[4];
+    PGD_TRY(agree_end(0, "the closing agreement", f2));
+    prof_collect(c, 0);
+    prof_collect(c, 1);
+    const int32_t it2 = f2[1], status2 = f2[2];
+    (void)it;
+    if (status != 0 || status2 != 0) return fail(c, PGD_ERR_SINGULAR, "sharded PCG breakdown (NaN) after %d iterations", it2);
+    // ---- everybody is healthy and has left the loop at the same iteration
+    if (ss && c->pcg_lag_x && it2 > 0 && ((it2 - 1) & 1) == 0)          // the last update had an even index: its term of x may be outstanding
+        PGD_TRY(pcg1_flush_x(c, xd, pd, rd, own0, own1, B, fold ? ((it2 - 1) & 1) : -1));
     if (scaled) {
-        guard.active = false;
+        guard.x_scaled = false;
         PGD_TRY(vec_div_mul(c, xd, scp, n, 1));                      // back to x = sc x~ (ghosts too; refreshed below)
-        op->uvals_valid = false;                                     // the slot arrays hold the scaled operator
-        op->uvals_scaled = false;
     }
     double sl[40];
     PGD_TRY(pgd_slots_download(h, sl, 0, 40));
     PGD_TRY(comm_halo(c, xh, x->d, own0, own1, lo_g, hi_g));     // the caller's x: ghosts current
-    if (iters) *iters = it;
+    if (iters) *iters = it2;
     const double bb = sl[B + 8], rr = sl[6];
     if (rel) *rel = bb > 0.0 ? sqrt(rr / bb) : 0.0;
     return PGD_OK;

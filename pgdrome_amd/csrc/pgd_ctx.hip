@@ -1,4 +1,5 @@
 // Context, handle table, device vectors: the plumbing of libpgd_amd.so.
+#include <algorithm>
 #include <cstdarg>
 #include <cstring>
 #include <mutex>
@@ -105,7 +106,22 @@ static int ensure_buf(Ctx *c, T **p, int64_t *cap, int64_t n) {
     return PGD_OK;
 }
 
-int ensure_partials(Ctx *c, int64_t n) { return ensure_buf(c, &c->partials, &c->partials_cap, n); }
+// The reduction scratch may be grown BETWEEN the launches of one reduction (several row ranges leaving their partial sums side by
+// side, c->partials_off > 0): what the earlier launches wrote must survive the move.
+int ensure_partials(Ctx *c, int64_t n) {
+    if (c->partials_cap >= n) return PGD_OK;
+    if (c->partials_off <= 0 || !c->partials) return ensure_buf(c, &c->partials, &c->partials_cap, n);
+    void *q = nullptr;
+    PGD_TRY(dev_alloc(c, &q, (size_t)n * sizeof(double)));
+    const int64_t keep = std::min<int64_t>(c->partials_off, c->partials_cap);
+    hipError_t e = hipMemcpyAsync(q, c->partials, (size_t)keep * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) { (void)hipFree(q); return fail(c, PGD_ERR_HIP, "ensure_partials: %s", hipGetErrorString(e)); }
+    (void)hipFree(c->partials);
+    c->partials = (double *)q;
+    c->partials_cap = n;
+    return PGD_OK;
+}
 int ensure_work(Ctx *c, int i, int64_t n) { return ensure_buf(c, &c->work[i], &c->work_cap[i], n); }
 int pcg_flag_snapshots(Ctx *c) {
     if (!c->flags_host) {
@@ -121,15 +137,31 @@ int pcg_flag_snapshots(Ctx *c) {
 int ensure_mask(Ctx *c, int64_t n) { return ensure_buf(c, &c->mask, &c->mask_cap, n); }
 int ensure_ibuf(Ctx *c, int64_t n) { return ensure_buf(c, &c->ibuf, &c->ibuf_cap, n); }
 
+static void prof_keep(Ctx *c, const Ctx::ProfRec &r) {
+    if (r.kind) { c->prof_upd_launches += 1; c->prof_upd_seconds += r.seconds; c->prof_upd_bytes += r.bytes; }
+    else { c->prof_launches += 1; c->prof_seconds += r.seconds; c->prof_bytes += r.bytes; c->prof_own_bytes += r.own; }
+}
+
 void prof_flush(Ctx *c) {
     if (c->ev_used == 0) return;
     (void)hipStreamSynchronize(c->stream);
     for (size_t i = 0; i + 1 < c->ev_used; i += 2) {
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) == hipSuccess)
-            (c->ev_kind[i / 2] ? c->prof_upd_seconds : c->prof_seconds) += 1e-3 * ms;
+        if (hipEventElapsedTime(&ms, c->ev[i], c->ev[i + 1]) != hipSuccess) continue;
+        Ctx::ProfRec r = c->ev_rec[i / 2];
+        r.seconds = 1e-3 * ms;
+        if (r.iter < 0) prof_keep(c, r); else c->prof_pend.push_back(r);
     }
     c->ev_used = 0;
+}
+
+void prof_commit(Ctx *c, int valid_products, int valid_updates) {
+    prof_flush(c);
+    for (const Ctx::ProfRec &r : c->prof_pend) {
+        if (r.iter < (r.kind ? valid_updates : valid_products)) prof_keep(c, r);
+        else c->prof_dropped += 1;
+    }
+    c->prof_pend.clear();
 }
 
 }  // namespace pgd
@@ -343,8 +375,10 @@ int pgd_prof_enable(pgd_handle h, int on) {
         c->prof_own_bytes = 0.0;
         c->prof_upd_launches = 0;
         c->prof_upd_seconds = c->prof_upd_bytes = 0.0;
+        c->prof_dropped = 0;
+        c->prof_pend.clear();
         if (c->ev.empty()) {
-            c->ev_kind.assign(1024, 0);
+            c->ev_rec.assign(1024, Ctx::ProfRec{0, -1, 0.0, 0.0, 0.0});
             c->ev.resize(2048);
             for (auto &e : c->ev) PGD_HIP(c, hipEventCreate(&e));
         }
@@ -367,6 +401,13 @@ int pgd_prof_read_update(pgd_handle h, int64_t *launches, double *seconds, doubl
     if (launches) *launches = c->prof_upd_launches;
     if (seconds) *seconds = c->prof_upd_seconds;
     if (bytes) *bytes = c->prof_upd_bytes;
+    return PGD_OK;
+}
+
+int pgd_prof_read_dropped(pgd_handle h, int64_t *dropped) {
+    PGD_CTX(c, h);
+    prof_flush(c);
+    if (dropped) *dropped = c->prof_dropped;
     return PGD_OK;
 }
 

@@ -137,6 +137,16 @@ struct Comm {
     bool overlap = false;         // halo exchange concurrent with the interior rows' product
     pgd_handle work[7] = {0, 0, 0, 0, 0, 0, 0};   // r, u, w, p, s, q, dinv of the sharded PCG
     int64_t work_n = 0;
+    double timeout_s = 60.0;      // deadline of the host-side waits of the sharded solve (pgd_comm_timeout; <= 0: none)
+    // boundary snapshots of the sharded loop (pinned): per slot 4 flag ints + the vote slot, and the event behind the copies
+    int *snap_flags = nullptr;    // 2 x 4 ints
+    double *snap_vote = nullptr;  // 2 doubles (same pinned allocation)
+    hipEvent_t snap_ev[2] = {nullptr, nullptr};
+    // phase timing (pgd_comm_prof): two sets of 7 markers, alternating with the parity of the chunk
+    bool prof = false;
+    hipEvent_t mark[2][7] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
+    bool mark_set[2] = {false, false};
+    double prof_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 struct Ctx {
@@ -174,6 +184,8 @@ struct Ctx {
     int64_t spmv_grid_min_plane_bytes = 0;   // structured grids whose planes of values are at least this large take the z-march (k_spmv_dia_march*)
     int spmv_zchunk_force = 0;    // > 0: exactly this many planes per march whatever the grid size (tests)
     int fault_iteration = -1;     // tests: pgd_pcg_solve_sharded fails on this rank in that iteration (once)
+    int fault_stage = 0;          // tests: ... or at this stage of the solve outside the loop (PGD_TUNE_FAULT_STAGE), once
+    int fault_stall_ms = 0;       // tests: ... or its stream stalls for this long in front of the first chunk (PGD_TUNE_FAULT_STALL_MS), once
     int64_t pcg_small_ss_rows = (int64_t)1 << 22;   // ... structured grids up to this many rows as well (PGD_TUNE_PCG_SMALL_ROWS; 128^3: +2 %, 256^3: a loss)
     int pcg_small_ss = 1;         // systems up to 2^20 rows: single-sync recurrence with the scalar step inside the update kernel (2 launches)
     int pcg_stream_hints = 1;     // single-sync recurrence: q, r, x non-temporal, p cached (PGD_TUNE_PCG_STREAM_HINTS)
@@ -206,7 +218,15 @@ struct Ctx {
     bool prof = false;
     bool prof_pcg_only = false;   // time only the PCG instance k_spmv_csr<dot,store>
     std::vector<hipEvent_t> ev;   // pairs
-    std::vector<uint8_t> ev_kind; // per pair: 0 = a product launch, 1 = the vector update of the single-sync recurrence
+    // per pair: kind 0 = a product launch, 1 = the vector update of the single-sync recurrence; the bytes it is priced with; the
+    // iteration of the PCG solve it belongs to (-1: not inside a solve's loop).  Launches queued behind the iteration that
+    // converged are no-ops (every kernel returns on the done flag): their samples are dropped when the solve knows how far it
+    // got (prof_commit), instead of entering the averages with full bytes and no time.
+    struct ProfRec { uint8_t kind; int iter; double bytes, own, seconds; };
+    std::vector<ProfRec> ev_rec;
+    std::vector<ProfRec> prof_pend;   // measured, waiting for their solve's verdict
+    int prof_iter = -1;               // iteration whose launches are being queued (set by the PCG loops)
+    int64_t prof_dropped = 0;
     size_t ev_used = 0;
     int64_t prof_upd_launches = 0, prof_upd_seen = 0;   // k_pcg1_update, timed like the products (one launch in four)
     double prof_upd_seconds = 0.0, prof_upd_bytes = 0.0;
@@ -235,6 +255,7 @@ int ensure_mask(Ctx *c, int64_t n);
 int pcg_flag_snapshots(Ctx *c);                      // pgd_ctx.hip: the pinned flag buffers and their events exist
 int ensure_ibuf(Ctx *c, int64_t n);
 void prof_flush(Ctx *c);
+void prof_commit(Ctx *c, int valid_products, int valid_updates);   // end of a solve: samples of iterations that ran are kept
 void comm_release(Ctx *c);          // pgd_comm.hip
 struct Mesh;
 struct Csr;

@@ -882,8 +882,14 @@ __global__ __launch_bounds__(TPB) void k_pcg1_step(double *__restrict__ x, doubl
                                                    const double *__restrict__ prod, int nprod, const double *__restrict__ vec_in, int nvec,
                                                    double *__restrict__ vec_out, double *__restrict__ slots, int *__restrict__ flags,
                                                    int par, int lag) {
-    if (flags[0]) return;
+    // The exit on the done flag must be WORKGROUP-UNIFORM: workgroup 0 of this very launch sets the flag when the stop test fires,
+    // and the waves of a workgroup that starts late could otherwise read different values - one leaves, the others go on into
+    // pcg1_wg_scalars with that wave's LDS entries never written, and update x / r / p of the converged solve with garbage.
     __shared__ double s_red[16];
+    __shared__ int s_done;
+    if (threadIdx.x == 0) s_done = flags[0];
+    __syncthreads();
+    if (s_done) return;
     typedef double d2 __attribute__((ext_vector_type(2)));
     const Pcg1Scalars S = pcg1_wg_scalars(prod, nprod, vec_in, nvec, slots, slots[S1F_EXACT + (par ^ 1)] != 0.0, s_red);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -1246,7 +1252,7 @@ int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const 
     const bool timed_u = c->prof && ((c->prof_upd_seen++ % 3) == 0);      // launch timing, as in pgd_pcg_solve
     if (timed_u) {
         if (c->ev_used + 2 > c->ev.size()) prof_flush(c);
-        c->ev_kind[c->ev_used / 2] = 1;
+        c->ev_rec[c->ev_used / 2] = Ctx::ProfRec{1, c->prof_iter, 0.0, 0.0, 0.0};
         PGD_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
     }
     if (fold_par >= 0) {
@@ -1256,10 +1262,9 @@ int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const 
     else k_pcg1_update<false, false><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, lag, 0, 0);
     if (timed_u) {
         PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
-        c->ev_used += 2;
-        c->prof_upd_launches += 1;
         // (outside the exact phase - all but the last few dozen iterations - the kernel does not read s; the host cannot see the flag)
-        c->prof_upd_bytes += ((lag == 1 ? 40.0 : 56.0) + (c->pcg_exact_phase ? 0.0 : 8.0)) * (double)(hi - lo);
+        c->ev_rec[c->ev_used / 2].bytes = ((lag == 1 ? 40.0 : 56.0) + (c->pcg_exact_phase ? 0.0 : 8.0)) * (double)(hi - lo);
+        c->ev_used += 2;
     }
     PGD_LAUNCH_CHECK(c);
     *nblocks = g;
@@ -1393,6 +1398,8 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     if (!o || !m || !b || !x || b->n != m->nv || x->n != m->nv || b == x || maxit < 0)
         return fail(c, PGD_ERR_INVALID, "pcg_solve: invalid handles or size mismatch");
     const int64_t n = m->nv;
+    struct ProfIterGuard { Ctx *c; ~ProfIterGuard() { c->prof_iter = -1; } } prof_iter_guard{c};
+    c->prof_pend.clear();
     PGD_TRY(csr_diag_inv(c, m, o));
     bool sym = false;
     PGD_TRY(ensure_sym(c, m, o, &sym));       // SPD solve: read every off-diagonal value once per product
@@ -1465,6 +1472,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         for (int k = 0; k < count; ++k) {
             const int out = S_PAIR + 2 * ((start + k) & 1), rz_old = S_PAIR + 2 * ((start + k + 1) & 1);
             int nparts = 0;
+            c->prof_iter = start + k;                    // launch timing: which iteration a sample belongs to (prof_commit)
             if (single_sync) {
                 c->spmv_qq = 1;
                 const int rc = launch_spmv_op(c, m, o, p, q, p, 0, n, true, true, c->flags, &nparts);
@@ -1483,7 +1491,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
                 const bool timed_u = c->prof && ((c->prof_upd_seen++ % 3) == 0);        // one in three: both halves of the x-update pairs get sampled
                 if (timed_u) {
                     if (c->ev_used + 2 > c->ev.size()) prof_flush(c);
-                    c->ev_kind[c->ev_used / 2] = 1;
+                    c->ev_rec[c->ev_used / 2] = Ctx::ProfRec{1, c->prof_iter, 0.0, 0.0, 0.0};
                     PGD_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
                 }
                 // the x update lags behind by one iteration in every other one (chunks start at even iteration indices)
@@ -1496,9 +1504,8 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
                 else k_pcg1_update<false, false><<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags, lag, 0, 0);
                 if (timed_u) {
                     PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+                    c->ev_rec[c->ev_used / 2].bytes = (lag == 1 ? 40.0 : 56.0) * (double)n;      // (a lag = 1 launch that meets beta < 0.01 moves 56)
                     c->ev_used += 2;
-                    c->prof_upd_launches += 1;
-                    c->prof_upd_bytes += (lag == 1 ? 40.0 : 56.0) * (double)n;      // (a lag = 1 launch that meets beta < 0.01 moves 56)
                 }
                 PGD_LAUNCH_CHECK(c);
                 continue;
@@ -1606,6 +1613,11 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         }
     }
     if (gexec) (void)hipGraphExecDestroy(gexec);
+    c->prof_iter = -1;
+    // launch timing: the product of iteration k ran if no earlier iteration had set the done flag - f[1] iterations were counted, and in
+    // the single-sync form the product of the iteration that NOTICED convergence ran as well; its update, and everything queued
+    // behind it, did nothing
+    if (c->prof) prof_commit(c, rc_loop == PGD_OK ? f[1] + (single_sync ? 1 : 0) : 0, rc_loop == PGD_OK ? f[1] : 0);
     if (rc_loop != PGD_OK) return rc_loop;
     if (scaled) {      // x = D^-1/2 x~, and the true r.r of the last iterate for the report
         const int g = grid_for(n);

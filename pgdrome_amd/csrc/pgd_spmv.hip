@@ -299,7 +299,7 @@ static int prof_begin(Ctx *c, bool dot, bool store, bool *timed) {
     *timed = candidate && ((c->prof_seen++ & 3) == 0);
     if (*timed) {
         if (c->ev_used + 2 > c->ev.size()) prof_flush(c);
-        c->ev_kind[c->ev_used / 2] = 0;
+        c->ev_rec[c->ev_used / 2] = Ctx::ProfRec{0, c->prof_iter, 0.0, 0.0, 0.0};
         PGD_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
     }
     return PGD_OK;
@@ -309,12 +309,12 @@ static int prof_begin(Ctx *c, bool dot, bool store, bool *timed) {
 // stored entry) of a CSR form, plus row pointer / pattern id, x and y per row
 static int prof_end(Ctx *c, const Mesh *m, int64_t nrows, double own_per_row) {
     PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
+    Ctx::ProfRec &rec = c->ev_rec[c->ev_used / 2];
     c->ev_used += 2;
-    c->prof_launches += 1;
     const double frac = m->nv > 0 ? (double)nrows / (double)m->nv : 0.0;
-    c->prof_bytes += 12.0 * (double)m->nnz * frac + 20.0 * (double)nrows;
-    c->prof_own_bytes += own_per_row > 0 ? own_per_row * (double)nrows
-                                         : -own_per_row * (double)m->nnz * frac + (own_per_row < -10.0 ? 20.0 : 22.0) * (double)nrows;
+    rec.bytes = 12.0 * (double)m->nnz * frac + 20.0 * (double)nrows;
+    rec.own = own_per_row > 0 ? own_per_row * (double)nrows
+                              : -own_per_row * (double)m->nnz * frac + (own_per_row < -10.0 ? 20.0 : 22.0) * (double)nrows;
     return PGD_OK;
 }
 
@@ -1812,6 +1812,8 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_UNIT_DIAG && value >= 0 && value <= 1) { c->spmv_unit_diag = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_DEFER_X && value >= 0 && value <= 1) { c->pcg_defer_x = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_FAULT_ITERATION && value >= -1 && value <= (1 << 30)) { c->fault_iteration = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_FAULT_STAGE && value >= 0 && value <= 4) { c->fault_stage = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_FAULT_STALL_MS && value >= 0 && value <= 20000) { c->fault_stall_ms = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_COMBINE_DIA && value >= 0 && value <= 1) { c->spmv_combine_dia = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_VARIANT && value >= 0 && value <= 2) { c->spmv_variant = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ROW_CLASSES && value >= 0 && value <= 1) { c->spmv_classes = (int)value; return PGD_OK; }

@@ -298,12 +298,31 @@ class TorchComm:
         self.halo_exchange(mesh, x)
         return iters, (np.sqrt(rr / bb) if bb > 0 else 0.0)
 
+    def _stuck(self, err):
+        """The library's deadline expired inside a sharded solve (PGD_ERR_TIMEOUT): a neighbour died or a collective was
+        never matched.  This rank's stream is stuck behind that collective for good - tearing the process group down would
+        block on it as well - so the PROCESS ends here, non-zero, with the library's one-line diagnosis (rank, iteration, last
+        collective issued) on stderr.  PGD_COMM_TIMEOUT_ACTION=raise hands the error to the caller instead (tests)."""
+        import sys
+        sys.stderr.write("[pgdrome_amd.dist] rank %d/%d: %s\n[pgdrome_amd.dist] collectives so far: %r; exiting with status 3\n"
+                         % (self.rank, self.world, err, self.stats))
+        sys.stderr.flush()
+        if os.environ.get("PGD_COMM_TIMEOUT_ACTION", "exit") == "raise":
+            raise err
+        os._exit(3)
+
     def pcg(self, mesh, op, b, x, rtol, atol, maxit):
         if self.in_library:
             part = mesh.part
             self._check_stream()
-            iters, rel = self.be.pcg_solve_sharded(op, b.dev(), x.dev(), part.own0, part.own1, part.lo_ghost,
-                                                   part.hi_ghost, rtol, atol, maxit)
+            try:
+                iters, rel = self.be.pcg_solve_sharded(op, b.dev(), x.dev(), part.own0, part.own1, part.lo_ghost,
+                                                       part.hi_ghost, rtol, atol, maxit)
+            except Exception as e:      # noqa: BLE001 - only the deadline is handled here
+                if getattr(e, "code", 0) == -7:
+                    self._stuck(e)
+                raise
+            self.stats["sharded_solves"] = self.stats.get("sharded_solves", 0) + 1
             x.touched_dev()
             x._host_ok = False
             x._halo_version = x.version      # the library returned x with current ghost planes

@@ -8,6 +8,8 @@ import numpy as np
 import pytest
 import torch.multiprocessing as mp
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def _free_port():
     with socket.socket() as s:
@@ -139,3 +141,19 @@ def test_slab_ranges_cover_all_planes():
         assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
     with pytest.raises(ValueError):
         slab_ranges(3, 4)
+
+
+def test_the_deadline_ends_the_process_with_a_diagnosis():
+    """dist.TorchComm._stuck (what a PGD_ERR_TIMEOUT of the in-library sharded solve leads to): one line on stderr, exit status 3 -
+    a fresh exit of the process, nothing is re-executed."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from pgdrome_amd import dist\n"
+            "c = dist.TorchComm.__new__(dist.TorchComm); c.rank, c.world, c.stats = 1, 2, {'halo': 5, 'allreduce': 7}\n"
+            "e = RuntimeError('libpgd_amd error -7: pcg_solve_sharded: rank 1/2: no progress for 60.0 s'); e.code = -7\n"
+            "c._stuck(e)\n"
+            "print('not reached')\n") % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 3
+    assert "no progress" in r.stderr and "rank 1/2" in r.stderr and "not reached" not in r.stdout

@@ -251,14 +251,84 @@ def test_sharded_solve_on_slabs_of_the_bench_plane():
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
 
 
+FAULT_CASES = (("iteration 7", 15, 7), ("stage 1", 33, 1), ("stage 2", 33, 2), ("stage 3", 33, 3), ("stage 4", 33, 4))
+
+
 def _faulty_worker(rank, world, port, shape, q):
-    """Rank 1 fails (rank-locally, injected) in iteration 7 of its first sharded solve."""
+    """Rank 1 fails rank-locally (injected) at one point of a sharded solve after the other: inside the loop, right after the
+    setup vote, between the setup's halo exchanges, between the setup all-reduce and the loop, after the loop.  Then one
+    solve without a fault: the contexts are still good."""
+    import time
     import torch
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    msg = "no error"
+    out = []
+    try:
+        from pgdrome_amd import dist as pdist, fem, problems
+        from pgdrome_amd.hip_backend import HipBackend
+        from pgdrome_amd.solver import PGDProblem
+        torch.cuda.set_device(0)
+        tstream = torch.cuda.Stream(device=0)
+        torch.cuda.set_stream(tstream)
+        be = fem.set_backend(HipBackend(0, tstream.cuda_stream))
+        comm = pdist.TorchComm(dist, be, in_library=True)
+        be.comm_timeout(120.0)
+        P = fem.Point
+        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+        for name, knob, value in FAULT_CASES + (("none", 0, 0),):
+            p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=2))
+            if rank == 1 and knob:
+                be.ctx.tune(knob, value)
+            t0 = time.time()
+            try:
+                p.solve_PGD(_problem="linear")
+                msg = "no error"
+            except Exception as e:      # noqa: BLE001 - the point of the test
+                msg = "%s: %s" % (type(e).__name__, e)
+            out.append((name, msg, time.time() - t0, getattr(p, "PGD_modes", None)))
+            dist.barrier()
+    finally:
+        q.put((rank, out))
+        dist.destroy_process_group()
+
+
+def test_a_rank_failing_anywhere_in_a_solve_takes_the_others_out_with_an_error():
+    """A rank-local failure at ANY point of the in-library sharded solve after its setup vote must end the solve on EVERY rank
+    with an error, promptly: the failing rank keeps issuing the protocol's collectives (NaN payloads) and votes at the next
+    agreement - before the first chunk, after every chunk, at the end - where all ranks leave together (PGD_ERR_PEER on the
+    healthy ones), instead of leaving its neighbours blocked in a halo exchange or an all-reduce."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_faulty_worker, args=(r, 2, port, (16, 12, 21), q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    got = dict(q.get(timeout=400) for _ in range(2))
+    for pr in procs:
+        pr.join(timeout=60)
+        assert pr.exitcode == 0
+    assert len(got[0]) == len(got[1]) == len(FAULT_CASES) + 1
+    for (name, m0, t0, _), (_, m1, t1, _) in zip(got[0][:-1], got[1][:-1]):
+        assert "injected fault" in m1, (name, m1)
+        assert "another rank failed" in m0 and "error -8" in m0, (name, m0)
+        assert t0 < 60 and t1 < 60, (name, t0, t1)
+    assert got[0][-1][1] == got[1][-1][1] == "no error" and got[0][-1][3] == 2
+
+
+def _stalled_worker(port, q):
+    """One rank whose stream stops making progress in front of the first chunk (a kernel that spins for 4 s): the library's
+    deadline (1 s here) must end the solve with PGD_ERR_TIMEOUT and a one-line diagnosis."""
+    import time
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["PGD_COMM_TIMEOUT_ACTION"] = "raise"      # (the default, os._exit(3), is covered on the CPU: tests/test_dist_cpu.py)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    msg, dt = "no error", 0.0
     try:
         from pgdrome_amd import dist as pdist, fem, problems
         from pgdrome_amd.hip_backend import HipBackend
@@ -269,33 +339,30 @@ def _faulty_worker(rank, world, port, shape, q):
         be = fem.set_backend(HipBackend(0, tstream.cuda_stream))
         comm = pdist.TorchComm(dist, be, in_library=True)
         P = fem.Point
-        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
-        p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=2))
-        if rank == 1:
-            be.ctx.tune(15, 7)
+        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), 16, 12, 21)
+        p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=1))
+        be.comm_timeout(1.0)
+        be.ctx.tune(34, 4000)
+        t0 = time.time()
         try:
             p.solve_PGD(_problem="linear")
-        except Exception as e:      # noqa: BLE001 - the point of the test
-            msg = "%s: %s" % (type(e).__name__, e)
+        except Exception as e:      # noqa: BLE001
+            msg = "%s: %s (code %s)" % (type(e).__name__, e, getattr(e, "code", None))
+        dt = time.time() - t0
+        torch.cuda.synchronize()          # the bounded stall drains before the process ends
     finally:
-        q.put((rank, msg))
+        q.put((msg, dt))
         dist.destroy_process_group()
 
 
-def test_a_rank_failing_in_mid_solve_takes_the_others_out_with_an_error():
-    """A rank-local failure inside the in-library sharded loop must end the solve on EVERY rank with an error - the
-    failing rank keeps issuing the chunk's collectives with NaN partial sums, so the others' convergence test trips -
-    instead of leaving them blocked in a halo exchange or an all-reduce."""
+def test_a_stream_without_progress_runs_into_the_deadline():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_faulty_worker, args=(r, 2, port, (16, 12, 21), q)) for r in range(2)]
-    for pr in procs:
-        pr.start()
-    got = dict(q.get(timeout=240) for _ in range(2))
-    for pr in procs:
-        pr.join(timeout=60)
-        assert pr.exitcode == 0
-    assert "injected fault" in got[1]
-    assert "breakdown" in got[0] or "NaN" in got[0]
+    pr = ctx.Process(target=_stalled_worker, args=(_free_port(), q))
+    pr.start()
+    msg, dt = q.get(timeout=300)
+    pr.join(timeout=60)
+    assert pr.exitcode == 0
+    assert "code -7" in msg and "no progress" in msg and "rank 0/1" in msg and "last collective issued" in msg, msg
+    assert 0.9 < dt < 30, dt

@@ -529,6 +529,15 @@ def test_products_agree_at_bench_size(ctx, npts):
         # ... and the march on the row-class dictionary (one code byte per row), several chunk lengths
         assert 1 <= ctx.op_classify(op) <= 64
         ctx.tune(6, 8)
+        # (a) the launch shape the solves take by DEFAULT: as many planes per march as fill every resident workgroup slot exactly
+        # once (PGD_TUNE_SPMV_ZCHUNK_CODED2 = 96: 256^3 -> 4 marches of 66 planes, 128^3 -> marches of 9) ...
+        c0 = ctx.kernel_counts()
+        ctx.vec_fill(yv, -1.0)
+        ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
+        assert ctx.kernel_counts()["diac_march"] == c0["diac_march"] + 1
+        ys["diac_march_default_rule"] = (ctx.vec_download(yv), ctx.slots_download(30, 1)[0])
+        # (b) ... and, with that rule OFF (it would override knob 21 at these sizes), marches of at most 24 / 12 / 5 planes
+        ctx.tune(32, 0)
         for zc in (24, 12, 5):                        # most planes per march (whole threes: 5 -> 3)
             ctx.tune(21, zc)
             c0 = ctx.kernel_counts()
@@ -541,8 +550,11 @@ def test_products_agree_at_bench_size(ctx, npts):
         ctx.tune(2, 1)
         ctx.tune(6, 8)
         ctx.tune(21, 24)
+        ctx.tune(32, 96)
     base = ys["csr"][0]
-    for name in ("csr_dict", "dia_march", "dia_rows", "diac_march_24", "diac_march_12", "diac_march_5"):
+    # (the dot's partial sums are grouped per workgroup: different march lengths give different last bits of the DOT, never of y)
+    assert len({ys["diac_march_%d" % zc][1] for zc in (24, 12, 5)} | {ys["diac_march_default_rule"][1]}) >= 2
+    for name in ("csr_dict", "dia_march", "dia_rows", "diac_march_default_rule", "diac_march_24", "diac_march_12", "diac_march_5"):
         assert np.array_equal(ys[name][0], base), (name, np.abs(ys[name][0] - base).max())
         assert abs(ys[name][1] - ys["csr"][1]) <= 1e-12 * np.abs(x) @ np.abs(base)
     assert np.all(base[bc] == x[bc])                                   # Dirichlet rows are identity rows

@@ -377,3 +377,82 @@ def test_reference_solver_problem_integration_case_vector_p2_on_gpu():
     mesh, ds loads) through the HIP engine: blocked layout, embedded atoms, Jacobi-PCG on the elasticity systems."""
     from tests import ref_cases
     ref_cases.check_solver_problem(fem, PGDProblem, "linear", exact_counts=False)
+
+
+def test_result_files_of_a_gpu_run_round_trip(hip_backend, tmp_path):
+    """SURVEY 8 f3 on the HIP path (reference: model.py:162-397 write_hdf5 / write_pxdmf, :399-575 load_pxdmf; its own round trip
+    tests/unit/test_pgdclass_dolfin.py:75-121): cfg4_small solved on the MI355X -> return_PGD() -> write_pxdmf + write_hdf5 ->
+    load_pxdmf: the stored datasets ARE the modes' vertex values, bit for bit, and the online evaluation of the reloaded
+    solution equals the in-memory one."""
+    import os
+    from pgdrome_amd import h5lite
+    from pgdrome_amd.model import PGD
+    run = [r for r in RUNS if r["case"] == "cfg4_small"][0]
+    p = pgd_cases.run_case(run)
+    assert hip_backend.name == "hip" and p.PGD_modes == run["PGD_modes"]
+    sol = p.return_PGD()
+    folder = str(tmp_path)
+    sol.write_pxdmf(folder, False)
+    sol.write_hdf5(folder)
+    files = set(os.listdir(folder))
+    assert {sol.name + ".pxdmf", "PGD1.xdmf", "PGD1.h5", "PGD1_data.h5", "PGD2.h5", "PGD2_data.h5"} <= files, files
+    back = PGD().load_pxdmf(os.path.join(folder, sol.name + ".pxdmf"))
+    assert back.num_pgd_var == 2 and back.numModes == p.PGD_modes
+    assert [m.numNodes for m in back.mesh] == [125, 9]
+    for d in range(2):
+        att = back.mesh[d].attributes[0]
+        for m in range(p.PGD_modes):
+            want = p.PGD_func[d][m].compute_vertex_values()
+            assert np.array_equal(att.data[m].reshape(-1), want), (d, m)          # the datasets, bit for bit
+        # ... and the dof vectors dolfin-style HDF5File wrote for every mode (<grid>_data.h5)
+        with h5lite.File(os.path.join(folder, "PGD%d_data.h5" % (d + 1)), "r") as hf:
+            for m in range(p.PGD_modes):
+                stored = np.array(hf["MODE_%d/vector_0" % m]).reshape(-1)
+                assert np.array_equal(np.sort(stored), np.sort(p.PGD_func[d][m].vector().host())), (d, m)
+        back.mesh[d].attributes[0].interpolationInfo = {"name": 1, "family": "P", "degree": 1, "_type": "scalar"}
+    for mu in (1.0, 4.2, 9.5):
+        a = sol.evaluate(0, [1], [mu], 0).compute_vertex_values()
+        b = back.evaluate(0, [1], [mu], 0).compute_vertex_values()
+        assert np.linalg.norm(a - b) <= 1e-14 * np.linalg.norm(a), mu
+    # the reloaded solution against the fixture of the reference's own run: the separated sum at mu = 4.2
+    c = sol.mode_factors([1], [4.2], 0)
+    ref = sum(c[k] * np.array(run["modes_vertex_values"][0][k]) for k in range(p.PGD_modes))
+    got = back.evaluate(0, [1], [4.2], 0).compute_vertex_values()
+    assert np.linalg.norm(got - ref) <= 1e-6 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("case", ["cfg4_small", "cfg3_small"])
+def test_randomized_start_on_gpu_equals_oracle(hip_backend, case, monkeypatch):
+    """fp_init = "randomized" (solver.py:193-197: the free entries of the start functions drawn with np.random.rand, unseeded
+    in the reference): with the generator patched to a seeded one the HIP run and the oracle-backend run draw the same start
+    vectors and must agree - pass counts exactly, modes to 1e-6."""
+    from oracle.backend_numpy import NumpyBackend
+    run = dict([r for r in RUNS if r["case"] == case][0])
+    run["knobs"] = dict(run["knobs"], fp_init="randomized")
+    draws = []
+
+    def go(backend):
+        fem.set_backend(backend)
+        fem.clear_caches()
+        rng = np.random.default_rng(20261004)
+
+        def rand(*shape):
+            out = rng.random(shape if shape else None)
+            draws.append(np.array(out, copy=True))
+            return out
+        monkeypatch.setattr(np.random, "rand", rand)
+        p = pgd_cases.run_case(run)
+        return p, [[f.compute_vertex_values() for f in p.PGD_func[d]] for d in range(p.num_pgd_var)]
+    try:
+        pg, mg = go(hip_backend)
+        ng = len(draws)
+        po, mo = go(NumpyBackend())
+    finally:
+        fem.set_backend(hip_backend)
+        fem.clear_caches()
+    assert ng > 0 and len(draws) == 2 * ng and all(np.array_equal(a, b) for a, b in zip(draws[:ng], draws[ng:]))
+    assert pg.PGD_modes == po.PGD_modes and [int(v) for v in pg.num_fp_it] == [int(v) for v in po.num_fp_it]
+    np.testing.assert_allclose(pg.amplitude, po.amplitude, rtol=1e-7)
+    for d in range(pg.num_pgd_var):
+        for m in range(pg.PGD_modes):
+            assert np.linalg.norm(mg[d][m] - mo[d][m]) <= 1e-6 * np.linalg.norm(mo[d][m]), (d, m)
