@@ -57,6 +57,12 @@ def parse():
     ap.add_argument("--defer-x", type=int, default=-1, help="PGD_TUNE_PCG_DEFER_X for A/B runs (-1: library default)")
     ap.add_argument("--no-pmc", action="store_true", help="do not start rocprofv3 --pmc child processes for roofline.traffic")
     ap.add_argument("--no-csr-section", action="store_true", help="skip the timed CSR products (roofline.csr_product)")
+    ap.add_argument("--no-general-paths", action="store_true",
+                    help="skip the passes without the row-class dictionary / on the CSR kernels (config.general_paths)")
+    ap.add_argument("--comm-timeout", type=float, default=float(os.environ.get("PGD_COMM_TIMEOUT_S", "60")),
+                    help="N > 1: deadline (s) of every host-side wait of the sharded solve and of torch.distributed's collectives")
+    ap.add_argument("--watchdog-seconds", type=float, default=1500.0,
+                    help="N > 1: the whole process exits non-zero with all Python stacks on stderr after this long (0: off)")
     return ap.parse_args()
 
 
@@ -80,9 +86,17 @@ def main():
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.dist_driver
     if sharded:
+        import datetime
+        import faulthandler
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        os.environ["PGD_COMM_TIMEOUT_S"] = repr(args.comm_timeout)       # read by the library when it binds its communicator
+        if args.watchdog_seconds > 0:
+            # nothing of a multi-process run may hang silently: a rendezvous or a bind that never returns ends HERE, with every
+            # thread's Python stack on stderr and a non-zero status (a fresh exit of this process; nothing is re-executed)
+            faulthandler.dump_traceback_later(args.watchdog_seconds, exit=True)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                timeout=datetime.timedelta(seconds=max(4.0 * args.comm_timeout, 120.0)))
 
     from pgdrome_amd import fem, problems
     from pgdrome_amd.hip_backend import HipBackend
@@ -141,6 +155,8 @@ def main():
         if passes == W:
             barrier()
             be.prof_enable(2)        # HIP events on the PCG instance of the product (fused dot, y stored) only
+            if sharded:
+                be.comm_prof(1)      # phase timing of the sharded loop: one iteration per chunk between HIP events
             kc0 = be.ctx.kernel_counts()
             state["its0"] = fem.STATS["pcg_iterations"]
             state["pcg0"] = fem.STATS["pcg_seconds"]
@@ -168,6 +184,22 @@ def main():
     prof = be.prof_read()
     be.prof_enable(False)
     elapsed = state["t1"] - state["t0"]
+    comm_phases = None
+    if sharded:
+        ph = be.comm_prof(0)
+        ns = max(ph.pop("samples"), 1.0)
+        host_wait = ph.pop("host_boundary_wait")
+        mine = [1e6 * ph[k] / ns for k in sorted(ph)] + [1e6 * host_wait / max(state["its1"] - state["its0"], 1), ns]
+        rows = [None] * world
+        if world > 1:
+            dist.all_gather_object(rows, mine)
+        else:
+            rows = [mine]
+        names = ["%s_us" % k for k in sorted(ph)] + ["host_wait_at_chunk_boundaries_us_per_iteration", "samples"]
+        comm_phases = {nm: {"max": max(r[i] for r in rows), "min": min(r[i] for r in rows)} for i, nm in enumerate(names)}
+        comm_phases["note"] = ("per rank: HIP events around the phases of ONE iteration per chunk of 16 (compute stream); halo_wait = the "
+                               "compute stream waiting for the ghost planes AFTER the interior rows' product (exposed halo time), allreduce "
+                               "includes waiting for the slowest rank; max / min over the ranks")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -227,6 +259,10 @@ def main():
                                                   {"product": 1e6 * avg, "vector_kernels_reductions_and_solve_setup": it_us - 1e6 * avg}),
                    "seconds_in_pcg_solves": pcg_seconds, "seconds_timed": elapsed,
                    "product_launches_by_kernel": kc,
+                   "launch_timing_samples_dropped_as_noops": prof.get("dropped_noop_samples"),
+                   "sharded_iteration_phases": comm_phases,
+                   "comm_timeout_s": (args.comm_timeout if sharded else None),
+                   "allreduces_outside_the_pcg_loop": (comm.stats.get("allreduce") if sharded else None),
                    "setup_seconds_untimed": t_setup},
         "roofline": {"bound": "hbm", "kernel": kernel_names[ran],
                      # PHYSICAL pricing: the bytes this kernel must move in the storage form it reads (diagonal form:
@@ -243,6 +279,10 @@ def main():
     }
     if rank == 0 and world == 1 and not args.no_csr_section:
         out["roofline"]["csr_product"] = csr_section(be, prob, n_sp, nnz)
+    general = None
+    if rank == 0 and world == 1 and not sharded and not args.no_general_paths and ran == "diac_march":
+        general = general_paths(be, spec, settings)
+        out["config"]["general_paths"] = general
     pmc = pmc_traffic(own, upd_bytes) if rank == 0 and world == 1 and n == 256 and sym["nx"] and not args.no_pmc else {}
     out["roofline"].update(pmc.get("product", {}))
     if upd_n and upd_avg > avg:
@@ -257,13 +297,19 @@ def main():
                            "launches": upd_n, "avg_launch_us": 1e6 * upd_avg, "bytes_per_launch": upd_bytes,
                            "bytes_per_row": upd_bytes / max(rows_local, 1),
                            "measured_copy_ceiling_GBps": 6290.0, "frac_of_measured_copy_ceiling": upd_achieved / 6290.0,
-                           "share_of_pcg_iteration": 1e6 * upd_avg / it_us if it_us > 0 else None}
+                           "share_of_pcg_iteration": 1e6 * upd_avg / it_us if it_us > 0 else None,
+                           "note": "of this kernel's streams p (134 MB at 256^3; written here, read by the product, read here again) is "
+                                   "served by the 256 MiB Infinity Cache, and FETCH_SIZE / WRITE_SIZE count those hits: `achieved` is a rate "
+                                   "relative to the HBM peak, not bytes that all came from HBM - it may exceed the chip's measured copy "
+                                   "ceiling (measured_copy_ceiling_GBps)"}
         out["roofline"].update(pmc.get("update", {}))
         spmv["share_of_pcg_iteration"] = 1e6 * avg / it_us if it_us > 0 else None
         if ran == "diac_march":
-            # the same product in the plain diagonal form streams 72 B per row (k_spmv_dia_march2, r02u: 262-275 us at 256^3)
+            # the same product in the plain diagonal form streams 72 B per row (k_spmv_dia_march2): timed in THIS run by
+            # config.general_paths.plain_march (a variable coefficient or a graded mesh takes that path)
             spmv["plain_diagonal_form_bytes_per_row"] = 72.0
-            spmv["speedup_over_plain_diagonal_form_r02u"] = 268.0e-6 / avg if avg > 0 else None
+            pm = (general or {}).get("plain_march", {}).get("product_us")
+            spmv["speedup_over_plain_diagonal_form_this_run"] = (1e-6 * pm / avg) if pm and avg > 0 else None
         out["roofline"]["spmv"] = spmv
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(prob, spec, be, pcg_its / K, args)
@@ -312,6 +358,59 @@ def csr_section(be, prob, n_sp, nnz):
         be.atom_free(op)
     res["note"] = ("frac of k_spmv_csr is physical (it streams values, column ids, row pointers, x, y = the 8d formula); the dictionary "
                    "form reads no column ids, so its physical fraction is kernel_min_bytes_frac")
+    return res
+
+
+def general_paths(be, spec, settings, passes=4, warm=1):
+    """The engine WITHOUT what the headline leans on, in the same run on the same workload: (1) `plain_march` - no row-class
+    dictionary (PGD_TUNE_SPMV_ROW_CLASSES = 0): the product streams the 72 B per row of the scaled diagonal form, which is what
+    any variable coefficient or graded mesh gets; (2) `csr` - no symmetric storage at all (PGD_TUNE_SPMV_SYM = 0): the north
+    star's CSR SpMV (k_spmv_csr_dict16) inside textbook Jacobi-PCG, what a mesh without grid structure gets.  `passes` timed
+    passes of solve_PGD each after `warm` untimed ones; products timed with HIP events like the headline's."""
+    import time
+    from pgdrome_amd import fem
+    from pgdrome_amd.solver import PGDProblem
+    res = {}
+    for name, knob, reset in (("plain_march", (19, 0), (19, 1)), ("csr", (3, 0), (3, 1))):
+        be.ctx.tune(*knob)
+        try:
+            prob = PGDProblem(**spec)
+            st = {}
+
+            def hook(n_pass, st=st):
+                if n_pass == warm:
+                    be.sync()
+                    be.prof_enable(2)
+                    st["k0"] = be.ctx.kernel_counts()
+                    st["i0"], st["s0"], st["t0"] = fem.STATS["pcg_iterations"], fem.STATS["pcg_seconds"], time.perf_counter()
+                elif n_pass == warm + passes:
+                    be.sync()
+                    st["t1"] = time.perf_counter()
+                    st["i1"], st["s1"] = fem.STATS["pcg_iterations"], fem.STATS["pcg_seconds"]
+                    st["k1"] = be.ctx.kernel_counts()
+                    raise _Done()
+            prob.pass_hook = hook
+            try:
+                for _ in range(100):
+                    prob.solve_PGD(_problem="linear", settings=settings)
+            except _Done:
+                pass
+            p = be.prof_read()
+            be.prof_enable(False)
+            its = max(st["i1"] - st["i0"], 1)
+            kc = {k: st["k1"][k] - st["k0"][k] for k in st["k1"]}
+            t = p["seconds"] / max(p["launches"], 1)
+            own = p["own_bytes"] / max(p["launches"], 1)
+            res[name] = {"passes_per_s": passes / (st["t1"] - st["t0"]), "passes": passes,
+                         "us_per_pcg_iteration": 1e6 * (st["s1"] - st["s0"]) / its, "pcg_iterations_per_pass": its / passes,
+                         "product_us": 1e6 * t, "product_kernel": max(kc, key=lambda k: kc[k]),
+                         "product_bytes_per_launch": own, "product_frac_of_peak": own / t / 8e12 if t > 0 else None,
+                         "knob": "pgd_tune(%d, %d)" % knob}
+        finally:
+            be.ctx.tune(*reset)
+            be.prof_enable(False)
+    res["note"] = ("same workload, same run, after the timed region: the headline's 17 B/row product needs a uniform lattice with constant "
+                   "coefficients; plain_march is the rate without that (72 B/row), csr the rate on the CSR kernels with textbook PCG")
     return res
 
 

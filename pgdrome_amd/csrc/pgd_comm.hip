@@ -568,9 +568,11 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         PGD_TRY(wait_deadline(S, k.snap_ev[sn], what));
         for (int i = 0; i < 4; ++i) f[i] = k.snap_flags[4 * sn + i];
         const double vote = k.snap_vote[sn];
+        // (a poisoned rank leaves like everybody else: at the first agreement that CARRIES its vote.  With the loop pipelined the
+        // agreement read here may have been issued before the failure - its vote is 0 and its flags are good on every rank)
+        if (vote == 0.0) return PGD_OK;
         if (S.poisoned()) { c->err = S.err; return S.rc; }
-        if (!(vote == 0.0)) return fail(c, PGD_ERR_PEER, "pcg_solve_sharded: another rank failed locally (%s); every rank leaves the solve", what);
-        return PGD_OK;
+        return fail(c, PGD_ERR_PEER, "pcg_solve_sharded: another rank failed locally (%s); every rank leaves the solve", what);
     };
 
     // w = A u on the owned rows, S[B + 2] (+ S[B + 3], S[B + 4]) <- local w.u: the rows that read no ghost entry first,

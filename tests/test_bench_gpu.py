@@ -37,3 +37,29 @@ def test_bench_line_contract():
     assert csr["k_spmv_csr<dot,store,64>"]["launches_timed"] >= 100 and 0 < csr["k_spmv_csr<dot,store,64>"]["frac"] <= 1.0
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == d["unit"]
+    # the engine without the row-class dictionary and on the CSR kernels, timed in the same run
+    gp = d["config"]["general_paths"]
+    assert gp["plain_march"]["product_kernel"] in ("dia_march", "dia_rows") and gp["csr"]["product_kernel"] == "csr_dict"
+    assert 0 < gp["csr"]["passes_per_s"] <= gp["plain_march"]["passes_per_s"] * 1.2 and gp["plain_march"]["product_us"] > 0
+    assert spmv["speedup_over_plain_diagonal_form_this_run"] > 1.0
+    assert isinstance(d["config"]["launch_timing_samples_dropped_as_noops"], int)
+    assert "Infinity Cache" in r.get("note", "") or "spmv" not in r
+
+
+def test_bench_line_of_the_sharded_driver_has_the_phase_timings():
+    """bench.py --dist-driver (one rank through the in-library sharded loop over RCCL): the fields a multi-GPU line carries -
+    per-rank max / min of the iteration's phases, the communicator's world size, the deadline."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--n", "104", "--steps", "3", "--warmup", "1", "--no-pmc",
+           "--no-cpu-baseline", "--dist-driver"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert c["sharded_pcg_driver"] == "in-library loop, RCCL" and c["rccl_world"] == 1 and c["comm_timeout_s"] == 60.0
+    ph = c["sharded_iteration_phases"]
+    for k in ("halo_wait_us", "allreduce_us", "product_interior_us", "product_boundary_us", "update_us", "local_sums_us"):
+        assert ph[k]["max"] >= ph[k]["min"] >= 0.0, k
+    assert ph["samples"]["min"] >= 10 and ph["product_interior_us"]["max"] > 1.0 and ph["update_us"]["max"] > 1.0
+    assert ph["allreduce_us"]["max"] > 0.0

@@ -23,6 +23,24 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def _collect(procs, q, n_results, timeout):
+    """Start the worker processes, take `n_results` items from the queue, join; whatever happens, no worker outlives the test
+    (a worker blocked in a collective would keep the test runner from exiting)."""
+    for pr in procs:
+        pr.start()
+    try:
+        out = [q.get(timeout=timeout) for _ in range(n_results)]
+        for pr in procs:
+            pr.join(timeout=120)
+            assert pr.exitcode == 0, pr.exitcode
+        return out
+    finally:
+        for pr in procs:
+            if pr.is_alive():
+                pr.kill()
+                pr.join(timeout=30)
+
+
 def test_sharded_driver_world1_matches_library_pcg():
     import torch
     import torch.distributed as dist
@@ -145,12 +163,7 @@ def test_sharded_solve_with_real_halos_on_one_gpu(world, in_library):
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, shape, q, in_library)) for r in range(world)]
-    for pr in procs:
-        pr.start()
-    out = q.get(timeout=300)
-    for pr in procs:
-        pr.join(timeout=120)
-        assert pr.exitcode == 0
+    out = _collect(procs, q, 1, 300)[0]
     assert out["num_fp_it"] == ref.num_fp_it
     np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
     for m in range(ref.PGD_modes):
@@ -189,12 +202,7 @@ def test_sharded_solve_marches_on_row_classes():
             q = ctx.Queue()
             port = _free_port()
             procs = [ctx.Process(target=_shared_gpu_worker, args=(r, 2, port, shape, q, True)) for r in range(2)]
-            for pr in procs:
-                pr.start()
-            out = outs[fold] = q.get(timeout=600)
-            for pr in procs:
-                pr.join(timeout=120)
-                assert pr.exitcode == 0
+            out = outs[fold] = _collect(procs, q, 1, 600)[0]
             assert out["kernels"]["diac_march"] > 100 and out["kernels"]["dia_rows"] > 100
             assert out["num_fp_it"] == ref.num_fp_it
             np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
@@ -238,12 +246,7 @@ def test_sharded_solve_on_slabs_of_the_bench_plane():
     port = _free_port()
     world = int(os.environ.get("PGD_TEST_SLAB_WORLD", "2"))      # (at most 5: the GPU box allows six processes on the card)
     procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, shape, q, True)) for r in range(world)]
-    for pr in procs:
-        pr.start()
-    out = q.get(timeout=600)
-    for pr in procs:
-        pr.join(timeout=120)
-        assert pr.exitcode == 0
+    out = _collect(procs, q, 1, 600)[0]
     assert out["kernels"]["diac_march"] > 100 and out["kernels"]["dia_rows"] > 100
     assert out["num_fp_it"] == ref.num_fp_it
     np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
@@ -304,12 +307,7 @@ def test_a_rank_failing_anywhere_in_a_solve_takes_the_others_out_with_an_error()
     q = ctx.Queue()
     port = _free_port()
     procs = [ctx.Process(target=_faulty_worker, args=(r, 2, port, (16, 12, 21), q)) for r in range(2)]
-    for pr in procs:
-        pr.start()
-    got = dict(q.get(timeout=400) for _ in range(2))
-    for pr in procs:
-        pr.join(timeout=60)
-        assert pr.exitcode == 0
+    got = dict(_collect(procs, q, 2, 400))
     assert len(got[0]) == len(got[1]) == len(FAULT_CASES) + 1
     for (name, m0, t0, _), (_, m1, t1, _) in zip(got[0][:-1], got[1][:-1]):
         assert "injected fault" in m1, (name, m1)
@@ -327,7 +325,10 @@ def _stalled_worker(port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["PGD_COMM_TIMEOUT_ACTION"] = "raise"      # (the default, os._exit(3), is covered on the CPU: tests/test_dist_cpu.py)
-    dist.init_process_group("gloo", rank=0, world_size=1)
+    torch.cuda.set_device(0)
+    # (RCCL binding: its collectives are queued on the stream and the host waits only at the agreements - where the deadline is;
+    # the callback binding of the other tests blocks inside gloo instead)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     msg, dt = "no error", 0.0
     try:
         from pgdrome_amd import dist as pdist, fem, problems
@@ -338,6 +339,7 @@ def _stalled_worker(port, q):
         torch.cuda.set_stream(tstream)
         be = fem.set_backend(HipBackend(0, tstream.cuda_stream))
         comm = pdist.TorchComm(dist, be, in_library=True)
+        assert comm.in_library == "rccl"
         P = fem.Point
         mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), 16, 12, 21)
         p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=1))
@@ -360,9 +362,6 @@ def test_a_stream_without_progress_runs_into_the_deadline():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     pr = ctx.Process(target=_stalled_worker, args=(_free_port(), q))
-    pr.start()
-    msg, dt = q.get(timeout=300)
-    pr.join(timeout=60)
-    assert pr.exitcode == 0
+    msg, dt = _collect([pr], q, 1, 300)[0]
     assert "code -7" in msg and "no progress" in msg and "rank 0/1" in msg and "last collective issued" in msg, msg
     assert 0.9 < dt < 30, dt
