@@ -217,8 +217,12 @@ def main():
     kc = {k: kc1[k] - kc0[k] for k in kc1}
     patterns = be.ctx.mesh_dict_count(space.handle())
     sym = be.ctx.mesh_sym_info(space.handle())
-    ran = max(("diac_march", "dia_march", "dia_rows", "sym_rows", "csr_dict", "csr"), key=lambda k: kc[k])
+    ran = max(("stencil_march", "diac_march", "dia_march", "dia_rows", "sym_rows", "csr_dict", "csr"), key=lambda k: kc[k])
     kernel_names = {
+        "stencil_march": "k_spmv_stencil_march<dot,store> (the row-class dictionary of the scaled operator reduced to ONE stencil + eliminated "
+                         "nodes, every row verified bit by bit: 8 couplings in scalar registers, a 64 x 16 patch of the %d x %d vertex grid "
+                         "marching along z, four rows per thread, x planes in LDS; the class byte is read only where a plane's codes differ "
+                         "from the plane below: 16 B per row)" % (sym["nx"], sym["ny"]),
         "diac_march": "k_spmv_diac_march2<dot,store> (symmetric half storage in diagonal form behind a lossless row-class dictionary: "
                       "one code byte per row, the classes' 8-tuples of slot values in LDS / registers; a 64 x 8 patch of the %d x %d "
                       "vertex grid marching along z, two rows per thread, x planes in LDS)" % (sym["nx"], sym["ny"]),
@@ -280,7 +284,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_csr_section:
         out["roofline"]["csr_product"] = csr_section(be, prob, n_sp, nnz)
     general = None
-    if rank == 0 and world == 1 and not sharded and not args.no_general_paths and ran == "diac_march":
+    if rank == 0 and world == 1 and not sharded and not args.no_general_paths and ran in ("diac_march", "stencil_march"):
         general = general_paths(be, spec, settings)
         out["config"]["general_paths"] = general
     pmc = pmc_traffic(own, upd_bytes) if rank == 0 and world == 1 and n == 256 and sym["nx"] and not args.no_pmc else {}
@@ -304,7 +308,7 @@ def main():
                                    "ceiling (measured_copy_ceiling_GBps)"}
         out["roofline"].update(pmc.get("update", {}))
         spmv["share_of_pcg_iteration"] = 1e6 * avg / it_us if it_us > 0 else None
-        if ran == "diac_march":
+        if ran in ("diac_march", "stencil_march"):
             # the same product in the plain diagonal form streams 72 B per row (k_spmv_dia_march2): timed in THIS run by
             # config.general_paths.plain_march (a variable coefficient or a graded mesh takes that path)
             spmv["plain_diagonal_form_bytes_per_row"] = 72.0
@@ -362,7 +366,9 @@ def csr_section(be, prob, n_sp, nnz):
 
 
 def general_paths(be, spec, settings, passes=4, warm=1):
-    """The engine WITHOUT what the headline leans on, in the same run on the same workload: (1) `plain_march` - no row-class
+    """The engine WITHOUT what the headline leans on, in the same run on the same workload: (0) `row_class_dictionary` - the
+    dictionary form of the product (PGD_TUNE_SPMV_STENCIL = 0: k_spmv_diac_march2, 17 B per row), which is what a uniform grid
+    with natural boundaries or piecewise-constant coefficients gets; (1) `plain_march` - no row-class
     dictionary (PGD_TUNE_SPMV_ROW_CLASSES = 0): the product streams the 72 B per row of the scaled diagonal form, which is what
     any variable coefficient or graded mesh gets; (2) `csr` - no symmetric storage at all (PGD_TUNE_SPMV_SYM = 0): the north
     star's CSR SpMV (k_spmv_csr_dict16) inside textbook Jacobi-PCG, what a mesh without grid structure gets.  `passes` timed
@@ -371,7 +377,7 @@ def general_paths(be, spec, settings, passes=4, warm=1):
     from pgdrome_amd import fem
     from pgdrome_amd.solver import PGDProblem
     res = {}
-    for name, knob, reset in (("plain_march", (19, 0), (19, 1)), ("csr", (3, 0), (3, 1))):
+    for name, knob, reset in (("row_class_dictionary", (35, 0), (35, 1)), ("plain_march", (19, 0), (19, 1)), ("csr", (3, 0), (3, 1))):
         be.ctx.tune(*knob)
         try:
             prob = PGDProblem(**spec)

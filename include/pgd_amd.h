@@ -298,6 +298,14 @@ int pgd_vec_multidot(pgd_handle ctx, pgd_handle x, const pgd_handle *ys, int k, 
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
+    PGD_TUNE_STENCIL_DEPTH = 38, /* plane fetches in flight per workgroup of k_spmv_stencil_march: 3, 4, 6, 8 or 10 (0, default: chosen by the launcher) */
+    PGD_TUNE_STENCIL_WG_PER_CU = 37, /* resident workgroups per CU assumed for k_spmv_stencil_march (default 2): sets the march length */
+    PGD_TUNE_SPMV_ZCHUNK_STENCIL = 36, /* > 0: planes per march of k_spmv_stencil_march; 0 (default): as many as fill every resident
+                                workgroup slot exactly once, in whole groups of the fetch depth */
+    PGD_TUNE_SPMV_STENCIL = 35, /* 1 (default): where the row classes of an operator are ONE 8-tuple plus the rows it becomes next to eliminated
+                                (Dirichlet) nodes and the rim of the grid - every row and slot verified bit by bit - the z-march takes the
+                                couplings from scalar registers, four rows per thread, and reads the code byte only where the codes of a plane
+                                differ from the plane below (k_spmv_stencil_march: 16 B per row); bit-identical y; 0: the dictionary form */
     PGD_TUNE_FAULT_STALL_MS = 34, /* tests only: the next pgd_pcg_solve_sharded queues, once, a kernel that spins for this many
                                 milliseconds (bounded: at most 20 000) in front of its first chunk - a stream that makes no progress,
                                 for the deadline of pgd_comm_timeout */
@@ -398,7 +406,7 @@ int pgd_prof_read_update(pgd_handle ctx, int64_t *launches, double *seconds, dou
  * on the done flag (full bytes, no time - they would bias the averages).  The counts above are the samples that were kept.   */
 int pgd_prof_read_dropped(pgd_handle ctx, int64_t *dropped);
 /* Launch counts per product kernel family since the context was created: [0] k_spmv_csr, [1] k_spmv_csr_dict*,
- * [2] k_spmv_sym (row order), [3] k_spmv_dia_rows, [4] k_spmv_dia_march*, [5] k_spmv_multi, [6] k_spmv_diac_march2; tests use them to
+ * [2] k_spmv_sym (row order), [3] k_spmv_dia_rows, [4] k_spmv_dia_march*, [5] k_spmv_multi, [6] k_spmv_diac_march2, [7] k_spmv_stencil_march; tests use them to
  * prove which kernel a call reached, bench.py for its per-kernel breakdown.                          */
 int pgd_kernel_counts(pgd_handle ctx, int64_t *out, int n);
 /* One HIP-event stopwatch on the context's stream (bench.py's micro-sections: N launches between start

@@ -569,7 +569,7 @@ class Context:
         return dict(launches=n.value, seconds=s.value, bytes=b.value, own_bytes=own.value,
                     update_launches=un.value, update_seconds=us.value, update_bytes=ub.value, dropped_noop_samples=dr.value)
 
-    KERNEL_FAMILIES = ("csr", "csr_dict", "sym_rows", "dia_rows", "dia_march", "multi", "diac_march")
+    KERNEL_FAMILIES = ("csr", "csr_dict", "sym_rows", "dia_rows", "dia_march", "multi", "diac_march", "stencil_march")
 
     def kernel_counts(self):
         out = (C.c_int64 * 8)()

@@ -47,7 +47,8 @@ def build(force: bool = False, verbose: bool = True) -> Path:
 
     def compile_one(src: str) -> Path:
         obj = objdir / (src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", str(CSRC / src), "-o", str(obj)]
+        # (HIPCC_EXTRA: extra flags of one-off instrumented builds, e.g. -DPGD_STENCIL_TIMING for tools/stencil_timing.py)
+        cmd = [hipcc, *FLAGS, *os.environ.get("HIPCC_EXTRA", "").split(), "-c", str(CSRC / src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)

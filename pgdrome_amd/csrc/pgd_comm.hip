@@ -630,7 +630,11 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         fault_at(2);
         if (!S.poisoned()) guard.op_scaled = true;
         SH_LOCAL(S, sym_scale(c, m, op, scp));
-        SH_LOCAL(S, dia_classify(c, m, op));                             // rank-local choice of kernel, same bits either way
+        {   // rank-local choice of kernel, same bits either way; the stencil form is verified on the OWNED planes (ghost rows are incomplete)
+            const int64_t plane = m && m->sym_nx > 0 ? (int64_t)m->sym_nx * m->sym_ny : 0;
+            const bool aligned = plane > 0 && own0 % plane == 0 && own1 % plane == 0;
+            SH_LOCAL(S, dia_classify(c, m, op, aligned ? (int)(own0 / plane) : -1, aligned ? (int)(own1 / plane) : -1));
+        }
         if (!S.poisoned()) guard.x_scaled = true;
         SH_LOCAL(S, vec_div_mul(c, xd, scp, n, 0));                      // x~ = x / sc on owned and ghost rows alike
     }

@@ -101,6 +101,11 @@ struct Csr : Obj {
     int *cls_same = nullptr;       // per plane: same codes, row by row, as the plane below
     double *cls_table = nullptr;   // owns the allocation: table, then the codes
     int cls_count = 0;
+    // the classes are ONE stencil + eliminated nodes on the planes [st_z0, st_z1) (dia_classify / k_stencil_verify): couplings
+    // c[slot], identity class id; valid exactly as long as cls_count > 0
+    bool st_ok = false;
+    int st_ident = -1, st_z0 = 0, st_z1 = 0, st_zm0 = 0, st_zm1 = 0;   // (st_zm0 .. st_zm1: the run of planes with identical codes; the rest of the verified planes hold identity rows only)
+    double st_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     bool cls_tried = false;        // atoms: the dictionary was looked for once for the current slot values (atom_fast_form)
     bool immutable = false;        // an ATOM (assembled / uploaded / embedded): its values change only through pgd_atom_embed(dst)
     uint64_t version = 0;          // bumped by every writer of `vals` after creation
@@ -199,6 +204,10 @@ struct Ctx {
     int atom_fast = 1;            // products with an atom whose diagonal form exists take the z-march (+ its own row classes, looked for once)
     int lazy_csr = 1;             // pgd_op_combine forms only the diagonal form where it can; CSR values on first use
     uint64_t next_serial = 1;
+    int spmv_stencil = 1;         // ... and its stencil form (couplings in scalar registers, four rows per thread) where every row verifies
+    int spmv_zchunk_stencil = 0;  // > 0: planes per march of k_spmv_stencil_march (0: fill every workgroup slot once)
+    int stencil_depth = 0;        // plane fetches in flight per workgroup of k_spmv_stencil_march (0: chosen from the march length; 3, 4, 6, 8, 10)
+    int stencil_wg_per_cu = 2;    // resident workgroups per CU of k_spmv_stencil_march (sets the march length)
     int spmv_classes = 1;         // row-class dictionary of the scaled diagonal form (k_spmv_diac_march2) where the operator has one
     void *cls_scratch = nullptr;  // hash slots of dia_classify
     double *gram_w = nullptr;     // pgd_start_gram: the products A v_j, one vector each
@@ -240,7 +249,7 @@ struct Ctx {
     int pcg_pipeline = 1;                            // 1: the next 16-iteration chunk is queued before the host looks at the flags of the last
 };
 
-enum { KC_CSR = 0, KC_CSR_DICT = 1, KC_SYM_ROWS = 2, KC_DIA_ROWS = 3, KC_DIA_MARCH = 4, KC_MULTI = 5, KC_DIAC_MARCH = 6 };
+enum { KC_CSR = 0, KC_CSR_DICT = 1, KC_SYM_ROWS = 2, KC_DIA_ROWS = 3, KC_DIA_MARCH = 4, KC_MULTI = 5, KC_DIAC_MARCH = 6, KC_STENCIL_MARCH = 7 };
 
 // ---- helpers implemented in pgd_ctx.hip
 Ctx *get_ctx(pgd_handle h);
@@ -280,7 +289,8 @@ int vec_sqrt(Ctx *c, double *v, int64_t n);
 int vec_div_mul(Ctx *c, double *x, const double *sc, int64_t n, int mul);
 int ensure_vals(Ctx *c, const Mesh *m, Csr *a);                 // pgd_pcg.hip: CSR values of an operator whose combine was deferred
 bool atom_fast_form(Ctx *c, const Mesh *m, Csr *a, int64_t r0, int64_t r1);   // pgd_spmv.hip
-int dia_classify(Ctx *c, const Mesh *m, Csr *a);                // pgd_spmv.hip: row-class dictionary of the current slot values
+// pgd_spmv.hip: row-class dictionary of the current slot values (+ its stencil form, verified on the planes [zlo, zhi) - whole grid: -1)
+int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo = -1, int zrange_hi = -1);
 int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *s);   // pgd_spmv.hip: slot values *= s_i s_j
 int launch_spmv_dia_rows2(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0a,
                           int64_t r1a, int64_t r0b, int64_t r1b, bool dot, const int *flags, int *nparts_out, bool *done);

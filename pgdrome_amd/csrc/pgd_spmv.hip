@@ -1082,6 +1082,361 @@ __global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
     }
 }
 
+// ------------------------------------------------------------------ STENCIL form of the row-class dictionary (r03)
+// Where dia_classify finds that the classes of an operator are ONE tuple (c0 .. c7) - the "base class" - plus the rows it
+// becomes next to eliminated (Dirichlet) nodes and next to the rim of the grid, i.e. every coupling a(i, j) is either c_s
+// bit for bit or an exact 0 where j is an identity row or lies outside the grid (k_stencil_verify checks EVERY row of the
+// planes a launch may touch, every slot, bitwise), the product needs no table at all:
+//     y_i = x_i                               for an identity row i,
+//     y_i = sum over the 15 neighbours of c_s * x~_j      otherwise,      x~_j = 0 for identity rows and outside the grid,
+// the same 15 fused multiply-adds in the same order as k_spmv_diac_march2 with the same factors - c_s * 0 adds the exact 0
+// that 0 * x_j adds there - so y is bit-identical for finite x.  That is the constant-coefficient operator on a uniform
+// lattice with Dirichlet nodes (cfg4: -Laplace + mu on the box, homogeneous hull); natural boundaries change the tuples of the
+// rim rows and keep the dictionary form.  One more condition keeps the kernel free of per-plane bookkeeping: the planes of the
+// verified range are [planes of identity rows only]* [a run of planes with identical codes: the MAIN run] [identity planes]*
+// (k_stencil_planes); anything else - Dirichlet nodes that change from plane to plane - stays with the dictionary form.
+// What it buys: a step of k_spmv_diac_march2 is ~150 instructions per wave for 128 rows, a third of them the product itself.
+// Here the couplings are 8 kernel arguments = SCALAR registers (v_fma_f64 takes one scalar operand), which frees the 68 vector
+// registers they took and pays for FOUR rows per thread (a 64 x 16 patch per 256 threads: 16 % instead of 29 % halo cells, half
+// the barriers, scalar work and staging per row, 9 instead of 11 LDS reads per row), and every per-lane condition of a step is
+// folded into state that is computed ONCE per march from the codes of a main plane:
+//   * loads and stores are raw buffer accesses through a descriptor of ONE plane: cells outside the grid, the halo cell of an
+//     eliminated node, rows that are not stored carry an offset beyond the plane - the range check returns 0 / drops the store;
+//     no exec masks, no 64-bit address arithmetic, no selects at staging;
+//   * the own cells of eliminated rows are loaded raw (their y = x is written when their plane is STAGED, the value being in
+//     registers then) and staged through a multiplier m in {0, 1}; the same m switches the rows' terms of the fused dots;
+//   * planes of identity rows only are copied at staging time and staged as zeros; no code byte is read in the march: 16 B/row.
+struct StencilArgs {
+    const uint8_t *cls;
+    double c[8];            // c[s] = coupling of slot s = dx + 2 dy + 4 dz (c[0]: the diagonal)
+    int ident;              // class id of the identity rows (-1: none)
+    const double *x;
+    double *y, *partials;
+    const int *flags;
+    int nx, ny, nz;
+    int zv0, zv1;           // planes the form was verified on (the grid, or the owned planes of a sharded slab)
+    int zm0, zm1;           // the main run within them; the other planes of [zv0, zv1) hold identity rows only
+    int z0, z1, zchunk, tiles_x, tiles_y;
+    int qq;
+    int whatif;             // instrumented builds only (PGD_STENCIL_TIMING): 1 no y stores, 2 no x fetches, 4 no LDS reads / FMAs
+};
+
+#ifdef PGD_STENCIL_TIMING
+#define PGD_ST_WHATIF(bit) (A.whatif & (bit))
+#else
+#define PGD_ST_WHATIF(bit) 0
+#endif
+
+typedef int st_v2i __attribute__((ext_vector_type(2)));
+
+template <bool DOT, bool STORE, int D, bool NTY>
+__global__ __launch_bounds__(256) void k_spmv_stencil_march(StencilArgs A) {
+    constexpr int NT = 256, PY = 16, HY = PY + 2, RW = 4;                   // 64 x 16 patch, four rows per thread
+    constexpr int NQ = 5;                                                   // cells a thread stages per plane: its own four + one halo cell
+    constexpr int SLOT = NQ * NT;                                           // 1280 >= 66 * 18 = 1188 cells (+ dump cells of idle stagers)
+    constexpr int OOB = (int)0x40000000;                                    // byte offset no plane reaches (planes < 2^27 rows: launcher)
+    constexpr int AUX_ST = NTY ? 2 : 0;                                     // nt
+    __shared__ double s_x[4 * SLOT];
+    __shared__ double s_red[4];
+    if (A.flags && A.flags[0]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_chunk = A.tiles_x * A.tiles_y;
+    const int chunk = b / per_chunk, tile = b - chunk * per_chunk;
+    const int ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+    const int x0 = tx * 64, y0 = ty * PY;
+    const int64_t P = (int64_t)A.nx * A.ny;
+    const unsigned P8 = (unsigned)(P * 8);
+    const int centre = (RW * wv + 1) * DM_HX + lane + 1;                    // row 0 of the thread's four; row r at + r * DM_HX
+    const int za = A.z0 + chunk * A.zchunk, zb = min(A.z1, za + A.zchunk);
+    if (za >= zb) {                                                         // uniform; the launcher sizes the grid so that no chunk is empty
+        if (DOT && tid == 0) { if (A.qq) { A.partials[2 * b] = 0.0; A.partials[2 * b + 1] = 0.0; } else A.partials[b] = 0.0; }
+        return;
+    }
+    // ---- per-thread state of the whole march, from the codes of one main plane
+    // cells this thread stages: q = 0..3 its own rows, q = 4 one cell of the halo ring (threads 164.. : a dump cell)
+    int lv[NQ], sv[RW], cell4;                                              // byte offsets of the loads / stores within a plane (or OOB)
+    double m[RW];                                                           // 1: the row is live and free, 0: eliminated or outside the grid
+    unsigned fix = 0;                                                       // bit r: row r is live and an identity row of the main planes
+    {
+        const uint8_t *cz = A.cls + P * min(max(A.zm0, 0), A.nz - 1);
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            int lx, ly;
+            if (q < RW) { lx = lane + 1; ly = RW * wv + q + 1; }
+            else if (tid < DM_HX) { lx = tid; ly = 0; }
+            else if (tid < 2 * DM_HX) { lx = tid - DM_HX; ly = HY - 1; }
+            else if (tid < 2 * DM_HX + PY) { lx = 0; ly = tid - 2 * DM_HX + 1; }
+            else { lx = DM_HX - 1; ly = tid - 2 * DM_HX - PY + 1; }
+            const bool ring = q < RW || tid < 2 * DM_HX + 2 * PY;
+            const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+            const bool in = ring && gx >= 0 && gx < A.nx && gy >= 0 && gy < A.ny;
+            const int off = in ? gx + A.nx * gy : 0;
+            const bool masked = in && A.ident >= 0 && (int)cz[off] == A.ident;
+            if (q < RW) {
+                lv[q] = in ? 8 * off : OOB;                                 // raw: an identity row's own value is its y
+                sv[q] = (in && !masked) ? 8 * off : OOB;
+                m[q] = (in && !masked) ? 1.0 : 0.0;
+                if (in && masked) fix |= 1u << q;
+            } else {
+                lv[q] = (in && !masked) ? 8 * off : OOB;                    // the halo cell of an eliminated node reads as 0
+                cell4 = ring ? ly * DM_HX + lx : DM_HX * HY + (tid - (2 * DM_HX + 2 * PY));
+            }
+        }
+    }
+    const bool fix_any = __any((int)fix) != 0;                              // uniform
+    const double c0 = A.c[0], c1 = A.c[1], c2 = A.c[2], c3 = A.c[3], c4 = A.c[4], c5 = A.c[5], c6 = A.c[6], c7 = A.c[7];
+    double dot = 0.0, dot2 = 0.0;
+    // plane z through a descriptor of its own (base + one plane of records): what lies outside the verified planes has no
+    // records at all.  Scalar arithmetic only.
+    auto rsrc_of = [&](const double *base, int z, bool live) {
+        const int zc = min(max(z, 0), A.nz - 1);
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base) + P * zc, 0, live ? (int)P8 : 0, 0x00020000);
+    };
+    auto fetch = [&](int z, double (&v)[NQ]) {
+        if (PGD_ST_WHATIF(2)) return;
+        const auto r = rsrc_of(A.x, z, z >= A.zv0 && z < A.zv1 && z <= zb);    // (planes behind the march's upper halo plane: no records)
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) {
+            const st_v2i t = __builtin_amdgcn_raw_buffer_load_b64(r, lv[q], 0, 0);
+            v[q] = __builtin_bit_cast(double, t);
+        }
+    };
+    // stage plane zz (values fetched D + 2 steps ago) and write the y of its identity rows
+    auto stage = [&](int zz, const double (&v)[NQ]) {
+        double *dst = s_x + (zz & 3) * SLOT;
+        const bool mainp = zz >= A.zm0 && zz < A.zm1;                       // uniform
+        const bool mine = zz >= za && zz < zb;                              // the march's own planes (not its two halo planes)
+        if (mainp) {
+#pragma unroll
+            for (int q = 0; q < RW; ++q) dst[centre + q * DM_HX] = v[q] * m[q];
+            dst[cell4] = v[RW];
+            if (fix_any && mine) {
+                const auto ry = rsrc_of(A.y, zz, STORE);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    const bool f = (fix >> r) & 1u;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(st_v2i, v[r]), ry, f ? lv[r] : OOB, 0, AUX_ST);
+                    if (DOT) { const double t = f ? v[r] : 0.0; dot = fma(t, t, dot); dot2 = fma(t, t, dot2); }
+                }
+            }
+        } else {
+            // identity rows only (or outside the verified planes: nothing was fetched): zeros for the neighbours, y = x
+#pragma unroll
+            for (int q = 0; q < RW; ++q) dst[centre + q * DM_HX] = 0.0;
+            dst[cell4] = 0.0;
+            if (mine && zz >= A.zv0 && zz < A.zv1) {
+                const auto ry = rsrc_of(A.y, zz, STORE);
+#pragma unroll
+                for (int r = 0; r < RW; ++r) {
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(st_v2i, v[r]), ry, lv[r], 0, AUX_ST);
+                    if (DOT) { const double t = lv[r] != OOB ? v[r] : 0.0; dot = fma(t, t, dot); dot2 = fma(t, t, dot2); }
+                }
+            }
+        }
+    };
+    double rr[D][NQ];                                                       // the D plane fetches in flight, rotating by name
+    {
+        double t0[NQ], t1[NQ], t2[NQ];
+        fetch(za - 1, t0); fetch(za, t1); fetch(za + 1, t2);
+        stage(za - 1, t0); stage(za, t1); stage(za + 1, t2);
+    }
+#pragma unroll
+    for (int s = 0; s < D; ++s) fetch(za + 2 + s, rr[s]);
+    __syncthreads();
+#ifdef PGD_STENCIL_TIMING
+    // debug build (tools/stencil_timing.py): s_memtime stamps of four workgroups' wave 0 at the phases of every step
+    long long st_prev = 0;
+    const int st_slot = b == 0 ? 0 : b == 100 ? 1 : b == 300 ? 2 : b == (int)gridDim.x - 1 ? 3 : -1;
+    int st_n = 0;
+#define PGD_ST_STAMP(k)                                                                                   \
+    do {                                                                                                  \
+        if (st_slot >= 0 && tid == 0 && st_n < 48 * 4) {                                                  \
+            long long t_;                                                                                 \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                   \
+            A.partials[4096 + st_slot * 256 + st_n] = (double)(t_ - st_prev);                             \
+            st_prev = t_;                                                                                 \
+            st_n += 1;                                                                                    \
+        }                                                                                                 \
+    } while (0)
+#else
+#define PGD_ST_STAMP(k) do { } while (0)
+#endif
+    // one step: rows of plane z; `rv` holds plane z + 2 (staged at the end of the step) and then takes the fetch of z + 2 + D
+    auto step = [&](int z, double (&rv)[NQ]) {
+        if (z >= A.zm0 && z < min(zb, A.zm1)) {                             // uniform: a main plane of the march (not an idle step behind it)
+            const double *xm = s_x + ((z - 1) & 3) * SLOT + centre;
+            const double *xc = s_x + (z & 3) * SLOT + centre;
+            const double *xp = s_x + ((z + 1) & 3) * SLOT + centre;
+            double acc[RW];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                const int o = r * DM_HX;
+                if (PGD_ST_WHATIF(4)) { acc[r] = c7; continue; }
+                double a = c7 * xm[o - DM_HX - 1];
+                a = fma(c6, xm[o - DM_HX], a);
+                a = fma(c5, xm[o - 1], a);
+                a = fma(c4, xm[o], a);
+                a = fma(c3, xc[o - DM_HX - 1], a);
+                a = fma(c2, xc[o - DM_HX], a);
+                a = fma(c1, xc[o - 1], a);
+                a = fma(c0, xc[o], a);
+                a = fma(c1, xc[o + 1], a);
+                a = fma(c2, xc[o + DM_HX], a);
+                a = fma(c3, xc[o + DM_HX + 1], a);
+                a = fma(c4, xp[o], a);
+                a = fma(c5, xp[o + 1], a);
+                a = fma(c6, xp[o + DM_HX], a);
+                a = fma(c7, xp[o + DM_HX + 1], a);
+                acc[r] = a;
+            }
+            const auto ry = rsrc_of(A.y, z, STORE && !PGD_ST_WHATIF(1));
+#pragma unroll
+            for (int r = 0; r < RW; ++r) {
+                if (STORE) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(st_v2i, acc[r]), ry, sv[r], 0, AUX_ST);
+                if (DOT) {
+                    const double d = acc[r] * m[r];            // the eliminated rows' sums are not part of y
+                    dot = fma(d, xc[r * DM_HX], dot); dot2 = fma(d, d, dot2);
+                }
+            }
+        }
+        PGD_ST_STAMP(0);
+        // slot (z + 2) & 3 held plane z - 2, which nobody reads any more
+        stage(z + 2, rv);
+        PGD_ST_STAMP(1);
+        fetch(z + 2 + D, rv);
+        PGD_ST_STAMP(2);
+        lds_barrier();
+        PGD_ST_STAMP(3);
+    };
+#pragma clang loop unroll(disable)
+    for (int z = za; z < zb; z += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) step(z + s, rr[s]);
+    }
+    if (DOT) {
+        for (int pass = 0; pass < (A.qq ? 2 : 1); ++pass) {
+            const double sum = wave_sum(pass ? dot2 : dot);
+            __syncthreads();
+            if (lane == 0) s_red[wv] = sum;
+            __syncthreads();
+            if (tid == 0) A.partials[A.qq ? 2 * b + pass : b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        }
+    }
+}
+#undef PGD_ST_STAMP
+#undef PGD_ST_WHATIF
+
+// Does the dictionary reduce to one stencil?  k_stencil_pick: base class = the class of the row in the middle of the planes
+// [z_lo, z_hi), identity class = the tuple (1, 0 .. 0).  A row's tuple holds only the UPPER half of its row: a free node whose
+// upper neighbours are all eliminated (the last free node before three faces) carries the identity tuple too.  k_stencil_split
+// gives those rows a class id of their own (same tuple, a duplicate table row: the dictionary product does not care), so that
+// "class == identity class" means an eliminated node: every coupling TO it is zero as well.  k_stencil_verify: every row of those
+// planes, every slot, bit for bit.
+struct StencilInfo { int ok, ident, base, split; double c[8]; int zm0, zm1, pad0, pad1; };
+
+__global__ void k_stencil_pick(const uint8_t *__restrict__ cls, double *__restrict__ table, const int *__restrict__ info,
+                               int nx, int ny, int z_lo, int z_hi, StencilInfo *S) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    S->ok = 0; S->ident = -1; S->base = -1; S->split = 0;
+    const int ncls = info[0];
+    if (info[1] != 0 || ncls <= 0 || ncls >= CLS_MAX || z_hi <= z_lo) return;      // (room for one more class id)
+    const int64_t mid = (int64_t)nx * ny * ((z_lo + z_hi) / 2) + (int64_t)nx * (ny / 2) + nx / 2;
+    for (int k = 0; k < ncls; ++k) {
+        bool id = table[k * 8 + cls_pos(0)] == 1.0;
+        for (int s = 1; s < 8; ++s) id = id && table[k * 8 + cls_pos(s)] == 0.0;
+        if (id) S->ident = k;
+    }
+    const int base = cls[mid];
+    if (base == S->ident) return;                            // (a grid whose middle is eliminated: keep the dictionary form)
+    S->base = base;
+    for (int s = 0; s < 8; ++s) S->c[s] = table[base * 8 + cls_pos(s)];
+    if (S->ident >= 0) {                                     // the duplicate row of the free nodes with the identity tuple, then the zero class
+        for (int s = 0; s < 8; ++s) { table[ncls * 8 + s] = table[S->ident * 8 + s]; table[(ncls + 1) * 8 + s] = 0.0; }
+    }
+    S->ok = 1;
+}
+
+__global__ __launch_bounds__(TPB) void k_stencil_split(uint8_t *__restrict__ cls, const double *__restrict__ table, const int *__restrict__ info,
+                                                       int nx, int ny, int64_t nv, StencilInfo *S) {
+    if (!S->ok || S->ident < 0) return;
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= nv || (int)cls[i] != S->ident) return;
+    const int64_t P = (int64_t)nx * ny;
+    const int z = (int)(i / P), rem = (int)(i - (int64_t)z * P), y = rem / nx, x = rem - y * nx;
+    bool coupled = false;
+#pragma unroll
+    for (int s = 1; s < 8; ++s) {                            // the lower neighbour whose slot s points at this row
+        const int dx = s & 1, dy = (s >> 1) & 1, dz = s >> 2;
+        if (x - dx < 0 || y - dy < 0 || z - dz < 0) continue;
+        const int kc = cls[i - dx - (int64_t)nx * dy - P * dz];      // (a neighbour re-coded meanwhile carries the same tuple)
+        coupled = coupled || table[kc * 8 + cls_pos(s)] != 0.0;
+    }
+    if (coupled) { cls[i] = (uint8_t)info[0]; S->split = 1; }
+}
+
+__global__ void k_stencil_commit(double *__restrict__ table, int *__restrict__ info, StencilInfo *S) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || !S->ok || S->ident < 0) return;
+    const int n = info[0];
+    if (S->split) info[0] = n + 1;                           // one more class; its zero class sits behind it
+    else for (int s = 0; s < 8; ++s) table[n * 8 + s] = 0.0;      // unused: row n is the zero class again
+}
+
+// allid[z] = 1 iff plane z holds identity rows only; samem[z] = 1 iff the identity rows of plane z sit where those of plane z - 1 do
+__global__ __launch_bounds__(TPB) void k_stencil_allid(const uint8_t *__restrict__ cls, int64_t plane, const StencilInfo *S, int *__restrict__ allid,
+                                                       int *__restrict__ samem) {
+    __shared__ int s_other, s_diff;
+    const int z = blockIdx.x;
+    if (threadIdx.x == 0) { s_other = 0; s_diff = 0; }
+    __syncthreads();
+    const uint8_t *a = cls + plane * z;
+    const int ident = S->ident;
+    bool other = false, diff = z == 0;
+    for (int64_t i = threadIdx.x; i < plane; i += TPB) {
+        const bool id = (int)a[i] == ident;
+        other = other || !id;
+        if (z > 0) diff = diff || id != ((int)a[i - plane] == ident);
+    }
+    if (other) s_other = 1;
+    if (diff) s_diff = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) { allid[z] = s_other ? 0 : 1; samem[z] = s_diff ? 0 : 1; }
+}
+
+// the planes of [z_lo, z_hi) must read [identity planes]* [one run of planes with the SAME identity rows] [identity planes]*
+__global__ void k_stencil_planes(const int *__restrict__ same, const int *__restrict__ allid, int z_lo, int z_hi, StencilInfo *S) {
+    if (threadIdx.x != 0 || blockIdx.x != 0 || !S->ok) return;
+    int a = z_lo, b = z_hi;
+    while (a < z_hi && allid[a]) ++a;
+    while (b > a && allid[b - 1]) --b;
+    bool simple = true;
+    for (int z = a; z < b; ++z) simple = simple && !allid[z] && (z == a || same[z] != 0);
+    S->zm0 = a; S->zm1 = b;
+    if (!simple) S->ok = 0;
+}
+
+__global__ __launch_bounds__(TPB) void k_stencil_verify(const uint8_t *__restrict__ cls, const double *__restrict__ table, int nx, int ny,
+                                                        int nz, int z_lo, int z_hi, StencilInfo *S) {
+    if (!S->ok) return;
+    const int64_t P = (int64_t)nx * ny;
+    const int64_t i = P * z_lo + (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= P * z_hi) return;
+    const int k = cls[i];
+    if (k == S->ident) return;
+    const int z = (int)(i / P), rem = (int)(i - (int64_t)z * P), y = rem / nx, x = rem - y * nx;
+    const double *t = table + k * 8;
+    bool good = __double_as_longlong(t[cls_pos(0)]) == __double_as_longlong(S->c[0]);
+#pragma unroll
+    for (int s = 1; s < 8; ++s) {
+        const int dx = s & 1, dy = (s >> 1) & 1, dz = s >> 2;
+        const bool inside = x + dx < nx && y + dy < ny && z + dz < nz;
+        const bool live = inside && (int)cls[i + dx + (int64_t)nx * dy + P * dz] != S->ident;
+        const double v = t[cls_pos(s)];
+        good = good && (live ? __double_as_longlong(v) == __double_as_longlong(S->c[s]) : v == 0.0);
+    }
+    if (!good) S->ok = 0;
+}
+
 // --- the classification (per solve, after the slot arrays got their final values)
 __device__ __forceinline__ unsigned long long cls_hash(const double *__restrict__ uvals, int64_t stride, int64_t i) {
     unsigned long long h = 0x9e3779b97f4a7c15ull;
@@ -1191,13 +1546,15 @@ __global__ __launch_bounds__(TPB) void k_cls_planes(const uint8_t *__restrict__ 
 
 // Row classes of the operator's CURRENT slot values (a->uvals, diagonal form).  a->cls_count > 0 afterwards when the
 // dictionary exists; any later change of the slot values must reset it (sym_scale, combine_dia, ensure_sym do).
-int dia_classify(Ctx *c, const Mesh *m, Csr *a) {
+int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
     a->cls_count = 0;
+    a->st_ok = false;
     if (!c->spmv_classes || m->sym_nx <= 0 || !(a->uvals && a->uvals_valid) || m->nv >= ((int64_t)1 << 31)) return PGD_OK;
     const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
     if (m->nv / plane < 3 || plane * 64 < c->spmv_grid_min_plane_bytes) return PGD_OK;          // no march on this grid anyway
     void *p;
-    if (!c->cls_scratch) { PGD_TRY(dev_alloc(c, &p, sizeof(ClsScratch))); c->cls_scratch = p; }
+    if (m->nv / plane > 65536) return PGD_OK;                                // (plane flags of the stencil check: room for 2^16 planes)
+    if (!c->cls_scratch) { PGD_TRY(dev_alloc(c, &p, sizeof(ClsScratch) + sizeof(StencilInfo) + 2 * 65536 * sizeof(int))); c->cls_scratch = p; }
     const int nzp = (int)(m->nv / plane);
     const size_t same_bytes = ((size_t)nzp * sizeof(int) + 63) / 64 * 64;
     if (!a->cls) {
@@ -1216,15 +1573,47 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a) {
     k_cls_insert<<<g, TPB, 0, st>>>(a->uvals, a->uvals_stride, m->nv, S);
     k_cls_table<<<1, CLS_SLOTS, 0, st>>>(a->uvals, a->uvals_stride, S, a->cls_table);
     k_cls_assign<<<g, TPB, 0, st>>>(a->uvals, a->uvals_stride, m->nv, S, a->cls_table, a->cls);
+    // ... and whether the classes are ONE stencil with eliminated nodes (k_spmv_stencil_march) on the planes [z_lo, z_hi) - the
+    // whole grid, or the owned planes of a sharded rank's slab, whose ghost-plane rows are incomplete by construction
+    int z_lo = 0, z_hi = nzp;
+    if (zrange_lo >= 0) { z_lo = std::max(0, zrange_lo); z_hi = std::min(nzp, zrange_hi); }
+    StencilInfo *SI = reinterpret_cast<StencilInfo *>(S + 1);
+    const bool try_stencil = c->spmv_stencil && z_hi - z_lo >= 3;
+    if (try_stencil) {
+        k_stencil_pick<<<1, 64, 0, st>>>(a->cls, a->cls_table, S->info, m->sym_nx, m->sym_ny, z_lo, z_hi, SI);
+        k_stencil_split<<<g, TPB, 0, st>>>(a->cls, a->cls_table, S->info, m->sym_nx, m->sym_ny, m->nv, SI);
+        k_stencil_commit<<<1, 64, 0, st>>>(a->cls_table, S->info, SI);
+    }
     k_cls_planes<<<nzp, TPB, 0, st>>>(a->cls, plane, nzp, a->cls_same);
-    int info[4] = {0, 1, 0, 0};
-    PGD_HIP(c, hipMemcpyAsync(info, S->info, sizeof info, hipMemcpyDeviceToHost, st));
+    if (try_stencil) {
+        const int64_t rows = plane * (z_hi - z_lo);
+        k_stencil_verify<<<(int)((rows + TPB - 1) / TPB), TPB, 0, st>>>(a->cls, a->cls_table, m->sym_nx, m->sym_ny, nzp, z_lo, z_hi, SI);
+        int *allid = reinterpret_cast<int *>(SI + 1);
+        k_stencil_allid<<<nzp, TPB, 0, st>>>(a->cls, plane, SI, allid, allid + 65536);
+        k_stencil_planes<<<1, 64, 0, st>>>(allid + 65536, allid, z_lo, z_hi, SI);
+    }
+    struct { int info[4]; StencilInfo si; } host;
+    host.info[0] = 0; host.info[1] = 1; host.si.ok = 0;
+    PGD_HIP(c, hipMemcpyAsync(host.info, S->info, sizeof host.info, hipMemcpyDeviceToHost, st));
+    if (try_stencil) PGD_HIP(c, hipMemcpyAsync(&host.si, SI, sizeof(StencilInfo), hipMemcpyDeviceToHost, st));
     PGD_HIP(c, hipStreamSynchronize(st));
     PGD_LAUNCH_CHECK(c);
     // (an operator without classes - a variable coefficient - costs 0.55 ms at 256^3 here: the insert pass gives up as soon as the
     // 256th class appears)
-    if (info[1] != 0 || info[0] <= 0 || info[0] > CLS_MAX) return PGD_OK;
-    a->cls_count = info[0];
+    if (host.info[1] != 0 || host.info[0] <= 0 || host.info[0] > CLS_MAX) return PGD_OK;
+    a->cls_count = host.info[0];
+    if (getenv("PGD_DEBUG_STENCIL"))
+        fprintf(stderr, "[dia_classify] classes %d info1 %d try %d ok %d ident %d base %d c = %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g  z [%d, %d)\n",
+                host.info[0], host.info[1], (int)try_stencil, host.si.ok, host.si.ident, host.si.base, host.si.c[0], host.si.c[1], host.si.c[2],
+                host.si.c[3], host.si.c[4], host.si.c[5], host.si.c[6], host.si.c[7], z_lo, z_hi);
+    if (getenv("PGD_DEBUG_STENCIL")) fprintf(stderr, "[dia_classify] main run [%d, %d)\n", host.si.zm0, host.si.zm1);
+    if (try_stencil && host.si.ok) {
+        a->st_ok = true;
+        a->st_ident = host.si.ident;
+        a->st_z0 = z_lo; a->st_z1 = z_hi;
+        a->st_zm0 = host.si.zm0; a->st_zm1 = host.si.zm1;
+        for (int s2 = 0; s2 < 8; ++s2) a->st_c[s2] = host.si.c[s2];
+    }
     return PGD_OK;
 }
 
@@ -1605,6 +1994,50 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
                 wgs_c = (D.z1 - D.z0 + zchunk_c - 1) / zchunk_c * D.tiles_x * D.tiles_y;
             }
             coded = coded && zchunk_c <= DIAC_MAXCHUNK;
+            // one stencil + eliminated nodes (dia_classify verified every row of the planes this launch reads couplings of: its
+            // own and the plane below its first): couplings in scalar registers, four rows per thread, no table
+            if (coded && c->spmv_stencil && a->st_ok && c->spmv_zchunk_force <= 0 && D.z1 <= a->st_z1 && plane < ((int64_t)1 << 26) &&
+                (D.z0 == 0 ? a->st_z0 == 0 : D.z0 - 1 >= a->st_z0)) {
+                StencilArgs F;
+                F.cls = a->cls; F.ident = a->st_ident; F.x = x; F.y = y; F.flags = flags;
+                F.zv0 = a->st_z0; F.zv1 = a->st_z1; F.zm0 = a->st_zm0; F.zm1 = a->st_zm1;
+                for (int s2 = 0; s2 < 8; ++s2) F.c[s2] = a->st_c[s2];
+                F.nx = D.nx; F.ny = D.ny; F.nz = D.nz; F.z0 = D.z0; F.z1 = D.z1; F.tiles_x = D.tiles_x; F.tiles_y = (D.ny + 15) / 16;
+                F.qq = D.qq;
+                F.whatif = 0;
+#ifdef PGD_STENCIL_TIMING
+                if (const char *wi = getenv("PGD_STENCIL_WHATIF")) F.whatif = atoi(wi);
+#endif
+                const bool nty = D.qq && c->pcg_stream_hints;
+                // march length: every resident workgroup slot filled once (two workgroups per CU), whole groups of the fetch depth
+                const int64_t tiles = (int64_t)F.tiles_x * F.tiles_y, slots = (int64_t)c->stencil_wg_per_cu * c->num_cu;
+                const int planes = D.z1 - D.z0;
+                int64_t marches = std::max<int64_t>(1, slots / tiles);
+                int zc = (int)((planes + marches - 1) / marches);
+                if (c->spmv_zchunk_stencil > 0) zc = c->spmv_zchunk_stencil;
+                int depth = (zc % 6 == 0 || zc >= 48) ? 6 : (zc % 4 == 0 || zc >= 16) ? 4 : 3;
+                if (c->stencil_depth > 0) depth = c->stencil_depth;
+                zc = std::max(depth, (zc + depth - 1) / depth * depth);
+                F.zchunk = zc;
+                const int wgs_s = (int)(((planes + zc - 1) / zc) * tiles);
+                if (nparts_out) *nparts_out = wgs_s;
+                if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + (D.qq ? 2 : 1) * (int64_t)wgs_s, 4 * MAX_VEC_BLOCKS)));
+                F.partials = c->partials + c->partials_off;
+#define PGD_STENCIL(DD)                                                                                       \
+    do {                                                                                                      \
+        if (dot && store && nty) k_spmv_stencil_march<true, true, DD, true><<<wgs_s, 256, 0, c->stream>>>(F);      \
+        else if (dot && store) k_spmv_stencil_march<true, true, DD, false><<<wgs_s, 256, 0, c->stream>>>(F);       \
+        else if (dot) k_spmv_stencil_march<true, false, DD, false><<<wgs_s, 256, 0, c->stream>>>(F);               \
+        else k_spmv_stencil_march<false, true, DD, false><<<wgs_s, 256, 0, c->stream>>>(F);                        \
+    } while (0)
+                if (depth == 10) PGD_STENCIL(10); else if (depth == 8) PGD_STENCIL(8); else if (depth == 6) PGD_STENCIL(6);
+                else if (depth == 4) PGD_STENCIL(4); else PGD_STENCIL(3);
+#undef PGD_STENCIL
+                c->kcount[KC_STENCIL_MARCH] += 1;
+                if (timed2) PGD_TRY(prof_end(c, m, nrows, 16.0));
+                PGD_LAUNCH_CHECK(c);
+                return PGD_OK;
+            }
             if (coded) {
                 // the operator has a row-class dictionary (dia_classify): one byte per row instead of the slot values
                 DiacArgs E;
@@ -1798,6 +2231,15 @@ using namespace pgd;
 
 extern "C" {
 
+#ifdef PGD_STENCIL_TIMING
+int pgd_debug_read_partials(pgd_handle h, double *out, int first, int count) {
+    PGD_CTX(c, h);
+    PGD_HIP(c, hipMemcpyAsync(out, c->partials + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    return PGD_OK;
+}
+#endif
+
 int pgd_tune(pgd_handle h, int knob, int64_t value) {
     PGD_CTX(c, h);
     if (knob == PGD_TUNE_SPMV_ROWS && (value == 64 || value == 128 || value == 256)) { c->spmv_rows = (int)value; return PGD_OK; }
@@ -1812,6 +2254,10 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_UNIT_DIAG && value >= 0 && value <= 1) { c->spmv_unit_diag = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_DEFER_X && value >= 0 && value <= 1) { c->pcg_defer_x = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_FAULT_ITERATION && value >= -1 && value <= (1 << 30)) { c->fault_iteration = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_STENCIL && value >= 0 && value <= 1) { c->spmv_stencil = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_SPMV_ZCHUNK_STENCIL && value >= 0 && value <= 1024) { c->spmv_zchunk_stencil = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_STENCIL_DEPTH && (value == 0 || value == 3 || value == 4 || value == 6 || value == 8 || value == 10)) { c->stencil_depth = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_STENCIL_WG_PER_CU && value >= 1 && value <= 8) { c->stencil_wg_per_cu = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_FAULT_STAGE && value >= 0 && value <= 4) { c->fault_stage = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_FAULT_STALL_MS && value >= 0 && value <= 20000) { c->fault_stall_ms = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_COMBINE_DIA && value >= 0 && value <= 1) { c->spmv_combine_dia = (int)value; return PGD_OK; }
