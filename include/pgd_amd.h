@@ -298,7 +298,7 @@ int pgd_vec_multidot(pgd_handle ctx, pgd_handle x, const pgd_handle *ys, int k, 
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
-    PGD_TUNE_STENCIL_DEPTH = 38, /* plane fetches in flight per workgroup of k_spmv_stencil_march: 3, 4, 6, 8 or 10 (0, default: chosen by the launcher) */
+    PGD_TUNE_STENCIL_DEPTH = 38, /* plane fetches in flight per workgroup of k_spmv_stencil_march: 3 or 6 (0, default: chosen by the launcher) */
     PGD_TUNE_STENCIL_WG_PER_CU = 37, /* resident workgroups per CU assumed for k_spmv_stencil_march (default 2): sets the march length */
     PGD_TUNE_SPMV_ZCHUNK_STENCIL = 36, /* > 0: planes per march of k_spmv_stencil_march; 0 (default): as many as fill every resident
                                 workgroup slot exactly once, in whole groups of the fetch depth */

@@ -206,7 +206,7 @@ struct Ctx {
     uint64_t next_serial = 1;
     int spmv_stencil = 1;         // ... and its stencil form (couplings in scalar registers, four rows per thread) where every row verifies
     int spmv_zchunk_stencil = 0;  // > 0: planes per march of k_spmv_stencil_march (0: fill every workgroup slot once)
-    int stencil_depth = 0;        // plane fetches in flight per workgroup of k_spmv_stencil_march (0: chosen from the march length; 3, 4, 6, 8, 10)
+    int stencil_depth = 0;        // plane fetches in flight per workgroup of k_spmv_stencil_march (0: chosen from the march length; 3 or 6)
     int stencil_wg_per_cu = 2;    // resident workgroups per CU of k_spmv_stencil_march (sets the march length)
     int spmv_classes = 1;         // row-class dictionary of the scaled diagonal form (k_spmv_diac_march2) where the operator has one
     void *cls_scratch = nullptr;  // hash slots of dia_classify

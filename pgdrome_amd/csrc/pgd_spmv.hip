@@ -1103,9 +1103,12 @@ __global__ __launch_bounds__(256) void k_spmv_diac_march2(DiacArgs A) {
 //   * loads and stores are raw buffer accesses through a descriptor of ONE plane: cells outside the grid, the halo cell of an
 //     eliminated node, rows that are not stored carry an offset beyond the plane - the range check returns 0 / drops the store;
 //     no exec masks, no 64-bit address arithmetic, no selects at staging;
-//   * the own cells of eliminated rows are loaded raw (their y = x is written when their plane is STAGED, the value being in
-//     registers then) and staged through a multiplier m in {0, 1}; the same m switches the rows' terms of the fused dots;
-//   * planes of identity rows only are copied at staging time and staged as zeros; no code byte is read in the march: 16 B/row.
+//   * the own cells are loaded raw, staged through a multiplier m in {0, 1} and KEPT in registers until their plane is
+//     multiplied two steps later (three planes, rotating by name): the y = x of an eliminated row leaves in the same full-line
+//     store as the sums of its neighbours (written on its own, early, it was a partial-line write per boundary row: 12 us of a
+//     65 us launch), and the fused dots take x from there;
+//   * planes of identity rows only are copies out of those registers and are staged as zeros; no code byte is read in the
+//     march: 16 B per row.
 struct StencilArgs {
     const uint8_t *cls;
     double c[8];            // c[s] = coupling of slot s = dx + 2 dy + 4 dz (c[0]: the diagonal)
@@ -1121,7 +1124,7 @@ struct StencilArgs {
     int whatif;             // instrumented builds only (PGD_STENCIL_TIMING): 1 no y stores, 2 no x fetches, 4 no LDS reads / FMAs
 };
 
-#ifdef PGD_STENCIL_TIMING
+#if defined(PGD_STENCIL_TIMING) || defined(PGD_STENCIL_WHATIF)
 #define PGD_ST_WHATIF(bit) (A.whatif & (bit))
 #else
 #define PGD_ST_WHATIF(bit) 0
@@ -1129,8 +1132,8 @@ struct StencilArgs {
 
 typedef int st_v2i __attribute__((ext_vector_type(2)));
 
-template <bool DOT, bool STORE, int D, bool NTY>
-__global__ __launch_bounds__(256) void k_spmv_stencil_march(StencilArgs A) {
+template <bool DOT, bool STORE, int D, bool NTY, int OCC>
+__global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) {
     constexpr int NT = 256, PY = 16, HY = PY + 2, RW = 4;                   // 64 x 16 patch, four rows per thread
     constexpr int NQ = 5;                                                   // cells a thread stages per plane: its own four + one halo cell
     constexpr int SLOT = NQ * NT;                                           // 1280 >= 66 * 18 = 1188 cells (+ dump cells of idle stagers)
@@ -1175,7 +1178,7 @@ __global__ __launch_bounds__(256) void k_spmv_stencil_march(StencilArgs A) {
             const bool masked = in && A.ident >= 0 && (int)cz[off] == A.ident;
             if (q < RW) {
                 lv[q] = in ? 8 * off : OOB;                                 // raw: an identity row's own value is its y
-                sv[q] = (in && !masked) ? 8 * off : OOB;
+                sv[q] = lv[q];                                              // every live row is stored: its sum, or its x
                 m[q] = (in && !masked) ? 1.0 : 0.0;
                 if (in && masked) fix |= 1u << q;
             } else {
@@ -1184,65 +1187,54 @@ __global__ __launch_bounds__(256) void k_spmv_stencil_march(StencilArgs A) {
             }
         }
     }
-    const bool fix_any = __any((int)fix) != 0;                              // uniform
+    const bool fixr[RW] = {(fix & 1u) != 0, (fix & 2u) != 0, (fix & 4u) != 0, (fix & 8u) != 0};
     const double c0 = A.c[0], c1 = A.c[1], c2 = A.c[2], c3 = A.c[3], c4 = A.c[4], c5 = A.c[5], c6 = A.c[6], c7 = A.c[7];
     double dot = 0.0, dot2 = 0.0;
-    // plane z through a descriptor of its own (base + one plane of records): what lies outside the verified planes has no
-    // records at all.  Scalar arithmetic only.
-    auto rsrc_of = [&](const double *base, int z, bool live) {
-        const int zc = min(max(z, 0), A.nz - 1);
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(base) + P * zc, 0, live ? (int)P8 : 0, 0x00020000);
+    // A plane is read and written through a descriptor of its own - base + one plane of records, none at all where the plane
+    // must not be touched - built from RUNNING pointers: a step's scalar work is two 64-bit additions, not three 64-bit
+    // multiplications (every wave executes the scalar stream of its workgroup again, in order with its vector instructions).
+    auto rsrc_of = [&](const double *plane_ptr, bool live) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(plane_ptr), 0, live ? (int)P8 : 0, 0x00020000);
     };
-    auto fetch = [&](int z, double (&v)[NQ]) {
+    auto fetch = [&](const double *xz, bool live, double (&v)[NQ]) {
         if (PGD_ST_WHATIF(2)) return;
-        const auto r = rsrc_of(A.x, z, z >= A.zv0 && z < A.zv1 && z <= zb);    // (planes behind the march's upper halo plane: no records)
+        const auto r = rsrc_of(xz, live);
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
             const st_v2i t = __builtin_amdgcn_raw_buffer_load_b64(r, lv[q], 0, 0);
             v[q] = __builtin_bit_cast(double, t);
         }
     };
-    // stage plane zz (values fetched D + 2 steps ago) and write the y of its identity rows
-    auto stage = [&](int zz, const double (&v)[NQ]) {
+    auto fetch_live = [&](int z) { return z >= A.zv0 && z < A.zv1 && z <= zb; };      // (planes behind the march's upper halo plane: no records)
+    // stage plane zz (values fetched D + 2 steps ago): the masked values for the neighbours, the raw own values into `own`
+    auto stage_main = [&](int zz, const double (&v)[NQ], double (&own)[RW]) {
         double *dst = s_x + (zz & 3) * SLOT;
-        const bool mainp = zz >= A.zm0 && zz < A.zm1;                       // uniform
-        const bool mine = zz >= za && zz < zb;                              // the march's own planes (not its two halo planes)
-        if (mainp) {
 #pragma unroll
-            for (int q = 0; q < RW; ++q) dst[centre + q * DM_HX] = v[q] * m[q];
-            dst[cell4] = v[RW];
-            if (fix_any && mine) {
-                const auto ry = rsrc_of(A.y, zz, STORE);
-#pragma unroll
-                for (int r = 0; r < RW; ++r) {
-                    const bool f = (fix >> r) & 1u;
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(st_v2i, v[r]), ry, f ? lv[r] : OOB, 0, AUX_ST);
-                    if (DOT) { const double t = f ? v[r] : 0.0; dot = fma(t, t, dot); dot2 = fma(t, t, dot2); }
-                }
-            }
-        } else {
-            // identity rows only (or outside the verified planes: nothing was fetched): zeros for the neighbours, y = x
-#pragma unroll
-            for (int q = 0; q < RW; ++q) dst[centre + q * DM_HX] = 0.0;
-            dst[cell4] = 0.0;
-            if (mine && zz >= A.zv0 && zz < A.zv1) {
-                const auto ry = rsrc_of(A.y, zz, STORE);
-#pragma unroll
-                for (int r = 0; r < RW; ++r) {
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(st_v2i, v[r]), ry, lv[r], 0, AUX_ST);
-                    if (DOT) { const double t = lv[r] != OOB ? v[r] : 0.0; dot = fma(t, t, dot); dot2 = fma(t, t, dot2); }
-                }
-            }
-        }
+        for (int q = 0; q < RW; ++q) { dst[centre + q * DM_HX] = v[q] * m[q]; own[q] = v[q]; }
+        dst[cell4] = v[RW];
     };
+    auto stage = [&](int zz, const double (&v)[NQ], double (&own)[RW]) {
+        if (zz >= A.zm0 && zz < A.zm1) { stage_main(zz, v, own); return; }  // uniform
+        // identity rows only (or outside the verified planes: nothing was fetched): zeros for the neighbours
+        double *dst = s_x + (zz & 3) * SLOT;
+#pragma unroll
+        for (int q = 0; q < RW; ++q) { dst[centre + q * DM_HX] = 0.0; own[q] = v[q]; }
+        dst[cell4] = 0.0;
+    };
+    const double *xq = A.x + P * (int64_t)(za - 1);                         // running pointers: the next plane to fetch ...
+    double *yq = A.y + P * (int64_t)(za - 1);                               // ... and the plane being staged / multiplied
     double rr[D][NQ];                                                       // the D plane fetches in flight, rotating by name
+    double own[3][RW];                                                      // raw own values of the planes z, z + 1, z + 2: own[(plane - za) % 3]
+    static_assert(D % 3 == 0, "the ring of own values rotates by name: the march is unrolled in multiples of three steps");
     {
         double t0[NQ], t1[NQ], t2[NQ];
-        fetch(za - 1, t0); fetch(za, t1); fetch(za + 1, t2);
-        stage(za - 1, t0); stage(za, t1); stage(za + 1, t2);
+        fetch(xq, fetch_live(za - 1), t0); fetch(xq + P, fetch_live(za), t1); fetch(xq + 2 * P, fetch_live(za + 1), t2);
+        stage(za - 1, t0, own[2]); stage(za, t1, own[0]); stage(za + 1, t2, own[1]);
     }
+    xq += 3 * P;
 #pragma unroll
-    for (int s = 0; s < D; ++s) fetch(za + 2 + s, rr[s]);
+    for (int s = 0; s < D; ++s) { fetch(xq, fetch_live(za + 2 + s), rr[s]); xq += P; }
+    yq += P;                                                                // = y + P za
     __syncthreads();
 #ifdef PGD_STENCIL_TIMING
     // debug build (tools/stencil_timing.py): s_memtime stamps of four workgroups' wave 0 at the phases of every step
@@ -1262,57 +1254,109 @@ __global__ __launch_bounds__(256) void k_spmv_stencil_march(StencilArgs A) {
 #else
 #define PGD_ST_STAMP(k) do { } while (0)
 #endif
-    // one step: rows of plane z; `rv` holds plane z + 2 (staged at the end of the step) and then takes the fetch of z + 2 + D
-    auto step = [&](int z, double (&rv)[NQ]) {
-        if (z >= A.zm0 && z < min(zb, A.zm1)) {                             // uniform: a main plane of the march (not an idle step behind it)
-            const double *xm = s_x + ((z - 1) & 3) * SLOT + centre;
-            const double *xc = s_x + (z & 3) * SLOT + centre;
-            const double *xp = s_x + ((z + 1) & 3) * SLOT + centre;
-            double acc[RW];
+    // the product of the rows of plane z (a main plane), yz = y + P z, xo = the plane's raw own values
+    auto rows = [&](int z, double *yz, bool live, const double (&xo)[RW]) {
+        const double *xm = s_x + ((z - 1) & 3) * SLOT + centre;
+        const double *xc = s_x + (z & 3) * SLOT + centre;
+        const double *xp = s_x + ((z + 1) & 3) * SLOT + centre;
+        // ALL 36 neighbour values of the four rows first (18 ds_read2_b64 in flight behind the barrier), then the four chains of 15
+        // fused multiply-adds side by side: left to itself the compiler reads just in time and runs one chain after the other -
+        // 60 dependent DP operations with an LDS round trip between every few of them.
+        double M[RW + 1][2], C[RW + 2][3], Q[RW + 1][2];
+        double acc[RW];
+        if (PGD_ST_WHATIF(4)) {
 #pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                const int o = r * DM_HX;
-                if (PGD_ST_WHATIF(4)) { acc[r] = c7; continue; }
-                double a = c7 * xm[o - DM_HX - 1];
-                a = fma(c6, xm[o - DM_HX], a);
-                a = fma(c5, xm[o - 1], a);
-                a = fma(c4, xm[o], a);
-                a = fma(c3, xc[o - DM_HX - 1], a);
-                a = fma(c2, xc[o - DM_HX], a);
-                a = fma(c1, xc[o - 1], a);
-                a = fma(c0, xc[o], a);
-                a = fma(c1, xc[o + 1], a);
-                a = fma(c2, xc[o + DM_HX], a);
-                a = fma(c3, xc[o + DM_HX + 1], a);
-                a = fma(c4, xp[o], a);
-                a = fma(c5, xp[o + 1], a);
-                a = fma(c6, xp[o + DM_HX], a);
-                a = fma(c7, xp[o + DM_HX + 1], a);
-                acc[r] = a;
+            for (int r = 0; r < RW; ++r) { acc[r] = c7; C[r + 1][1] = c6; }
+        } else {
+#pragma unroll
+            for (int j = 0; j <= RW; ++j) { M[j][0] = xm[(j - 1) * DM_HX - 1]; M[j][1] = xm[(j - 1) * DM_HX]; }
+#pragma unroll
+            for (int j = 0; j <= RW + 1; ++j) {
+                if (j <= RW) C[j][0] = xc[(j - 1) * DM_HX - 1];
+                C[j][1] = xc[(j - 1) * DM_HX];
+                if (j >= 1) C[j][2] = xc[(j - 1) * DM_HX + 1];
             }
-            const auto ry = rsrc_of(A.y, z, STORE && !PGD_ST_WHATIF(1));
 #pragma unroll
-            for (int r = 0; r < RW; ++r) {
-                if (STORE) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(st_v2i, acc[r]), ry, sv[r], 0, AUX_ST);
-                if (DOT) {
-                    const double d = acc[r] * m[r];            // the eliminated rows' sums are not part of y
-                    dot = fma(d, xc[r * DM_HX], dot); dot2 = fma(d, d, dot2);
-                }
+            for (int j = 0; j <= RW; ++j) { Q[j][0] = xp[j * DM_HX]; Q[j][1] = xp[j * DM_HX + 1]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) acc[r] = c7 * M[r][0];
+#define PGD_ST_ROWS(cc, V)                           \
+    _Pragma("unroll") for (int r = 0; r < RW; ++r) acc[r] = fma(cc, V, acc[r])
+            PGD_ST_ROWS(c6, M[r][1]);
+            PGD_ST_ROWS(c5, M[r + 1][0]);
+            PGD_ST_ROWS(c4, M[r + 1][1]);
+            PGD_ST_ROWS(c3, C[r][0]);
+            PGD_ST_ROWS(c2, C[r][1]);
+            PGD_ST_ROWS(c1, C[r + 1][0]);
+            PGD_ST_ROWS(c0, C[r + 1][1]);
+            PGD_ST_ROWS(c1, C[r + 1][2]);
+            PGD_ST_ROWS(c2, C[r + 2][1]);
+            PGD_ST_ROWS(c3, C[r + 2][2]);
+            PGD_ST_ROWS(c4, Q[r][0]);
+            PGD_ST_ROWS(c5, Q[r][1]);
+            PGD_ST_ROWS(c6, Q[r + 1][0]);
+            PGD_ST_ROWS(c7, Q[r + 1][1]);
+#undef PGD_ST_ROWS
+        }
+        const auto ry = rsrc_of(yz, live && STORE && !PGD_ST_WHATIF(1));
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const double yv = fixr[r] ? xo[r] : acc[r];        // an eliminated row: y = x, in the same full-line store as its neighbours' sums
+            if (STORE) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(st_v2i, yv), ry, sv[r], 0, AUX_ST);
+            if (DOT) {                                         // (a row outside the grid: x = 0 was loaded for it, and its sum is one of zeros)
+                dot = fma(yv, xo[r], dot);
+                const double t = sv[r] != OOB ? yv : 0.0;
+                dot2 = fma(t, t, dot2);
             }
         }
-        PGD_ST_STAMP(0);
-        // slot (z + 2) & 3 held plane z - 2, which nobody reads any more
-        stage(z + 2, rv);
-        PGD_ST_STAMP(1);
-        fetch(z + 2 + D, rv);
-        PGD_ST_STAMP(2);
-        lds_barrier();
-        PGD_ST_STAMP(3);
     };
-#pragma clang loop unroll(disable)
-    for (int z = za; z < zb; z += D) {
+    // a plane of identity rows only: y = x out of the registers
+    auto copy_rows = [&](double *yz, const double (&xo)[RW]) {
+        const auto ry = rsrc_of(yz, STORE);
 #pragma unroll
-        for (int s = 0; s < D; ++s) step(z + s, rr[s]);
+        for (int r = 0; r < RW; ++r) {
+            if (STORE) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(st_v2i, xo[r]), ry, sv[r], 0, AUX_ST);
+            if (DOT) { dot = fma(xo[r], xo[r], dot); dot2 = fma(xo[r], xo[r], dot2); }
+        }
+    };
+    // PURE: every plane the march touches - its own, its two halo planes - is a main plane: no plane tests in the steps
+    const bool pure = za - 1 >= A.zm0 && zb < A.zm1;
+    int z = za;
+    if (pure) {
+#pragma clang loop unroll(disable)
+        for (; z + D <= zb; z += D) {
+#pragma unroll
+            for (int s = 0; s < D; ++s) {
+                // one step: rows of plane z + s; rr[s] holds plane z + s + 2 (staged now) and then takes the fetch of z + s + 2 + D
+                rows(z + s, yq, true, own[s % 3]);
+                PGD_ST_STAMP(0);
+                stage_main(z + s + 2, rr[s], own[(s + 2) % 3]);      // slot (z + 2) & 3 held plane z - 2, which nobody reads any more
+                PGD_ST_STAMP(1);
+                fetch(xq, z + s + 2 + D <= zb, rr[s]);
+                PGD_ST_STAMP(2);
+                xq += P; yq += P;
+                if (!PGD_ST_WHATIF(8)) lds_barrier();
+                PGD_ST_STAMP(3);
+            }
+        }
+    }
+    // the same steps with every plane test in them: marches that touch planes of identity rows or the rim of the verified
+    // planes, and the last (incomplete) group of steps of any march
+#pragma clang loop unroll(disable)
+    for (; z < zb; z += D) {
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            const int zs = z + s;
+            if (zs < zb) {                                                    // uniform (idle steps behind the march's last plane)
+                if (zs >= A.zm0 && zs < A.zm1) rows(zs, yq, true, own[s % 3]);
+                else if (zs >= A.zv0 && zs < A.zv1) copy_rows(yq, own[s % 3]);
+            }
+            stage(zs + 2, rr[s], own[(s + 2) % 3]);
+            fetch(xq, fetch_live(zs + 2 + D), rr[s]);
+            xq += P; yq += P;
+            lds_barrier();
+        }
     }
     if (DOT) {
         for (int pass = 0; pass < (A.qq ? 2 : 1); ++pass) {
@@ -2005,7 +2049,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
                 F.nx = D.nx; F.ny = D.ny; F.nz = D.nz; F.z0 = D.z0; F.z1 = D.z1; F.tiles_x = D.tiles_x; F.tiles_y = (D.ny + 15) / 16;
                 F.qq = D.qq;
                 F.whatif = 0;
-#ifdef PGD_STENCIL_TIMING
+#if defined(PGD_STENCIL_TIMING) || defined(PGD_STENCIL_WHATIF)
                 if (const char *wi = getenv("PGD_STENCIL_WHATIF")) F.whatif = atoi(wi);
 #endif
                 const bool nty = D.qq && c->pcg_stream_hints;
@@ -2015,23 +2059,22 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
                 int64_t marches = std::max<int64_t>(1, slots / tiles);
                 int zc = (int)((planes + marches - 1) / marches);
                 if (c->spmv_zchunk_stencil > 0) zc = c->spmv_zchunk_stencil;
-                int depth = (zc % 6 == 0 || zc >= 48) ? 6 : (zc % 4 == 0 || zc >= 16) ? 4 : 3;
+                int depth = 3;                                 // (six plane fetches in flight: no faster, 60 registers more)
                 if (c->stencil_depth > 0) depth = c->stencil_depth;
-                zc = std::max(depth, (zc + depth - 1) / depth * depth);
+                zc = std::max(depth, zc);                      // (an incomplete last group of steps idles behind the march's last plane)
                 F.zchunk = zc;
                 const int wgs_s = (int)(((planes + zc - 1) / zc) * tiles);
                 if (nparts_out) *nparts_out = wgs_s;
                 if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + (D.qq ? 2 : 1) * (int64_t)wgs_s, 4 * MAX_VEC_BLOCKS)));
                 F.partials = c->partials + c->partials_off;
-#define PGD_STENCIL(DD)                                                                                       \
+#define PGD_STENCIL(DD, OC)                                                                                   \
     do {                                                                                                      \
-        if (dot && store && nty) k_spmv_stencil_march<true, true, DD, true><<<wgs_s, 256, 0, c->stream>>>(F);      \
-        else if (dot && store) k_spmv_stencil_march<true, true, DD, false><<<wgs_s, 256, 0, c->stream>>>(F);       \
-        else if (dot) k_spmv_stencil_march<true, false, DD, false><<<wgs_s, 256, 0, c->stream>>>(F);               \
-        else k_spmv_stencil_march<false, true, DD, false><<<wgs_s, 256, 0, c->stream>>>(F);                        \
+        if (dot && store && nty) k_spmv_stencil_march<true, true, DD, true, OC><<<wgs_s, 256, 0, c->stream>>>(F);      \
+        else if (dot && store) k_spmv_stencil_march<true, true, DD, false, OC><<<wgs_s, 256, 0, c->stream>>>(F);       \
+        else if (dot) k_spmv_stencil_march<true, false, DD, false, OC><<<wgs_s, 256, 0, c->stream>>>(F);               \
+        else k_spmv_stencil_march<false, true, DD, false, OC><<<wgs_s, 256, 0, c->stream>>>(F);                        \
     } while (0)
-                if (depth == 10) PGD_STENCIL(10); else if (depth == 8) PGD_STENCIL(8); else if (depth == 6) PGD_STENCIL(6);
-                else if (depth == 4) PGD_STENCIL(4); else PGD_STENCIL(3);
+                if (depth == 6) PGD_STENCIL(6, 2); else PGD_STENCIL(3, 2);
 #undef PGD_STENCIL
                 c->kcount[KC_STENCIL_MARCH] += 1;
                 if (timed2) PGD_TRY(prof_end(c, m, nrows, 16.0));
@@ -2231,7 +2274,7 @@ using namespace pgd;
 
 extern "C" {
 
-#ifdef PGD_STENCIL_TIMING
+#if defined(PGD_STENCIL_TIMING) || defined(PGD_STENCIL_WHATIF)
 int pgd_debug_read_partials(pgd_handle h, double *out, int first, int count) {
     PGD_CTX(c, h);
     PGD_HIP(c, hipMemcpyAsync(out, c->partials + first, (size_t)count * sizeof(double), hipMemcpyDeviceToHost, c->stream));
@@ -2256,7 +2299,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_FAULT_ITERATION && value >= -1 && value <= (1 << 30)) { c->fault_iteration = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_STENCIL && value >= 0 && value <= 1) { c->spmv_stencil = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK_STENCIL && value >= 0 && value <= 1024) { c->spmv_zchunk_stencil = (int)value; return PGD_OK; }
-    if (knob == PGD_TUNE_STENCIL_DEPTH && (value == 0 || value == 3 || value == 4 || value == 6 || value == 8 || value == 10)) { c->stencil_depth = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_STENCIL_DEPTH && (value == 0 || value == 3 || value == 6)) { c->stencil_depth = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_STENCIL_WG_PER_CU && value >= 1 && value <= 8) { c->stencil_wg_per_cu = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_FAULT_STAGE && value >= 0 && value <= 4) { c->fault_stage = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_FAULT_STALL_MS && value >= 0 && value <= 20000) { c->fault_stall_ms = (int)value; return PGD_OK; }

@@ -18,9 +18,11 @@ variant = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 ctx = _lib.Context(0)
 coords, cells = fem.box_mesh_arrays((0, 0, 0), (1, 1, 1), n - 1, n - 1, n - 1)
 mesh = ctx.mesh_upload(coords, cells)
+# the bench's operator: homogeneous Dirichlet conditions on the whole hull (PMC_NATURAL=1: natural boundaries, 27 row classes, no stencil form)
+bnd = None if os.environ.get("PMC_NATURAL") else np.where(np.any((coords <= 1e-12) | (coords >= 1 - 1e-12), axis=1))[0].astype(np.int32)
 del coords, cells
 ak, am = ctx.atom_assemble(mesh, fem.STIFF), ctx.atom_assemble(mesh, fem.MASS)
-op = ctx.op_combine(mesh, [ak, am], [1.0, 1.0])
+op = ctx.op_combine(mesh, [ak, am], [1.0, 1.0], bnd)
 nv = ctx.mesh_info(mesh)["nv"]
 x = ctx.vec_from(np.random.default_rng(1234).uniform(-1, 1, nv))
 y = ctx.vec_alloc(nv)

@@ -34,7 +34,7 @@ out = np.zeros(1024)
 # one more launch, then read the stamps before anything overwrites the scratch
 ctx.lib.pgd_spmv_dot_slot(ctx.h, op, x, y, x, 0, nv, 30)
 assert ctx.lib.pgd_debug_read_partials(ctx.h, out.ctypes.data_as(C.POINTER(C.c_double)), 4096, 1024) == 0
-for slot in range(4):
+for slot in range(4 if out.any() else 0):
     d = out[slot * 256: slot * 256 + 192].reshape(-1, 4)
     d = d[1:]          # the first row's first delta is an absolute time
     d = d[np.any(d != 0, axis=1)]
