@@ -1391,8 +1391,14 @@ __global__ void k_stencil_pick(const uint8_t *__restrict__ cls, double *__restri
         for (int s = 1; s < 8; ++s) id = id && table[k * 8 + cls_pos(s)] == 0.0;
         if (id) S->ident = k;
     }
-    const int base = cls[mid];
-    if (base == S->ident) return;                            // (a grid whose middle is eliminated: keep the dictionary form)
+    // base class: the tuple with the most couplings (the row in the middle of a thin grid sits next to a face); the middle row's on ties
+    int base = cls[mid], best = -1;
+    for (int k = 0; k < ncls; ++k) {
+        int nzc = 0;
+        for (int s = 1; s < 8; ++s) nzc += table[k * 8 + cls_pos(s)] != 0.0 ? 1 : 0;
+        if (nzc > best || (nzc == best && k == (int)cls[mid])) { best = nzc; base = k; }
+    }
+    if (base == S->ident) return;                            // (nothing but identity rows: keep the dictionary form)
     S->base = base;
     for (int s = 0; s < 8; ++s) S->c[s] = table[base * 8 + cls_pos(s)];
     if (S->ident >= 0) {                                     // the duplicate row of the free nodes with the identity tuple, then the zero class
@@ -2040,8 +2046,15 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
             coded = coded && zchunk_c <= DIAC_MAXCHUNK;
             // one stencil + eliminated nodes (dia_classify verified every row of the planes this launch reads couplings of: its
             // own and the plane below its first): couplings in scalar registers, four rows per thread, no table
-            if (coded && c->spmv_stencil && a->st_ok && c->spmv_zchunk_force <= 0 && D.z1 <= a->st_z1 && plane < ((int64_t)1 << 26) &&
-                (D.z0 == 0 ? a->st_z0 == 0 : D.z0 - 1 >= a->st_z0)) {
+            // (tests force the march onto small grids with PGD_TUNE_SPMV_ZCHUNK_FORCE, which selects the dictionary kernel - unless
+            // PGD_TUNE_SPMV_ZCHUNK_STENCIL names a march length for this one)
+            // Every plane the launch READS - its own and one halo plane either way - must be a verified plane or lie outside the grid
+            // (the kernel stages what is outside the verified planes as zeros: right for the rim of the grid, wrong for a ghost plane
+            // of a sharded slab, whose rows hold the neighbour rank's x)
+            const bool st_lower = D.z0 == 0 ? a->st_z0 == 0 : D.z0 - 1 >= a->st_z0;
+            const bool st_upper = D.z1 == D.nz ? a->st_z1 == D.nz : D.z1 + 1 <= a->st_z1;
+            if (coded && c->spmv_stencil && a->st_ok && (c->spmv_zchunk_force <= 0 || c->spmv_zchunk_stencil > 0) && st_lower && st_upper &&
+                plane < ((int64_t)1 << 26)) {
                 StencilArgs F;
                 F.cls = a->cls; F.ident = a->st_ident; F.x = x; F.y = y; F.flags = flags;
                 F.zv0 = a->st_z0; F.zv1 = a->st_z1; F.zm0 = a->st_zm0; F.zm1 = a->st_zm1;

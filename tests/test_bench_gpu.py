@@ -26,13 +26,13 @@ def test_bench_line_contract():
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["vs_baseline"] is None and d["dtype"] == "f64"
     assert d["value"] > 0 and abs(d["value"] * d["ms_per_step"] / 1e3 - 1.0) < 1e-9
     assert "workload" in d["config"] and d["config"]["us_per_pcg_iteration"] > 0
-    assert d["config"]["product_launches_by_kernel"]["diac_march"] > 0          # the row-class dictionary is what ran
+    assert d["config"]["product_launches_by_kernel"]["stencil_march"] > 0       # the stencil form of the row-class dictionary is what ran
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert 0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(r["achieved"] - r["bytes_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e9) <= 1e-6 * r["achieved"]
     spmv = r.get("spmv", r)                            # the product's entry: under roofline.spmv when the vector update dominates
-    assert "k_spmv_diac_march2" in spmv["kernel"] and spmv["bytes_per_row"] == 17.0 and 0 < spmv["frac"] <= 1.0
+    assert "k_spmv_stencil_march" in spmv["kernel"] and spmv["bytes_per_row"] == 16.0 and 0 < spmv["frac"] <= 1.0
     csr = spmv["csr_product"]
     assert csr["k_spmv_csr<dot,store,64>"]["launches_timed"] >= 100 and 0 < csr["k_spmv_csr<dot,store,64>"]["frac"] <= 1.0
     cb = d["cpu_baseline"]
@@ -40,6 +40,7 @@ def test_bench_line_contract():
     # the engine without the row-class dictionary and on the CSR kernels, timed in the same run
     gp = d["config"]["general_paths"]
     assert gp["plain_march"]["product_kernel"] in ("dia_march", "dia_rows") and gp["csr"]["product_kernel"] == "csr_dict"
+    assert gp["row_class_dictionary"]["product_kernel"] == "diac_march"
     assert 0 < gp["csr"]["passes_per_s"] <= gp["plain_march"]["passes_per_s"] * 1.2 and gp["plain_march"]["product_us"] > 0
     assert spmv["speedup_over_plain_diagonal_form_this_run"] > 1.0
     assert isinstance(d["config"]["launch_timing_samples_dropped_as_noops"], int)

@@ -529,6 +529,18 @@ def test_products_agree_at_bench_size(ctx, npts):
         # ... and the march on the row-class dictionary (one code byte per row), several chunk lengths
         assert 1 <= ctx.op_classify(op) <= 64
         ctx.tune(6, 8)
+        # (s) the STENCIL form (the hull is Dirichlet: one tuple + eliminated nodes) in the launch shape the solves take by default -
+        # marches that fill every workgroup slot once (256^3: 8 marches of 32 planes, an incomplete last group of steps) - and
+        # with marches of 7 / 33 planes
+        for L in (0, 7, 33):
+            ctx.tune(36, L)
+            c0 = ctx.kernel_counts()
+            ctx.vec_fill(yv, -1.0)
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
+            assert ctx.kernel_counts()["stencil_march"] == c0["stencil_march"] + 1
+            ys["stencil_march_%d" % L] = (ctx.vec_download(yv), ctx.slots_download(30, 1)[0])
+        ctx.tune(36, 0)
+        ctx.tune(35, 0)                               # ... and the dictionary form of the same classes from here on
         # (a) the launch shape the solves take by DEFAULT: as many planes per march as fill every resident workgroup slot exactly
         # once (PGD_TUNE_SPMV_ZCHUNK_CODED2 = 96: 256^3 -> 4 marches of 66 planes, 128^3 -> marches of 9) ...
         c0 = ctx.kernel_counts()
@@ -551,10 +563,13 @@ def test_products_agree_at_bench_size(ctx, npts):
         ctx.tune(6, 8)
         ctx.tune(21, 24)
         ctx.tune(32, 96)
+        ctx.tune(35, 1)
+        ctx.tune(36, 0)
     base = ys["csr"][0]
     # (the dot's partial sums are grouped per workgroup: different march lengths give different last bits of the DOT, never of y)
     assert len({ys["diac_march_%d" % zc][1] for zc in (24, 12, 5)} | {ys["diac_march_default_rule"][1]}) >= 2
-    for name in ("csr_dict", "dia_march", "dia_rows", "diac_march_default_rule", "diac_march_24", "diac_march_12", "diac_march_5"):
+    for name in ("csr_dict", "dia_march", "dia_rows", "stencil_march_0", "stencil_march_7", "stencil_march_33", "diac_march_default_rule",
+                 "diac_march_24", "diac_march_12", "diac_march_5"):
         assert np.array_equal(ys[name][0], base), (name, np.abs(ys[name][0] - base).max())
         assert abs(ys[name][1] - ys["csr"][1]) <= 1e-12 * np.abs(x) @ np.abs(base)
     assert np.all(base[bc] == x[bc])                                   # Dirichlet rows are identity rows
@@ -700,7 +715,7 @@ def test_single_sync_recurrence_walks_the_textbook_iterates(ctx):
                 k0 = ctx.kernel_counts()
                 it, rel = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, maxit)
                 k1 = ctx.kernel_counts()
-                assert k1["dia_march"] + k1["diac_march"] > k0["dia_march"] + k0["diac_march"]
+                assert sum(k1[k] for k in ("dia_march", "diac_march", "stencil_march")) > sum(k0[k] for k in ("dia_march", "diac_march", "stencil_march"))
                 x = ctx.vec_download(xv)
                 if maxit == 10000:
                     it2, _ = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, maxit)
@@ -948,6 +963,149 @@ def test_deferred_csr_values_and_atom_products(ctx):
         ctx.tune(28, 1)
     for v in (xv, yv, bv):
         ctx.vec_free(v)
+    for a in (ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
+@pytest.mark.parametrize("shape", sorted(GRID_SHAPES))
+def test_stencil_form_is_lossless(ctx, shape):
+    """k_spmv_stencil_march: where the row classes of an operator are ONE 8-tuple plus the rows it becomes next to eliminated
+    nodes and the rim of the grid - every row and slot verified bit by bit on the device - the z-march takes the couplings
+    from scalar registers (four rows per thread, 64 x 16 patches, buffer addressing, identity rows stored out of a register
+    ring).  y must be bit-identical to the march over the slot values for ANY x (non-zero entries on the Dirichlet rows
+    included): all march lengths incl. incomplete last groups, several tiles with partial last tiles, plane-aligned slabs.
+    Operators that are not of that form (natural boundaries, a Dirichlet face only, a Dirichlet node that exists in one
+    plane only) must keep the dictionary kernel; a Dirichlet column that runs through all planes keeps the stencil form."""
+    nx, ny, nz = GRID_SHAPES[shape]
+    coords, cells = F.box_mesh((0, 0, 0), (1.0, 0.7, 1.3), nx - 1, ny - 1, nz - 1)
+    h = ctx.mesh_upload(coords, cells)
+    n = coords.shape[0]
+    plane = nx * ny
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bnd = boundary_dofs(coords).astype(np.int32)
+    face = np.where(coords[:, 2] <= 1e-12)[0].astype(np.int32)
+    ix, iy = min(5, nx - 2), min(2, ny - 2)
+    column = (ix + nx * iy + plane * np.arange(nz)).astype(np.int32)             # an interior Dirichlet column through all planes
+    single = np.array([ix + nx * iy + plane * (nz // 2)], dtype=np.int32)       # ... and a single interior Dirichlet node
+    rng = np.random.default_rng(7)
+    x = rng.uniform(-1, 1, n)
+    xv, yv = ctx.vec_from(x), ctx.vec_alloc(n)
+    ctx.flags_reset()
+    cases = (("hull", bnd, True), ("hull + column", np.union1d(bnd, column).astype(np.int32), True),
+             ("hull + one interior node", np.union1d(bnd, single).astype(np.int32), False),
+             ("natural", np.zeros(0, dtype=np.int32), False), ("one face", face, False))
+    try:
+        for name, bc, expect in cases:
+            op = ctx.op_combine(h, [ak, am], [1.0, 0.37], bc)
+            assert ctx.op_symmetrize(op) is True
+            ctx.tune(7, 4)
+            ctx.tune(36, 0)
+            ctx.tune(19, 0)
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)                  # the march over the slot values
+            ctx.tune(19, 1)
+            y_ref, d_ref = ctx.vec_download(yv), ctx.slots_download(30, 1)[0]
+            assert 1 <= ctx.op_classify(op) <= 255
+            if len(bc):
+                assert np.array_equal(y_ref[bc], x[bc])                   # identity rows
+            for L in (1, 2, 3, 4, 7, 16, 1000):
+                ctx.tune(36, L)
+                k0 = ctx.kernel_counts()
+                ctx.vec_fill(yv, -5.0)
+                ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 31)
+                k1 = ctx.kernel_counts()
+                ran = {k for k in k1 if k1[k] != k0[k]}
+                assert ran == ({"stencil_march"} if expect else {"diac_march"}), (name, L, ran)
+                y = ctx.vec_download(yv)
+                assert np.array_equal(y, y_ref), (shape, name, L, np.abs(y - y_ref).max(), np.where(y != y_ref)[0][:8])
+                assert abs(ctx.slots_download(31, 1)[0] - d_ref) <= 1e-12 * np.abs(x) @ np.abs(y_ref)
+                if nz >= 5:
+                    z0, z1 = 1, nz - 1                                    # a plane-aligned slab: rows outside it untouched
+                    ctx.vec_fill(yv, -7.0)
+                    ctx.spmv_dot_slot(op, xv, yv, xv, z0 * plane, z1 * plane, 32)
+                    y2 = ctx.vec_download(yv)
+                    assert np.array_equal(y2[z0 * plane:z1 * plane], y_ref[z0 * plane:z1 * plane]), (shape, name, L)
+                    assert np.all(y2[:z0 * plane] == -7.0) and np.all(y2[z1 * plane:] == -7.0)
+                    s_ref = x[z0 * plane:z1 * plane] @ y_ref[z0 * plane:z1 * plane]
+                    assert abs(ctx.slots_download(32, 1)[0] - s_ref) <= 1e-12 * np.abs(x) @ np.abs(y_ref)
+            # the plain product without the fused dot (no w), and switched off
+            ctx.tune(36, 5)
+            ctx.vec_fill(yv, -1.0)
+            ctx.spmv(op, xv, yv)
+            assert np.array_equal(ctx.vec_download(yv), y_ref), (shape, name)
+            ctx.tune(35, 0)
+            k0 = ctx.kernel_counts()
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 31)
+            k1 = ctx.kernel_counts()
+            ctx.tune(35, 1)
+            assert k1["stencil_march"] == k0["stencil_march"] and k1["diac_march"] == k0["diac_march"] + 1
+            assert np.array_equal(ctx.vec_download(yv), y_ref)
+            # new values through the same handle: no stale stencil
+            op = ctx.op_combine(h, [ak, am], [2.0, 0.1], bc, op=op)
+            k0 = ctx.kernel_counts()
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 31)
+            k1 = ctx.kernel_counts()
+            assert k1["stencil_march"] == k0["stencil_march"] and k1["diac_march"] == k0["diac_march"]
+            ctx.atom_free(op)
+    finally:
+        ctx.tune(7, 0)
+        ctx.tune(36, 0)
+        ctx.tune(35, 1)
+        ctx.tune(19, 1)
+    for v in (xv, yv):
+        ctx.vec_free(v)
+    for a in (ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
+def test_pcg_on_the_stencil_form_walks_the_same_iterates(ctx):
+    """The library's PCG with the scaled operator in its stencil form (k_spmv_stencil_march) against the same solve on the
+    row-class dictionary: y is bit-identical, the fused dots are grouped per workgroup (64 x 16 patches instead of 64 x 8), so
+    the iterates agree to rounding - iteration counts within one, the solution to 1e-9, the true residual at the tolerance."""
+    from pgdrome_amd import fem
+    npts = 104
+    mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), npts - 1, npts - 1, npts - 1)
+    coords = mesh.coordinates()
+    h = ctx.mesh_upload(coords, mesh.cells())
+    n = coords.shape[0]
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bc = np.where(np.any((coords <= 1e-12) | (coords >= 1 - 1e-12), axis=1))[0].astype(np.int32)
+    rng = np.random.default_rng(21)
+    b = rng.uniform(-1, 1, n)
+    b[bc] = rng.uniform(-1, 1, bc.size)                  # non-zero Dirichlet values: the identity rows carry them
+    bv = ctx.vec_from(b)
+    out = {}
+    try:
+        for stencil in (1, 0):
+            ctx.tune(35, stencil)
+            op = ctx.op_combine(h, [ak, am], [1.0, 3.0], bc)
+            xv = ctx.vec_alloc(n)
+            k0 = ctx.kernel_counts()
+            it, rel = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, 10000)
+            k1 = ctx.kernel_counts()
+            st, coded = k1["stencil_march"] - k0["stencil_march"], k1["diac_march"] - k0["diac_march"]
+            # (launches replayed from the captured chunk are not counted: the eager first chunk and the capture are)
+            assert (st > 10 and coded == 0) if stencil else (st == 0 and coded > 10), (stencil, st, coded)
+            assert it > 100
+            xs = ctx.vec_download(xv)
+            out[stencil] = (it, rel, xs)
+            assert np.abs(xs[bc] - b[bc]).max() <= 1e-9        # identity rows: solved by the iteration like every other row
+            # the true residual through the CSR kernel of the unscaled operator
+            yv = ctx.vec_alloc(n)
+            ctx.flags_reset()
+            ctx.tune(3, 0)
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
+            ctx.tune(3, 1)
+            assert np.linalg.norm(b - ctx.vec_download(yv)) <= 1.05e-10 * np.linalg.norm(b)
+            for v in (yv, xv):
+                ctx.vec_free(v)
+            ctx.atom_free(op)
+    finally:
+        ctx.tune(35, 1)
+        ctx.tune(3, 1)
+    assert abs(out[1][0] - out[0][0]) <= 1 and np.linalg.norm(out[1][2] - out[0][2]) <= 1e-9 * np.linalg.norm(out[0][2])
+    ctx.vec_free(bv)
     for a in (ak, am):
         ctx.atom_free(a)
     ctx.mesh_free(h)
