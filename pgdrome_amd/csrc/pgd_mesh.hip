@@ -237,23 +237,31 @@ __device__ __forceinline__ void p1_geometry(const AsmArgs &A, const int *u, doub
 }
 
 // entry (i = test, j = trial) of the local matrix; closed forms for P1 simplices
+// gi = gradient of the row's own basis function (selected by the caller without dynamic register indexing: a private array
+// indexed with a run-time index lives in SCRATCH memory - 112 bytes per lane here, 40 GB of scratch traffic per atom at 256^3,
+// profiles/r03_assembly_counters.txt), gj = that of column j (compile-time j)
 template <int D>
-__device__ __forceinline__ double p1_entry(int kind, int da, int db, int i, int j, double vol,
-                                           const double g[D + 1][D], const double *wl) {
+__device__ __forceinline__ double p1_entry(int kind, int da, int db, int i, int j, double vol, const double (&gi)[D],
+                                           const double (&gj)[D], const double (&wl)[D + 1]) {
     constexpr double MFAC = 1.0 / ((D + 1) * (D + 2));
     constexpr double WFAC = (D == 1) ? 1.0 / 24.0 : (D == 2) ? 2.0 / 120.0 : 6.0 / 720.0;   // D!/(D+3)!
+    double gib = gi[0], gja = gj[0];                         // components db of gi and da of gj
+#pragma unroll
+    for (int k = 1; k < D; ++k) { if (k == db) gib = gi[k]; if (k == da) gja = gj[k]; }
     switch (kind) {
         case PGD_ATOM_MASS: return vol * MFAC * (i == j ? 2.0 : 1.0);
         case PGD_ATOM_STIFF: {
             double s = 0.0;
-            for (int k = 0; k < D; ++k) s += g[i][k] * g[j][k];
+#pragma unroll
+            for (int k = 0; k < D; ++k) s += gi[k] * gj[k];
             return vol * s;
         }
-        case PGD_ATOM_DUDV: return vol * g[i][db] * g[j][da];
-        case PGD_ATOM_CONV: return vol * (1.0 / (D + 1)) * g[j][da];
-        case PGD_ATOM_CONVT: return vol * (1.0 / (D + 1)) * g[i][db];
+        case PGD_ATOM_DUDV: return vol * gib * gja;
+        case PGD_ATOM_CONV: return vol * (1.0 / (D + 1)) * gja;
+        case PGD_ATOM_CONVT: return vol * (1.0 / (D + 1)) * gib;
         case PGD_ATOM_WMASS: {
             double s = 0.0;
+#pragma unroll
             for (int k = 0; k < D + 1; ++k) {
                 const double cijk = (i == j) ? (k == i ? 6.0 : 2.0) : ((k == i || k == j) ? 2.0 : 1.0);
                 s += cijk * wl[k];
@@ -262,14 +270,15 @@ __device__ __forceinline__ double p1_entry(int kind, int da, int db, int i, int 
         }
         case PGD_ATOM_WSTIFF: {
             double s = 0.0, wb = 0.0;
-            for (int k = 0; k < D; ++k) s += g[i][k] * g[j][k];
+#pragma unroll
+            for (int k = 0; k < D; ++k) s += gi[k] * gj[k];
+#pragma unroll
             for (int k = 0; k < D + 1; ++k) wb += wl[k];
             return vol * (wb * (1.0 / (D + 1))) * s;
         }
     }
     return 0.0;
 }
-
 template <int D>
 __global__ __launch_bounds__(TPB) void k_assemble_p1(AsmArgs A) {
     __shared__ double s_acc[ASM_CAP];
@@ -301,15 +310,27 @@ __global__ __launch_bounds__(TPB) void k_assemble_p1(AsmArgs A) {
             int i = 0;
 #pragma unroll
             for (int t = 0; t < D + 1; ++t) if (u[t] == r) i = t;
-            double vol, g[D + 1][D], wl[D + 1];
+            double vol, g[D + 1][D], wl[D + 1], gi[D];
             p1_geometry<D>(A, u, vol, g);
 #pragma unroll
             for (int t = 0; t < D + 1; ++t) wl[t] = A.w ? A.w[u[t]] : 0.0;
 #pragma unroll
+            for (int k = 0; k < D; ++k) {
+                gi[k] = g[0][k];
+#pragma unroll
+                for (int t = 1; t < D + 1; ++t) if (i == t) gi[k] = g[t][k];
+            }
+#pragma unroll
             for (int j = 0; j < D + 1; ++j) {
-                const double val = p1_entry<D>(A.kind, A.da, A.db, i, j, vol, g, wl);
+                const double val = p1_entry<D>(A.kind, A.da, A.db, i, j, vol, gi, g[j], wl);
+                // cols are sorted and contain u[j]: branch-free lower bound, log2(len) steps (the linear walk it replaces was ~1400
+                // LDS reads per row - 24 cells x 4 entries x ~15 - and most of the kernel's instructions)
                 int pos = 0;
-                while (pos < len - 1 && rc[pos] < u[j]) ++pos;   // cols are sorted and contain u[j]
+                for (int nleft = len; nleft > 1;) {
+                    const int half = nleft >> 1;
+                    pos += rc[pos + half - 1] < u[j] ? half : 0;
+                    nleft -= half;
+                }
                 acc[pos] += val;
             }
         }
