@@ -56,7 +56,9 @@ class TorchComm:
         self._slots = None
         self._work = {}
         self._views = {}
-        self.stats = {"halo": 0, "allreduce": 0}
+        # "allreduce": every all-reduce issued through this class; "allreduce_host": those whose result the HOST waits for (the
+        # functionals of the callbacks, the Gram data of a solve's start - not the slot all-reduces of a PCG loop)
+        self.stats = {"halo": 0, "allreduce": 0, "allreduce_host": 0}
         # PGD_SHARDED_DRIVER=python keeps the recurrence in this file (torch.distributed transport) without a code change
         if in_library and getattr(backend, "name", "") == "hip" and os.environ.get("PGD_SHARDED_DRIVER", "library") != "python":
             self.bind_library()
@@ -143,6 +145,7 @@ class TorchComm:
         t = self.torch.tensor([float(value)], dtype=self.torch.float64, device=dev)
         self.dist.all_reduce(t)
         self.stats["allreduce"] += 1
+        self.stats["allreduce_host"] += 1
         return float(t.item())
 
     def allreduce_maxloc(self, value, payload):
@@ -160,6 +163,7 @@ class TorchComm:
         t = self.torch.tensor(np.asarray(values, dtype=np.float64), dtype=self.torch.float64, device=dev)
         self.dist.all_reduce(t)
         self.stats["allreduce"] += 1
+        self.stats["allreduce_host"] += 1
         return t.cpu().numpy()
 
     def _staged(self, t):

@@ -2167,6 +2167,117 @@ def _dots_with_stored_products(be, atom, other, Ag, swapped, lo, hi, lay=None):
     return float(vals[0])
 
 
+# ---- learned prefetch of the functionals of one call site -----------------------------------------------------------
+# A user callback asks for its functionals one assemble() at a time and uses each answer on the spot (solver.py:547-612):
+# every answer on a large or row-sharded dimension is a device pass + a host synchronisation (+ an all-reduce across the
+# ranks).  Which functionals a call site asks for hardly changes from pass to pass - the same atoms, the current iterates
+# of the other dimensions, the stored modes, the loads - so a call site RECORDS its requests (functional_scope) and the next
+# time it is entered they are computed ahead of the callback in one batch: the missing products, one multi-dot per left
+# factor, ONE host synchronisation and ONE fixed-length all-reduce; the callback's assemble() calls then find their values
+# in the memo.  Nothing depends on the guess being right: a request that was not prefetched takes the ordinary path.
+PREFETCH_FUNCTIONALS = os.environ.get("PGD_PREFETCH_FUNCTIONALS", "1") != "0"
+_PREFETCH_MAX = 510                      # values per batch (the all-reduced message has a fixed length)
+_FUNCTIONAL_PLANS = {}                   # call-site tag -> [(lay, atom, f_ref, g_ref, symmetric)]
+_RECORDING = None
+STATS_PREFETCH = {"batches": 0, "values": 0, "requests": 0, "hits": 0}
+
+
+class functional_scope:
+    """``with functional_scope(tag, iterates):`` around the evaluation of a call site's functionals.  `iterates`: the vectors
+    that change from call to call (the current factors of all dimensions), in an order that is the same every time; every
+    other vector of a request is taken to be immutable (a stored mode, a load) and referenced weakly."""
+
+    def __init__(self, tag, iterates):
+        self.tag, self.iterates = tag, list(iterates)
+
+    def _ref(self, v):
+        for k, it in enumerate(self.iterates):
+            if it is v:
+                return ("it", k)
+        return ("obj", weakref.ref(v), v.version)
+
+    def _deref(self, ref):
+        if ref[0] == "it":
+            return self.iterates[ref[1]] if ref[1] < len(self.iterates) else None
+        v = ref[1]()
+        return v if v is not None and v.version == ref[2] else None
+
+    def note(self, lay, atom, f, g, symmetric):
+        self.seen.append((lay, atom, self._ref(f), self._ref(g), symmetric))
+
+    def __enter__(self):
+        global _RECORDING
+        self.outer, self.seen = _RECORDING, []
+        if PREFETCH_FUNCTIONALS:
+            plan = _FUNCTIONAL_PLANS.get(self.tag)
+            if plan:
+                reqs = []
+                for lay, atom, fr, gr, sym in plan:
+                    f, g = self._deref(fr), self._deref(gr)
+                    if f is not None and g is not None:
+                        reqs.append((lay, atom, f, g, sym))
+                _prefetch_functionals(reqs)
+            _RECORDING = self
+        return self
+
+    def __exit__(self, *exc):
+        global _RECORDING
+        if PREFETCH_FUNCTIONALS:
+            _RECORDING = self.outer
+            if exc[0] is None:
+                _FUNCTIONAL_PLANS[self.tag] = self.seen
+        return False
+
+
+def _prefetch_functionals(reqs):
+    be = get_backend()
+    todo = {}
+    for lay, atom, f, g, sym in reqs:
+        key = (atom, id(f), f.version, id(g), g.version)
+        hit = _SCALAR_MEMO.get(key)
+        if hit is not None and hit[1]() is f and hit[2]() is g:
+            continue
+        if lay.part is None and g._small():
+            continue                                     # host arithmetic: nothing to batch
+        Ag, other = _cached_product(atom, g), f
+        if Ag is None and sym and f is not g:
+            Af = _cached_product(atom, f)
+            if Af is not None:
+                Ag, other = Af, g
+        if Ag is None:
+            if lay.part is None and not (KEEP_FUNCTIONAL_PRODUCTS and be.atom_product_form(atom) > 0):
+                continue                                 # the fused product-dot over the CSR atom stays the cheaper way
+            Ag = _matvec_cached(lay, atom, g)
+        todo.setdefault(id(lay), (lay, []))[1].append((key, f, g, other, Ag))
+    for lay, items in todo.values():
+        if len(items) < 2 or len(items) > _PREFETCH_MAX:
+            continue
+        lo, hi = lay.owned_range()
+        groups = {}
+        for it in items:
+            groups.setdefault(id(it[3]), (it[3], []))[1].append(it)
+        vals, order = [], []
+        for other, its in groups.values():
+            outs = [it[4].dev() for it in its]
+            local = be.vec_multidot(other.dev(), outs, lo, hi) if len(outs) > 1 else [be.vec_dot(other.dev(), outs[0], lo, hi)]
+            vals.extend(float(v) for v in local)
+            order.extend(its)
+        if lay.part is not None:
+            k = len(vals)
+            msg = np.zeros(_PREFETCH_MAX + 2)
+            msg[0], msg[1], msg[2:2 + k] = k, k * k, vals
+            msg = lay.part.comm.allreduce_array(msg)
+            if lay.part.comm.world * msg[1] != msg[0] * msg[0]:      # the ranks' plans differ in length: nobody keeps anything
+                LOG.warning("prefetched functionals: the ranks hold different plans; ordinary path")
+                continue
+            vals = msg[2:2 + k]
+        _memo_make_room(len(order))
+        for (key, f, g, _o, _a), val in zip(order, vals):
+            _SCALAR_MEMO[key] = (float(val), weakref.ref(f), weakref.ref(g))
+        STATS_PREFETCH["batches"] += 1
+        STATS_PREFETCH["values"] += len(order)
+
+
 def _bilinear_scalar(lay, atom, f, g, symmetric=False):
     """f^T A g with memoisation on (atom, vector identity, vector version).
 
@@ -2174,8 +2285,13 @@ def _bilinear_scalar(lay, atom, f, g, symmetric=False):
     change, and the right-hand-side assembly has multiplied them once - the functional is a dot
     product (2 vector reads) instead of a pass over the matrix."""
     key = (atom, id(f), f.version, id(g), g.version)
+    if _RECORDING is not None:
+        _RECORDING.note(lay, atom, f, g, symmetric)
+        STATS_PREFETCH["requests"] += 1
     hit = _SCALAR_MEMO.get(key)
     if hit is not None and hit[1]() is f and hit[2]() is g:
+        if _RECORDING is not None:
+            STATS_PREFETCH["hits"] += 1
         return hit[0]
     be = get_backend()
     lo, hi = lay.owned_range()
@@ -2863,6 +2979,7 @@ def solve(eq, u, bcs=None, solver_parameters=None, **kw):
 
 
 def clear_caches():
+    _FUNCTIONAL_PLANS.clear()
     _SCALAR_MEMO.clear()
     _MV_CACHE.clear()
     _DS_CACHE.clear()

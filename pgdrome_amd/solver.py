@@ -299,15 +299,17 @@ class PGDProblem:
             elif crit == "norm":
                 # |new - old|^2 of the rank-one tensors = nn + oo - 2 no, factor by factor
                 nn = no = oo = 1.0
-                for d in range(D):
-                    if self._is_fd(solve_modes, d):
-                        nn *= self._mm_quad(d, Fs[d], Fs[d])
-                        no *= self._mm_quad(d, Fs[d], Fs_init[d])
-                        oo *= self._mm_quad(d, Fs_init[d], Fs_init[d])
-                    else:
-                        nn *= fem.norm(Fs[d]) ** 2
-                        no *= fem.assemble(fem.inner(Fs[d], Fs_init[d]) * fem.dx(self.meshes[d]))
-                        oo *= fem.norm(Fs_init[d]) ** 2
+                its = [F.vector() for F in list(Fs) + list(Fs_init) if hasattr(F, "vector")]
+                with fem.functional_scope(("stop", id(self)), its):
+                    for d in range(D):
+                        if self._is_fd(solve_modes, d):
+                            nn *= self._mm_quad(d, Fs[d], Fs[d])
+                            no *= self._mm_quad(d, Fs[d], Fs_init[d])
+                            oo *= self._mm_quad(d, Fs_init[d], Fs_init[d])
+                        else:
+                            nn *= fem.norm(Fs[d]) ** 2
+                            no *= fem.assemble(fem.inner(Fs[d], Fs_init[d]) * fem.dx(self.meshes[d]))
+                            oo *= fem.norm(Fs_init[d]) ** 2
                 max_error = float(np.sqrt(np.absolute(nn + oo - 2 * no)))
                 if max_error < self.tol_fp_it:
                     self.logger.info(f"fix point iteration converged !!! in number of steps: {fpi + 1} (error {max_error:8.6e})")
@@ -335,9 +337,12 @@ class PGDProblem:
         bc = self.bc[dim]
 
         def forms(u):
-            a = self.lhs_fct(u, var_F, Fs, self.meshes, self.dom, self.param, self.prob[dim], dim)
-            l = self.rhs_fct(u, var_F, Fs, self.meshes, self.dom, self.param, self.load, self.PGD_func,
-                             self.prob[dim], n_enr, dim)
+            # (the functionals the two callbacks evaluate - eagerly, one assemble() at a time - are learned per call site and
+            # computed ahead in one batch the next time round: fem.functional_scope)
+            with fem.functional_scope(("solve", id(self), dim), [F.vector() for F in Fs if hasattr(F, "vector")]):
+                a = self.lhs_fct(u, var_F, Fs, self.meshes, self.dom, self.param, self.prob[dim], dim)
+                l = self.rhs_fct(u, var_F, Fs, self.meshes, self.dom, self.param, self.load, self.PGD_func,
+                                 self.prob[dim], n_enr, dim)
             return a, l
 
         if self._is_fem(solve_modes, dim):

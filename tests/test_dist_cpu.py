@@ -133,6 +133,40 @@ def test_batched_functionals_on_a_sharded_dimension_use_one_allreduce():
     assert a["stats"]["allreduce"] < b["stats"]["allreduce"], (a["stats"], b["stats"])
 
 
+def test_prefetched_functionals_cut_the_collectives_of_a_pass():
+    """fem.functional_scope: the functionals a call site asked for last time are computed ahead of the callbacks in one batch -
+    one all-reduce per call site instead of one per assemble() - and the run is the same run."""
+    ctx = mp.get_context("spawn")
+    outs = {}
+    saved = os.environ.get("PGD_PREFETCH_FUNCTIONALS")
+    try:
+        for pre in ("1", "0"):
+            os.environ["PGD_PREFETCH_FUNCTIONALS"] = pre
+            q = ctx.Queue()
+            port = _free_port()
+            procs = [ctx.Process(target=_worker, args=(r, 2, port, (4, 3, 5), q, True, "norm")) for r in range(2)]
+            for pr in procs:
+                pr.start()
+            outs[pre] = q.get(timeout=240)
+            for pr in procs:
+                pr.join(timeout=120)
+                assert pr.exitcode == 0
+    finally:
+        if saved is None:
+            os.environ.pop("PGD_PREFETCH_FUNCTIONALS", None)
+        else:
+            os.environ["PGD_PREFETCH_FUNCTIONALS"] = saved
+    a, b = outs["1"], outs["0"]
+    assert a["num_fp_it"] == b["num_fp_it"]
+    np.testing.assert_allclose(a["amplitude"], b["amplitude"], rtol=1e-12)
+    for m in range(len(a["modes_x"])):
+        assert np.linalg.norm(a["modes_x"][m] - b["modes_x"][m]) <= 1e-10 * np.linalg.norm(b["modes_x"][m])
+    # (both counts include the all-reduces of the host-driven PCG loop of the oracle backend, the same number in both runs)
+    assert a["stats"]["allreduce_host"] < b["stats"]["allreduce_host"], (a["stats"], b["stats"])
+    print("host-synchronised all-reduces with / without the prefetch:", a["stats"]["allreduce_host"], b["stats"]["allreduce_host"],
+          "passes", sum(a["num_fp_it"]))
+
+
 def test_slab_ranges_cover_all_planes():
     from pgdrome_amd.dist import slab_ranges
     for n, w in ((256, 8), (256, 3), (7, 7), (10, 4)):
