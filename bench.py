@@ -264,6 +264,8 @@ def main():
                    "seconds_in_pcg_solves": pcg_seconds, "seconds_timed": elapsed,
                    "product_launches_by_kernel": kc,
                    "launch_timing_samples_dropped_as_noops": prof.get("dropped_noop_samples"),
+                   "row_class_classifications": be.ctx.classify_counts(),
+                   "host_synchronised_allreduces_per_step": ((comm.stats.get("allreduce_host", 0) / max(W + K, 1)) if sharded else None),
                    "sharded_iteration_phases": comm_phases,
                    "comm_timeout_s": (args.comm_timeout if sharded else None),
                    "allreduces_outside_the_pcg_loop": (comm.stats.get("allreduce") if sharded else None),

@@ -298,6 +298,11 @@ int pgd_vec_multidot(pgd_handle ctx, pgd_handle x, const pgd_handle *ys, int k, 
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
+    PGD_TUNE_CLS_CACHE = 39, /* 1 (default): a mesh remembers the class codes of the operators classified on it (by the signature of their
+                                Dirichlet set, scaled or not): the next operator with that structure - the same atoms with other
+                                coefficients, every solve of a fixed-point pass - copies the codes, rebuilds the table from the classes'
+                                representative rows and verifies EVERY row against its class bit by bit (any mismatch: full classification);
+                                0: always the full classification */
     PGD_TUNE_STENCIL_DEPTH = 38, /* plane fetches in flight per workgroup of k_spmv_stencil_march: 3 or 6 (0, default: chosen by the launcher) */
     PGD_TUNE_STENCIL_WG_PER_CU = 37, /* resident workgroups per CU assumed for k_spmv_stencil_march (default 2): sets the march length */
     PGD_TUNE_SPMV_ZCHUNK_STENCIL = 36, /* > 0: planes per march of k_spmv_stencil_march; 0 (default): as many as fill every resident
@@ -409,6 +414,9 @@ int pgd_prof_read_dropped(pgd_handle ctx, int64_t *dropped);
  * [2] k_spmv_sym (row order), [3] k_spmv_dia_rows, [4] k_spmv_dia_march*, [5] k_spmv_multi, [6] k_spmv_diac_march2, [7] k_spmv_stencil_march; tests use them to
  * prove which kernel a call reached, bench.py for its per-kernel breakdown.                          */
 int pgd_kernel_counts(pgd_handle ctx, int64_t *out, int n);
+/* Row-class classifications since the context was created: done in full (three passes over the slot values with hashing) / served
+ * by the mesh's structure cache (codes copied, every row verified against its class: one pass) - PGD_TUNE_CLS_CACHE.   */
+int pgd_classify_counts(pgd_handle ctx, int64_t *full, int64_t *cached);
 /* One HIP-event stopwatch on the context's stream (bench.py's micro-sections: N launches between start
  * and stop; stop synchronises on its event).                                                        */
 /* Calibration of the PMC byte model: one pass over `vec` with 8- or 16-byte loads (store = 0) or stores (store = 1)

@@ -105,6 +105,7 @@ SIGNATURES = {
     "pgd_prof_read_update": (C.c_int, [H, PI64, PD, PD]),
     "pgd_prof_read_dropped": (C.c_int, [H, PI64]),
     "pgd_kernel_counts": (C.c_int, [H, PI64, C.c_int]),
+    "pgd_classify_counts": (C.c_int, [H, PI64, PI64]),
     "pgd_calib_stream": (C.c_int, [H, H, C.c_int, C.c_int]),
     "pgd_timer_start": (C.c_int, [H]),
     "pgd_timer_stop": (C.c_int, [H, PD]),
@@ -575,6 +576,11 @@ class Context:
         out = (C.c_int64 * 8)()
         self._ck(self.lib.pgd_kernel_counts(self.h, out, 8))
         return {k: int(out[i]) for i, k in enumerate(self.KERNEL_FAMILIES)}
+
+    def classify_counts(self):
+        full, cached = I64(), I64()
+        self._ck(self.lib.pgd_classify_counts(self.h, C.byref(full), C.byref(cached)))
+        return {"full": full.value, "cached": cached.value}
 
     def calib_stream(self, v, bytes_per_lane, store=False):
         self._ck(self.lib.pgd_calib_stream(self.h, v, int(bytes_per_lane), int(bool(store))))

@@ -72,6 +72,20 @@ struct Mesh : Obj {
     // edge vectors as whole lattice steps, so congruent cells get identical local matrices
     bool lattice = false;
     double lat_h[3] = {0.0, 0.0, 0.0};
+    // What dia_classify learned about operators on this mesh (pgd_spmv.hip): the class CODES of an operator depend on its atoms'
+    // structure and its Dirichlet set, not on the coefficients it is combined with - every solve of a fixed-point pass classifies
+    // "the same operator with other numbers".  A later classification with the same signature copies the codes, rebuilds the class
+    // table from the representative rows and VERIFIES every row against its class bit by bit (+ the class-level stencil relations):
+    // one pass over the slot values instead of three with hashing; any mismatch falls back to the full classification.
+    struct ClsCache {
+        uint64_t sig = 0; int scaled = 0, z_lo = 0, z_hi = 0, ncls = 0;
+        uint8_t *codes = nullptr; int *same = nullptr; int *reps = nullptr; size_t bytes = 0;
+        bool st_ok = false; int ident = -1, base = -1, zm0 = 0, zm1 = 0;
+        uint8_t zero_pat[256];      // per class: bit s = slot s is an exact zero (a coupling to an eliminated node / the rim)
+        uint64_t used = 0;
+    };
+    mutable std::vector<ClsCache> cls_cache;
+    mutable uint64_t cls_clock = 0;
     uint16_t *pids = nullptr;    // nv
     int *dict_off = nullptr;     // dict_count x DICT_DLEN relative offsets
     int dict_count = 0;          // 0: dictionary not available (irregular pattern) -> plain CSR kernel
@@ -79,6 +93,7 @@ struct Mesh : Obj {
         for (void *p : {(void *)coords, (void *)cells, (void *)cellsN, (void *)v2c_ptr, (void *)v2c,
                         (void *)row_ptr, (void *)cols, (void *)pids, (void *)dict_off, (void *)sym_tab})
             if (p) (void)hipFree(p);
+        for (ClsCache &e : cls_cache) if (e.same) (void)hipFree(e.same);      // (the block starts at `same`)
     }
 };
 
@@ -101,6 +116,7 @@ struct Csr : Obj {
     int *cls_same = nullptr;       // per plane: same codes, row by row, as the plane below
     double *cls_table = nullptr;   // owns the allocation: table, then the codes
     int cls_count = 0;
+    uint64_t bc_sig = 0;           // signature of the Dirichlet set the operator was combined with (a hint for Mesh::cls_cache)
     // the classes are ONE stencil + eliminated nodes on the planes [st_z0, st_z1) (dia_classify / k_stencil_verify): couplings
     // c[slot], identity class id; valid exactly as long as cls_count > 0
     bool st_ok = false;
@@ -204,6 +220,8 @@ struct Ctx {
     int atom_fast = 1;            // products with an atom whose diagonal form exists take the z-march (+ its own row classes, looked for once)
     int lazy_csr = 1;             // pgd_op_combine forms only the diagonal form where it can; CSR values on first use
     uint64_t next_serial = 1;
+    int cls_cache_on = 1;         // classification of an operator whose structure was seen before: codes copied, every row verified (PGD_TUNE_CLS_CACHE)
+    int64_t cls_fast = 0, cls_full = 0;      // classifications served by the cache / done in full
     int spmv_stencil = 1;         // ... and its stencil form (couplings in scalar registers, four rows per thread) where every row verifies
     int spmv_zchunk_stencil = 0;  // > 0: planes per march of k_spmv_stencil_march (0: fill every workgroup slot once)
     int stencil_depth = 0;        // plane fetches in flight per workgroup of k_spmv_stencil_march (0: chosen from the march length; 3 or 6)

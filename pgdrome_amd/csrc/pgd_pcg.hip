@@ -9,6 +9,8 @@
 // bank, and a `done` flag turns every later launch into a no-op, so the host
 // only looks at the flag every CHECK_EVERY iterations.  All reductions are
 // wavefront-shuffle -> LDS -> fixed-order final pass: bitwise reproducible.
+#include <chrono>
+
 #include "pgd_internal.h"
 
 #include <algorithm>
@@ -1349,6 +1351,16 @@ int pgd_op_combine(pgd_handle h, pgd_handle mh, const pgd_handle *atoms, const d
     for (int t = 0; t < n; ++t) { o->rec_serials[(size_t)t] = atom_objs[t]->serial; o->rec_versions[(size_t)t] = atom_objs[t]->version; }
     if (o->rec_bc && o->rec_bc_bytes < (size_t)nbc * sizeof(int)) { dev_release(c, o->rec_bc, o->rec_bc_bytes); o->rec_bc = nullptr; }
     o->rec_nbc = nbc;
+    {   // signature of the Dirichlet set + the atoms' identities: only a HINT for the mesh's classification cache (a sample of the
+        // list: what the cache hands back is verified row by row)
+        uint64_t hsig = 0x9e3779b97f4a7c15ull ^ (uint64_t)nbc;
+        auto mix = [&](uint64_t v) { hsig = (hsig ^ v) * 0xff51afd7ed558ccdull; hsig ^= hsig >> 32; };
+        const int64_t step = nbc > 4096 ? nbc / 4096 : 1;
+        for (int64_t i = 0; i < nbc; i += step) mix((uint64_t)(uint32_t)bc_dofs[i]);
+        if (nbc > 0) mix((uint64_t)(uint32_t)bc_dofs[nbc - 1]);
+        for (int t = 0; t < n; ++t) mix(atom_objs[t]->serial);
+        o->bc_sig = hsig ? hsig : 1;
+    }
     const uint8_t *mask = nullptr;
     if (nbc > 0) {
         if (!o->rec_bc) {
@@ -1398,6 +1410,10 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     if (!o || !m || !b || !x || b->n != m->nv || x->n != m->nv || b == x || maxit < 0)
         return fail(c, PGD_ERR_INVALID, "pcg_solve: invalid handles or size mismatch");
     const int64_t n = m->nv;
+    const bool dbg_t = getenv("PGD_DEBUG_PCG") != nullptr;
+    auto dbg_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double dbg_t0 = dbg_now();
+    double dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0;
     struct ProfIterGuard { Ctx *c; ~ProfIterGuard() { c->prof_iter = -1; } } prof_iter_guard{c};
     c->prof_pend.clear();
     PGD_TRY(csr_diag_inv(c, m, o));
@@ -1548,6 +1564,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     // 256^3 the replay still saves ~2 % (549 vs 560 us per iteration).  With launch timing on, every PROF_EAGER_EVERY-th
     // chunk is issued eagerly so that its products carry their HIP events; the capture itself records none.
     hipGraphExec_t gexec = nullptr;
+    if (dbg_t) { (void)hipStreamSynchronize(c->stream); dbg_t1 = dbg_now(); }
     if (maxit >= CHECK_EVERY) {
         // everything a chunk allocates lazily must exist before the capture starts
         PGD_TRY(ensure_partials(c, std::max<int64_t>(4 * (int64_t)MAX_VEC_BLOCKS, 2 * ((n + 63) / 64) + 64)));
@@ -1568,6 +1585,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     }
     int f[4] = {0, 0, 0, 0};
     int enq = 0, rc_loop = PGD_OK;
+    if (dbg_t) dbg_t2 = dbg_now();
     auto issue = [&](int chunk) -> int {
         const bool eager_for_timing = c->prof && ((enq / CHECK_EVERY) % PROF_EAGER_EVERY == 0);
         if (gexec && chunk == CHECK_EVERY && !eager_for_timing) {
@@ -1612,6 +1630,8 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
             enq += chunk;
         }
     }
+    if (dbg_t) { (void)hipStreamSynchronize(c->stream); dbg_t3 = dbg_now(); }
+    if (dbg_t) fprintf(stderr, "[pcg_solve] n %lld graph %s iterations queued %d counted %d stencil %d cls %d | setup %.2f ms capture %.2f ms loop %.2f ms = %.1f us/it\n", (long long)n, gexec ? "yes" : "NO", enq, f[1], (int)o->st_ok, o->cls_count, 1e3 * (dbg_t1 - dbg_t0), 1e3 * (dbg_t2 - dbg_t1), 1e3 * (dbg_t3 - dbg_t2), 1e6 * (dbg_t3 - dbg_t2) / (f[1] > 0 ? f[1] : 1));
     if (gexec) (void)hipGraphExecDestroy(gexec);
     c->prof_iter = -1;
     // launch timing: the product of iteration k ran if no earlier iteration had set the done flag - f[1] iterations were counted, and in

@@ -17,6 +17,9 @@
 //
 // The logical row-block index is remapped so each XCD walks a contiguous range
 // of row blocks (neighbouring blocks share x planes in that XCD's L2).
+#include <chrono>
+#include <cstring>
+
 #include "pgd_internal.h"
 
 #include <algorithm>
@@ -1594,6 +1597,83 @@ __global__ __launch_bounds__(TPB) void k_cls_planes(const uint8_t *__restrict__ 
     if (threadIdx.x == 0) same[z] = s_diff ? 0 : 1;
 }
 
+// ---- classification with known codes (Mesh::cls_cache)
+__global__ void k_cls_table_known(const double *__restrict__ uvals, int64_t stride, int64_t nv, const int *__restrict__ reps, int ncls,
+                                  double *__restrict__ table) {
+    const int k = threadIdx.x;
+    if (k < ncls) {
+        const int64_t r = reps[k];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) table[k * 8 + cls_pos(s)] = (r >= 0 && r < nv) ? uvals[(int64_t)s * stride + r] : 0.0;
+    } else if (k == ncls) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) table[k * 8 + s] = 0.0;                 // the zero class
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_cls_verify_known(const double *__restrict__ uvals, int64_t stride, int64_t nv,
+                                                          const double *__restrict__ table, const uint8_t *__restrict__ cls, int ncls,
+                                                          int *__restrict__ info) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= nv) return;
+    const int k = cls[i];
+    bool same = k < ncls;
+    if (same) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            same = same && __double_as_longlong(uvals[(int64_t)s * stride + i]) == __double_as_longlong(table[k * 8 + cls_pos(s)]);
+    }
+    if (!same) info[1] = 2;
+}
+
+struct ZeroPat { uint8_t b[256]; };
+
+// the class-level relations of the stencil form for known codes: the identity tuple, and every class = the base tuple with
+// exact zeros where (and only where) the structure - verified row by row when the codes were first seen - has them
+__global__ void k_stencil_known(const double *__restrict__ table, int ncls, int ident, int base, ZeroPat pat, StencilInfo *S) {
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    const int k = threadIdx.x;
+    if (k < ncls) {
+        bool good = true;
+        if (k == ident) {
+            good = table[k * 8 + cls_pos(0)] == 1.0;
+            for (int s = 1; s < 8; ++s) good = good && table[k * 8 + cls_pos(s)] == 0.0;
+        } else {
+            good = __double_as_longlong(table[k * 8 + cls_pos(0)]) == __double_as_longlong(table[base * 8 + cls_pos(0)]);
+            for (int s = 1; s < 8; ++s) {
+                const double v = table[k * 8 + cls_pos(s)];
+                good = good && (((pat.b[k] >> s) & 1) ? v == 0.0
+                                                      : __double_as_longlong(v) == __double_as_longlong(table[base * 8 + cls_pos(s)]));
+            }
+        }
+        if (!good) s_bad = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        S->ok = s_bad ? 0 : 1; S->ident = ident; S->base = base; S->split = 0;
+        for (int s = 0; s < 8; ++s) S->c[s] = table[base * 8 + cls_pos(s)];
+    }
+}
+
+// after a full classification: a representative row per class, the zero patterns
+__global__ __launch_bounds__(TPB) void k_cls_reps(const uint8_t *__restrict__ cls, int64_t nv, int *__restrict__ reps) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    const bool active = i < nv;
+    const int code = active ? (int)cls[i] : -1;
+    // one atomic per distinct code of the wavefront (its lowest lane holds the lowest row), and none where the class already has
+    // a representative further down: 16.7 M atomics on nine addresses took 188 ms
+    unsigned long long todo = __ballot(active);
+    const int lane = threadIdx.x & 63;
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int c0 = __shfl(code, leader);
+        todo &= ~__ballot(active && code == c0);
+        if (lane == leader && reps[c0] > (int)i) atomicMin(&reps[c0], (int)i);
+    }
+}
+
 // Row classes of the operator's CURRENT slot values (a->uvals, diagonal form).  a->cls_count > 0 afterwards when the
 // dictionary exists; any later change of the slot values must reset it (sym_scale, combine_dia, ensure_sym do).
 int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
@@ -1616,19 +1696,60 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
     }
     ClsScratch *S = (ClsScratch *)c->cls_scratch;
     hipStream_t st = c->stream;
+    const int g = (int)((m->nv + TPB - 1) / TPB);
+    int z_lo = 0, z_hi = nzp;
+    if (zrange_lo >= 0) { z_lo = std::max(0, zrange_lo); z_hi = std::min(nzp, zrange_hi); }
+    StencilInfo *SI = reinterpret_cast<StencilInfo *>(S + 1);
+    const bool try_stencil = c->spmv_stencil && z_hi - z_lo >= 3;
+    struct { int info[4]; StencilInfo si; } host;
+    const int scaled_key = (a->uvals_scaled ? 1 : 0) + (a->uvals_unit ? 2 : 0) + (try_stencil ? 4 : 0);
+    // ---- known structure: codes copied, table from the representative rows, EVERY row compared with its class bit by bit
+    if (c->cls_cache_on) {
+        for (size_t e = 0; e < m->cls_cache.size(); ++e) {
+            Mesh::ClsCache &E = m->cls_cache[e];
+            if (E.sig != a->bc_sig || E.scaled != scaled_key || E.z_lo != z_lo || E.z_hi != z_hi || !E.codes) continue;
+            PGD_HIP(c, hipMemsetAsync(S->info, 0, sizeof S->info, st));
+            PGD_HIP(c, hipMemcpyAsync(a->cls, E.codes, (size_t)m->nv, hipMemcpyDeviceToDevice, st));
+            PGD_HIP(c, hipMemcpyAsync(a->cls_same, E.same, (size_t)nzp * sizeof(int), hipMemcpyDeviceToDevice, st));
+            k_cls_table_known<<<1, 256, 0, st>>>(a->uvals, a->uvals_stride, m->nv, E.reps, E.ncls, a->cls_table);
+            k_cls_verify_known<<<g, TPB, 0, st>>>(a->uvals, a->uvals_stride, m->nv, a->cls_table, a->cls, E.ncls, S->info);
+            host.si.ok = 0;
+            if (E.st_ok) {
+                ZeroPat zp;
+                memcpy(zp.b, E.zero_pat, sizeof zp.b);
+                k_stencil_known<<<1, 256, 0, st>>>(a->cls_table, E.ncls, E.ident, E.base, zp, SI);
+            }
+            host.info[1] = 1;
+            PGD_HIP(c, hipMemcpyAsync(host.info, S->info, sizeof host.info, hipMemcpyDeviceToHost, st));
+            if (E.st_ok) PGD_HIP(c, hipMemcpyAsync(&host.si, SI, sizeof(StencilInfo), hipMemcpyDeviceToHost, st));
+            PGD_HIP(c, hipStreamSynchronize(st));
+            PGD_LAUNCH_CHECK(c);
+            if (host.info[1] != 0 || (E.st_ok && !host.si.ok)) {          // not that structure after all: forget it, classify in full
+                (void)hipFree(E.same);
+                m->cls_cache.erase(m->cls_cache.begin() + (long)e);
+                break;
+            }
+            E.used = ++m->cls_clock;
+            c->cls_fast += 1;
+            a->cls_count = E.ncls;
+            if (E.st_ok) {
+                a->st_ok = true;
+                a->st_ident = E.ident;
+                a->st_z0 = z_lo; a->st_z1 = z_hi; a->st_zm0 = E.zm0; a->st_zm1 = E.zm1;
+                for (int s2 = 0; s2 < 8; ++s2) a->st_c[s2] = host.si.c[s2];
+            }
+            return PGD_OK;
+        }
+    }
+    c->cls_full += 1;
     PGD_HIP(c, hipMemsetAsync(S->keys, 0, sizeof S->keys, st));
     PGD_HIP(c, hipMemsetAsync(S->rep, 0x7f, sizeof S->rep, st));
     PGD_HIP(c, hipMemsetAsync(S->info, 0, sizeof S->info, st));
-    const int g = (int)((m->nv + TPB - 1) / TPB);
     k_cls_insert<<<g, TPB, 0, st>>>(a->uvals, a->uvals_stride, m->nv, S);
     k_cls_table<<<1, CLS_SLOTS, 0, st>>>(a->uvals, a->uvals_stride, S, a->cls_table);
     k_cls_assign<<<g, TPB, 0, st>>>(a->uvals, a->uvals_stride, m->nv, S, a->cls_table, a->cls);
     // ... and whether the classes are ONE stencil with eliminated nodes (k_spmv_stencil_march) on the planes [z_lo, z_hi) - the
     // whole grid, or the owned planes of a sharded rank's slab, whose ghost-plane rows are incomplete by construction
-    int z_lo = 0, z_hi = nzp;
-    if (zrange_lo >= 0) { z_lo = std::max(0, zrange_lo); z_hi = std::min(nzp, zrange_hi); }
-    StencilInfo *SI = reinterpret_cast<StencilInfo *>(S + 1);
-    const bool try_stencil = c->spmv_stencil && z_hi - z_lo >= 3;
     if (try_stencil) {
         k_stencil_pick<<<1, 64, 0, st>>>(a->cls, a->cls_table, S->info, m->sym_nx, m->sym_ny, z_lo, z_hi, SI);
         k_stencil_split<<<g, TPB, 0, st>>>(a->cls, a->cls_table, S->info, m->sym_nx, m->sym_ny, m->nv, SI);
@@ -1642,7 +1763,6 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
         k_stencil_allid<<<nzp, TPB, 0, st>>>(a->cls, plane, SI, allid, allid + 65536);
         k_stencil_planes<<<1, 64, 0, st>>>(allid + 65536, allid, z_lo, z_hi, SI);
     }
-    struct { int info[4]; StencilInfo si; } host;
     host.info[0] = 0; host.info[1] = 1; host.si.ok = 0;
     PGD_HIP(c, hipMemcpyAsync(host.info, S->info, sizeof host.info, hipMemcpyDeviceToHost, st));
     if (try_stencil) PGD_HIP(c, hipMemcpyAsync(&host.si, SI, sizeof(StencilInfo), hipMemcpyDeviceToHost, st));
@@ -1663,6 +1783,55 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
         a->st_z0 = z_lo; a->st_z1 = z_hi;
         a->st_zm0 = host.si.zm0; a->st_zm1 = host.si.zm1;
         for (int s2 = 0; s2 < 8; ++s2) a->st_c[s2] = host.si.c[s2];
+    }
+    // ---- remember the structure for the next operator with this signature (at most four per mesh, least recently used out)
+    if (c->cls_cache_on) {
+        const int ncls = a->cls_count;
+        Mesh::ClsCache E;
+        E.sig = a->bc_sig; E.scaled = scaled_key; E.z_lo = z_lo; E.z_hi = z_hi; E.ncls = ncls;
+        const size_t same_b = ((size_t)nzp * sizeof(int) + 63) / 64 * 64, reps_b = 256 * sizeof(int);
+        E.bytes = (size_t)m->nv + same_b + reps_b + 64;
+        void *q = nullptr;
+        if (hipMalloc(&q, E.bytes + PAD_BYTES) == hipSuccess) {
+            E.same = (int *)q;
+            E.reps = (int *)((uint8_t *)q + same_b);
+            E.codes = (uint8_t *)q + same_b + reps_b;          // (freed through this pointer's base: keep the base first)
+            // layout note: the allocation starts at E.same; hipFree takes that address
+            double tab[(CLS_MAX + 1) * 8];
+            bool okc = hipMemcpyAsync(E.codes, a->cls, (size_t)m->nv, hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                       hipMemcpyAsync(E.same, a->cls_same, (size_t)nzp * sizeof(int), hipMemcpyDeviceToDevice, st) == hipSuccess &&
+                       hipMemsetAsync(E.reps, 0x7f, reps_b, st) == hipSuccess;
+            if (okc) {
+                k_cls_reps<<<g, TPB, 0, st>>>(a->cls, m->nv, E.reps);
+                okc = hipMemcpyAsync(tab, a->cls_table, (size_t)(ncls + 1) * 8 * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
+                      hipStreamSynchronize(st) == hipSuccess;
+            }
+            if (okc) {
+                E.st_ok = a->st_ok; E.ident = a->st_ident; E.base = try_stencil ? host.si.base : -1; E.zm0 = a->st_zm0; E.zm1 = a->st_zm1;
+                for (int k = 0; k < 256; ++k) {
+                    uint8_t b = 0;
+                    if (k < ncls) for (int s2 = 1; s2 < 8; ++s2) if (tab[k * 8 + cls_pos(s2)] == 0.0) b |= (uint8_t)(1u << s2);
+                    E.zero_pat[k] = b;
+                }
+                // (a structural zero of the BASE tuple itself is no pattern bit: such a slot is compared with the base value)
+                if (E.base >= 0) for (int k = 0; k < ncls; ++k) E.zero_pat[k] &= (uint8_t)~E.zero_pat[E.base];
+                E.codes = (uint8_t *)q + same_b + reps_b;
+                E.used = ++m->cls_clock;
+                // keep the allocation's base in `same` (first member of the block); free through it
+                if (m->cls_cache.size() >= 4) {
+                    size_t old = 0;
+                    for (size_t e = 1; e < m->cls_cache.size(); ++e) if (m->cls_cache[e].used < m->cls_cache[old].used) old = e;
+                    (void)hipFree(m->cls_cache[old].same);
+                    m->cls_cache.erase(m->cls_cache.begin() + (long)old);
+                }
+                m->cls_cache.push_back(E);
+            } else {
+                (void)hipFree(q);
+                (void)hipGetLastError();
+            }
+        } else {
+            (void)hipGetLastError();
+        }
     }
     return PGD_OK;
 }
@@ -2296,6 +2465,13 @@ int pgd_debug_read_partials(pgd_handle h, double *out, int first, int count) {
 }
 #endif
 
+int pgd_classify_counts(pgd_handle h, int64_t *full, int64_t *cached) {
+    PGD_CTX(c, h);
+    if (full) *full = c->cls_full;
+    if (cached) *cached = c->cls_fast;
+    return PGD_OK;
+}
+
 int pgd_tune(pgd_handle h, int knob, int64_t value) {
     PGD_CTX(c, h);
     if (knob == PGD_TUNE_SPMV_ROWS && (value == 64 || value == 128 || value == 256)) { c->spmv_rows = (int)value; return PGD_OK; }
@@ -2310,6 +2486,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_UNIT_DIAG && value >= 0 && value <= 1) { c->spmv_unit_diag = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_DEFER_X && value >= 0 && value <= 1) { c->pcg_defer_x = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_FAULT_ITERATION && value >= -1 && value <= (1 << 30)) { c->fault_iteration = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_CLS_CACHE && value >= 0 && value <= 1) { c->cls_cache_on = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_STENCIL && value >= 0 && value <= 1) { c->spmv_stencil = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK_STENCIL && value >= 0 && value <= 1024) { c->spmv_zchunk_stencil = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_STENCIL_DEPTH && (value == 0 || value == 3 || value == 6)) { c->stencil_depth = (int)value; return PGD_OK; }
@@ -2498,7 +2675,13 @@ int pgd_start_gram(pgd_handle h, pgd_handle ah, const pgd_handle *vhs, int k, pg
     PGD_TRY(ensure_work(c, 3, m->nv));                  // w: the PCG's q buffer (no solve is running)
     PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS > 256 ? 2 * (int64_t)MAX_VEC_BLOCKS : 256));
     double *w = c->work[3], *res = c->work[6];          // res: k columns of (j + 2) values, packed
-    if (k >= 4) PGD_TRY(dia_classify(c, m, a));        // uniform grids: the k products below read a code byte per row (0.5 ms for 9 x 0.19 ms)
+    // uniform grids: the k products below read a code byte per row or take the stencil form (the classification is a copy + one
+    // verifying pass once the mesh has seen the structure: worth it from two products on)
+    const bool dbg_t = getenv("PGD_DEBUG_PCG") != nullptr;
+    auto dbg_now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double dbg_t0 = dbg_now();
+    if (k >= 2) PGD_TRY(dia_classify(c, m, a));
+    if (dbg_t) fprintf(stderr, "[start_gram] k %d classify %.2f ms (cls %d stencil %d)\n", k, 1e3 * (dbg_now() - dbg_t0), a->cls_count, (int)a->st_ok);
     if (k <= GRAM9) {
         // the products first, each into its own vector; then all dots in one pass
         const size_t need = (size_t)k * (size_t)m->nv * sizeof(double);

@@ -1059,6 +1059,85 @@ def test_stencil_form_is_lossless(ctx, shape):
     ctx.mesh_free(h)
 
 
+def test_classification_cache_is_verified_not_trusted(ctx):
+    """A mesh remembers the class codes of the operators classified on it; the next operator with that structure (other
+    coefficients: every solve of a fixed-point pass) gets the codes copied and EVERY row verified against its class
+    (pgd_classify_counts: served by the cache).  Same product bit for bit with the cache on and off; an operator with the same
+    signature but another structure - the hint is a sample of the Dirichlet list - must fall back to the full classification
+    and still give the right product; new coefficients must give new couplings, not the cached operator's."""
+    nx, ny, nz = 130, 37, 41
+    coords, cells = F.box_mesh((0, 0, 0), (1.0, 0.7, 1.3), nx - 1, ny - 1, nz - 1)
+    h = ctx.mesh_upload(coords, cells)
+    n = coords.shape[0]
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bnd = boundary_dofs(coords).astype(np.int32)
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-1, 1, n)
+    xv, yv = ctx.vec_from(x), ctx.vec_alloc(n)
+    ctx.flags_reset()
+
+    def product(op, L=5):
+        ctx.tune(7, 4)
+        ctx.tune(36, L)
+        ctx.vec_fill(yv, -2.0)
+        ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
+        return ctx.vec_download(yv)
+
+    def reference(op):
+        ctx.tune(3, 0)
+        ctx.vec_fill(yv, -2.0)
+        ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
+        ctx.tune(3, 1)
+        assert ctx.op_symmetrize(op)
+        return ctx.vec_download(yv)
+    try:
+        c0 = ctx.classify_counts()
+        ys = {}
+        for cache in (1, 0):
+            ctx.tune(39, cache)
+            for coefs in ((1.0, 0.37), (2.5, 0.01), (1.0, 0.37)):
+                op = ctx.op_combine(h, [ak, am], list(coefs), bnd)
+                ref = reference(op)
+                assert ctx.op_classify(op) > 0
+                k0 = ctx.kernel_counts()
+                y = product(op)
+                assert ctx.kernel_counts()["stencil_march"] == k0["stencil_march"] + 1
+                assert np.array_equal(y, ref), (cache, coefs)
+                ys[(cache, coefs)] = y
+                ctx.atom_free(op)
+        c1 = ctx.classify_counts()
+        assert c1["cached"] - c0["cached"] == 2 and c1["full"] - c0["full"] == 4      # cache on: 1 full + 2 served; off: 3 full
+        assert not np.array_equal(ys[(1, (1.0, 0.37))], ys[(1, (2.5, 0.01))])
+        for coefs in ((1.0, 0.37), (2.5, 0.01)):
+            assert np.array_equal(ys[(1, coefs)], ys[(0, coefs)])
+        # the same sampled signature, another Dirichlet set: every 4096th entry of the list is kept, one in between is dropped -
+        # the vertex becomes a free node on the rim, its row and its neighbours' rows change
+        ctx.tune(39, 1)
+        step = max(1, bnd.size // 4096)
+        drop = 1 if step > 1 else None
+        if drop is not None:
+            bnd2 = np.delete(bnd, drop)
+            op = ctx.op_combine(h, [ak, am], [1.0, 0.37], bnd2)
+            ref = reference(op)
+            c2 = ctx.classify_counts()
+            ncls = ctx.op_classify(op)
+            c3 = ctx.classify_counts()
+            assert c3["full"] == c2["full"] + 1 and c3["cached"] == c2["cached"]       # the cached structure did not verify
+            y = product(op)
+            assert np.array_equal(y, ref) and ncls > 0
+            ctx.atom_free(op)
+    finally:
+        ctx.tune(7, 0)
+        ctx.tune(36, 0)
+        ctx.tune(39, 1)
+        ctx.tune(3, 1)
+    for v in (xv, yv):
+        ctx.vec_free(v)
+    for a in (ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
 def test_pcg_on_the_stencil_form_walks_the_same_iterates(ctx):
     """The library's PCG with the scaled operator in its stencil form (k_spmv_stencil_march) against the same solve on the
     row-class dictionary: y is bit-identical, the fused dots are grouped per workgroup (64 x 16 patches instead of 64 x 8), so
