@@ -211,7 +211,10 @@ def main():
     pcg_its = state["its1"] - state["its0"]
     pcg_seconds = state["pcg1"] - state["pcg0"]
     launches = max(prof["launches"], 1)
-    avg = prof["seconds"] / launches
+    # event times minus what a pair of events adds to the kernel it brackets (calibrated by the library: t(n kernels) = overhead + n t)
+    ev_over = prof.get("event_overhead", 0.0)
+    avg_raw = prof["seconds"] / launches
+    avg = max(avg_raw - ev_over, 1e-9) if prof["launches"] else 0.0
     rows_local = n_sp // world if sharded else n_sp
     # which product ran in the SPD solves (launch counters of the library, not a guess)
     kc = {k: kc1[k] - kc0[k] for k in kc1}
@@ -239,7 +242,8 @@ def main():
     achieved = own / avg / 1e9 if avg > 0 else 0.0
     # the vector update of the single-sync recurrence (r, p and - every other launch - x in one kernel: 40 / 56 B per row)
     upd_n = prof.get("update_launches", 0)
-    upd_avg = prof["update_seconds"] / upd_n if upd_n else 0.0
+    upd_avg_raw = prof["update_seconds"] / upd_n if upd_n else 0.0
+    upd_avg = max(upd_avg_raw - ev_over, 1e-9) if upd_n else 0.0
     upd_bytes = prof["update_bytes"] / upd_n if upd_n else 0.0
     upd_achieved = upd_bytes / upd_avg / 1e9 if upd_avg > 0 else 0.0
     it_us = 1e6 * pcg_seconds / max(pcg_its, 1)
@@ -275,6 +279,7 @@ def main():
                      # 8 slots x 8 B + x + y = 80 B per row) / its average launch time (HIP events, this run)
                      "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0, "traffic": None,
                      "launches": prof["launches"], "avg_launch_us": 1e6 * avg,
+                     "avg_launch_us_raw_events": 1e6 * avg_raw, "event_pair_overhead_us": 1e6 * ev_over,
                      "bytes_per_launch": own, "bytes_per_row": own / max(rows_local, 1),
                      # for orientation: the same rate against the chip's measured streaming ceiling (float4 copy 6.29 TB/s,
                      # MI355X_MICROARCH.md) instead of the 8 TB/s specification that `peak` / `frac` use
@@ -300,7 +305,8 @@ def main():
                                      "as a two-term update in every other launch; 16-byte accesses; 3 vectors read + 2 written, or 4 + 3: "
                                      "averages over both kinds of launch)",
                            "achieved": upd_achieved, "peak": 8000.0, "unit": "GB/s", "frac": upd_achieved / 8000.0, "traffic": None,
-                           "launches": upd_n, "avg_launch_us": 1e6 * upd_avg, "bytes_per_launch": upd_bytes,
+                           "launches": upd_n, "avg_launch_us": 1e6 * upd_avg, "avg_launch_us_raw_events": 1e6 * upd_avg_raw,
+                           "event_pair_overhead_us": 1e6 * ev_over, "bytes_per_launch": upd_bytes,
                            "bytes_per_row": upd_bytes / max(rows_local, 1),
                            "measured_copy_ceiling_GBps": 6290.0, "frac_of_measured_copy_ceiling": upd_achieved / 6290.0,
                            "share_of_pcg_iteration": 1e6 * upd_avg / it_us if it_us > 0 else None,
@@ -352,7 +358,7 @@ def csr_section(be, prob, n_sp, nnz):
                 ctx.spmv_dot_slot(op, x, y, x, 0, n_sp, 30)
             p = ctx.prof_read()
             ctx.prof_enable(0)
-            t = p["seconds"] / max(p["launches"], 1)
+            t = max(p["seconds"] / max(p["launches"], 1) - p.get("event_overhead", 0.0), 1e-9)
             res[name] = {"launches_timed": p["launches"], "launches": 400, "avg_launch_us": 1e6 * t,
                          "bytes_per_launch_survey_8d": alg, "achieved": alg / t / 1e9, "unit": "GB/s", "frac": alg / t / 8e12,
                          "kernel_min_bytes_per_launch": own, "kernel_min_bytes_frac": own / t / 8e12}
@@ -407,7 +413,7 @@ def general_paths(be, spec, settings, passes=4, warm=1):
             be.prof_enable(False)
             its = max(st["i1"] - st["i0"], 1)
             kc = {k: st["k1"][k] - st["k0"][k] for k in st["k1"]}
-            t = p["seconds"] / max(p["launches"], 1)
+            t = max(p["seconds"] / max(p["launches"], 1) - p.get("event_overhead", 0.0), 1e-9)
             own = p["own_bytes"] / max(p["launches"], 1)
             res[name] = {"passes_per_s": passes / (st["t1"] - st["t0"]), "passes": passes,
                          "us_per_pcg_iteration": 1e6 * (st["s1"] - st["s0"]) / its, "pcg_iterations_per_pass": its / passes,
@@ -450,7 +456,7 @@ def pmc_traffic(own_bytes, upd_bytes):
     import subprocess
     import tempfile
     fallback = os.path.join(ROOT, "profiles", "pmc_spmv_latest.json")
-    kernels = {"product": (lambda name: "k_spmv_dia" in name and "<true, true" in name, own_bytes),
+    kernels = {"product": (lambda name: ("k_spmv_dia" in name or "k_spmv_stencil" in name) and "<true, true" in name, own_bytes),
                "update": (lambda name: "k_pcg1_update" in name, upd_bytes)}
     res = {k: {"traffic": None, "traffic_source": None} for k in kernels}
     rp = shutil.which("rocprofv3")

@@ -410,6 +410,10 @@ int pgd_prof_read_update(pgd_handle ctx, int64_t *launches, double *seconds, dou
 /* Timed launches that were NOT counted: queued behind the iteration in which their solve converged, every kernel of them returned
  * on the done flag (full bytes, no time - they would bias the averages).  The counts above are the samples that were kept.   */
 int pgd_prof_read_dropped(pgd_handle ctx, int64_t *dropped);
+/* Seconds a pair of HIP events adds to the kernel it brackets on this context's stream: t(n kernels in one pair) = overhead + n t,
+ * measured with n = 1, 2 when the timing is first switched on.  The seconds of pgd_prof_read* are raw event times; bench.py
+ * subtracts launches x overhead so that its averages are kernel durations, as rocprofv3 --kernel-trace reports them.       */
+int pgd_prof_event_overhead(pgd_handle ctx, double *seconds);
 /* Launch counts per product kernel family since the context was created: [0] k_spmv_csr, [1] k_spmv_csr_dict*,
  * [2] k_spmv_sym (row order), [3] k_spmv_dia_rows, [4] k_spmv_dia_march*, [5] k_spmv_multi, [6] k_spmv_diac_march2, [7] k_spmv_stencil_march; tests use them to
  * prove which kernel a call reached, bench.py for its per-kernel breakdown.                          */

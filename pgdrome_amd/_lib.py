@@ -104,6 +104,7 @@ SIGNATURES = {
     "pgd_prof_read_own": (C.c_int, [H, PD]),
     "pgd_prof_read_update": (C.c_int, [H, PI64, PD, PD]),
     "pgd_prof_read_dropped": (C.c_int, [H, PI64]),
+    "pgd_prof_event_overhead": (C.c_int, [H, PD]),
     "pgd_kernel_counts": (C.c_int, [H, PI64, C.c_int]),
     "pgd_classify_counts": (C.c_int, [H, PI64, PI64]),
     "pgd_calib_stream": (C.c_int, [H, H, C.c_int, C.c_int]),
@@ -565,10 +566,12 @@ class Context:
         self._ck(self.lib.pgd_prof_read_own(self.h, C.byref(own)))
         un, us, ub = I64(), F64(), F64()
         self._ck(self.lib.pgd_prof_read_update(self.h, C.byref(un), C.byref(us), C.byref(ub)))
-        dr = I64()
+        dr, ov = I64(), F64()
         self._ck(self.lib.pgd_prof_read_dropped(self.h, C.byref(dr)))
+        self._ck(self.lib.pgd_prof_event_overhead(self.h, C.byref(ov)))
         return dict(launches=n.value, seconds=s.value, bytes=b.value, own_bytes=own.value,
-                    update_launches=un.value, update_seconds=us.value, update_bytes=ub.value, dropped_noop_samples=dr.value)
+                    update_launches=un.value, update_seconds=us.value, update_bytes=ub.value, dropped_noop_samples=dr.value,
+                    event_overhead=ov.value)
 
     KERNEL_FAMILIES = ("csr", "csr_dict", "sym_rows", "dia_rows", "dia_march", "multi", "diac_march", "stencil_march")
 

@@ -254,6 +254,7 @@ struct Ctx {
     std::vector<ProfRec> prof_pend;   // measured, waiting for their solve's verdict
     int prof_iter = -1;               // iteration whose launches are being queued (set by the PCG loops)
     int64_t prof_dropped = 0;
+    double prof_overhead = -1.0;      // seconds a pair of HIP events adds to the kernel it brackets (prof_calibrate; -1: not measured)
     size_t ev_used = 0;
     int64_t prof_upd_launches = 0, prof_upd_seen = 0;   // k_pcg1_update, timed like the products (one launch in four)
     double prof_upd_seconds = 0.0, prof_upd_bytes = 0.0;
