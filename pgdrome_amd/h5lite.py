@@ -747,7 +747,8 @@ class Group:
 
 
 class File(Group):
-    """``File(path, "r")`` reads, ``File(path, "w")`` builds the file in memory and writes it on close."""
+    """``File(path, "r")`` reads, ``File(path, "w")`` builds the file in memory and writes it on close, ``File(path, "a")`` does the
+    same starting from what the file already holds."""
 
     def __init__(self, path, mode="r", **_ignored):
         self.filename, self.mode = str(path), mode
@@ -758,12 +759,34 @@ class File(Group):
             except OSError as e:
                 raise OSError("unable to open %s: %s" % (self.filename, e)) from e
             Group.__init__(self, self, "/", rd, rd.messages(rd.root))
-        elif mode in ("w", "w-", "x"):
+        elif mode in ("w", "w-", "x", "a", "r+"):
+            import os
             self._writer = _Writer(self.filename)
             Group.__init__(self, self, "/", node=self._writer.root)
+            if mode in ("a", "r+") and os.path.exists(self.filename):
+                # APPEND: what the file holds is read into the writer's tree (groups, datasets, attributes) and goes out again,
+                # together with what is added, when the file is closed - the writer builds files whole
+                self._open = True
+                with File(self.filename, "r") as old:
+                    self._adopt(old, self)
+            elif mode == "r+":
+                raise OSError("unable to open %s: no such file" % self.filename)
         else:
-            raise H5Error("h5lite opens files with mode 'r' or 'w' (got %r)" % (mode,))
+            raise H5Error("h5lite opens files with mode 'r', 'w' or 'a' (got %r)" % (mode,))
         self._open = True
+
+    @staticmethod
+    def _adopt(src, dst):
+        for k, v in src.attrs.items():
+            dst.attrs[k] = v
+        for k in src.keys():
+            c = src._child(k)
+            if isinstance(c, Dataset):
+                d = dst.create_dataset(k, data=np.array(c))
+                for ak, av in c.attrs.items():
+                    d.attrs[ak] = av
+            elif c is not None:
+                File._adopt(c, dst.create_group(k))
 
     def _root(self):
         return self

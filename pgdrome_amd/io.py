@@ -67,7 +67,9 @@ class HDF5File:
         if mode == "r" and not os.path.exists(self._path):
             raise RuntimeError("Unable to open HDF5 file %s: file does not exist" % self._path)      # dolfin raises RuntimeError
         try:
-            self._f = h5lite.File(self._path, "w" if mode in ("w", "a") else "r")
+            # ("a" appends like dolfin's: the existing groups and datasets are kept.  The writer holds the whole file in memory
+            # until close() - result files of a PGD run are a few vectors per mode, not a time series of 256^3 fields)
+            self._f = h5lite.File(self._path, mode if mode in ("w", "a") else "r")
         except (OSError, h5lite.H5Error) as e:
             raise RuntimeError("Unable to open HDF5 file %s: %s" % (self._path, e)) from e
 
