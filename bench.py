@@ -328,12 +328,12 @@ def main():
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
-    if sharded and args.watchdog_seconds > 0:
-        import faulthandler
-        faulthandler.cancel_dump_traceback_later()
     if sharded:
         dist.barrier()
         dist.destroy_process_group()
+        if args.watchdog_seconds > 0:
+            import faulthandler
+            faulthandler.cancel_dump_traceback_later()
 
 
 def csr_section(be, prob, n_sp, nnz):
