@@ -298,6 +298,15 @@ int pgd_vec_multidot(pgd_handle ctx, pgd_handle x, const pgd_handle *ys, int k, 
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
+    PGD_TUNE_MG_MARCH_MIN = 42, /* multigrid levels with at least this many nodes along x and y run their stencil passes in
+                                k_spmv_stencil_march (default 64); smaller ones in the plain kernels of pgd_mg.hip */
+    PGD_TUNE_MG_CHUNK = 41, /* PCG iterations queued between two looks at the convergence flags when the multigrid preconditioner is on
+                                (default 4; the Jacobi form queues 16) */
+    PGD_TUNE_PCG_PRECOND = 40, /* preconditioner of pgd_pcg_solve: 0 (default) Jacobi = the symmetric diagonal scaling; 1 a geometric
+                                multigrid V(1,1) cycle on the scaled operator WHERE it is one stencil on a lattice whose eliminated
+                                nodes are exactly the hull (every row verified, pgd_mg.hip), Jacobi everywhere else.  Changes the
+                                iterates (same stop test, same tolerance), not the system solved.  The frontend sets it from
+                                settings["preconditioner"] (solver.py:593-594: forwarded to the linear solver). */
     PGD_TUNE_CLS_CACHE = 39, /* 1 (default): a mesh remembers the class codes of the operators classified on it (by the signature of their
                                 Dirichlet set, scaled or not): the next operator with that structure - the same atoms with other
                                 coefficients, every solve of a fixed-point pass - copies the codes, rebuilds the table from the classes'
@@ -421,6 +430,9 @@ int pgd_kernel_counts(pgd_handle ctx, int64_t *out, int n);
 /* Row-class classifications since the context was created: done in full (three passes over the slot values with hashing) / served
  * by the mesh's structure cache (codes copied, every row verified against its class: one pass) - PGD_TUNE_CLS_CACHE.   */
 int pgd_classify_counts(pgd_handle ctx, int64_t *full, int64_t *cached);
+/* Solves that asked for the multigrid preconditioner (PGD_TUNE_PCG_PRECOND = 1) since the context was created: preconditioned by
+ * the V-cycle / fallen back to Jacobi because the operator is not one stencil with an eliminated hull.                  */
+int pgd_mg_counts(pgd_handle ctx, int64_t *solves, int64_t *fallbacks);
 /* One HIP-event stopwatch on the context's stream (bench.py's micro-sections: N launches between start
  * and stop; stop synchronises on its event).                                                        */
 /* Calibration of the PMC byte model: one pass over `vec` with 8- or 16-byte loads (store = 0) or stores (store = 1)

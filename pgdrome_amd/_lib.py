@@ -107,6 +107,7 @@ SIGNATURES = {
     "pgd_prof_event_overhead": (C.c_int, [H, PD]),
     "pgd_kernel_counts": (C.c_int, [H, PI64, C.c_int]),
     "pgd_classify_counts": (C.c_int, [H, PI64, PI64]),
+    "pgd_mg_counts": (C.c_int, [H, PI64, PI64]),
     "pgd_calib_stream": (C.c_int, [H, H, C.c_int, C.c_int]),
     "pgd_timer_start": (C.c_int, [H]),
     "pgd_timer_stop": (C.c_int, [H, PD]),
@@ -584,6 +585,11 @@ class Context:
         full, cached = I64(), I64()
         self._ck(self.lib.pgd_classify_counts(self.h, C.byref(full), C.byref(cached)))
         return {"full": full.value, "cached": cached.value}
+
+    def mg_stats(self):
+        a, b = I64(), I64()
+        self._ck(self.lib.pgd_mg_counts(self.h, C.byref(a), C.byref(b)))
+        return {"solves": a.value, "fallbacks": b.value}
 
     def calib_stream(self, v, bytes_per_lane, store=False):
         self._ck(self.lib.pgd_calib_stream(self.h, v, int(bytes_per_lane), int(bool(store))))

@@ -17,7 +17,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIBDIR = HERE / "lib"
 LIB = LIBDIR / "libpgd_amd.so"
-SOURCES = ["pgd_ctx.hip", "pgd_vec.hip", "pgd_mesh.hip", "pgd_spmv.hip", "pgd_pcg.hip", "pgd_comm.hip"]
+SOURCES = ["pgd_ctx.hip", "pgd_vec.hip", "pgd_mesh.hip", "pgd_spmv.hip", "pgd_pcg.hip", "pgd_comm.hip", "pgd_mg.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-result",
          "-fno-gpu-rdc"]
 

@@ -733,7 +733,7 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         if (chunk > 0) {
             const int set = nchunks & 1;
             for (int j = 0; j < chunk; ++j) {
-                const bool sample = k.prof && j == 5 && !S.poisoned();
+                const bool sample = k.prof && j == 5 + set && !S.poisoned();      // both parities of the iteration index: x is updated in every other one
                 marks = sample ? k.mark[set] : nullptr;
                 PGD_TRY(iterate(enq + j));
                 if (sample) k.mark_set[set] = true;

@@ -221,6 +221,7 @@ int pgd_ctx_destroy(pgd_handle h) {
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
     comm_release(c);
+    mg_release(c);
     c->objs.clear();
     for (auto &kv : c->pool) (void)hipFree(kv.second);
     c->pool.clear();

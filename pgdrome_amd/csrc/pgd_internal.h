@@ -220,6 +220,12 @@ struct Ctx {
     int atom_fast = 1;            // products with an atom whose diagonal form exists take the z-march (+ its own row classes, looked for once)
     int lazy_csr = 1;             // pgd_op_combine forms only the diagonal form where it can; CSR values on first use
     uint64_t next_serial = 1;
+    int pcg_precond = 0;          // pgd_pcg_solve: 0 = Jacobi (the diagonal scaling), 1 = geometric multigrid V-cycle where the scaled operator is one
+                                  // stencil on a lattice whose eliminated nodes are exactly its hull (pgd_mg.hip); anything else falls back to 0
+    struct Mg *mg = nullptr;      // its levels and work vectors, kept across solves on the same lattice
+    int64_t mg_solves = 0, mg_fallbacks = 0;
+    int mg_chunk = 4;             // iterations queued between two looks at the flags when the multigrid preconditioner is on
+    int mg_march_min = 64;        // levels with at least this many nodes along x and y run their stencil passes in k_spmv_stencil_march
     int cls_cache_on = 1;         // classification of an operator whose structure was seen before: codes copied, every row verified (PGD_TUNE_CLS_CACHE)
     int64_t cls_fast = 0, cls_full = 0;      // classifications served by the cache / done in full
     int spmv_stencil = 1;         // ... and its stencil form (couplings in scalar registers, four rows per thread) where every row verifies
@@ -310,6 +316,14 @@ int ensure_vals(Ctx *c, const Mesh *m, Csr *a);                 // pgd_pcg.hip: 
 bool atom_fast_form(Ctx *c, const Mesh *m, Csr *a, int64_t r0, int64_t r1);   // pgd_spmv.hip
 // pgd_spmv.hip: row-class dictionary of the current slot values (+ its stencil form, verified on the planes [zlo, zhi) - whole grid: -1)
 int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo = -1, int zrange_hi = -1);
+int launch_stencil_pass(Ctx *c, const uint8_t *cls, int ident, const double cst[8], int nx, int ny, int nz, int zm0, int zm1,
+                        const double *x, const double *b, double *y, double w, int epi, bool dot, int *nparts);      // pgd_spmv.hip
+// pgd_mg.hip: multigrid preconditioner of the scaled stencil operator
+bool mg_prepare(Ctx *c, const Mesh *m, const Csr *a);                          // true: usable for this operator (levels built, buffers there)
+int mg_fix_start(Ctx *c, const Csr *a, const double *b, double *x, int64_t n);    // x = b on the eliminated rows
+int mg_vcycle(Ctx *c, const double *r, bool dot, int *nparts);                 // z = M r into mg_result(c); partial sums of r.z into c->partials
+double *mg_result(Ctx *c);
+void mg_release(Ctx *c);
 int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *s);   // pgd_spmv.hip: slot values *= s_i s_j
 int launch_spmv_dia_rows2(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0a,
                           int64_t r1a, int64_t r0b, int64_t r1b, bool dot, const int *flags, int *nparts_out, bool *done);

@@ -1,0 +1,390 @@
+// Geometric multigrid preconditioner for pgd_pcg_solve (settings["preconditioner"] of the reference's solver parameters,
+// solver.py:593-594 / 634-635 forwards them to PETSc; "amg"-type values map here, PGD_TUNE_PCG_PRECOND).
+//
+// Where it applies: the diagonally scaled operator of the solve is ONE stencil c[0..7] (dia_classify's stencil form: every row
+// verified bit by bit) on an nx x ny x nz lattice whose eliminated (Dirichlet) nodes are exactly the hull of the lattice - cfg4 /
+// cfg3 / cfg5: -Laplace + mu on the box with a homogeneous hull.  Everything else keeps the Jacobi-PCG.
+//
+// The hierarchy needs no matrix at all:
+//   * P1 on the 6-tets-per-cube mesh is nested under doubling of the spacing (the cube's long diagonal is an edge of all six
+//     tets), so the P1 interpolation P from the lattice of every other node has the operator's own 15-point shape - weight 1 at
+//     the node, 1/2 at the 14 neighbours along the mesh edges - and the Galerkin operator P^T A P of a 15-point stencil is again
+//     a 15-point stencil: eight numbers per level, computed on the host from the level above (mg_galerkin; entries off the
+//     pattern are checked to vanish).
+//   * node k of a coarse level is node 2k of the level above; a coarse node is eliminated iff that fine node is.  Where a lattice
+//     has an even number of nodes its far hull face has no coarse counterpart: the last coarse node is free and what lies beyond
+//     it reads as zero - a homogeneous Dirichlet node one coarse spacing out instead of half a spacing.  The preconditioner stays
+//     symmetric positive definite; PCG does the rest (measured: 18 - 20 iterations for rtol 1e-10 from 32^3 to 256^3, even and
+//     odd node counts alike).
+//   * V(1,1) with damped Jacobi (omega = 0.8, lambda_max(D^-1 A) = 2 for these stencils), the pre-smoothing step from a zero
+//     start folded into the residual (x1 = w b:  r = b - w A b) and into the prolongation (x = w b + P e); the coarsest level
+//     (at most 4096 nodes) is 24 sweeps inside one workgroup.
+// Invariant that keeps the kernels free of range logic: every vector of the cycle is ZERO on eliminated nodes, the faces x = 0,
+// y = 0, z = 0 are eliminated on every level, so a neighbour index that runs over the end of a line or a plane lands on such a
+// node (or behind the array: tested) and contributes the zero the ghost node would.
+//
+// Levels with at least mg_march_min nodes along x and y run their two stencil passes in k_spmv_stencil_march (epilogues 1 and 2,
+// pgd_spmv.hip: 16 and 24 B per row at the product's rate); the small ones in the plain kernels below.
+#include "pgd_internal.h"
+
+#include <cmath>
+#include <cstring>
+
+namespace pgd {
+
+struct MgGrid { int nx, ny, nz, fx, fy, fz; };         // f* = 1: the far face along that axis holds eliminated nodes (else: free, zero beyond)
+struct MgSt { double c[8]; double w; };                // couplings (slot s = dx + 2 dy + 4 dz) and omega / c[0]
+
+struct MgLevel {
+    MgGrid g;
+    int64_t n = 0;
+    MgSt s;
+    double *b = nullptr, *x = nullptr, *t = nullptr;    // right-hand side, result, work (level 0: b is the caller's r)
+    uint8_t *cls = nullptr;                             // code byte per node for the march kernel: 1 = eliminated (levels >= 1; level 0: the operator's)
+};
+
+struct Mg {
+    int nx = 0, ny = 0, nz = 0;
+    std::vector<MgLevel> lv;
+    double key[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool have_key = false;
+    int *bad = nullptr;                                 // device flag of the hull check
+    const uint8_t *cls0 = nullptr;                      // level 0: the operator's codes of THIS solve
+    int ident0 = -1;
+    int np0 = 0;                                        // partial sums the level-0 post-smoothing pass leaves
+};
+
+__device__ __forceinline__ bool mg_is_free(const MgGrid &g, int x, int y, int z) {
+    return x >= 1 && y >= 1 && z >= 1 && x <= g.nx - 1 - g.fx && y <= g.ny - 1 - g.fy && z <= g.nz - 1 - g.fz;
+}
+
+// (A v)_i for a free node i: lower neighbours exist (x, y, z >= 1), upper ones may run over the end of the array
+__device__ __forceinline__ double mg_apply(const MgSt &S, const double *__restrict__ v, int64_t i, int64_t n, int nx, int64_t P) {
+    double acc = S.c[0] * v[i];
+#pragma unroll
+    for (int s = 1; s < 8; ++s) {
+        const int64_t off = (s & 1) + (int64_t)nx * ((s >> 1) & 1) + P * (s >> 2);
+        const int64_t j = i + off;
+        const double hi = j < n ? v[j] : 0.0;
+        acc = fma(S.c[s], v[i - off] + hi, acc);
+    }
+    return acc;
+}
+
+// MODE 0: out = in - w A in            (residual behind the pre-smoothing step x1 = w in from a zero start)
+// MODE 1: out = in + w (b - A in)      (post-smoothing step);  DOT: partial sums of b . out per workgroup
+template <int MODE, bool DOT>
+__global__ __launch_bounds__(256) void k_mg_pass(MgGrid g, MgSt S, const double *__restrict__ in, const double *__restrict__ b,
+                                                 double *__restrict__ out, double *__restrict__ partials, const int *__restrict__ flags) {
+    __shared__ double s_red[4];
+    if (flags && flags[0]) return;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+    double d = 0.0;
+    if (x < g.nx && y < g.ny) {
+        const int64_t P = (int64_t)g.nx * g.ny, n = P * g.nz, i = P * z + (int64_t)g.nx * y + x;
+        double o = 0.0;
+        if (mg_is_free(g, x, y, z)) {
+            const double a = mg_apply(S, in, i, n, g.nx, P);
+            if (MODE == 0) o = fma(-S.w, a, in[i]);
+            else { const double bi = b[i]; o = fma(S.w, bi - a, in[i]); if (DOT) d = bi * o; }
+        }
+        out[i] = o;
+    }
+    if (DOT) {
+        d = block_sum(d, s_red);
+        if (threadIdx.x == 0) partials[(int64_t)blockIdx.x + (int64_t)gridDim.x * (blockIdx.y + (int64_t)gridDim.y * blockIdx.z)] = d;
+    }
+}
+
+// bc = P^T r: the node's own value + half of its 14 neighbours along the mesh edges of the fine lattice
+__global__ __launch_bounds__(256) void k_mg_restrict(MgGrid gc, MgGrid gf, const double *__restrict__ r, double *__restrict__ bc,
+                                                     const int *__restrict__ flags) {
+    if (flags && flags[0]) return;
+    const int X = blockIdx.x * 64 + (threadIdx.x & 63), Y = blockIdx.y * 4 + (threadIdx.x >> 6), Z = blockIdx.z;
+    if (X >= gc.nx || Y >= gc.ny) return;
+    const int64_t Pc = (int64_t)gc.nx * gc.ny, I = Pc * Z + (int64_t)gc.nx * Y + X;
+    double o = 0.0;
+    if (mg_is_free(gc, X, Y, Z)) {
+        const int64_t Pf = (int64_t)gf.nx * gf.ny, nf = Pf * gf.nz, i = Pf * (2 * Z) + (int64_t)gf.nx * (2 * Y) + 2 * X;
+        double h = 0.0;
+#pragma unroll
+        for (int s = 1; s < 8; ++s) {
+            const int64_t off = (s & 1) + (int64_t)gf.nx * ((s >> 1) & 1) + Pf * (s >> 2);
+            const int64_t j = i + off;
+            h += r[i - off] + (j < nf ? r[j] : 0.0);
+        }
+        o = fma(0.5, h, r[i]);
+    }
+    bc[I] = o;
+}
+
+// t = w b + P e on the fine lattice: a fine node is a coarse node (all coordinates even) or the midpoint of ONE coarse edge
+__global__ __launch_bounds__(256) void k_mg_prolong(MgGrid gf, MgGrid gc, double w, const double *__restrict__ b, const double *__restrict__ e,
+                                                    double *__restrict__ t, const int *__restrict__ flags) {
+    if (flags && flags[0]) return;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6), z = blockIdx.z;
+    if (x >= gf.nx || y >= gf.ny) return;
+    const int64_t Pf = (int64_t)gf.nx * gf.ny, i = Pf * z + (int64_t)gf.nx * y + x;
+    double o = 0.0;
+    if (mg_is_free(gf, x, y, z)) {
+        const int64_t Pc = (int64_t)gc.nx * gc.ny, nc = Pc * gc.nz;
+        const int64_t ja = Pc * (z >> 1) + (int64_t)gc.nx * (y >> 1) + (x >> 1);
+        const int64_t jb = Pc * ((z + 1) >> 1) + (int64_t)gc.nx * ((y + 1) >> 1) + ((x + 1) >> 1);
+        const double ea = e[ja], eb = jb < nc ? e[jb] : 0.0;      // (ja == jb on a coarse node: 0.5 (e + e))
+        o = fma(w, b[i], 0.5 * (ea + eb));
+    }
+    t[i] = o;
+}
+
+// the coarsest level inside one workgroup: `sweeps` damped-Jacobi steps from a zero start
+constexpr int MG_BOTTOM_MAX = 4096;
+__global__ __launch_bounds__(1024) void k_mg_bottom(MgGrid g, MgSt S, const double *__restrict__ b, double *__restrict__ x, int sweeps,
+                                                    const int *__restrict__ flags) {
+    __shared__ double s_v[2][MG_BOTTOM_MAX];
+    if (flags && flags[0]) return;
+    const int P = g.nx * g.ny, n = P * g.nz;
+    double bi[4];
+    bool fr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = threadIdx.x + 1024 * k;
+        fr[k] = false; bi[k] = 0.0;
+        if (i < n) {
+            const int z = i / P, rem = i - z * P, y = rem / g.nx, xx = rem - y * g.nx;
+            fr[k] = mg_is_free(g, xx, y, z);
+            bi[k] = fr[k] ? b[i] : 0.0;
+            s_v[0][i] = S.w * bi[k];
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int sw = 1; sw < sweeps; ++sw) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int i = threadIdx.x + 1024 * k;
+            if (i < n) s_v[cur ^ 1][i] = fr[k] ? fma(S.w, bi[k] - mg_apply(S, s_v[cur], i, n, g.nx, P), s_v[cur][i]) : 0.0;
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = threadIdx.x + 1024 * k;
+        if (i < n) x[i] = s_v[cur][i];
+    }
+}
+
+// are the eliminated nodes of the operator exactly the hull of the lattice?
+__global__ __launch_bounds__(TPB) void k_mg_hull_check(const uint8_t *__restrict__ cls, int ident, int nx, int ny, int nz, int *__restrict__ bad) {
+    const int64_t P = (int64_t)nx * ny, n = P * nz;
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int z = (int)(i / P), rem = (int)(i - (int64_t)z * P), y = rem / nx, x = rem - y * nx;
+    const bool hull = x == 0 || y == 0 || z == 0 || x == nx - 1 || y == ny - 1 || z == nz - 1;
+    if (((int)cls[i] == ident) != hull) *bad = 1;
+}
+
+__global__ __launch_bounds__(TPB) void k_mg_codes(MgGrid g, uint8_t *__restrict__ cls) {
+    const int64_t P = (int64_t)g.nx * g.ny, n = P * g.nz;
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int z = (int)(i / P), rem = (int)(i - (int64_t)z * P), y = rem / g.nx, x = rem - y * g.nx;
+    cls[i] = mg_is_free(g, x, y, z) ? 0 : 1;
+}
+
+__global__ __launch_bounds__(TPB) void k_mg_fix_start(const uint8_t *__restrict__ cls, int ident, const double *__restrict__ b,
+                                                      double *__restrict__ x, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < n && (int)cls[i] == ident) x[i] = b[i];
+}
+
+// Galerkin coarse stencil P^T A P on the infinite lattice.  false: it leaves the 15-point pattern (not a P1 operator of this mesh)
+static bool mg_galerkin(const double cf[8], double cc[8]) {
+    double S[3][3][3], W[3][3][3];
+    std::memset(S, 0, sizeof S);
+    std::memset(W, 0, sizeof W);
+    for (int s = 0; s < 8; ++s) {
+        const int dx = s & 1, dy = (s >> 1) & 1, dz = s >> 2;
+        S[1 + dz][1 + dy][1 + dx] = cf[s]; S[1 - dz][1 - dy][1 - dx] = cf[s];
+        W[1 + dz][1 + dy][1 + dx] = s ? 0.5 : 1.0; W[1 - dz][1 - dy][1 - dx] = s ? 0.5 : 1.0;
+    }
+    // y = A (P e_0): support radius 2 around the fine node of coarse node 0
+    double Y[5][5][5];
+    std::memset(Y, 0, sizeof Y);
+    for (int gz = -2; gz <= 2; ++gz) for (int gy = -2; gy <= 2; ++gy) for (int gx = -2; gx <= 2; ++gx) {
+        double a = 0.0;
+        for (int az = -1; az <= 1; ++az) for (int ay = -1; ay <= 1; ++ay) for (int ax = -1; ax <= 1; ++ax) {
+            const int fz = gz + az, fy = gy + ay, fx = gx + ax;
+            if (fz < -1 || fz > 1 || fy < -1 || fy > 1 || fx < -1 || fx > 1) continue;
+            a += S[1 + az][1 + ay][1 + ax] * W[1 + fz][1 + fy][1 + fx];
+        }
+        Y[2 + gz][2 + gy][2 + gx] = a;
+    }
+    double scale = 0.0, leak = 0.0;
+    for (int Dz = -1; Dz <= 1; ++Dz) for (int Dy = -1; Dy <= 1; ++Dy) for (int Dx = -1; Dx <= 1; ++Dx) {
+        double a = 0.0;
+        for (int ez = -1; ez <= 1; ++ez) for (int ey = -1; ey <= 1; ++ey) for (int ex = -1; ex <= 1; ++ex) {
+            const int gz = 2 * Dz + ez, gy = 2 * Dy + ey, gx = 2 * Dx + ex;
+            if (gz < -2 || gz > 2 || gy < -2 || gy > 2 || gx < -2 || gx > 2) continue;
+            a += W[1 + ez][1 + ey][1 + ex] * Y[2 + gz][2 + gy][2 + gx];
+        }
+        // on the pattern: all components of D in {0, 1} or all in {0, -1}
+        const bool up = Dx >= 0 && Dy >= 0 && Dz >= 0, dn = Dx <= 0 && Dy <= 0 && Dz <= 0;
+        if (up) cc[Dx + 2 * Dy + 4 * Dz] = a;
+        if (!up && !dn) leak = std::max(leak, std::fabs(a));
+        scale = std::max(scale, std::fabs(a));
+    }
+    return cc[0] > 0.0 && leak <= 1e-10 * scale;
+}
+
+void mg_release(Ctx *c) {
+    if (!c->mg) return;
+    Mg *M = c->mg;
+    for (MgLevel &L : M->lv) {
+        if (L.b) (void)hipFree(L.b);
+        if (L.x) (void)hipFree(L.x);
+        if (L.t) (void)hipFree(L.t);
+        if (L.cls) (void)hipFree(L.cls);
+    }
+    if (M->bad) (void)hipFree(M->bad);
+    delete M;
+    c->mg = nullptr;
+}
+
+double *mg_result(Ctx *c) { return c->mg && !c->mg->lv.empty() ? c->mg->lv[0].x : nullptr; }
+
+static dim3 mg_grid(const MgGrid &g) { return dim3((unsigned)((g.nx + 63) / 64), (unsigned)((g.ny + 3) / 4), (unsigned)g.nz); }
+
+bool mg_prepare(Ctx *c, const Mesh *m, const Csr *a) {
+    if (!m || !a || !a->st_ok || a->st_ident < 0 || !a->cls || m->sym_nx <= 0) return false;
+    const int nx = m->sym_nx, ny = m->sym_ny, nz = (int)(m->nv / ((int64_t)nx * ny));
+    if ((int64_t)nx * ny * nz != m->nv || std::min(nx, std::min(ny, nz)) < 8 || nz > 65535 || ny > 4 * 65535) return false;
+    if (a->st_z0 != 0 || a->st_z1 != nz) return false;                     // (the whole lattice was verified, not a slab of it)
+    for (int s = 1; s < 8; ++s) if (!(a->st_c[s] == a->st_c[s])) return false;
+    if (!(a->st_c[0] > 0.0)) return false;
+    if (!c->mg) c->mg = new Mg();
+    Mg *M = c->mg;
+    if (!M->bad) {
+        void *q = nullptr;
+        if (hipMalloc(&q, sizeof(int)) != hipSuccess) return false;
+        M->bad = (int *)q;
+    }
+    // the eliminated nodes must be the hull, nothing else (one pass over the code bytes; read back with the solve's first look)
+    int bad = 0;
+    if (hipMemsetAsync(M->bad, 0, sizeof(int), c->stream) != hipSuccess) return false;
+    k_mg_hull_check<<<(unsigned)((m->nv + TPB - 1) / TPB), TPB, 0, c->stream>>>(a->cls, a->st_ident, nx, ny, nz, M->bad);
+    if (hipMemcpyAsync(&bad, M->bad, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess)
+        return false;
+    if (bad) return false;
+    if (M->nx != nx || M->ny != ny || M->nz != nz) {                       // another lattice: new levels and buffers
+        mg_release(c);
+        c->mg = new Mg();
+        M = c->mg;
+        void *q = nullptr;
+        if (hipMalloc(&q, sizeof(int)) != hipSuccess) return false;
+        M->bad = (int *)q;
+        M->nx = nx; M->ny = ny; M->nz = nz;
+        MgGrid g{nx, ny, nz, 1, 1, 1};
+        for (;;) {
+            MgLevel L;
+            L.g = g;
+            L.n = (int64_t)g.nx * g.ny * g.nz;
+            M->lv.push_back(L);
+            if (std::min(g.nx, std::min(g.ny, g.nz)) < 8) break;
+            MgGrid h;
+            h.nx = (g.nx + 1) / 2; h.ny = (g.ny + 1) / 2; h.nz = (g.nz + 1) / 2;
+            h.fx = g.fx && (g.nx & 1); h.fy = g.fy && (g.ny & 1); h.fz = g.fz && (g.nz & 1);
+            g = h;
+        }
+        if (M->lv.size() < 2 || M->lv.back().n > MG_BOTTOM_MAX) { M->nx = 0; M->lv.clear(); return false; }
+        for (size_t l = 0; l < M->lv.size(); ++l) {
+            MgLevel &L = M->lv[l];
+            void *q2 = nullptr;
+            const size_t bytes = (size_t)L.n * sizeof(double);
+            if (l > 0) { if (hipMalloc(&q2, bytes) != hipSuccess) { M->nx = 0; return false; } L.b = (double *)q2; }
+            if (hipMalloc(&q2, bytes) != hipSuccess) { M->nx = 0; return false; }
+            L.x = (double *)q2;
+            if (l + 1 < M->lv.size()) { if (hipMalloc(&q2, bytes) != hipSuccess) { M->nx = 0; return false; } L.t = (double *)q2; }
+            if (l > 0 && l + 1 < M->lv.size()) {
+                if (hipMalloc(&q2, (size_t)L.n) != hipSuccess) { M->nx = 0; return false; }
+                L.cls = (uint8_t *)q2;
+                k_mg_codes<<<(unsigned)((L.n + TPB - 1) / TPB), TPB, 0, c->stream>>>(L.g, L.cls);
+            }
+        }
+        M->have_key = false;
+    }
+    if (!M->have_key || std::memcmp(M->key, a->st_c, sizeof M->key) != 0) {
+        double cf[8];
+        for (int s = 0; s < 8; ++s) cf[s] = a->st_c[s];
+        for (size_t l = 0; l < M->lv.size(); ++l) {
+            MgLevel &L = M->lv[l];
+            for (int s = 0; s < 8; ++s) L.s.c[s] = cf[s];
+            L.s.w = 0.8 / cf[0];
+            if (l + 1 < M->lv.size()) {
+                double cc[8];
+                if (!mg_galerkin(cf, cc)) { M->have_key = false; return false; }
+                for (int s = 0; s < 8; ++s) cf[s] = cc[s];
+            }
+        }
+        std::memcpy(M->key, a->st_c, sizeof M->key);
+        M->have_key = true;
+    }
+    M->cls0 = a->cls;
+    M->ident0 = a->st_ident;
+    const dim3 g0 = mg_grid(M->lv[0].g);
+    M->np0 = (int)((int64_t)g0.x * g0.y * g0.z);
+    if (ensure_partials(c, std::max<int64_t>(M->np0 + 64, 4 * (int64_t)MAX_VEC_BLOCKS)) != PGD_OK) return false;
+    return true;
+}
+
+int mg_fix_start(Ctx *c, const Csr *a, const double *b, double *x, int64_t n) {
+    k_mg_fix_start<<<(unsigned)((n + TPB - 1) / TPB), TPB, 0, c->stream>>>(a->cls, a->st_ident, b, x, n);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+int mg_vcycle(Ctx *c, const double *r, bool dot, int *nparts) {
+    Mg *M = c->mg;
+    if (!M || M->lv.size() < 2) return fail(c, PGD_ERR_INVALID, "mg_vcycle: no hierarchy");
+    const int nl = (int)M->lv.size();
+    const dim3 blk(256, 1, 1);      // 64 x 4 nodes of one plane
+    const int *flags = c->flags;
+    // a level's stencil passes run in the march kernel of the product where the lattice is wide enough to fill its 64 x 16 patches
+    auto march = [&](int l) {
+        const MgLevel &L = M->lv[l];
+        return c->mg_march_min > 0 && L.g.nx >= c->mg_march_min && L.g.ny >= c->mg_march_min && L.g.nz >= 8 &&
+               (int64_t)L.g.nx * L.g.ny < ((int64_t)1 << 26) && (l == 0 || L.cls);
+    };
+    auto pass = [&](int l, int epi, const double *in, const double *b, double *out, bool want_dot, int *np) -> int {
+        const MgLevel &L = M->lv[l];
+        return launch_stencil_pass(c, l == 0 ? M->cls0 : L.cls, l == 0 ? M->ident0 : 1, L.s.c, L.g.nx, L.g.ny, L.g.nz, 1, L.g.nz - L.g.fz,
+                                   in, b, out, L.s.w, epi, want_dot, np);
+    };
+    int np_dot = M->np0;
+    // down: residual behind the folded pre-smoothing step, restriction
+    for (int l = 0; l + 1 < nl; ++l) {
+        MgLevel &L = M->lv[l], &C = M->lv[l + 1];
+        const double *b = l == 0 ? r : L.b;
+        if (march(l)) PGD_TRY(pass(l, 1, b, nullptr, L.t, false, nullptr));
+        else k_mg_pass<0, false><<<mg_grid(L.g), blk, 0, c->stream>>>(L.g, L.s, b, nullptr, L.t, nullptr, flags);
+        k_mg_restrict<<<mg_grid(C.g), blk, 0, c->stream>>>(C.g, L.g, L.t, C.b, flags);
+    }
+    {
+        MgLevel &B = M->lv[nl - 1];
+        k_mg_bottom<<<1, 1024, 0, c->stream>>>(B.g, B.s, B.b, B.x, 24, flags);
+    }
+    // up: x = w b + P e, one more damped-Jacobi step
+    for (int l = nl - 2; l >= 0; --l) {
+        MgLevel &L = M->lv[l], &C = M->lv[l + 1];
+        const double *b = l == 0 ? r : L.b;
+        k_mg_prolong<<<mg_grid(L.g), blk, 0, c->stream>>>(L.g, C.g, L.s.w, b, C.x, L.t, flags);
+        if (march(l)) PGD_TRY(pass(l, 2, L.t, b, L.x, l == 0 && dot, l == 0 && dot ? &np_dot : nullptr));
+        else if (l == 0 && dot) k_mg_pass<1, true><<<mg_grid(L.g), blk, 0, c->stream>>>(L.g, L.s, L.t, b, L.x, c->partials, flags);
+        else k_mg_pass<1, false><<<mg_grid(L.g), blk, 0, c->stream>>>(L.g, L.s, L.t, b, L.x, nullptr, flags);
+    }
+    if (nparts) *nparts = np_dot;
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+}  // namespace pgd

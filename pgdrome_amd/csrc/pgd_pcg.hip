@@ -1427,6 +1427,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     // all 16-iteration chunks are identical and can be replayed as one hipGraph.
     constexpr int S_INIT = 18, S_PAIR = 16;
     const bool scaled = sym && c->pcg_scaled && n >= 2;
+    bool mg_on = false;
     double *sc = z;                     // the scaled recurrence has no z: its buffer holds s = d^-1/2
     // On EVERY exit after x and the slot arrays were scaled (a failing launch, graph replay or copy included): x back to
     // D^-1/2 x~ and the slot arrays no longer taken for A - a later product with this operator must not read the scaled
@@ -1450,6 +1451,13 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         guard.active = true;            // x is scaled from here on
         PGD_TRY(sym_scale(c, m, o, sc));
         PGD_TRY(dia_classify(c, m, o));         // uniform grids: a code byte per row instead of its slot values
+        // multigrid preconditioner (PGD_TUNE_PCG_PRECOND): one stencil on a lattice whose eliminated nodes are its hull, else Jacobi.
+        // Its cycle works on vectors that vanish on the eliminated rows: x = b there from the start (their exact solution, s = 1)
+        if (c->pcg_precond == 1) {
+            mg_on = mg_prepare(c, m, o);
+            if (mg_on) { c->mg_solves += 1; PGD_TRY(mg_fix_start(c, o, b->d, x->d, n)); }
+            else c->mg_fallbacks += 1;
+        }
         PGD_TRY(launch_spmv_op(c, m, o, x->d, q, nullptr, 0, n, false, true, nullptr, nullptr));
         const int g = grid_for(n);
         PGD_TRY(ensure_partials(c, 4 * (int64_t)MAX_VEC_BLOCKS));
@@ -1462,18 +1470,24 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     }
     k_pcg_tol<<<1, 64, 0, c->stream>>>(c->slots, c->flags, rtol, atol, S_INIT + 1, S_INIT + 2, S_TOL2);
     PGD_LAUNCH_CHECK(c);
+    if (mg_on) {                        // p0 = z0 = M r0; the first "previous r.z"
+        int np = 0;
+        PGD_TRY(mg_vcycle(c, r, true, &np));
+        PGD_TRY(reduce_partials(c, c->partials, np, 1, S_INIT, -1, 0, 0));
+        PGD_HIP(c, hipMemcpyAsync(p, mg_result(c), (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+    }
 
     // second partials buffer for the folded reductions (the x / r update reads the product's partials while writing its own)
     PGD_TRY(ensure_work(c, 6, 4 * (int64_t)MAX_VEC_BLOCKS));
     double *part2 = c->work[6];                         // (the two-launch form of small systems alternates between this half and the next)
     // large systems: the x update rides in the p kernel (PGD_TUNE_PCG_DEFER_X); the folded small-system form keeps its own kernels
     // systems of up to 2^20 rows: single-sync recurrence in two launches per iteration (k_pcg1_step) ...
-    const bool fold = scaled && c->pcg_single_sync && c->pcg_small_ss && (n <= ((int64_t)1 << 20) || (n <= c->pcg_small_ss_rows && m->sym_nx > 0));
+    const bool fold = !mg_on && scaled && c->pcg_single_sync && c->pcg_small_ss && (n <= ((int64_t)1 << 20) || (n <= c->pcg_small_ss_rows && m->sym_nx > 0));
     // ... or the two-reduction recurrence with its final reduction passes folded into their consumers (three launches)
-    const bool folded_form = scaled && c->pcg_fold_reduce && n <= ((int64_t)1 << 20) && !fold;
-    const bool single_sync = fold || (scaled && c->pcg_single_sync && !folded_form && m->sym_nx > 0);
+    const bool folded_form = !mg_on && scaled && c->pcg_fold_reduce && n <= ((int64_t)1 << 20) && !fold;
+    const bool single_sync = !mg_on && (fold || (scaled && c->pcg_single_sync && !folded_form && m->sym_nx > 0));
     double *part2b = part2 + 2 * (int64_t)MAX_VEC_BLOCKS;
-    const bool deferred_x = scaled && c->pcg_defer_x && !folded_form && !single_sync;
+    const bool deferred_x = !mg_on && scaled && c->pcg_defer_x && !folded_form && !single_sync;
     const bool lag_x = single_sync && c->pcg_lag_x;
     // (two-launch form above 2^20 rows: 512 workgroups in the update, every one of which sums all partial sums)
     const int g2v = grid_for((n + 1) / 2, TPB, (n > ((int64_t)1 << 20) && n <= c->pcg_small_ss_rows && c->pcg_small_ss) ? 512 : MAX_VEC_BLOCKS);
@@ -1527,6 +1541,19 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
                 continue;
             }
             PGD_TRY(launch_spmv_op(c, m, o, p, q, p, 0, n, true, true, c->flags, &nparts));
+            if (mg_on) {
+                // textbook PCG with z = M r from the V-cycle: the stop test stays the one of the Jacobi form (true r.r in the exact phase)
+                const int g2 = grid_for((n + 1) / 2);
+                int np = 0;
+                PGD_TRY(reduce_partials(c, c->partials, nparts, 1, S_PQ, 0, 0, 0));
+                k_pcg_xr_s<<<g2, TPB, 0, c->stream>>>(x->d, r, p, q, sc, n, c->slots, rz_old, S_PQ, c->partials, c->flags);
+                PGD_LAUNCH_CHECK(c);
+                PGD_TRY(reduce_partials(c, c->partials, g2, 2, out, 2, out + 1, S_TOL2));      // counts the iteration, tests
+                PGD_TRY(mg_vcycle(c, r, true, &np));
+                PGD_TRY(reduce_partials(c, c->partials, np, 1, out, -1, 0, 0));                // r.z over the r~.r~ the test has used
+                k_pcg_p<true><<<g2, TPB, 0, c->stream>>>(p, mg_result(c), 0, n, c->slots, out, rz_old, c->flags);
+                continue;
+            }
             // (pays only where the launches, not the bytes, set the pace: 256^2 rows +22 %, 128^3 +-0, 256^3 -2 %)
             if (scaled && c->pcg_fold_reduce && nparts > 0 && nparts <= 8192 && n <= ((int64_t)1 << 20)) {
                 const int g2 = grid_for((n + 1) / 2);
@@ -1565,7 +1592,9 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     // chunk is issued eagerly so that its products carry their HIP events; the capture itself records none.
     hipGraphExec_t gexec = nullptr;
     if (dbg_t) { (void)hipStreamSynchronize(c->stream); dbg_t1 = dbg_now(); }
-    if (maxit >= CHECK_EVERY) {
+    // (a multigrid iteration is ~50 launches and a solve ~20 iterations: shorter chunks, less queued behind the converged one)
+    const int CE = mg_on ? std::max(1, std::min(c->mg_chunk, CHECK_EVERY)) : CHECK_EVERY;
+    if (maxit >= CE) {
         // everything a chunk allocates lazily must exist before the capture starts
         PGD_TRY(ensure_partials(c, std::max<int64_t>(4 * (int64_t)MAX_VEC_BLOCKS, 2 * ((n + 63) / 64) + 64)));
         PGD_TRY(ensure_work(c, 5, 4096));
@@ -1573,7 +1602,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         c->prof = false;
         hipGraph_t graph = nullptr;
         if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-            const int rc = enqueue(0, CHECK_EVERY);
+            const int rc = enqueue(0, CE);
             const hipError_t e = hipStreamEndCapture(c->stream, &graph);
             if (rc != PGD_OK || e != hipSuccess || !graph ||
                 hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) != hipSuccess)
@@ -1587,8 +1616,8 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     int enq = 0, rc_loop = PGD_OK;
     if (dbg_t) dbg_t2 = dbg_now();
     auto issue = [&](int chunk) -> int {
-        const bool eager_for_timing = c->prof && ((enq / CHECK_EVERY) % PROF_EAGER_EVERY == 0);
-        if (gexec && chunk == CHECK_EVERY && !eager_for_timing) {
+        const bool eager_for_timing = c->prof && ((enq / CE) % PROF_EAGER_EVERY == 0);
+        if (gexec && chunk == CE && !eager_for_timing) {
             if (hipGraphLaunch(gexec, c->stream) != hipSuccess) return fail(c, PGD_ERR_HIP, "pcg_solve: hipGraphLaunch failed");
             return PGD_OK;
         }
@@ -1607,7 +1636,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         int cur = 0;
         hipError_t e = snap(0);                           // the flags after the initial residual
         while (e == hipSuccess) {
-            const int chunk = (maxit - enq < CHECK_EVERY) ? maxit - enq : CHECK_EVERY;
+            const int chunk = (maxit - enq < CE) ? maxit - enq : CE;
             if (chunk > 0) {
                 if ((rc_loop = issue(chunk)) != PGD_OK) break;
                 enq += chunk;
@@ -1625,7 +1654,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) { rc_loop = fail(c, PGD_ERR_HIP, "pcg_solve: %s", hipGetErrorString(e)); break; }
             if (f[0] || enq >= maxit) break;
-            const int chunk = (maxit - enq < CHECK_EVERY) ? maxit - enq : CHECK_EVERY;
+            const int chunk = (maxit - enq < CE) ? maxit - enq : CE;
             if ((rc_loop = issue(chunk)) != PGD_OK) break;
             enq += chunk;
         }

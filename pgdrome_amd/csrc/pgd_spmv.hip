@@ -1125,6 +1125,8 @@ struct StencilArgs {
     int z0, z1, zchunk, tiles_x, tiles_y;
     int qq;
     int whatif;             // instrumented builds only (PGD_STENCIL_TIMING): 1 no y stores, 2 no x fetches, 4 no LDS reads / FMAs
+    const double *b;        // epilogues of the multigrid passes (EPI 1: y = x - w A x;  EPI 2: y = x + w (b - A x), fused dot b . y)
+    double w;
 };
 
 #if defined(PGD_STENCIL_TIMING) || defined(PGD_STENCIL_WHATIF)
@@ -1135,7 +1137,7 @@ struct StencilArgs {
 
 typedef int st_v2i __attribute__((ext_vector_type(2)));
 
-template <bool DOT, bool STORE, int D, bool NTY, int OCC>
+template <bool DOT, bool STORE, int D, bool NTY, int OCC, int EPI = 0>
 __global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) {
     constexpr int NT = 256, PY = 16, HY = PY + 2, RW = 4;                   // 64 x 16 patch, four rows per thread
     constexpr int NQ = 5;                                                   // cells a thread stages per plane: its own four + one halo cell
@@ -1226,6 +1228,7 @@ __global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) 
     };
     const double *xq = A.x + P * (int64_t)(za - 1);                         // running pointers: the next plane to fetch ...
     double *yq = A.y + P * (int64_t)(za - 1);                               // ... and the plane being staged / multiplied
+    const double *bq = EPI == 2 ? A.b + P * (int64_t)za : nullptr;          // (EPI 2: the right-hand side's plane beside it)
     double rr[D][NQ];                                                       // the D plane fetches in flight, rotating by name
     double own[3][RW];                                                      // raw own values of the planes z, z + 1, z + 2: own[(plane - za) % 3]
     static_assert(D % 3 == 0, "the ring of own values rotates by name: the march is unrolled in multiples of three steps");
@@ -1259,6 +1262,12 @@ __global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) 
 #endif
     // the product of the rows of plane z (a main plane), yz = y + P z, xo = the plane's raw own values
     auto rows = [&](int z, double *yz, bool live, const double (&xo)[RW]) {
+        double bv[RW];
+        if (EPI == 2) {                                                     // issued first: in flight behind the LDS reads and the chains
+            const auto rb = rsrc_of(bq, live);
+#pragma unroll
+            for (int r = 0; r < RW; ++r) bv[r] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rb, sv[r], 0, 0));
+        }
         const double *xm = s_x + ((z - 1) & 3) * SLOT + centre;
         const double *xc = s_x + (z & 3) * SLOT + centre;
         const double *xp = s_x + ((z + 1) & 3) * SLOT + centre;
@@ -1305,9 +1314,11 @@ __global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) 
         const auto ry = rsrc_of(yz, live && STORE && !PGD_ST_WHATIF(1));
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
-            const double yv = fixr[r] ? xo[r] : acc[r];        // an eliminated row: y = x, in the same full-line store as its neighbours' sums
+            const double ev = EPI == 0 ? acc[r] : EPI == 1 ? fma(-A.w, acc[r], xo[r]) : fma(A.w, bv[r] - acc[r], xo[r]);
+            const double yv = fixr[r] ? xo[r] : ev;            // an eliminated row: y = x, in the same full-line store as its neighbours' sums
             if (STORE) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(st_v2i, yv), ry, sv[r], 0, AUX_ST);
-            if (DOT) {                                         // (a row outside the grid: x = 0 was loaded for it, and its sum is one of zeros)
+            if (DOT && EPI == 2) dot = fma(yv, bv[r], dot);    // (rows outside the grid: b = 0 was loaded)
+            else if (DOT) {                                    // (a row outside the grid: x = 0 was loaded for it, and its sum is one of zeros)
                 dot = fma(yv, xo[r], dot);
                 const double t = sv[r] != OOB ? yv : 0.0;
                 dot2 = fma(t, t, dot2);
@@ -1320,7 +1331,7 @@ __global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) 
 #pragma unroll
         for (int r = 0; r < RW; ++r) {
             if (STORE) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(st_v2i, xo[r]), ry, sv[r], 0, AUX_ST);
-            if (DOT) { dot = fma(xo[r], xo[r], dot); dot2 = fma(xo[r], xo[r], dot2); }
+            if (DOT && EPI == 0) { dot = fma(xo[r], xo[r], dot); dot2 = fma(xo[r], xo[r], dot2); }      // (EPI 2: b . y with y = x = 0 there)
         }
     };
     // PURE: every plane the march touches - its own, its two halo planes - is a main plane: no plane tests in the steps
@@ -1339,6 +1350,7 @@ __global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) 
                 fetch(xq, z + s + 2 + D <= zb, rr[s]);
                 PGD_ST_STAMP(2);
                 xq += P; yq += P;
+                if (EPI == 2) bq += P;
                 if (!PGD_ST_WHATIF(8)) lds_barrier();
                 PGD_ST_STAMP(3);
             }
@@ -1358,6 +1370,7 @@ __global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) 
             stage(zs + 2, rr[s], own[(s + 2) % 3]);
             fetch(xq, fetch_live(zs + 2 + D), rr[s]);
             xq += P; yq += P;
+            if (EPI == 2) bq += P;
             lds_barrier();
         }
     }
@@ -1488,6 +1501,35 @@ __global__ __launch_bounds__(TPB) void k_stencil_verify(const uint8_t *__restric
         good = good && (live ? __double_as_longlong(v) == __double_as_longlong(S->c[s]) : v == 0.0);
     }
     if (!good) S->ok = 0;
+}
+
+// The stencil march with an epilogue, over the whole lattice (pgd_mg.hip: the two stencil passes of a multigrid level):
+//   epi 1: y = x - w A x;   epi 2: y = x + w (b - A x), dot: partial sums of b . y (one per workgroup, *nparts of them in c->partials).
+// cls / ident as in the product: code byte per node, `ident` marks eliminated nodes; planes [zm0, zm1) share one pattern of
+// eliminated nodes, the planes outside hold eliminated nodes only.  x must vanish on eliminated nodes (then y does).
+int launch_stencil_pass(Ctx *c, const uint8_t *cls, int ident, const double cst[8], int nx, int ny, int nz, int zm0, int zm1,
+                        const double *x, const double *b, double *y, double w, int epi, bool dot, int *nparts) {
+    StencilArgs F;
+    F.cls = cls; F.ident = ident; F.x = x; F.y = y; F.b = b; F.w = w; F.flags = c->flags;
+    for (int s2 = 0; s2 < 8; ++s2) F.c[s2] = cst[s2];
+    F.nx = nx; F.ny = ny; F.nz = nz; F.zv0 = 0; F.zv1 = nz; F.zm0 = zm0; F.zm1 = zm1; F.z0 = 0; F.z1 = nz;
+    F.tiles_x = (nx + 63) / 64; F.tiles_y = (ny + 15) / 16;
+    F.qq = 0; F.whatif = 0;
+    const int64_t tiles = (int64_t)F.tiles_x * F.tiles_y, slots = (int64_t)c->stencil_wg_per_cu * c->num_cu;
+    const int64_t marches = std::max<int64_t>(1, slots / tiles);
+    const int zc = std::max(3, (int)((nz + marches - 1) / marches));
+    F.zchunk = zc;
+    const int wgs = (int)(((nz + zc - 1) / zc) * tiles);
+    if (nparts) *nparts = wgs;
+    if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + (int64_t)wgs, 4 * MAX_VEC_BLOCKS)));
+    F.partials = c->partials + c->partials_off;
+    if (epi == 1) k_spmv_stencil_march<false, true, 3, false, 2, 1><<<wgs, 256, 0, c->stream>>>(F);
+    else if (epi == 2 && dot) k_spmv_stencil_march<true, true, 3, false, 2, 2><<<wgs, 256, 0, c->stream>>>(F);
+    else if (epi == 2) k_spmv_stencil_march<false, true, 3, false, 2, 2><<<wgs, 256, 0, c->stream>>>(F);
+    else return fail(c, PGD_ERR_INVALID, "launch_stencil_pass: epilogue %d", epi);
+    c->kcount[KC_STENCIL_MARCH] += 1;
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
 }
 
 // --- the classification (per solve, after the slot arrays got their final values)
@@ -2231,6 +2273,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
                 F.nx = D.nx; F.ny = D.ny; F.nz = D.nz; F.z0 = D.z0; F.z1 = D.z1; F.tiles_x = D.tiles_x; F.tiles_y = (D.ny + 15) / 16;
                 F.qq = D.qq;
                 F.whatif = 0;
+                F.b = nullptr; F.w = 0.0;
 #if defined(PGD_STENCIL_TIMING) || defined(PGD_STENCIL_WHATIF)
                 if (const char *wi = getenv("PGD_STENCIL_WHATIF")) F.whatif = atoi(wi);
 #endif
@@ -2465,6 +2508,13 @@ int pgd_debug_read_partials(pgd_handle h, double *out, int first, int count) {
 }
 #endif
 
+int pgd_mg_counts(pgd_handle h, int64_t *solves, int64_t *fallbacks) {
+    PGD_CTX(c, h);
+    if (solves) *solves = c->mg_solves;
+    if (fallbacks) *fallbacks = c->mg_fallbacks;
+    return PGD_OK;
+}
+
 int pgd_classify_counts(pgd_handle h, int64_t *full, int64_t *cached) {
     PGD_CTX(c, h);
     if (full) *full = c->cls_full;
@@ -2509,6 +2559,9 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_ATOM_FAST && value >= 0 && value <= 1) { c->atom_fast = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_LAZY_CSR && value >= 0 && value <= 1) { c->lazy_csr = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK_CODED && value >= 3 && value <= 1024) { c->spmv_zchunk_coded = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_PCG_PRECOND && value >= 0 && value <= 1) { c->pcg_precond = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_MG_CHUNK && value >= 1 && value <= 16) { c->mg_chunk = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_MG_MARCH_MIN && value >= 0 && value <= 1 << 20) { c->mg_march_min = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }
 

@@ -1568,3 +1568,69 @@ def test_error_paths(ctx):
     with pytest.raises(PgdError):
         ctx.atom_assemble(h, 42)
     ctx.mesh_free(h)
+
+
+@pytest.mark.parametrize("npts", [40, 65, 104])
+def test_multigrid_pcg_solves_the_same_system(ctx, npts):
+    """PGD_TUNE_PCG_PRECOND = 1: the V-cycle of pgd_mg.hip as the preconditioner of pgd_pcg_solve where the scaled operator is one
+    stencil on a lattice with an eliminated hull (even and odd node counts: the far faces with and without a coarse counterpart).
+    Same system, same stop test: the solution agrees with the Jacobi form's to the tolerance of the solves, non-zero Dirichlet
+    values are met exactly, the true residual through the CSR kernel is at the tolerance, in a number of iterations that does not
+    grow with the lattice.  An operator whose eliminated nodes are not the hull falls back to Jacobi (counted)."""
+    from pgdrome_amd import fem
+    mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), npts - 1, npts - 1, npts - 1)
+    coords = mesh.coordinates()
+    h = ctx.mesh_upload(coords, mesh.cells())
+    n = coords.shape[0]
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bc = np.where(np.any((coords <= 1e-12) | (coords >= 1 - 1e-12), axis=1))[0].astype(np.int32)
+    rng = np.random.default_rng(22)
+    b = rng.uniform(-1, 1, n)
+    b[bc] = rng.uniform(-1, 1, bc.size)
+    bv = ctx.vec_from(b)
+    out = {}
+    try:
+        for prec in (0, 1, 2):                                   # 2: the V-cycle with every level in the plain kernels of pgd_mg.hip
+            ctx.tune(40, min(prec, 1))
+            ctx.tune(42, 0 if prec == 2 else 64)
+            op = ctx.op_combine(h, [ak, am], [1.0, 3.0], bc)
+            xv = ctx.vec_from(rng.uniform(-1, 1, n))             # a start that violates the Dirichlet values
+            it, rel = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, 10000)
+            xs = ctx.vec_download(xv)
+            out[prec] = (it, rel, xs)
+            assert np.abs(xs[bc] - b[bc]).max() <= (0.0 if prec else 1e-9)
+            yv = ctx.vec_alloc(n)
+            ctx.flags_reset()
+            ctx.tune(3, 0)
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
+            ctx.tune(3, 1)
+            assert np.linalg.norm(b - ctx.vec_download(yv)) <= 1.05e-10 * np.linalg.norm(b)
+            assert rel <= 1e-10
+            for v in (yv, xv):
+                ctx.vec_free(v)
+            ctx.atom_free(op)
+        assert out[1][0] <= 26 and out[0][0] > 3 * out[1][0], (out[0][0], out[1][0])
+        assert np.linalg.norm(out[1][2] - out[0][2]) <= 2e-8 * np.linalg.norm(out[0][2])
+        # the march kernel's epilogues against the plain passes: the same cycle up to the order of the sums
+        assert abs(out[2][0] - out[1][0]) <= 1 and np.linalg.norm(out[2][2] - out[1][2]) <= 2e-8 * np.linalg.norm(out[1][2])
+        st = ctx.mg_stats()
+        assert st["solves"] >= 1
+        # eliminated nodes on one face only: not the structure the hierarchy is built for -> Jacobi, and it says so
+        face = np.where(coords[:, 2] <= 1e-12)[0].astype(np.int32)
+        op = ctx.op_combine(h, [ak, am], [1.0, 3.0], face)
+        xv = ctx.vec_alloc(n)
+        b2 = b.copy(); b2[bc] = 0.0
+        b2v = ctx.vec_from(b2)
+        it2, rel2 = ctx.pcg_solve(op, b2v, xv, 1e-10, 0.0, 10000)
+        assert rel2 <= 1e-10 and ctx.mg_stats()["fallbacks"] == st["fallbacks"] + 1
+        for v in (xv, b2v):
+            ctx.vec_free(v)
+        ctx.atom_free(op)
+    finally:
+        ctx.tune(40, 0)
+        ctx.tune(42, 64)
+        ctx.tune(3, 1)
+    ctx.vec_free(bv)
+    for a in (ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
