@@ -292,8 +292,12 @@ def main():
         out["roofline"]["csr_product"] = csr_section(be, prob, n_sp, nnz)
     general = None
     if rank == 0 and world == 1 and not sharded and not args.no_general_paths and ran in ("diac_march", "stencil_march"):
+        import numpy as np
+        n_done = min(len(prob.num_fp_it), min(len(f) for f in prob.PGD_func)) if getattr(prob, "PGD_func", None) else 0
+        modes_ref = [[np.asarray(f[k].vector()[:]).copy() for f in prob.PGD_func] for k in range(n_done)]
         general = general_paths(be, spec, settings)
         out["config"]["general_paths"] = general
+        out["config"]["multigrid_preconditioner"] = multigrid_path(be, spec, settings, modes_ref)
     pmc = pmc_traffic(own, upd_bytes) if rank == 0 and world == 1 and n == 256 and sym["nx"] and not args.no_pmc else {}
     out["roofline"].update(pmc.get("product", {}))
     if upd_n and upd_avg > avg:
@@ -428,6 +432,55 @@ def general_paths(be, spec, settings, passes=4, warm=1):
             be.prof_enable(False)
     res["note"] = ("same workload, same run, after the timed region: the headline's 17 B/row product needs a uniform lattice with constant "
                    "coefficients; plain_march is the rate without that (72 B/row), csr the rate on the CSR kernels with textbook PCG")
+    return res
+
+
+def multigrid_path(be, spec, settings, modes_ref, passes=8, warm=2):
+    """The same workload with settings["preconditioner"] = "amg" (the reference forwards the key to its linear solver,
+    solver.py:593-594): pgd_pcg_solve preconditioned by the matrix-free V-cycle of pgdrome_amd/csrc/pgd_mg.hip instead of the
+    diagonal scaling.  NOT the headline - the north star names Jacobi-PCG - but what the engine does for this problem when asked:
+    same systems, same stop test, same tolerance; the modes of the timed passes are compared with the headline run's."""
+    import time
+    import numpy as np
+    from pgdrome_amd import fem
+    from pgdrome_amd.solver import PGDProblem
+    st = {}
+    prob = PGDProblem(**spec)
+
+    def hook(n_pass):
+        if n_pass == warm:
+            be.sync()
+            st["i0"], st["s0"], st["m0"], st["t0"] = fem.STATS["pcg_iterations"], fem.STATS["pcg_seconds"], fem.STATS["mg_solves"], time.perf_counter()
+        elif n_pass == warm + passes:
+            be.sync()
+            st["t1"] = time.perf_counter()
+            st["i1"], st["s1"], st["m1"] = fem.STATS["pcg_iterations"], fem.STATS["pcg_seconds"], fem.STATS["mg_solves"]
+            raise _Done()
+    prob.pass_hook = hook
+    try:
+        for _ in range(100):
+            prob.solve_PGD(_problem="linear", settings=dict(settings, preconditioner="amg"))
+    except _Done:
+        pass
+    its = max(st["i1"] - st["i0"], 1)
+    res = {"passes_per_s": passes / (st["t1"] - st["t0"]), "passes": passes, "ms_per_pass": 1e3 * (st["t1"] - st["t0"]) / passes,
+           "pcg_iterations_per_pass": its / passes, "us_per_pcg_iteration": 1e6 * (st["s1"] - st["s0"]) / its,
+           "solves_preconditioned_by_the_v_cycle": st["m1"] - st["m0"], "seconds_in_pcg_solves": st["s1"] - st["s0"],
+           "settings": {"preconditioner": "amg"}, "knob": "pgd_tune(40, 1)",
+           "note": "geometric multigrid V(1,1) on the stencil form (Galerkin stencils of the nested P1 lattices, damped Jacobi), "
+                   "same stop test and tolerance as the headline's Jacobi-PCG; single GPU only"}
+    if modes_ref:
+        # completed modes of this run against the headline run's (rank-1 products: the sign of a mode's factors is not fixed)
+        n_cmp = min(len(modes_ref), len(prob.PGD_func[0]) if getattr(prob, "PGD_func", None) else 0)
+        worst = 0.0
+        for k in range(n_cmp):
+            a = [np.asarray(f[k].vector()[:]) for f in prob.PGD_func]
+            b = modes_ref[k]
+            sgn = 1.0 if float(np.dot(a[0], b[0])) >= 0 else -1.0
+            num = np.linalg.norm(a[0] * sgn - b[0]) / max(np.linalg.norm(b[0]), 1e-300)
+            worst = max(worst, float(num))
+        res["modes_compared_with_the_headline_run"] = n_cmp
+        res["worst_relative_l2_difference_of_a_spatial_mode"] = worst
     return res
 
 

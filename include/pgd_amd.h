@@ -301,7 +301,7 @@ enum {
     PGD_TUNE_MG_MARCH_MIN = 42, /* multigrid levels with at least this many nodes along x and y run their stencil passes in
                                 k_spmv_stencil_march (default 64); smaller ones in the plain kernels of pgd_mg.hip */
     PGD_TUNE_MG_CHUNK = 41, /* PCG iterations queued between two looks at the convergence flags when the multigrid preconditioner is on
-                                (default 4; the Jacobi form queues 16) */
+                                (even, default 2: an iteration is ~50 launches, the next chunk is queued while the flags of the last travel; the Jacobi form queues 16) */
     PGD_TUNE_PCG_PRECOND = 40, /* preconditioner of pgd_pcg_solve: 0 (default) Jacobi = the symmetric diagonal scaling; 1 a geometric
                                 multigrid V(1,1) cycle on the scaled operator WHERE it is one stencil on a lattice whose eliminated
                                 nodes are exactly the hull (every row verified, pgd_mg.hip), Jacobi everywhere else.  Changes the

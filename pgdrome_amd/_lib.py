@@ -586,6 +586,12 @@ class Context:
         self._ck(self.lib.pgd_classify_counts(self.h, C.byref(full), C.byref(cached)))
         return {"full": full.value, "cached": cached.value}
 
+    def precondition(self, multigrid):
+        """Select the preconditioner of the next pcg_solve calls (1: the multigrid V-cycle where the operator allows it,
+        0: Jacobi); returns the number of solves the V-cycle has preconditioned so far."""
+        self.tune(40, 1 if multigrid else 0)
+        return self.mg_stats()["solves"]
+
     def mg_stats(self):
         a, b = I64(), I64()
         self._ck(self.lib.pgd_mg_counts(self.h, C.byref(a), C.byref(b)))

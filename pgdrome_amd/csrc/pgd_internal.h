@@ -224,7 +224,7 @@ struct Ctx {
                                   // stencil on a lattice whose eliminated nodes are exactly its hull (pgd_mg.hip); anything else falls back to 0
     struct Mg *mg = nullptr;      // its levels and work vectors, kept across solves on the same lattice
     int64_t mg_solves = 0, mg_fallbacks = 0;
-    int mg_chunk = 4;             // iterations queued between two looks at the flags when the multigrid preconditioner is on
+    int mg_chunk = 2;             // iterations queued between two looks at the flags when the multigrid preconditioner is on (even: the slot parity of a replayed chunk)
     int mg_march_min = 64;        // levels with at least this many nodes along x and y run their stencil passes in k_spmv_stencil_march
     int cls_cache_on = 1;         // classification of an operator whose structure was seen before: codes copied, every row verified (PGD_TUNE_CLS_CACHE)
     int64_t cls_fast = 0, cls_full = 0;      // classifications served by the cache / done in full

@@ -1593,7 +1593,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     hipGraphExec_t gexec = nullptr;
     if (dbg_t) { (void)hipStreamSynchronize(c->stream); dbg_t1 = dbg_now(); }
     // (a multigrid iteration is ~50 launches and a solve ~20 iterations: shorter chunks, less queued behind the converged one)
-    const int CE = mg_on ? std::max(1, std::min(c->mg_chunk, CHECK_EVERY)) : CHECK_EVERY;
+    const int CE = mg_on ? std::max(2, std::min(c->mg_chunk & ~1, CHECK_EVERY)) : CHECK_EVERY;      // (even: iteration k uses the slot pair of parity k & 1, and the chunk is replayed)
     if (maxit >= CE) {
         // everything a chunk allocates lazily must exist before the capture starts
         PGD_TRY(ensure_partials(c, std::max<int64_t>(4 * (int64_t)MAX_VEC_BLOCKS, 2 * ((n + 63) / 64) + 64)));

@@ -2560,7 +2560,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_LAZY_CSR && value >= 0 && value <= 1) { c->lazy_csr = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK_CODED && value >= 3 && value <= 1024) { c->spmv_zchunk_coded = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_PRECOND && value >= 0 && value <= 1) { c->pcg_precond = (int)value; return PGD_OK; }
-    if (knob == PGD_TUNE_MG_CHUNK && value >= 1 && value <= 16) { c->mg_chunk = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_MG_CHUNK && value >= 2 && value <= 16 && value % 2 == 0) { c->mg_chunk = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_MG_MARCH_MIN && value >= 0 && value <= 1 << 20) { c->mg_march_min = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);
 }

@@ -2836,13 +2836,27 @@ def _solve_linear(A, b, x, prm):
             t_solve = time.perf_counter()
             if WARM_START_RESCALE and not x._zero:
                 _rescale_start(A.lay, op, b, x)
-            if mesh.part is not None:
-                it, rel = mesh.part.comm.pcg(mesh, op, b, x, rtol, atol, maxit)
-            else:
-                it, rel = be.pcg(op, b.dev(), x.dev(), rtol, atol, maxit)
-                x.touched_dev()
+            # settings["preconditioner"] (forwarded to PETSc by the reference, solver.py:593-594): the multigrid family asks for
+            # the V-cycle of pgd_mg.hip, which the library uses where the operator has the structure for it and says so in its
+            # counters; every other value is the Jacobi-PCG.  The row-sharded solve has the Jacobi form only.
+            prec = prm.get("preconditioner", "default")
+            want_mg = (not isinstance(prec, _Params)) and str(prec).lower() in MULTIGRID_NAMES and mesh.part is None
+            mg0 = None
+            if want_mg and hasattr(be, "precondition"):
+                mg0 = be.precondition(1)
+            try:
+                if mesh.part is not None:
+                    it, rel = mesh.part.comm.pcg(mesh, op, b, x, rtol, atol, maxit)
+                else:
+                    it, rel = be.pcg(op, b.dev(), x.dev(), rtol, atol, maxit)
+                    x.touched_dev()
+            finally:
+                if mg0 is not None:
+                    used = be.precondition(0) - mg0
             STATS["pcg_seconds"] += time.perf_counter() - t_solve      # the solve returns synchronised
-            info.update(method="jacobi_pcg", iterations=it, relres=rel)
+            info.update(method="mg_pcg" if mg0 is not None and used > 0 else "jacobi_pcg", iterations=it, relres=rel)
+            if mg0 is not None and used > 0:
+                STATS["mg_solves"] = STATS.get("mg_solves", 0) + 1
             if rel > max(rtol, 1e-14) * 1.0001 and it >= maxit:
                 # dolfin's Krylov solvers raise on non-convergence unless told otherwise (error_on_nonconvergence,
                 # default True): an unconverged mode must not be stored silently
@@ -2855,11 +2869,13 @@ def _solve_linear(A, b, x, prm):
     finally:
         be.atom_free(op)
     STATS["linear_solves"] += 1
-    STATS["pcg_iterations"] += info.get("iterations", 0) if info.get("method") == "jacobi_pcg" else 0
+    STATS["pcg_iterations"] += info.get("iterations", 0) if info.get("method") in ("jacobi_pcg", "mg_pcg") else 0
     return info
 
 
-STATS = {"linear_solves": 0, "pcg_iterations": 0, "pcg_seconds": 0.0}
+STATS = {"linear_solves": 0, "pcg_iterations": 0, "pcg_seconds": 0.0, "mg_solves": 0}
+# values of settings["preconditioner"] that select the geometric multigrid V-cycle (dolfin's names of its algebraic ones included)
+MULTIGRID_NAMES = ("amg", "hypre_amg", "petsc_amg", "ml_amg", "gmg", "multigrid", "mg")
 
 
 def _apply_bcs_system(A, b, bcs):

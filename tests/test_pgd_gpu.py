@@ -532,3 +532,51 @@ def test_randomized_start_on_gpu_equals_oracle(hip_backend, case, monkeypatch):
     for d in range(pg.num_pgd_var):
         for m in range(pg.PGD_modes):
             assert np.linalg.norm(mg[d][m] - mo[d][m]) <= 1e-6 * np.linalg.norm(mo[d][m]), (d, m)
+
+
+def test_multigrid_setting_equals_oracle_run_on_a_mid_size_problem(hip_backend):
+    """settings["preconditioner"] = "amg" (the reference forwards the key to its linear solver, solver.py:593-594): the spatial
+    solves of a 33^3 x 17 run go through the V-cycle of pgd_mg.hip - counted - and the run equals the oracle backend's (direct
+    host solves of the same systems): same pass counts, amplitudes, modes to the north star's 1e-6."""
+    from oracle.backend_numpy import NumpyBackend
+
+    def run(backend, settings):
+        fem.set_backend(backend)
+        fem.clear_caches()
+        spec = problems.reaction_diffusion(fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), 32, 32, 32), 17, PGD_nmax=3)
+        p = PGDProblem(**spec)
+        p.solve_PGD(_problem="linear", settings=settings)
+        return p, [[f.compute_vertex_values() for f in p.PGD_func[d]] for d in range(2)]
+    try:
+        s0, i0 = hip_backend.ctx.mg_stats(), fem.STATS["pcg_iterations"]
+        pg, mg = run(hip_backend, {"linear_solver": "cg", "preconditioner": "amg", "relative_tolerance": 1e-10})
+        s1, i1 = hip_backend.ctx.mg_stats(), fem.STATS["pcg_iterations"]
+        po, mo = run(NumpyBackend(), {"linear_solver": "cg", "preconditioner": "jacobi", "relative_tolerance": 1e-10})
+    finally:
+        fem.set_backend(hip_backend)
+        fem.clear_caches()
+    spatial_solves = sum(int(k) for k in pg.num_fp_it)
+    assert s1["solves"] - s0["solves"] >= spatial_solves and s1["fallbacks"] == s0["fallbacks"]
+    assert (i1 - i0) <= 25 * (s1["solves"] - s0["solves"])                       # a V-cycle solve: some 15 - 20 iterations
+    assert hip_backend.ctx.mg_stats()["solves"] == s1["solves"]                   # (the knob was reset behind every solve)
+    assert pg.num_fp_it == po.num_fp_it and pg.PGD_modes == po.PGD_modes
+    np.testing.assert_allclose(pg.amplitude, po.amplitude, rtol=1e-7)
+    np.testing.assert_allclose(pg.alpha, po.alpha, rtol=1e-7)
+    for d in range(2):
+        for m in range(pg.PGD_modes):
+            assert np.linalg.norm(mg[d][m] - mo[d][m]) <= 1e-6 * np.linalg.norm(mo[d][m])
+
+
+def test_cfg3_full_size_with_the_multigrid_setting(hip_backend):
+    """BASELINE config 3 at full size with settings["preconditioner"] = "amg": the pass counts and amplitudes of the Jacobi run."""
+    from pgdrome_amd import problems as P
+    spec = P.CONFIGS["cfg3"][0]()
+    p = PGDProblem(**spec)
+    s0 = hip_backend.ctx.mg_stats()
+    p.solve_PGD(_problem="linear", settings=dict(SETTINGS, preconditioner="amg"))
+    s1 = hip_backend.ctx.mg_stats()
+    assert s1["solves"] - s0["solves"] >= 44 and s1["fallbacks"] == s0["fallbacks"]
+    assert p.PGD_modes == 20 and [int(k) for k in p.num_fp_it] == FULL_SIZE["cfg3"]
+    np.testing.assert_allclose(p.amplitude[:4], [1.0, 0.10968546374117613, 0.046622979973166515, 0.02145789914285189], rtol=1e-6)
+    rel, exact = _resolve_first_spatial_system(p, spec, hip_backend)
+    assert exact and rel <= 1e-8
