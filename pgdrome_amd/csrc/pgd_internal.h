@@ -321,7 +321,7 @@ int launch_stencil_pass(Ctx *c, const uint8_t *cls, int ident, const double cst[
 // pgd_mg.hip: multigrid preconditioner of the scaled stencil operator
 bool mg_prepare(Ctx *c, const Mesh *m, const Csr *a);                          // true: usable for this operator (levels built, buffers there)
 int mg_fix_start(Ctx *c, const Csr *a, const double *b, double *x, int64_t n);    // x = b on the eliminated rows
-int mg_vcycle(Ctx *c, const double *r, bool dot, int *nparts);                 // z = M r into mg_result(c); partial sums of r.z into c->partials
+int mg_vcycle(Ctx *c, const double *r, bool dot, int *nparts, double *z_out = nullptr);      // z = M r into z_out (default: mg_result(c)); partial sums of r.z into c->partials
 double *mg_result(Ctx *c);
 void mg_release(Ctx *c);
 int sym_scale(Ctx *c, const Mesh *m, Csr *a, const double *s);   // pgd_spmv.hip: slot values *= s_i s_j

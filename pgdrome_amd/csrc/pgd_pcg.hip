@@ -1465,6 +1465,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
         PGD_LAUNCH_CHECK(c);
         PGD_TRY(reduce_partials(c, c->partials, g, 3, S_INIT, -1, 0, 0));
     } else {
+        if (c->pcg_precond == 1) c->mg_fallbacks += 1;      // (no symmetric storage, or the scaled recurrence switched off: Jacobi)
         PGD_TRY(launch_spmv_op(c, m, o, x->d, q, nullptr, 0, n, false, true, nullptr, nullptr));
         PGD_TRY(pcg_init(c, b->d, q, o->dinv, r, z, p, 0, n, S_INIT));
     }
@@ -1472,9 +1473,8 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
     PGD_LAUNCH_CHECK(c);
     if (mg_on) {                        // p0 = z0 = M r0; the first "previous r.z"
         int np = 0;
-        PGD_TRY(mg_vcycle(c, r, true, &np));
+        PGD_TRY(mg_vcycle(c, r, true, &np, p));
         PGD_TRY(reduce_partials(c, c->partials, np, 1, S_INIT, -1, 0, 0));
-        PGD_HIP(c, hipMemcpyAsync(p, mg_result(c), (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
     }
 
     // second partials buffer for the folded reductions (the x / r update reads the product's partials while writing its own)

@@ -1634,3 +1634,45 @@ def test_multigrid_pcg_solves_the_same_system(ctx, npts):
     for a in (ak, am):
         ctx.atom_free(a)
     ctx.mesh_free(h)
+
+
+@pytest.mark.parametrize("npts", [32, 41])
+def test_multigrid_pcg_walks_like_its_cpu_restatement(ctx, npts):
+    """The HIP path against oracle/mg_numpy.py (the same hierarchy, cycle and stop test in numpy): the same system from a zero
+    start takes the same number of iterations (+-1: the sums are grouped differently) and ends at the same solution."""
+    from oracle import mg_numpy as MG
+    from pgdrome_amd import fem
+    mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), npts - 1, npts - 1, npts - 1)
+    coords = mesh.coordinates()
+    h = ctx.mesh_upload(coords, mesh.cells())
+    n = coords.shape[0]
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bc = np.where(np.any((coords <= 1e-12) | (coords >= 1 - 1e-12), axis=1))[0].astype(np.int32)
+    rng = np.random.default_rng(23)
+    b = rng.uniform(-1, 1, n)
+    bv = ctx.vec_from(b)
+    # the stencil of the unscaled operator from the atoms' rows of a node in the middle
+    Ko, Mo = F.assemble_atom(coords, mesh.cells(), F.STIFF).tocsr(), F.assemble_atom(coords, mesh.cells(), F.MASS).tocsr()
+    mid = (npts // 2) * npts * npts + (npts // 2) * npts + npts // 2
+    c = np.array([Ko[mid, mid + dx + npts * dy + npts * npts * dz] + 3.0 * Mo[mid, mid + dx + npts * dy + npts * npts * dz]
+                  for dx, dy, dz in MG.OFFS])
+    try:
+        ctx.tune(40, 1)
+        op = ctx.op_combine(h, [ak, am], [1.0, 3.0], bc)
+        xv = ctx.vec_alloc(n)
+        s0 = ctx.mg_stats()
+        it, rel = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, 1000)
+        assert ctx.mg_stats()["solves"] == s0["solves"] + 1
+        xs = ctx.vec_download(xv)
+        ctx.vec_free(xv)
+        ctx.atom_free(op)
+    finally:
+        ctx.tune(40, 0)
+    shape = (npts, npts, npts)
+    xo, ito, relo = MG.pcg(shape, c, b.reshape(shape))
+    assert abs(it - ito) <= 1, (it, ito)
+    assert np.linalg.norm(xs - xo.ravel()) <= 1e-8 * np.linalg.norm(xo)
+    ctx.vec_free(bv)
+    for a in (ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)

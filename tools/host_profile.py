@@ -17,12 +17,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("config")
 ap.add_argument("--modes", type=int, default=3)
 ap.add_argument("--top", type=int, default=45)
+ap.add_argument("--preconditioner", default="jacobi")
 args = ap.parse_args()
 be = fem.set_backend(HipBackend(0))
 spec = problems.CONFIGS[args.config][0]()
 spec["PGD_nmax"] = 1
 p = PGDProblem(**spec)
-p.solve_PGD(_problem="linear", settings={"linear_solver": "cg", "preconditioner": "jacobi", "relative_tolerance": 1e-10})   # warm-up: atoms, caches
+p.solve_PGD(_problem="linear", settings={"linear_solver": "cg", "preconditioner": args.preconditioner, "relative_tolerance": 1e-10})   # warm-up: atoms, caches
 fem.clear_caches() if False else None
 spec = problems.CONFIGS[args.config][0]()
 spec["PGD_nmax"] = args.modes
@@ -30,7 +31,7 @@ p = PGDProblem(**spec)
 be.sync()
 pr = cProfile.Profile()
 pr.enable()
-p.solve_PGD(_problem="linear", settings={"linear_solver": "cg", "preconditioner": "jacobi", "relative_tolerance": 1e-10})
+p.solve_PGD(_problem="linear", settings={"linear_solver": "cg", "preconditioner": args.preconditioner, "relative_tolerance": 1e-10})
 be.sync()
 pr.disable()
 print("passes", p.fp_passes, "pcg seconds", fem.STATS["pcg_seconds"])

@@ -18,6 +18,7 @@ ap.add_argument("config")
 ap.add_argument("--modes", type=int, default=0)
 ap.add_argument("--problem", default="linear")
 ap.add_argument("--rtol", type=float, default=1e-10)
+ap.add_argument("--preconditioner", default="jacobi", help='settings["preconditioner"]: "jacobi" (default) or a multigrid name ("amg")')
 ap.add_argument("--trace", action="store_true", help="one line per enrichment step on stderr: seconds, passes, PCG iterations")
 args = ap.parse_args()
 
@@ -44,7 +45,7 @@ if args.trace:
                  1e3 * (dt - (fem.STATS["pcg_seconds"] - s0)) / max(passes, 1)), file=sys.stderr, flush=True)
         return out
     p.FP_solve = _timed
-p.solve_PGD(_problem=args.problem, settings={"linear_solver": "cg", "preconditioner": "jacobi",
+p.solve_PGD(_problem=args.problem, settings={"linear_solver": "cg", "preconditioner": args.preconditioner,
                                              "relative_tolerance": args.rtol})
 be.sync()
 t2 = time.time()
@@ -55,4 +56,5 @@ print(json.dumps({
     "amplitude": p.amplitude, "err_fp_it": [float(e) for e in p.err_fp_it],
     "linear_solves": fem.STATS["linear_solves"], "pcg_iterations": fem.STATS["pcg_iterations"],
     "not_converged": p.simulation_info.count("NOT converged"), "pcg_seconds": fem.STATS["pcg_seconds"],
-    "product_launches_by_kernel": be.ctx.kernel_counts()}))
+    "product_launches_by_kernel": be.ctx.kernel_counts(), "preconditioner": args.preconditioner,
+    "solves_preconditioned_by_the_v_cycle": be.ctx.mg_stats()["solves"], "multigrid_fallbacks_to_jacobi": be.ctx.mg_stats()["fallbacks"]}))
