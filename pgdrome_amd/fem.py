@@ -2239,20 +2239,34 @@ def _prefetch_functionals(reqs):
             continue
         if lay.part is None and g._small():
             continue                                     # host arithmetic: nothing to batch
-        Ag, other = _cached_product(atom, g), f
-        if Ag is None and sym and f is not g:
+        # f^T A g as a dot of one factor with the stored product of the other: either way round where A is symmetric and both
+        # products are kept.  Which way is decided below, per layout: the way that shares its left factor with the most requests
+        # (stored modes against the iterate: ONE multi-dot with the iterate on the left, not one per stored mode)
+        ways = []
+        Ag = _cached_product(atom, g)
+        if Ag is not None:
+            ways.append((f, Ag))
+        if sym and f is not g:
             Af = _cached_product(atom, f)
             if Af is not None:
-                Ag, other = Af, g
-        if Ag is None:
+                ways.append((g, Af))
+        if not ways:
             if lay.part is None and not (KEEP_FUNCTIONAL_PRODUCTS and be.atom_product_form(atom) > 0):
                 continue                                 # the fused product-dot over the CSR atom stays the cheaper way
-            Ag = _matvec_cached(lay, atom, g)
-        todo.setdefault(id(lay), (lay, []))[1].append((key, f, g, other, Ag))
-    for lay, items in todo.values():
-        if len(items) < 2 or len(items) > _PREFETCH_MAX:
+            ways.append((f, _matvec_cached(lay, atom, g)))
+        todo.setdefault(id(lay), (lay, []))[1].append((key, f, g, ways))
+    for lay, requests in todo.values():
+        if len(requests) < 2 or len(requests) > _PREFETCH_MAX:
             continue
         lo, hi = lay.owned_range()
+        shared = {}
+        for _key, _f, _g, ways in requests:
+            for other, _prod in ways:
+                shared[id(other)] = shared.get(id(other), 0) + 1
+        items = []
+        for key, f, g, ways in requests:
+            other, prod = max(ways, key=lambda w: shared[id(w[0])])      # (ties: the first way, as before)
+            items.append((key, f, g, other, prod))
         groups = {}
         for it in items:
             groups.setdefault(id(it[3]), (it[3], []))[1].append(it)
