@@ -43,6 +43,11 @@ def test_bench_line_contract():
     assert gp["row_class_dictionary"]["product_kernel"] == "diac_march"
     assert 0 < gp["csr"]["passes_per_s"] <= gp["plain_march"]["passes_per_s"] * 1.2 and gp["plain_march"]["product_us"] > 0
     assert spmv["speedup_over_plain_diagonal_form_this_run"] > 1.0
+    # the same workload with settings["preconditioner"] = "amg": every spatial solve through the V-cycle, the same modes
+    mg = d["config"]["multigrid_preconditioner"]
+    assert mg["solves_preconditioned_by_the_v_cycle"] >= mg["passes"] and mg["pcg_iterations_per_pass"] < 40
+    assert mg["passes_per_s"] > d["value"] and mg["modes_compared_with_the_headline_run"] >= 1
+    assert mg["worst_relative_l2_difference_of_a_spatial_mode"] <= 1e-6
     assert isinstance(d["config"]["launch_timing_samples_dropped_as_noops"], int)
     assert "Infinity Cache" in r.get("note", "") or "spmv" not in r
 
