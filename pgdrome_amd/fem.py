@@ -49,6 +49,7 @@ def set_backend(be):
     """Install a backend object (see hip_backend.HipBackend for the interface)."""
     global _backend
     _backend = be
+    _FAST_PLANS.clear()          # (plans name atoms of the backend they were made under)
     return be
 
 
@@ -961,6 +962,33 @@ class Poly(Expr):
         return self.terms
 
 
+class _FastProd(Expr):
+    """Product of plain scalar Functions - each undifferentiated, differentiated once (``G.dx(0)``) or an
+    ``inner(grad(G), grad(F))`` pair - as the operators of Function build it: the integrands of the callbacks' functionals
+    (``assemble(G * F * dx(m))``, the reference's call sites solver.py:547-612).  A pass of a D-dimensional problem with n
+    stored modes asks for ~6 D n of them, and the general polynomial (a Term and a Factor per operand and product) was half
+    of what such a request cost on the host.  `fs`: tuple of (leaf, deriv, other) as in Factor; the polynomial is formed
+    only where something other than ``* Function`` / ``* dx`` happens to the product."""
+    __slots__ = ("fs",)
+
+    def __init__(self, fs):
+        self.fs = fs
+
+    def _poly(self):
+        return [Term(1.0, tuple(Factor(l, d, o) for l, d, o in self.fs))]
+
+    def __mul__(self, o):
+        t = type(o)
+        if t is Measure:
+            return _FastForm(self.fs, o)
+        if t is Function:
+            if o._V._ncomp == 1:
+                return _FastProd(self.fs + ((o, None, None),))
+        elif t is _FastProd:
+            return _FastProd(self.fs + o.fs)
+        return Expr.__mul__(self, o)
+
+
 def _scalar_of(e):
     """Value of an expression that contains no fields (products of Constants and floats)."""
     p = e._poly()
@@ -1046,6 +1074,9 @@ class Grad:
     """grad(f): only meaningful inside inner()/dot()."""
 
     def __init__(self, f):
+        if type(f) is Function and f._V._ncomp == 1:
+            self.num, self.consts, self.leaf = 1.0, (), f
+            return
         p = _as_poly(f)
         if len(p) != 1 or len(p[0].factors) != 1 or p[0].factors[0].deriv is not None:
             raise NotImplementedError("grad() of anything but a plain function")
@@ -1197,6 +1228,8 @@ def inner(a, b):
             acc = ListTensor._add(acc, ListTensor._mul(a.a[idx], b.a[idx]))
         return acc if isinstance(acc, Expr) else Poly([Term(float(acc), ())])
     if isinstance(a, Grad) and isinstance(b, Grad):
+        if type(a.leaf) is Function and type(b.leaf) is Function and a.num == 1.0 and b.num == 1.0 and not a.consts and not b.consts:
+            return _FastProd(((a.leaf, "grad", b.leaf),))
         return Poly([Term(a.num * b.num, (Factor(a.leaf, "grad", b.leaf),), a.consts + b.consts)])
     if isinstance(a, Grad) or isinstance(b, Grad):
         raise NotImplementedError("inner(grad f, g) with a non-gradient g")
@@ -1304,6 +1337,24 @@ class Form:
         return first or 0
 
 
+class _FastForm(Form):
+    """``_FastProd * dx(mesh)``: a functional of plain Functions.  assemble() takes it from its operands (_fast_scalar);
+    the general list of integrals is formed on first use by anything else (sums, scalings, ds integrals)."""
+
+    def __init__(self, fs, measure):
+        self.fs, self.measure = fs, measure
+
+    def __getattr__(self, name):
+        if name == "integrals":
+            v = [(Term(1.0, tuple(Factor(l, d, o) for l, d, o in self.fs)), self.measure)]
+            self.integrals = v
+            return v
+        raise AttributeError(name)
+
+    def rank(self):
+        return 0
+
+
 class Equation:
     def __init__(self, lhs, rhs):
         self.lhs, self.rhs = lhs, rhs
@@ -1404,6 +1455,24 @@ class Function(Expr):
 
     def interpolate(self, other):
         self.assign(other)
+
+    def __mul__(self, o):
+        # products of plain scalar Functions and their integrals: _FastProd
+        if self._V._ncomp == 1:
+            t = type(o)
+            if t is Function:
+                if o._V._ncomp == 1:
+                    return _FastProd(((self, None, None), (o, None, None)))
+            elif t is _FastProd:
+                return _FastProd(((self, None, None),) + o.fs)
+            elif t is Measure:
+                return _FastForm(((self, None, None),), o)
+        return Expr.__mul__(self, o)
+
+    def dx(self, *axes):
+        if self._V._ncomp == 1 and len(axes) == 1:
+            return _FastProd(((self, int(axes[0]), None),))
+        return Expr.dx(self, *axes)
 
     def _poly(self):
         if self._V._ncomp > 1:
@@ -2065,6 +2134,8 @@ _MV_CACHE = {}        # (atom handle, id(vec)) -> (version, result Vector)   A @
 
 
 def _purge_atom(atom):
+    for k in [k for k, p in _FAST_PLANS.items() if p[1] == atom]:
+        del _FAST_PLANS[k]
     for k in [k for k in _MV_CACHE if k[0] == atom]:
         del _MV_CACHE[k]
     for k in [k for k in _SCALAR_MEMO if k[0] == atom]:
@@ -2189,11 +2260,12 @@ class functional_scope:
 
     def __init__(self, tag, iterates):
         self.tag, self.iterates = tag, list(iterates)
+        self.roles = {id(v): k for k, v in enumerate(self.iterates)}      # (_fast_scalar: an iterate is named by its position)
 
     def _ref(self, v):
-        for k, it in enumerate(self.iterates):
-            if it is v:
-                return ("it", k)
+        k = self.roles.get(id(v))
+        if k is not None:
+            return ("it", k)
         return ("obj", weakref.ref(v), v.version)
 
     def _deref(self, ref):
@@ -2338,7 +2410,8 @@ def _ones(lay):
     return lay._ones
 
 
-def _term_scalar(term, lay):
+def _term_operands(term, lay):
+    """(atom, f, g, symmetric) with  integral of the term = coef * f^T A g  for a term without arguments."""
     test, trial, coefs, gd = _classify(term, lay)
     if test is not None or trial is not None:
         raise ValueError("scalar assemble of a form with arguments")
@@ -2352,15 +2425,14 @@ def _term_scalar(term, lay):
             atom = lay.atom(WSTIFF, 0, 0, _coef_vec(coefs[0].leaf, lay))
         else:
             atom = lay.atom(STIFF)
-        return term.coef * _bilinear_scalar(lay, atom, f, g, symmetric=True)
+        return atom, f, g, True
     if len(coefs) == 0:
         one = _ones(lay)
-        return term.coef * _bilinear_scalar(lay, _lay_atom(lay, MASS, 0, 0, None), one, one)
+        return _lay_atom(lay, MASS, 0, 0, None), one, one, False
     if len(coefs) == 1:
         c = coefs[0]
         kind, da, db, w = _atom_for(Factor(None, None), Factor(None, c.deriv), [], lay)
-        return term.coef * _bilinear_scalar(lay, _lay_atom(lay, kind, da, db, w, None, c.comp), _ones(lay),
-                                            _coef_vec(c.leaf, lay))
+        return _lay_atom(lay, kind, da, db, w, None, c.comp), _ones(lay), _coef_vec(c.leaf, lay), False
     # f (test side) is the first factor, g (trial side) the second, further undifferentiated ones weight
     der = [c for c in coefs if c.deriv is not None]
     plain = [c for c in coefs if c.deriv is None]
@@ -2371,9 +2443,85 @@ def _term_scalar(term, lay):
     ordered = der + plain
     f, g, rest = ordered[0], ordered[1], ordered[2:]
     kind, da, db, w = _atom_for(Factor(None, f.deriv), Factor(None, g.deriv), rest, lay)
-    return term.coef * _bilinear_scalar(lay, _lay_atom(lay, kind, da, db, w, f.comp, g.comp), _coef_vec(f.leaf, lay),
-                                        _coef_vec(g.leaf, lay),
-                                        symmetric=(kind in _SYMMETRIC_KINDS or (kind == DUDV and da == db)) and f.comp == g.comp)
+    return (_lay_atom(lay, kind, da, db, w, f.comp, g.comp), _coef_vec(f.leaf, lay), _coef_vec(g.leaf, lay),
+            (kind in _SYMMETRIC_KINDS or (kind == DUDV and da == db)) and f.comp == g.comp)
+
+
+def _term_scalar(term, lay):
+    atom, f, g, symmetric = _term_operands(term, lay)
+    return term.coef * _bilinear_scalar(lay, atom, f, g, symmetric=symmetric)
+
+
+# ---- functionals of plain Functions (_FastForm): the structure of a request is resolved once ------------------------------
+# What _term_operands works out for a functional - layout, atom, which operand stands on which side - depends on WHICH
+# vectors the integrand names and how, not on their values.  A request names its vectors by role: the iterates of the
+# enclosing functional_scope by their position (they are new objects after every solve, solver.py:746), every other vector -
+# stored modes, loads, weights: long-lived - by identity.  The plan of a structure is kept with weak references to those
+# long-lived vectors (an address is reused once a vector has died) and, for a weighted atom, the version of the weight the
+# atom was assembled from; the value itself goes through _bilinear_scalar and its memo as before.
+_FAST_PLANS = {}
+_FAST_PLANS_MAX = 65536
+STATS_FAST = {"requests": 0, "planned": 0}
+
+
+def _fast_scalar(form):
+    fs, mesh = form.fs, form.measure.mesh
+    scope = _RECORDING
+    roles = scope.roles if scope is not None else {}
+    vecs = []
+    key = [id(_backend), id(mesh)]
+    for l, d, o in fs:
+        v = l._vec
+        vecs.append(v)
+        key.append(roles.get(id(v), id(v)))
+        key.append(d)
+        if o is not None:
+            v = o._vec
+            vecs.append(v)
+            key.append(roles.get(id(v), id(v)))
+    key = tuple(key)
+    STATS_FAST["requests"] += 1
+    plan = _FAST_PLANS.get(key)
+    if plan is not None:
+        lref, atom, fi, gi, sym, refs, wi, wver, mref = plan
+        lay = lref()
+        ok = mref() is mesh and lay is not None
+        if ok:
+            for r, v in zip(refs, vecs):
+                if (r is not None and r() is not v) or v.V._lay is not lay:
+                    ok = False
+                    break
+        if ok and wi >= 0:
+            w = vecs[wi]
+            ok = w.version == wver and w.version < vecs[fi].version and w.version < vecs[gi].version
+        if ok:
+            STATS_FAST["planned"] += 1
+            return _bilinear_scalar(lay, atom, vecs[fi] if fi >= 0 else _ones(lay), vecs[gi] if gi >= 0 else _ones(lay), sym)
+        del _FAST_PLANS[key]
+    term = Term(1.0, tuple(Factor(l, d, o) for l, d, o in fs))
+    m = mesh if mesh is not None else Form([(term, form.measure)]).mesh()
+    lay = _integral_layout(term, m)
+    atom, f, g, sym = _term_operands(term, lay)
+    # keep the plan where every operand of the atom's product is one of the named vectors (or the layout's vector of ones)
+    # and a weight - the one vector that is neither side - is a long-lived vector, strictly older than both sides (which
+    # of three undifferentiated factors weights the other two is decided by their versions: _weight_last)
+    ones = lay._ones
+    fi = next((i for i, v in enumerate(vecs) if v is f), -1)
+    gi = next((i for i, v in enumerate(vecs) if v is g and i != fi), -1)
+    rest = [i for i in range(len(vecs)) if i != fi and i != gi]
+    plannable = mesh is not None and (fi >= 0 or f is ones) and (gi >= 0 or g is ones) and len(rest) <= 1
+    wi, wver = -1, 0
+    if plannable and rest:
+        wi = rest[0]
+        w = vecs[wi]
+        wver = w.version
+        plannable = (fi >= 0 and gi >= 0 and id(w) not in roles and w.version < vecs[fi].version and w.version < vecs[gi].version)
+    if plannable:
+        if len(_FAST_PLANS) >= _FAST_PLANS_MAX:
+            _FAST_PLANS.clear()
+        refs = tuple(None if id(v) in roles else weakref.ref(v) for v in vecs)
+        _FAST_PLANS[key] = (weakref.ref(lay), atom, fi, gi, sym, refs, wi, wver, weakref.ref(mesh))
+    return _bilinear_scalar(lay, atom, f, g, symmetric=sym)
 
 
 def _term_vector(term, lay):
@@ -2504,6 +2652,8 @@ def assemble(form, tensor=None, **kw):
     """Scalar, vector or matrix of a Form - dolfin.assemble."""
     if isinstance(form, numbers.Real):
         return float(form)
+    if type(form) is _FastForm and form.measure.kind == "dx":
+        return _fast_scalar(form)
     rank = form.rank()
     if rank == 0:
         total = 0.0
@@ -3010,6 +3160,7 @@ def solve(eq, u, bcs=None, solver_parameters=None, **kw):
 
 def clear_caches():
     _FUNCTIONAL_PLANS.clear()
+    _FAST_PLANS.clear()
     _SCALAR_MEMO.clear()
     _MV_CACHE.clear()
     _DS_CACHE.clear()
