@@ -232,7 +232,7 @@ int pgd_ctx_destroy(pgd_handle h) {
     if (c->cls_scratch) (void)hipFree(c->cls_scratch);
     if (c->gram_w) (void)hipFree(c->gram_w);
     for (void *p : {(void *)c->slots, (void *)c->flags, (void *)c->partials, (void *)c->mask,
-                    (void *)c->ibuf})
+                    (void *)c->ibuf, (void *)c->set_idx, (void *)c->set_vals})
         if (p) (void)hipFree(p);
     for (double *w : c->work)
         if (w) (void)hipFree(w);

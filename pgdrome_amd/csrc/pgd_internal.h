@@ -86,6 +86,12 @@ struct Mesh : Obj {
     };
     mutable std::vector<ClsCache> cls_cache;
     mutable uint64_t cls_clock = 0;
+    // the Dirichlet list of the last operator combined on this mesh (pgd_op_combine): every solve of a fixed-point pass brings the
+    // same list again - compared on the host, word by word, it saves the range check, the upload (1.5 MB at 256^3) and the
+    // host synchronisation behind it
+    std::vector<int32_t> bc_host;
+    int *bc_dev = nullptr;
+    size_t bc_dev_bytes = 0;
     uint16_t *pids = nullptr;    // nv
     int *dict_off = nullptr;     // dict_count x DICT_DLEN relative offsets
     int dict_count = 0;          // 0: dictionary not available (irregular pattern) -> plain CSR kernel
@@ -94,6 +100,7 @@ struct Mesh : Obj {
                         (void *)row_ptr, (void *)cols, (void *)pids, (void *)dict_off, (void *)sym_tab})
             if (p) (void)hipFree(p);
         for (ClsCache &e : cls_cache) if (e.same) (void)hipFree(e.same);      // (the block starts at `same`)
+        if (bc_dev) (void)hipFree(bc_dev);
     }
 };
 
@@ -196,6 +203,15 @@ struct Ctx {
     int64_t mask_cap = 0;
     int *ibuf = nullptr;          // small int32 scratch (bc dofs, index lists)
     int64_t ibuf_cap = 0;
+    // pgd_vec_set: the last index list and its values (host copies + what is on the device in ibuf / set_vals): the Dirichlet
+    // values of every right-hand side of a fixed-point pass are the same 390 152 (index, value) pairs at 256^3
+    std::vector<int32_t> set_idx_host;
+    std::vector<double> set_val_host;
+    int *set_idx = nullptr;
+    double *set_vals = nullptr;
+    int64_t set_idx_cap = 0, set_vals_cap = 0;
+    int32_t set_idx_max = 0;
+    bool set_idx_on_dev = false, set_val_on_dev = false;
 
     Comm comm;
 

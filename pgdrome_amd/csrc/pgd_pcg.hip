@@ -13,6 +13,8 @@
 
 #include "pgd_internal.h"
 
+#include <cstring>
+
 #include <algorithm>
 
 namespace pgd {
@@ -1326,8 +1328,12 @@ int pgd_op_combine(pgd_handle h, pgd_handle mh, const pgd_handle *atoms, const d
         if (*op && atoms[t] == *op) return fail(c, PGD_ERR_INVALID, "op_combine: output aliases an input");
         atom_objs[t] = a;
     }
-    for (int64_t i = 0; i < nbc; ++i)
-        if (bc_dofs[i] < 0 || bc_dofs[i] >= m->nv) return fail(c, PGD_ERR_INVALID, "op_combine: bc dof out of range");
+    // the same Dirichlet list as the last operator on this mesh (checked word by word): it was range-checked then and is on the device
+    const bool bc_known = nbc > 0 && m->bc_dev && m->bc_host.size() == (size_t)nbc &&
+                          std::memcmp(m->bc_host.data(), bc_dofs, (size_t)nbc * sizeof(int32_t)) == 0;
+    if (!bc_known)
+        for (int64_t i = 0; i < nbc; ++i)
+            if (bc_dofs[i] < 0 || bc_dofs[i] >= m->nv) return fail(c, PGD_ERR_INVALID, "op_combine: bc dof out of range");
     Csr *o = nullptr;
     if (*op) {
         o = get_csr(c, *op);
@@ -1371,7 +1377,23 @@ int pgd_op_combine(pgd_handle h, pgd_handle mh, const pgd_handle *atoms, const d
         }
         PGD_TRY(ensure_mask(c, m->nv));
         PGD_HIP(c, hipMemsetAsync(c->mask, 0, (size_t)m->nv, c->stream));
-        PGD_HIP(c, hipMemcpyAsync(o->rec_bc, bc_dofs, (size_t)nbc * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        if (!bc_known) {
+            m->bc_host.clear();
+            if (m->bc_dev && m->bc_dev_bytes < (size_t)nbc * sizeof(int)) { (void)hipFree(m->bc_dev); m->bc_dev = nullptr; }
+            if (!m->bc_dev) {
+                void *p = nullptr;
+                m->bc_dev_bytes = (size_t)nbc * sizeof(int);
+                if (hipMalloc(&p, m->bc_dev_bytes + PAD_BYTES) != hipSuccess) { (void)hipGetLastError(); m->bc_dev_bytes = 0; }
+                m->bc_dev = (int *)p;
+            }
+            PGD_HIP(c, hipMemcpyAsync(o->rec_bc, bc_dofs, (size_t)nbc * sizeof(int), hipMemcpyHostToDevice, c->stream));
+            if (m->bc_dev) {
+                PGD_HIP(c, hipMemcpyAsync(m->bc_dev, o->rec_bc, (size_t)nbc * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+                m->bc_host.assign(bc_dofs, bc_dofs + nbc);
+            }
+        } else {
+            PGD_HIP(c, hipMemcpyAsync(o->rec_bc, m->bc_dev, (size_t)nbc * sizeof(int), hipMemcpyDeviceToDevice, c->stream));
+        }
         k_mask_set<<<grid_for(nbc), TPB, 0, c->stream>>>(c->mask, o->rec_bc, nbc);
         mask = c->mask;
     }
@@ -1381,7 +1403,7 @@ int pgd_op_combine(pgd_handle h, pgd_handle mh, const pgd_handle *atoms, const d
     // ... and where that form exists the solve, its start and its products read nothing else: the CSR values (8 nnz (T + 1)
     // bytes of streaming, 1.5 ms at 256^3) are formed by the first reader that asks for them, usually nobody
     if (!(c->lazy_csr && o->uvals_valid)) PGD_TRY(ensure_vals(c, m, o));
-    PGD_HIP(c, hipStreamSynchronize(c->stream));   // bc_dofs is caller-owned
+    if (nbc > 0 && !bc_known) PGD_HIP(c, hipStreamSynchronize(c->stream));   // bc_dofs is caller-owned
     return PGD_OK;
 }
 

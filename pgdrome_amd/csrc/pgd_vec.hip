@@ -4,6 +4,8 @@
 // with a grid-stride loop (guide: Guideline 11).
 #include "pgd_internal.h"
 
+#include <cstring>
+
 namespace pgd {
 
 __global__ __launch_bounds__(TPB) void k_fill(double *__restrict__ v, double a, int64_t n) {
@@ -343,15 +345,61 @@ int pgd_vec_set(pgd_handle h, pgd_handle vh, const int32_t *idx, const double *v
     Vec *v = get_vec(c, vh);
     if (!v || n < 0 || (n > 0 && (!idx || !val))) return fail(c, PGD_ERR_INVALID, "vec_set: bad arguments");
     if (n == 0) return PGD_OK;
-    for (int64_t i = 0; i < n; ++i)
-        if (idx[i] < 0 || idx[i] >= v->n) return fail(c, PGD_ERR_INVALID, "vec_set: index %d out of range", idx[i]);
-    PGD_TRY(ensure_ibuf(c, n));
-    PGD_TRY(ensure_work(c, 5, n));
-    PGD_HIP(c, hipMemcpyAsync(c->ibuf, idx, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    PGD_HIP(c, hipMemcpyAsync(c->work[5], val, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
-    k_set<<<grid_for(n), TPB, 0, c->stream>>>(v->d, c->ibuf, c->work[5], n);
+    // Large lists (the Dirichlet values of a right-hand side, the same in every solve of a fixed-point pass) are kept: indices
+    // and values that equal the last call's, word by word, are on the device already - no range check, no upload, no
+    // host synchronisation.  Small ones go the direct way through the shared scratch.
+    if (n < 4096) {
+        for (int64_t i = 0; i < n; ++i)
+            if (idx[i] < 0 || idx[i] >= v->n) return fail(c, PGD_ERR_INVALID, "vec_set: index %d out of range", idx[i]);
+        PGD_TRY(ensure_ibuf(c, n));
+        PGD_TRY(ensure_work(c, 5, n));
+        PGD_HIP(c, hipMemcpyAsync(c->ibuf, idx, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        PGD_HIP(c, hipMemcpyAsync(c->work[5], val, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        k_set<<<grid_for(n), TPB, 0, c->stream>>>(v->d, c->ibuf, c->work[5], n);
+        PGD_LAUNCH_CHECK(c);
+        PGD_HIP(c, hipStreamSynchronize(c->stream));   // host buffers are caller-owned
+        return PGD_OK;
+    }
+    const bool same_idx = c->set_idx_on_dev && c->set_idx_host.size() == (size_t)n &&
+                          std::memcmp(c->set_idx_host.data(), idx, (size_t)n * sizeof(int32_t)) == 0;
+    // (the largest index the kept list was checked against may exceed a shorter vector: the check below covers it)
+    bool uploaded = false;
+    auto grow = [&](void **buf, int64_t *cap, size_t elem) -> int {       // (contents are not kept: the caller uploads anew)
+        if (*cap >= n) return PGD_OK;
+        PGD_HIP(c, hipStreamSynchronize(c->stream));
+        if (*buf) (void)hipFree(*buf);
+        *buf = nullptr; *cap = 0;
+        if (hipMalloc(buf, (size_t)n * elem + PAD_BYTES) != hipSuccess) { (void)hipGetLastError(); return fail(c, PGD_ERR_NOMEM, "vec_set: out of device memory"); }
+        *cap = n;
+        return PGD_OK;
+    };
+    if (!same_idx) {
+        for (int64_t i = 0; i < n; ++i)
+            if (idx[i] < 0 || idx[i] >= v->n) return fail(c, PGD_ERR_INVALID, "vec_set: index %d out of range", idx[i]);
+        c->set_idx_on_dev = false;
+        PGD_TRY(grow(reinterpret_cast<void **>(&c->set_idx), &c->set_idx_cap, sizeof(int)));
+        PGD_HIP(c, hipMemcpyAsync(c->set_idx, idx, n * sizeof(int), hipMemcpyHostToDevice, c->stream));
+        c->set_idx_host.assign(idx, idx + n);
+        c->set_idx_max = 0;
+        for (int64_t i = 0; i < n; ++i) if (idx[i] > c->set_idx_max) c->set_idx_max = idx[i];
+        c->set_idx_on_dev = true;
+        uploaded = true;
+    } else if (c->set_idx_max >= v->n) {
+        return fail(c, PGD_ERR_INVALID, "vec_set: index %d out of range", (int)c->set_idx_max);
+    }
+    const bool same_val = c->set_val_on_dev && c->set_val_host.size() == (size_t)n &&
+                          std::memcmp(c->set_val_host.data(), val, (size_t)n * sizeof(double)) == 0;
+    if (!same_val) {
+        c->set_val_on_dev = false;
+        PGD_TRY(grow(reinterpret_cast<void **>(&c->set_vals), &c->set_vals_cap, sizeof(double)));
+        PGD_HIP(c, hipMemcpyAsync(c->set_vals, val, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        c->set_val_host.assign(val, val + n);
+        c->set_val_on_dev = true;
+        uploaded = true;
+    }
+    k_set<<<grid_for(n), TPB, 0, c->stream>>>(v->d, c->set_idx, c->set_vals, n);
     PGD_LAUNCH_CHECK(c);
-    PGD_HIP(c, hipStreamSynchronize(c->stream));   // host buffers are caller-owned
+    if (uploaded) PGD_HIP(c, hipStreamSynchronize(c->stream));   // host buffers are caller-owned
     return PGD_OK;
 }
 

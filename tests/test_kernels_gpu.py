@@ -1387,6 +1387,77 @@ def test_vector_ops(ctx):
         ctx.vec_free(yv)
 
 
+def test_kept_index_lists_are_compared_not_trusted(ctx):
+    """pgd_vec_set keeps a large index list and its values on the device, pgd_op_combine the Dirichlet list of the last operator
+    on a mesh (the same lists come back in every solve of a fixed-point pass): a call is served from what is kept only when its
+    arrays equal the kept ones word by word - one changed index or value, another length, a vector too short for a kept index
+    must all be seen."""
+    from pgdrome_amd import _lib, fem
+    rng = np.random.default_rng(77)
+    n = 50_000
+    idx = np.sort(rng.choice(n, size=9000, replace=False)).astype(np.int32)
+    val = rng.standard_normal(idx.size)
+    xv = ctx.vec_alloc(n)
+
+    def check(i, v):
+        ctx.vec_fill(xv, 2.5)
+        ctx.vec_set(xv, i, v)
+        want = np.full(n, 2.5)
+        want[i] = v
+        assert np.array_equal(ctx.vec_download(xv), want)
+
+    check(idx, val)
+    check(idx, val)                                   # served from the kept lists
+    v2 = val.copy(); v2[4321] += 1.0
+    check(idx, v2)                                    # one value differs
+    i2 = idx.copy(); i2[-1] = n - 1 if idx[-1] != n - 1 else n - 2
+    check(i2, v2)                                     # one index differs
+    check(idx[:8000], val[:8000])                     # another length
+    check(idx[:17], val[:17])                         # a small list in between (its own scratch) ...
+    check(idx[:8000], val[:8000])                     # ... leaves the kept one intact
+    short = ctx.vec_alloc(int(idx[7999]))             # the kept list's largest index is out of range for this vector
+    with pytest.raises(_lib.PgdError):
+        ctx.vec_set(short, idx[:8000], val[:8000])
+    ctx.vec_free(short)
+    ctx.vec_free(xv)
+    # the Dirichlet list of pgd_op_combine
+    mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), 15, 13, 11)
+    coords = mesh.coordinates()
+    h = ctx.mesh_upload(coords, mesh.cells())
+    nv = coords.shape[0]
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    bc = np.where(np.any((coords <= 1e-12) | (coords >= 1 - 1e-12), axis=1))[0].astype(np.int32)
+    x = rng.standard_normal(nv)
+    xv, yv = ctx.vec_from(x), ctx.vec_alloc(nv)
+
+    def product(bcs, coefs):
+        op = ctx.op_combine(h, [ak, am], coefs, bcs)
+        ctx.spmv(op, xv, yv)
+        y = ctx.vec_download(yv)
+        ctx.atom_free(op)
+        return y
+
+    y0 = product(bc, [1.0, 3.0])
+    assert np.array_equal(y0[bc], x[bc])
+    assert np.array_equal(product(bc, [1.0, 3.0]), y0)               # the kept list
+    y1 = product(bc, [2.0, 0.5])                                     # ... with other coefficients
+    assert np.array_equal(y1[bc], x[bc]) and not np.array_equal(y1, y0)
+    free = np.setdiff1d(np.arange(nv), bc)
+    bc2 = bc.copy(); bc2[bc.size // 2] = free[free.size // 2]; bc2.sort()      # same length, one node swapped
+    y2 = product(bc2, [1.0, 3.0])
+    assert np.array_equal(y2[bc2], x[bc2]) and not np.array_equal(y2, y0)
+    assert np.array_equal(product(bc, [1.0, 3.0]), y0)
+    with pytest.raises(_lib.PgdError):
+        bad = bc.copy(); bad[-1] = nv
+        product(bad, [1.0, 3.0])
+    assert np.array_equal(product(bc, [1.0, 3.0]), y0)
+    for v in (xv, yv):
+        ctx.vec_free(v)
+    for a in (ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
 def test_multidot_matches_single_dots(ctx):
     """pgd_vec_multidot: x . y_j for 1 .. 40 vectors (chunks of 17) and a partial range, against numpy and against
     pgd_vec_dot (the functionals of one iterate against all stored modes go through it, fem._dots_with_stored_products)."""
