@@ -298,6 +298,11 @@ int pgd_vec_multidot(pgd_handle ctx, pgd_handle x, const pgd_handle *ys, int k, 
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
+    PGD_TUNE_PCG_DERIVE_SCALED = 43, /* 1 (default): where the operator of pgd_pcg_solve is itself ONE stencil + eliminated nodes on the whole
+                                grid (every row verified, PGD_TUNE_SPMV_STENCIL) the couplings of D^-1/2 A D^-1/2 are derived from A's with
+                                the arithmetic the scaling pass would apply to every row - no pass over the slot arrays, no second
+                                classification, the slot arrays keep A.  0: scale the slot arrays and classify them (the same couplings,
+                                bit for bit). */
     PGD_TUNE_MG_MARCH_MIN = 42, /* multigrid levels with at least this many nodes along x and y run their stencil passes in
                                 k_spmv_stencil_march (default 64); smaller ones in the plain kernels of pgd_mg.hip */
     PGD_TUNE_MG_CHUNK = 41, /* PCG iterations queued between two looks at the convergence flags when the multigrid preconditioner is on

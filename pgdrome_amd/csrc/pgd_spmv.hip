@@ -2174,9 +2174,43 @@ bool atom_fast_form(Ctx *c, const Mesh *m, Csr *a, int64_t r0, int64_t r1) {
     return true;
 }
 
+// planes per march of the plain z-march over the planes [z0, z1) of a structured grid (0 marches: row order)
+static int dia_march_chunks(const Ctx *c, const Mesh *m, int z0, int z1, int wy, int *zchunk_out) {
+    const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
+    const int tiles_x = (m->sym_nx + 63) / 64, tiles_y = (m->sym_ny + wy - 1) / wy;
+    int zchunk = 0, chunks = 0;
+    if (c->spmv_zchunk > 0 && plane * 64 >= c->spmv_grid_min_plane_bytes) {
+        const int64_t tile_planes = (int64_t)tiles_x * tiles_y * (z1 - z0);
+        zchunk = (int)std::min<int64_t>(c->spmv_zchunk, tile_planes * (wy / 4) / (4 * (int64_t)c->num_cu));
+        if (c->spmv_zchunk_force > 0) zchunk = c->spmv_zchunk_force;       // tests: the march on any grid size
+        chunks = (zchunk >= 3 || c->spmv_zchunk_force > 0) ? (z1 - z0 + zchunk - 1) / zchunk : 0;
+    }
+    *zchunk_out = zchunk;
+    return chunks;
+}
+
+// would a product over ALL rows of this operator (a PCG product: w = x, or no dot) run in k_spmv_stencil_march?  The conditions of
+// launch_spmv_op, for the solve that wants to hold the scaled operator as a stencil only (Csr::st_virtual)
+bool stencil_whole_grid(const Ctx *c, const Mesh *m, const Csr *a) {
+    if (!(c->spmv_sym && m->sym_w && a->uvals_valid && a->uvals) || m->sym_nx <= 0) return false;
+    const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
+    const int nz = (int)(m->nv / plane);
+    int zchunk = 0;
+    if (dia_march_chunks(c, m, 0, nz, c->spmv_variant <= 1 ? 8 : 4, &zchunk) <= 0) return false;
+    const bool coded = c->spmv_variant == 0 && c->spmv_classes && a->cls_count > 0;
+    return coded && c->spmv_stencil && a->st_ok && (c->spmv_zchunk_force <= 0 || c->spmv_zchunk_stencil > 0) &&
+           a->st_z0 == 0 && a->st_z1 == nz && plane < ((int64_t)1 << 26);
+}
+
 int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0,
                    int64_t r1, bool dot, bool store, const int *flags, int *nparts_out) {
+    // (st_virtual: the stencil couplings describe D^-1/2 A D^-1/2 while the slot arrays and the CSR values hold A - inside
+    // pgd_pcg_solve, which has checked that its products take the stencil form; anything else must not compute with the wrong numbers)
+    auto not_virtual = [&]() -> int {
+        return a->st_virtual ? fail(c, PGD_ERR_INVALID, "spmv: the operator is held as a scaled stencil; this launch cannot take that form") : PGD_OK;
+    };
     if (!(c->spmv_sym && m->sym_w && a->uvals_valid && a->uvals)) {
+        PGD_TRY(not_virtual());
         PGD_TRY(ensure_vals(c, m, const_cast<Csr *>(a)));
         return launch_spmv(c, m, a->vals, x, y, w, r0, r1, dot, store, flags, nparts_out);
     }
@@ -2206,16 +2240,12 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         D.qq = (dot && c->spmv_qq) ? 1 : 0;                  // set by the single-sync recurrence around its product launches
         // plane-aligned row range, PCG product (w = x) or plain product, planes large enough: the LDS march
         int chunks = 0;
-        if (c->spmv_zchunk > 0 && (!dot || w == x) && r0 % plane == 0 && r1 % plane == 0 &&
-            plane * 64 >= c->spmv_grid_min_plane_bytes) {
+        if ((!dot || w == x) && r0 % plane == 0 && r1 % plane == 0) {
             // planes per march: as long as the launch still has ~4 workgroups per CU (measured on z-slabs of the 256 x 256
             // grid, tools/bench_spmv_slab.py: 30 planes - the interior of an 8-GPU rank - 31.9 us marching 8 planes vs 41.4 us
             // in row order; a march of fewer than 3 planes pays its prologue too often, and a single plane - the boundary
             // launches of the sharded solve - is faster in row order: 7.1 vs 8-14 us)
-            const int64_t tile_planes = (int64_t)D.tiles_x * D.tiles_y * (D.z1 - D.z0);
-            D.zchunk = (int)std::min<int64_t>(c->spmv_zchunk, tile_planes * (wy / 4) / (4 * (int64_t)c->num_cu));
-            if (c->spmv_zchunk_force > 0) D.zchunk = c->spmv_zchunk_force;       // tests: the march on any grid size
-            chunks = (D.zchunk >= 3 || c->spmv_zchunk_force > 0) ? (D.z1 - D.z0 + D.zchunk - 1) / D.zchunk : 0;
+            chunks = dia_march_chunks(c, m, D.z0, D.z1, wy, &D.zchunk);
         }
         const int64_t gg = (int64_t)chunks * D.tiles_x * D.tiles_y;
         bool timed2 = false;
@@ -2306,6 +2336,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
                 PGD_LAUNCH_CHECK(c);
                 return PGD_OK;
             }
+            PGD_TRY(not_virtual());
             if (coded) {
                 // the operator has a row-class dictionary (dia_classify): one byte per row instead of the slot values
                 DiacArgs E;
@@ -2341,6 +2372,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
 #undef PGD_MARCH
             c->kcount[KC_DIA_MARCH] += 1;
         } else {
+            PGD_TRY(not_virtual());
             PGD_TRY(prof_begin(c, dot, store, &timed2));
             if (dot && store) k_spmv_dia_rows<true, true><<<nblk, 64, 0, c->stream>>>(D);
             else if (dot) k_spmv_dia_rows<true, false><<<nblk, 64, 0, c->stream>>>(D);
@@ -2351,6 +2383,7 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         PGD_LAUNCH_CHECK(c);
         return PGD_OK;
     }
+    PGD_TRY(not_virtual());
     const int grid = nblk;
     bool timed = false;
     PGD_TRY(prof_begin(c, dot, store, &timed));
@@ -2560,6 +2593,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_LAZY_CSR && value >= 0 && value <= 1) { c->lazy_csr = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ZCHUNK_CODED && value >= 3 && value <= 1024) { c->spmv_zchunk_coded = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_PRECOND && value >= 0 && value <= 1) { c->pcg_precond = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_PCG_DERIVE_SCALED && value >= 0 && value <= 1) { c->pcg_derive_scaled = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_MG_CHUNK && value >= 2 && value <= 16 && value % 2 == 0) { c->mg_chunk = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_MG_MARCH_MIN && value >= 0 && value <= 1 << 20) { c->mg_march_min = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);

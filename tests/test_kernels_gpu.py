@@ -1243,6 +1243,75 @@ def test_pcg_on_row_classes_is_bit_identical(ctx):
     ctx.mesh_free(h)
 
 
+def test_derived_scaled_stencil_is_the_classified_one(ctx):
+    """pgd_pcg_solve on an operator that is one stencil + eliminated nodes: the couplings of D^-1/2 A D^-1/2 DERIVED from A's
+    (PGD_TUNE_PCG_DERIVE_SCALED: no scaling pass, no second classification) against those of the scaled and classified slot
+    arrays - iteration counts, reported residuals and x IDENTICAL (the same eight numbers go into the same kernel); with the
+    diagonal set to 1 and not, under the multigrid preconditioner as well; the operator multiplies as A afterwards; an operator
+    with a natural boundary keeps the scaling pass either way."""
+    from pgdrome_amd import fem
+    npts = 104
+    mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, 1), npts - 1, npts - 1, npts - 1)
+    coords = mesh.coordinates()
+    h = ctx.mesh_upload(coords, mesh.cells())
+    n = coords.shape[0]
+    ak, am = ctx.atom_assemble(h, F.STIFF), ctx.atom_assemble(h, F.MASS)
+    hull = np.where(np.any((coords <= 1e-12) | (coords >= 1 - 1e-12), axis=1))[0].astype(np.int32)
+    face = np.where(coords[:, 2] <= 1e-12)[0].astype(np.int32)          # natural boundaries elsewhere: not one stencil
+    rng = np.random.default_rng(51)
+    b = rng.uniform(-1, 1, n)
+    bv = ctx.vec_from(b)
+    x0 = 0.01 * rng.uniform(-1, 1, n)
+    out = {}
+    try:
+        for derive in (1, 0):
+            ctx.tune(43, derive)
+            for key, bc, unit, mg in (("hull", hull, 1, 0), ("hull-nounit", hull, 0, 0), ("hull-mg", hull, 1, 1), ("face", face, 1, 0)):
+                ctx.tune(17, unit)
+                ctx.tune(40, mg)
+                op = ctx.op_combine(h, [ak, am], [1.0, 3.0], bc)
+                xs = x0.copy(); xs[bc] = 0.0
+                xv = ctx.vec_from(xs)
+                cc0 = sum(ctx.classify_counts().values())
+                k0 = ctx.kernel_counts()
+                it, rel = ctx.pcg_solve(op, bv, xv, 1e-10, 0.0, 10000)
+                k1 = ctx.kernel_counts()
+                ncls = sum(ctx.classify_counts().values()) - cc0
+                st = k1["stencil_march"] - k0["stencil_march"]
+                assert (st > 0) == (key != "face"), (key, st)
+                # derived: A is classified (here: nobody has before), and that is all; an operator that turns out not to be one
+                # stencil has its scaled slot arrays classified as well.  Not derived: the scaled slot arrays only
+                assert ncls == (2 if derive and key == "face" else 1), (key, derive, ncls)
+                xsol = ctx.vec_download(xv)
+                out[(derive, key)] = (it, rel, xsol)
+                assert rel <= 1e-10 and it > 5
+                # afterwards the operator multiplies as A: the true residual through the CSR kernel
+                yv = ctx.vec_alloc(n)
+                ctx.tune(3, 0)
+                ctx.spmv(op, xv, yv)
+                ctx.tune(3, 1)
+                rhs = b.copy()
+                assert np.linalg.norm(rhs - ctx.vec_download(yv)) <= 1.05e-10 * np.linalg.norm(rhs)
+                # ... and through its own fast form
+                ctx.spmv(op, xv, yv)
+                assert np.linalg.norm(rhs - ctx.vec_download(yv)) <= 1.05e-10 * np.linalg.norm(rhs)
+                for v in (xv, yv):
+                    ctx.vec_free(v)
+                ctx.atom_free(op)
+    finally:
+        ctx.tune(43, 1)
+        ctx.tune(17, 1)
+        ctx.tune(40, 0)
+        ctx.tune(3, 1)
+    for key in ("hull", "hull-nounit", "hull-mg", "face"):
+        a, c = out[(1, key)], out[(0, key)]
+        assert a[0] == c[0] and a[1] == c[1] and np.array_equal(a[2], c[2]), (key, a[0], c[0], a[1], c[1])
+    ctx.vec_free(bv)
+    for a in (ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
 def test_lagged_x_update_leaves_the_recurrence_alone(ctx):
     """Single-sync recurrence with x updated every other iteration (two terms, the earlier direction reconstructed from
     p = r + beta' p'): iteration counts and reported residuals are IDENTICAL to the every-iteration update - nothing of the
