@@ -294,6 +294,13 @@ int pgd_start_gram(pgd_handle ctx, pgd_handle A, const pgd_handle *vecs, int k, 
 int pgd_vec_multidot(pgd_handle ctx, pgd_handle x, const pgd_handle *ys, int k, int64_t lo, int64_t hi,
                      double *out);
 
+/* Two left factors against the same k <= 128 vectors: out[j] = x0 . y_j, out[k + j] = x1 . y_j over [lo, hi); every y_j is
+ * read once for both (ceil(k / 16) passes over x0 and x1), ONE host synchronisation.  The functionals of an iterate F against
+ * the stored modes m_j of its dimension under two symmetric atoms (solver.py:568-612: F^T K m_j and F^T M m_j inside the
+ * callbacks) as (K F) . m_j and (M F) . m_j: k + 2 vector reads where F . (K m_j), F . (M m_j) take 2 k + 1.            */
+int pgd_vec_multidot_pair(pgd_handle ctx, pgd_handle x0, pgd_handle x1, const pgd_handle *ys, int k, int64_t lo,
+                          int64_t hi, double *out);
+
 /* ------------------------------------------------------------------ tuning --- */
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */

@@ -136,6 +136,9 @@ class NumpyBackend:
     def vec_multidot(self, x, ys, lo=0, hi=-1):
         return np.array([self.vec_dot(x, y, lo, hi) for y in ys])
 
+    def vec_multidot_pair(self, x0, x1, ys, lo=0, hi=-1):
+        return self.vec_multidot(x0, ys, lo, hi), self.vec_multidot(x1, ys, lo, hi)
+
     # ---- atoms and operators
     def atom_product_form(self, atom):
         return 0

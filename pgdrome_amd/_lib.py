@@ -68,6 +68,7 @@ SIGNATURES = {
     "pgd_start_gram": (C.c_int, [H, H, PH, C.c_int, H, I64, I64, PD]),
     "pgd_atom_product_form": (C.c_int, [H, H, C.POINTER(C.c_int)]),
     "pgd_vec_multidot": (C.c_int, [H, H, PH, C.c_int, I64, I64, PD]),
+    "pgd_vec_multidot_pair": (C.c_int, [H, H, H, PH, C.c_int, I64, I64, PD]),
     "pgd_pcg_solve": (C.c_int, [H, H, H, H, F64, F64, C.c_int, C.POINTER(C.c_int), PD]),
     "pgd_band_solve": (C.c_int, [H, H, H, H]),
     "pgd_slots_ptr": (C.c_int, [H, C.POINTER(VP)]),
@@ -336,6 +337,14 @@ class Context:
         out = np.zeros(k, dtype=np.float64)
         self._ck(self.lib.pgd_vec_multidot(self.h, x, arr, k, int(lo), int(hi), dptr(out)))
         return out
+
+    def vec_multidot_pair(self, x0, x1, ys, lo=0, hi=-1):
+        """([x0 . y for y in ys], [x1 . y for y in ys]) over [lo, hi): every y read once for both, one host synchronisation."""
+        k = len(ys)
+        arr = (H * k)(*[int(v) for v in ys])
+        out = np.zeros(2 * k, dtype=np.float64)
+        self._ck(self.lib.pgd_vec_multidot_pair(self.h, x0, x1, arr, k, int(lo), int(hi), dptr(out)))
+        return out[:k], out[k:]
 
     # ---- atoms / operators
     def atom_product_form(self, atom):

@@ -2435,6 +2435,42 @@ __global__ __launch_bounds__(TPB) void k_multidot(MultiDotArgs A) {
     }
 }
 
+// Two left factors against the same vectors: acc[l][m] = w_l . v_m - the functionals of an iterate F against the stored modes
+// of its dimension under two atoms, taken as (K F) . m_j and (M F) . m_j: the modes are read once for both, where
+// F . (K m_j) and F . (M m_j) read a stored product per mode and atom (pgd_vec_multidot_pair).
+constexpr int PAIR_MAXV = 16;
+struct MultiDot2Args {
+    const double *w0, *w1;
+    const double *v[PAIR_MAXV];
+    int nv;
+    int64_t lo, hi;
+    double *partials;            // [block][2 nv]: the w0 dots, then the w1 dots
+};
+
+__global__ __launch_bounds__(TPB) void k_multidot2(MultiDot2Args A) {
+    __shared__ double s_red[4];
+    double a0[PAIR_MAXV], a1[PAIR_MAXV];
+#pragma unroll
+    for (int m = 0; m < PAIR_MAXV; ++m) a0[m] = a1[m] = 0.0;
+    for (int64_t i = A.lo + (int64_t)blockIdx.x * TPB + threadIdx.x; i < A.hi; i += (int64_t)gridDim.x * TPB) {
+        const double x0 = A.w0[i], x1 = A.w1[i];
+#pragma unroll
+        for (int m = 0; m < PAIR_MAXV; ++m)
+            if (m < A.nv) { const double y = A.v[m][i]; a0[m] = fma(y, x0, a0[m]); a1[m] = fma(y, x1, a1[m]); }
+    }
+#pragma unroll
+    for (int m = 0; m < PAIR_MAXV; ++m) {
+        if (m < A.nv) {                                      // uniform
+            const double s0 = block_sum(a0[m], s_red);
+            const double s1 = block_sum(a1[m], s_red);
+            if (threadIdx.x == 0) {
+                A.partials[(int64_t)blockIdx.x * (2 * A.nv) + m] = s0;
+                A.partials[(int64_t)blockIdx.x * (2 * A.nv) + A.nv + m] = s1;
+            }
+        }
+    }
+}
+
 // All of the start's Gram data in ONE pass over the vectors once the products W_j = A v_j are stored (up to 9 vectors):
 // G[i][j] = v_i . w_j for i <= j (A is symmetric) and g[j] = v_j . b - 2 k + 1 vector reads instead of the (k + 2)(k + 3) / 2 of
 // a k_multidot per column.  Partial sums per workgroup: value q = j (j + 1) / 2 + i for the pair (i <= j), then the k values of g.
@@ -2735,6 +2771,48 @@ int pgd_vec_multidot(pgd_handle h, pgd_handle xh, const pgd_handle *yhs, int k, 
         const int nv = std::min(GRAM_MAXV, k - j0);
         for (int q = 0; q < nv; ++q) out[j0 + q] = host[(size_t)(off + q)];
         off += nv + 1;
+    }
+    return PGD_OK;
+}
+
+int pgd_vec_multidot_pair(pgd_handle h, pgd_handle x0h, pgd_handle x1h, const pgd_handle *yhs, int k, int64_t lo, int64_t hi, double *out) {
+    PGD_CTX(c, h);
+    Vec *x0 = get_vec(c, x0h), *x1 = get_vec(c, x1h);
+    if (!x0 || !x1 || x0->n != x1->n || !yhs || !out || k < 1 || k > 128)
+        return fail(c, PGD_ERR_INVALID, "vec_multidot_pair: invalid handles or count (1..128)");
+    if (hi < 0) hi = x0->n;
+    if (lo < 0 || lo > hi || hi > x0->n) return fail(c, PGD_ERR_INVALID, "vec_multidot_pair: bad range");
+    std::vector<const double *> y((size_t)k);
+    for (int j = 0; j < k; ++j) {
+        Vec *v = get_vec(c, yhs[j]);
+        if (!v || v->n != x0->n) return fail(c, PGD_ERR_INVALID, "vec_multidot_pair: invalid vector %d", j);
+        y[(size_t)j] = v->d;
+    }
+    for (int j = 0; j < 2 * k; ++j) out[j] = 0.0;
+    if (hi == lo) return PGD_OK;
+    PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS > 512 ? 2 * (int64_t)MAX_VEC_BLOCKS : 512));
+    double *res = c->work[6];
+    const int g = grid_for(hi - lo);
+    PGD_TRY(ensure_partials(c, std::max<int64_t>((int64_t)g * 2 * PAIR_MAXV, 4 * MAX_VEC_BLOCKS)));
+    int off = 0;
+    for (int j0 = 0; j0 < k; j0 += PAIR_MAXV) {
+        const int nv = std::min(PAIR_MAXV, k - j0);
+        MultiDot2Args A;
+        A.w0 = x0->d; A.w1 = x1->d; A.nv = nv; A.lo = lo; A.hi = hi; A.partials = c->partials;
+        for (int q = 0; q < PAIR_MAXV; ++q) A.v[q] = y[(size_t)(j0 + std::min(q, nv - 1))];
+        k_multidot2<<<g, TPB, 0, c->stream>>>(A);
+        PGD_LAUNCH_CHECK(c);
+        PGD_TRY(reduce_partials_to(c, c->partials, g, 2 * nv, res + off));
+        off += 2 * nv;
+    }
+    std::vector<double> host((size_t)off);
+    PGD_HIP(c, hipMemcpyAsync(host.data(), res, (size_t)off * sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    off = 0;
+    for (int j0 = 0; j0 < k; j0 += PAIR_MAXV) {
+        const int nv = std::min(PAIR_MAXV, k - j0);
+        for (int q = 0; q < nv; ++q) { out[j0 + q] = host[(size_t)(off + q)]; out[k + j0 + q] = host[(size_t)(off + nv + q)]; }
+        off += 2 * nv;
     }
     return PGD_OK;
 }

@@ -2247,6 +2247,7 @@ def _dots_with_stored_products(be, atom, other, Ag, swapped, lo, hi, lay=None):
 # factor, ONE host synchronisation and ONE fixed-length all-reduce; the callback's assemble() calls then find their values
 # in the memo.  Nothing depends on the guess being right: a request that was not prefetched takes the ordinary path.
 PREFETCH_FUNCTIONALS = os.environ.get("PGD_PREFETCH_FUNCTIONALS", "1") != "0"
+PAIR_FUNCTIONALS = os.environ.get("PGD_PAIR_FUNCTIONALS", "1") != "0"        # 0: one left factor per multi-dot (A/B)
 _PREFETCH_MAX = 510                      # values per batch (the all-reduced message has a fixed length)
 _FUNCTIONAL_PLANS = {}                   # call-site tag -> [(lay, atom, f_ref, g_ref, symmetric)]
 _RECORDING = None
@@ -2331,6 +2332,40 @@ def _prefetch_functionals(reqs):
         if len(requests) < 2 or len(requests) > _PREFETCH_MAX:
             continue
         lo, hi = lay.owned_range()
+        vals, order = [], []
+        # Two PRODUCTS that many requests can take as their left factor - K F and M F of the iterate F, against the stored modes
+        # m_j - go through ONE pass that reads every m_j once for both (pgd_vec_multidot_pair): 2 + k vector reads for 2 k
+        # functionals, where F . (K m_j), F . (M m_j) read a stored product per mode and atom.  Taken where it reads less.
+        if PAIR_FUNCTIONALS and hasattr(be, "vec_multidot_pair"):
+            by_prod = {}
+            for rq in requests:
+                for other, prod in rq[3]:
+                    by_prod.setdefault(id(prod), (prod, []))[1].append((rq, other))
+            cands = sorted((e for e in by_prod.values() if len(e[1]) >= 2), key=lambda e: -len(e[1]))
+            while len(cands) >= 2:
+                (p0, c0), (p1, c1) = cands[0], cands[1]
+                cands = cands[2:]
+                done = {id(it[0]) for it in order}
+                rights, covered = {}, []
+                for left, cs in ((0, c0), (1, c1)):
+                    for rq, other in cs:
+                        if id(rq[0]) in done:
+                            continue
+                        done.add(id(rq[0]))
+                        rights.setdefault(id(other), other)
+                        covered.append((rq, left, other))
+                rl = list(rights.values())
+                if len(rl) > 128 or 2 + len(rl) >= len(covered):
+                    continue
+                a = be.vec_multidot_pair(p0.dev(), p1.dev(), [r.dev() for r in rl], lo, hi)
+                pos = {id(r): i for i, r in enumerate(rl)}
+                for rq, left, other in covered:
+                    vals.append(float(a[left][pos[id(other)]]))
+                    order.append((rq[0], rq[1], rq[2], other, None))
+                STATS_PREFETCH["pair_values"] = STATS_PREFETCH.get("pair_values", 0) + len(covered)
+            if order:
+                taken = {id(it[0]) for it in order}
+                requests = [rq for rq in requests if id(rq[0]) not in taken]
         shared = {}
         for _key, _f, _g, ways in requests:
             for other, _prod in ways:
@@ -2342,7 +2377,6 @@ def _prefetch_functionals(reqs):
         groups = {}
         for it in items:
             groups.setdefault(id(it[3]), (it[3], []))[1].append(it)
-        vals, order = [], []
         for other, its in groups.values():
             outs = [it[4].dev() for it in its]
             local = be.vec_multidot(other.dev(), outs, lo, hi) if len(outs) > 1 else [be.vec_dot(other.dev(), outs[0], lo, hi)]

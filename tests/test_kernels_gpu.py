@@ -1554,6 +1554,39 @@ def test_multidot_matches_single_dots(ctx):
             ctx.vec_free(v)
 
 
+def test_multidot_pair_matches_single_dots(ctx):
+    """pgd_vec_multidot_pair: x0 . y_j and x1 . y_j for 1 .. 40 vectors (chunks of 16), every y_j read once for both, against
+    numpy and pgd_vec_dot (fem._prefetch_functionals: (K F) . m_j and (M F) . m_j of an iterate against the stored modes)."""
+    from pgdrome_amd._lib import PgdError
+    rng = np.random.default_rng(78)
+    for n, lo, hi in ((1, 0, -1), (257, 3, 200), (100_003, 0, -1), (100_003, 999, 54_321)):
+        x0, x1 = rng.standard_normal(n), rng.standard_normal(n)
+        ys = [rng.standard_normal(n) for _ in range(40)]
+        v0, v1, yv = ctx.vec_from(x0), ctx.vec_from(x1), [ctx.vec_from(y) for y in ys]
+        stop = n if hi < 0 else hi
+        for k in (1, 2, 15, 16, 17, 32, 33, 40):
+            g0, g1 = ctx.vec_multidot_pair(v0, v1, yv[:k], lo, hi)
+            for got, x, xv in ((g0, x0, v0), (g1, x1, v1)):
+                want = np.array([x[lo:stop] @ y[lo:stop] for y in ys[:k]])
+                scale = np.array([np.abs(x[lo:stop]) @ np.abs(y[lo:stop]) for y in ys[:k]])
+                assert np.all(np.abs(got - want) <= 4e-16 * np.sqrt(max(stop - lo, 1)) * scale + 1e-300), (n, k)
+                one = np.array([ctx.vec_dot(xv, v, lo, hi) for v in yv[:k]])
+                assert np.all(np.abs(got - one) <= 1e-14 * scale + 1e-300)
+            h0, h1 = ctx.vec_multidot_pair(v0, v1, yv[:k], lo, hi)
+            assert np.array_equal(g0, h0) and np.array_equal(g1, h1)                  # fixed summation order
+        # the same vector on both sides, and as a right-hand vector
+        s0, s1 = ctx.vec_multidot_pair(v0, v0, [v0, yv[0]], lo, hi)
+        assert np.array_equal(s0, s1) and s0[0] > 0.0 or stop == lo
+        z0, z1 = ctx.vec_multidot_pair(v0, v1, yv[:3], 0, 0)
+        assert np.array_equal(z0, np.zeros(3)) and np.array_equal(z1, np.zeros(3))
+        with pytest.raises(PgdError):
+            ctx.vec_multidot_pair(v0, v1, [yv[0], 999999], lo, hi)
+        with pytest.raises(PgdError):
+            ctx.vec_multidot_pair(v0, v1, yv[:2], 5, n + 1)
+        for v in [v0, v1] + yv:
+            ctx.vec_free(v)
+
+
 @pytest.mark.parametrize("kind", ["mass", "stiff", "conv", "convt", "wmass", "wstiff"])
 def test_p2_interval_atoms_match_oracle(ctx, kind):
     """Quadratic elements on a non-uniform interval mesh: pattern bit-exact, values to rounding."""
