@@ -485,6 +485,13 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     if ((lo_g > 0) != (k.rank > 0) || (hi_g > 0) != (k.rank < k.world - 1))
         return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: ghost planes do not match the rank's position");
     constexpr int B = 24, CHECK = 16, V = SH_VOTE;       // slot base of the recurrence (pgdrome_amd/dist.py uses the same)
+    const bool dbg_t = getenv("PGD_DEBUG_PCG") != nullptr;     // host timers of the call's phases on stderr (each behind a stream synchronisation)
+    auto dbg_now = [&]() -> double {
+        if (!dbg_t) return 0.0;
+        (void)hipStreamSynchronize(c->stream);
+        return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    };
+    const double dbg_t0 = dbg_now();
     static_assert(V == B - 1, "the vote rides in front of the recurrence's slots");
     Mesh *m = get_mesh(c, op->mesh);
 
@@ -524,6 +531,7 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         sym = sym && got[1] == 0.0;                     // scaled only if EVERY rank can
         ss_all = got[2] == 0.0;                         // ... and the single-sync recurrence only if every rank's slab is a grid
     }
+    const double dbg_t1 = dbg_now();
     const bool scaled = sym && c->pcg_scaled;
     const bool ss = scaled && ss_all;                   // single-sync recurrence: 7 (here 8: the true norm every iteration) vector passes
     const pgd_handle r = k.work[0], u = k.work[1], w = k.work[2], p = k.work[3], s = k.work[4], q = k.work[5], dinv = k.work[6];
@@ -727,6 +735,7 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         c->fault_stall_ms = 0;
         k_comm_stall<<<1, 1, 0, c->stream>>>(ticks);
     }
+    const double dbg_t2 = dbg_now();
     PGD_TRY(agree_begin(0, "agreement before the first chunk"));
     for (;;) {
         const int chunk = std::min(CHECK, maxit - enq);
@@ -749,6 +758,7 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         cur ^= 1;
     }
     c->prof_iter = -1;
+    const double dbg_t3 = dbg_now();
     if (c->prof) prof_commit(c, f[1] + (ss ? 1 : 0), f[1]);      // samples of launches behind the converged iteration are dropped
     const int32_t done = f[0], it = f[1], status = f[2];
     if (scaled && !ss && !done && enq > 0) {
@@ -783,6 +793,12 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     PGD_TRY(pgd_slots_download(h, sl, 0, 40));
     PGD_TRY(comm_halo(c, xh, x->d, own0, own1, lo_g, hi_g));     // the caller's x: ghosts current
     if (iters) *iters = it2;
+    if (dbg_t) {
+        const double dbg_t4 = dbg_now();
+        fprintf(stderr, "[pcg_solve_sharded] n %lld rows %lld iterations %d queued %d | vote %.2f ms, setup %.2f ms, loop %.2f ms = %.1f us/it, end %.2f ms\n",
+                (long long)n, (long long)(own1 - own0), it2, enq, 1e3 * (dbg_t1 - dbg_t0), 1e3 * (dbg_t2 - dbg_t1), 1e3 * (dbg_t3 - dbg_t2),
+                1e6 * (dbg_t3 - dbg_t2) / (it2 > 0 ? it2 : 1), 1e3 * (dbg_t4 - dbg_t3));
+    }
     const double bb = sl[B + 8], rr = sl[6];
     if (rel) *rel = bb > 0.0 ? sqrt(rr / bb) : 0.0;
     return PGD_OK;
