@@ -257,7 +257,8 @@ def main():
                    "spatial_dofs": n_sp, "nnz": nnz, "parallelism": "z-slab row sharding x%d" % world if sharded else "single GPU",
                    "sharded_pcg_driver": (("in-library loop, RCCL" if comm.in_library == "rccl" else
                                            "python loop, torch.distributed") if sharded else None),
-                   "halo_overlap": (bool(getattr(comm, "halo_overlap", False)) if sharded else None),
+                   "halo_overlap": (bool(be.comm_overlap(-2)) if sharded and getattr(comm, "in_library", None) == "rccl" else (False if sharded else None)),
+                   "halo_overlap_available": (bool(getattr(comm, "halo_overlap", False)) if sharded else None),
                    "rccl_world": (be.comm_info()["world"] if sharded and comm.in_library == "rccl" else
                                   (dist.get_world_size() if sharded else None)),
                    "pcg_iterations_per_step": pcg_its / K, "modes_completed": len(prob.num_fp_it),

@@ -255,7 +255,8 @@ int pgd_comm_bind_rccl(pgd_handle ctx, const uint8_t *id128, int rank, int world
  * communicator (ncclCommSplit) on its own HIP stream, ordered against the compute stream by two events.
  * mode 1: try to enable - COLLECTIVE, call on every rank after all ranks bound successfully; the ranks must then
  * agree (e.g. MIN all-reduce of *state) and call mode 0 everywhere if any rank reports 0.  mode 0: disable.
- * mode -1: query.  *state: 1 = the sharded solve overlaps, 0 = the exchange stays on the compute stream.   */
+ * mode -1: query.  *state: 1 = the sharded solve CAN overlap, 0 = the exchange stays on the compute stream.  A solve uses the
+ * second stream only above PGD_TUNE_HALO_OVERLAP_MIN_ROWS rows per rank; mode -2: *state = did the last solve.            */
 int pgd_comm_overlap(pgd_handle ctx, int mode, int *state);
 int pgd_comm_unbind(pgd_handle ctx);
 /* Deadline of the host-side waits inside pgd_pcg_solve_sharded (the look at the flags after every chunk of iterations, the
@@ -305,6 +306,15 @@ int pgd_vec_multidot_pair(pgd_handle ctx, pgd_handle x0, pgd_handle x1, const pg
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
+    PGD_TUNE_HALO_OVERLAP_MIN_ROWS = 45, /* pgd_pcg_solve_sharded sends the halo exchange of its products through the second communicator and
+                                stream (pgd_comm_overlap) only where the ranks own at least this many rows on average (default 6 000 000;
+                                environment: PGD_HALO_OVERLAP_MIN_ROWS; a property of the current binding).  The second stream costs two event
+                                hand-overs per iteration - 10 to 14 us measured - and hides at most the interior rows' product: 17 us on the
+                                slab of an 8-GPU rank at 256^3.  Decided from the all-reduced row count: the same on every rank. */
+    PGD_TUNE_COMM_SELF_PERIODIC = 44, /* tests only: with ONE rank, pgd_pcg_solve_sharded and pgd_comm_halo accept ghost planes on both sides
+                                and the rank is its own neighbour - the ghost plane below receives the rank's top plane, the one above its
+                                bottom plane (a problem periodic in z): the halo communicator, its stream and events, the overlap with the
+                                interior rows' product and real RCCL send / receive run inside the iteration loop on a single GPU */
     PGD_TUNE_PCG_DERIVE_SCALED = 43, /* 1 (default): where the operator of pgd_pcg_solve is itself ONE stencil + eliminated nodes on the whole
                                 grid (every row verified, PGD_TUNE_SPMV_STENCIL) the couplings of D^-1/2 A D^-1/2 are derived from A's with
                                 the arithmetic the scaling pass would apply to every row - no pass over the slot arrays, no second

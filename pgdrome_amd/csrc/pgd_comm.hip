@@ -101,6 +101,11 @@ static void comm_env_defaults(Comm &k) {
         const double v = strtod(env, &end);
         if (end != env) k.timeout_s = v;
     }
+    if (const char *env = getenv("PGD_HALO_OVERLAP_MIN_ROWS")) {
+        char *end = nullptr;
+        const long long v = strtoll(env, &end, 10);
+        if (end != env && v >= 0) k.overlap_min_rows = v;
+    }
 }
 
 // neighbour planes -> ghost planes of v (local numbering: [0, lo_g) ghost below, [own0, own1) owned,
@@ -128,13 +133,22 @@ static int comm_halo_begin(Ctx *c, pgd_handle vh, double *v, int64_t own0, int64
         PGD_HIP(c, hipStreamWaitEvent(k.halo_stream, k.ev_ready, 0));
     }
     PGD_NCCL(c, api, api->GroupStart());
-    if (lo_g) {
-        PGD_NCCL(c, api, api->Send(v + own0, (size_t)lo_g, NCCL_F64, k.rank - 1, comm, st));
-        PGD_NCCL(c, api, api->Recv(v, (size_t)lo_g, NCCL_F64, k.rank - 1, comm, st));
-    }
-    if (hi_g) {
-        PGD_NCCL(c, api, api->Send(v + own1 - hi_g, (size_t)hi_g, NCCL_F64, k.rank + 1, comm, st));
-        PGD_NCCL(c, api, api->Recv(v + own1, (size_t)hi_g, NCCL_F64, k.rank + 1, comm, st));
+    if (k.self_periodic && k.world == 1) {
+        // tests: the rank is its own neighbour on both sides (periodic in z).  Transfers between the same pair of ranks are matched
+        // in the order they are issued: the top plane first (-> the ghost plane below), then the bottom plane (-> the one above)
+        if (lo_g) PGD_NCCL(c, api, api->Send(v + own1 - lo_g, (size_t)lo_g, NCCL_F64, 0, comm, st));
+        if (lo_g) PGD_NCCL(c, api, api->Recv(v, (size_t)lo_g, NCCL_F64, 0, comm, st));
+        if (hi_g) PGD_NCCL(c, api, api->Send(v + own0, (size_t)hi_g, NCCL_F64, 0, comm, st));
+        if (hi_g) PGD_NCCL(c, api, api->Recv(v + own1, (size_t)hi_g, NCCL_F64, 0, comm, st));
+    } else {
+        if (lo_g) {
+            PGD_NCCL(c, api, api->Send(v + own0, (size_t)lo_g, NCCL_F64, k.rank - 1, comm, st));
+            PGD_NCCL(c, api, api->Recv(v, (size_t)lo_g, NCCL_F64, k.rank - 1, comm, st));
+        }
+        if (hi_g) {
+            PGD_NCCL(c, api, api->Send(v + own1 - hi_g, (size_t)hi_g, NCCL_F64, k.rank + 1, comm, st));
+            PGD_NCCL(c, api, api->Recv(v + own1, (size_t)hi_g, NCCL_F64, k.rank + 1, comm, st));
+        }
     }
     PGD_NCCL(c, api, api->GroupEnd());
     if (over) PGD_HIP(c, hipEventRecord(k.ev_halo, k.halo_stream));
@@ -292,8 +306,11 @@ int pgd_comm_overlap(pgd_handle h, int mode, int *state) {
         if (!k.nccl_halo) comm_setup_overlap(c);
     } else if (mode == 0) {
         k.overlap = false;
+    } else if (mode == -2) {
+        if (state) *state = k.overlap_used ? 1 : 0;      // did the last pgd_pcg_solve_sharded take the second stream?
+        return PGD_OK;
     } else if (mode != -1) {
-        return fail(c, PGD_ERR_INVALID, "comm_overlap: mode must be 1 (enable), 0 (disable) or -1 (query)");
+        return fail(c, PGD_ERR_INVALID, "comm_overlap: mode must be 1 (enable), 0 (disable), -1 (query) or -2 (the last solve)");
     }
     if (state) *state = k.overlap ? 1 : 0;
     return PGD_OK;
@@ -482,8 +499,10 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: partition does not fit the vectors");
     Comm &k = c->comm;
     if (k.kind == 0) return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: no communication binding");
-    if ((lo_g > 0) != (k.rank > 0) || (hi_g > 0) != (k.rank < k.world - 1))
+    if (!(k.self_periodic && k.world == 1) && ((lo_g > 0) != (k.rank > 0) || (hi_g > 0) != (k.rank < k.world - 1)))
         return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: ghost planes do not match the rank's position");
+    if (k.self_periodic && k.world == 1 && lo_g != hi_g)
+        return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: a rank that is its own neighbour needs ghost planes of equal size on both sides");
     constexpr int B = 24, CHECK = 16, V = SH_VOTE;       // slot base of the recurrence (pgdrome_amd/dist.py uses the same)
     const bool dbg_t = getenv("PGD_DEBUG_PCG") != nullptr;     // host timers of the call's phases on stderr (each behind a stream synchronisation)
     auto dbg_now = [&]() -> double {
@@ -499,6 +518,7 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     // the choice of recurrence, are agreed on with one all-reduce: a rank whose operator did not qualify for the symmetric
     // storage must not take another branch (the scaled recurrence has one more halo exchange) than its neighbours.
     bool sym = false, ss_all = false;
+    double rows_all = 0.0;
     auto setup = [&]() -> int {
         if (!m) return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: operator without a mesh");
         if (k.work_n != n) {      // r, u, w, p, s, q, dinv as library vectors (the slot kernels take handles)
@@ -520,16 +540,20 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     const std::string err_setup = c->err;
     {
         const bool can_ss = rc_setup == PGD_OK && sym && c->pcg_scaled && c->pcg_single_sync && m && m->sym_nx > 0;
-        const double vote[3] = {rc_setup != PGD_OK ? 1.0 : 0.0, (rc_setup == PGD_OK && sym && c->pcg_scaled) ? 0.0 : 1.0, can_ss ? 0.0 : 1.0};
-        double got[3] = {1.0, 1.0, 1.0};
-        int rc = pgd_slots_upload(h, vote, B, 3);
-        if (rc == PGD_OK) rc = comm_allreduce(c, B, 3);
-        if (rc == PGD_OK) rc = pgd_slots_download(h, got, B, 3);
+        // (the fourth number: the rows this rank owns - their sum decides, identically everywhere, whether the halo exchange of the
+        // products takes the second stream)
+        const double vote[4] = {rc_setup != PGD_OK ? 1.0 : 0.0, (rc_setup == PGD_OK && sym && c->pcg_scaled) ? 0.0 : 1.0, can_ss ? 0.0 : 1.0,
+                                (double)(own1 - own0)};
+        double got[4] = {1.0, 1.0, 1.0, 0.0};
+        int rc = pgd_slots_upload(h, vote, B, 4);
+        if (rc == PGD_OK) rc = comm_allreduce(c, B, 4);
+        if (rc == PGD_OK) rc = pgd_slots_download(h, got, B, 4);
         if (rc_setup != PGD_OK) { c->err = err_setup; return rc_setup; }
         if (rc != PGD_OK) return rc;
         if (got[0] != 0.0) return fail(c, PGD_ERR_PEER, "pcg_solve_sharded: the setup failed on another rank");
         sym = sym && got[1] == 0.0;                     // scaled only if EVERY rank can
         ss_all = got[2] == 0.0;                         // ... and the single-sync recurrence only if every rank's slab is a grid
+        rows_all = got[3];
     }
     const double dbg_t1 = dbg_now();
     const bool scaled = sym && c->pcg_scaled;
@@ -590,7 +614,9 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     // Returns an error only for what ends the protocol (a failing collective); local failures poison S.
     int64_t glo = lo_g, ghi = hi_g;
     if (own1 - own0 < glo + ghi) { glo = own1 - own0; ghi = 0; }     // a rank that owns a single plane: nothing to overlap
-    const bool async = k.overlap;                                    // the SAME choice on every rank (agreed on at bind time)
+    // the SAME choice on every rank: the capability was agreed on at bind time, the row count is all-reduced
+    const bool async = k.overlap && rows_all >= (double)k.overlap_min_rows * (double)k.world;
+    k.overlap_used = async;
     hipEvent_t *marks = nullptr;                                     // phase timing of the iteration being queued (or none)
     auto mark = [&](int i) { if (marks) (void)hipEventRecord(marks[i], c->stream); };
     auto product = [&](pgd_handle uh, double *ud, double *wdst, bool folded, int *np_total) -> int {

@@ -2630,6 +2630,8 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_SPMV_ZCHUNK_CODED && value >= 3 && value <= 1024) { c->spmv_zchunk_coded = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_PRECOND && value >= 0 && value <= 1) { c->pcg_precond = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_DERIVE_SCALED && value >= 0 && value <= 1) { c->pcg_derive_scaled = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_COMM_SELF_PERIODIC && value >= 0 && value <= 1) { c->comm.self_periodic = value != 0; return PGD_OK; }
+    if (knob == PGD_TUNE_HALO_OVERLAP_MIN_ROWS && value >= 0) { c->comm.overlap_min_rows = value; return PGD_OK; }
     if (knob == PGD_TUNE_MG_CHUNK && value >= 2 && value <= 16 && value % 2 == 0) { c->mg_chunk = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_MG_MARCH_MIN && value >= 0 && value <= 1 << 20) { c->mg_march_min = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);

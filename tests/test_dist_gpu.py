@@ -107,6 +107,94 @@ def test_sharded_driver_world1_matches_library_pcg():
         dist.destroy_process_group()
 
 
+def test_halo_exchange_with_itself_overlapped_or_not_is_the_same_solve():
+    """ONE rank that is its own neighbour on both sides (PGD_TUNE_COMM_SELF_PERIODIC: a problem periodic in z): the sharded
+    solve with real ghost planes, boundary-plane launches and RCCL send / receive INSIDE the iteration loop on a single GPU -
+    (a) through the callback binding (the exchange as two device copies on the compute stream), (b) over RCCL on the compute
+    stream, (c) over RCCL on the halo communicator and its stream, overlapped with the interior rows' product: the same
+    launches in the same order, so iteration counts, residuals and x must be IDENTICAL; the solution checked through the CSR
+    kernels with the ghost planes filled on the host."""
+    import torch
+    import torch.distributed as dist
+    from pgdrome_amd import dist as pdist, fem
+    from pgdrome_amd.hip_backend import HipBackend
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    old = fem._backend
+    try:
+        tstream = torch.cuda.Stream(device=0)
+        torch.cuda.set_stream(tstream)
+        be = fem.set_backend(HipBackend(0, tstream.cuda_stream))
+        fem.clear_caches()
+        ctx = be.ctx
+        nx, ny, nzl = 256, 256, 34                       # 32 owned planes between two ghost planes: the slab of an 8-GPU rank at 256^3
+        mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, (nzl - 1) / 255.0), nx - 1, ny - 1, nzl - 1)
+        coords = mesh.coordinates()
+        h = ctx.mesh_upload(coords, mesh.cells())
+        n, plane = coords.shape[0], nx * ny
+        own0, own1 = plane, n - plane
+        ak, am = ctx.atom_assemble(h, 1), ctx.atom_assemble(h, 0)
+        hull = np.where((coords[:, 0] <= 1e-12) | (coords[:, 0] >= 1 - 1e-12) | (coords[:, 1] <= 1e-12) | (coords[:, 1] >= 1 - 1e-12))[0].astype(np.int32)
+        op = ctx.op_combine(h, [ak, am], [1.0, 3.0], hull)
+        rng = np.random.default_rng(9)
+        b = rng.uniform(-1, 1, n)
+        b[hull] = 0.0
+        bv = ctx.vec_from(b)
+
+        def cb_halo(vec, o0, o1, lo_g, hi_g):
+            t = be.vec_tensor(vec)
+            t[0:lo_g].copy_(t[o1 - lo_g:o1])
+            t[o1:o1 + hi_g].copy_(t[o0:o0 + hi_g])
+
+        def cb_allreduce(first, count):
+            pass
+
+        uid = ctx.comm_unique_id()
+        out = {}
+        for variant in ("callbacks", "rccl", "rccl+overlap"):
+            ctx.comm_unbind()
+            if variant == "callbacks":
+                ctx.comm_bind_callbacks(cb_halo, cb_allreduce, 0, 1)
+            else:
+                ctx.comm_bind_rccl(uid if variant == "rccl" else ctx.comm_unique_id(), 0, 1)
+                assert ctx.comm_overlap(1 if variant == "rccl+overlap" else 0) == (variant == "rccl+overlap")
+            ctx.tune(44, 1)                              # (a binding starts from the defaults)
+            ctx.tune(45, 0)                              # the second stream whatever the slab's size
+            xv = ctx.vec_alloc(n)
+            k0 = ctx.kernel_counts()
+            it, rel = ctx.pcg_solve_sharded(op, bv, xv, own0, own1, plane, plane, 1e-10, 0.0, 10000)
+            k1 = ctx.kernel_counts()
+            assert k1["stencil_march"] > k0["stencil_march"] and k1["dia_rows"] > k0["dia_rows"]     # interior march + boundary planes
+            assert ctx.comm_overlap(-2) == (variant == "rccl+overlap")
+            x = ctx.vec_download(xv)
+            out[variant] = (it, rel, x)
+            assert it > 50 and rel <= 1e-10
+            # the library returns x with current ghost planes: its own far boundary planes
+            assert np.array_equal(x[:plane], x[own1 - plane:own1]) and np.array_equal(x[own1:], x[own0:own0 + plane])
+            # the residual on the owned rows through the CSR kernels
+            yv = ctx.vec_alloc(n)
+            ctx.tune(3, 0)
+            ctx.spmv(op, xv, yv, own0, own1)
+            ctx.tune(3, 1)
+            r = (b - ctx.vec_download(yv))[own0:own1]
+            assert np.linalg.norm(r) <= 1.05e-10 * np.linalg.norm(b[own0:own1])
+            for v in (xv, yv):
+                ctx.vec_free(v)
+        a = out["callbacks"]
+        for variant in ("rccl", "rccl+overlap"):
+            c = out[variant]
+            assert a[0] == c[0] and a[1] == c[1] and np.array_equal(a[2], c[2]), (variant, a[0], c[0], a[1], c[1])
+        ctx.comm_unbind()
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream(0))
+        fem.set_backend(old)
+        fem.clear_caches()
+        dist.destroy_process_group()
+
+
 def _shared_gpu_worker(rank, world, port, shape, q, in_library):
     """One of several ranks that all use GPU 0: HIP kernels for the local arithmetic, gloo (staged
     through the host) for the exchange steps."""

@@ -1,0 +1,59 @@
+"""The sharded iteration of ONE rank with ghost planes on both sides, on a single GPU: the rank is its own neighbour
+(PGD_TUNE_COMM_SELF_PERIODIC), so the halo exchange is real RCCL send / receive, the product is an interior launch + the two
+boundary planes, and the phases can be timed - everything of an N > 1 iteration but the wire and the other ranks.
+
+    PGD_DEBUG_PCG=1 python tools/bench_self_periodic.py [--planes 32] [--nxy 256]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import torch.distributed as dist
+from pgdrome_amd import fem
+from pgdrome_amd.hip_backend import HipBackend
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--planes", type=int, default=32, help="owned planes (256 / 8 = the slab of an 8-GPU rank at 256^3)")
+ap.add_argument("--nxy", type=int, default=256)
+args = ap.parse_args()
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29541")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+tstream = torch.cuda.Stream(device=0)
+torch.cuda.set_stream(tstream)
+be = fem.set_backend(HipBackend(0, tstream.cuda_stream))
+ctx = be.ctx
+nx = ny = args.nxy
+nzl = args.planes + 2
+mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, (nzl - 1) / (nx - 1.0)), nx - 1, ny - 1, nzl - 1)
+coords = mesh.coordinates()
+h = ctx.mesh_upload(coords, mesh.cells())
+n, plane = coords.shape[0], nx * ny
+own0, own1 = plane, n - plane
+ak, am = ctx.atom_assemble(h, 1), ctx.atom_assemble(h, 0)
+hull = np.where((coords[:, 0] <= 1e-12) | (coords[:, 0] >= 1 - 1e-12) | (coords[:, 1] <= 1e-12) | (coords[:, 1] >= 1 - 1e-12))[0].astype(np.int32)
+op = ctx.op_combine(h, [ak, am], [1.0, 3.0], hull)
+b = np.random.default_rng(9).uniform(-1, 1, n)
+b[hull] = 0.0
+bv = ctx.vec_from(b)
+for variant in ("rccl", "rccl+overlap"):
+    ctx.comm_unbind()
+    ctx.comm_bind_rccl(ctx.comm_unique_id(), 0, 1)
+    ctx.comm_overlap(1 if variant == "rccl+overlap" else 0)
+    ctx.tune(44, 1)
+    for rep in range(2):
+        xv = ctx.vec_alloc(n)
+        if rep:
+            ctx.comm_prof(1)
+        it, rel = ctx.pcg_solve_sharded(op, bv, xv, own0, own1, plane, plane, 1e-10, 0.0, 10000)
+        ctx.vec_free(xv)
+    ph = ctx.comm_prof(0)
+    ns = max(ph.pop("samples"), 1.0)
+    print(variant, "iterations", it, "phases (us, one iteration per chunk between HIP events, each incl. the event pair's own ~4.8 us):",
+          {k: round(1e6 * v / ns, 1) for k, v in ph.items() if k != "host_boundary_wait"}, flush=True)
+dist.destroy_process_group()
