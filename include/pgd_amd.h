@@ -306,6 +306,10 @@ int pgd_vec_multidot_pair(pgd_handle ctx, pgd_handle x0, pgd_handle x1, const pg
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
+    PGD_TUNE_SHARD_ONE_MARCH = 46, /* 1 (default): where the halo exchange of pgd_pcg_solve_sharded runs in stream order and the rank's operator is one
+                                stencil whose ghost planes hold the same eliminated nodes as its own (checked per solve), the product is ONE march
+                                over all owned planes with the ghost planes staged as data; 0: interior march + the boundary planes in row
+                                order (what the overlapped exchange always does).  The same y; the fused dots are grouped differently. */
     PGD_TUNE_HALO_OVERLAP_MIN_ROWS = 45, /* pgd_pcg_solve_sharded sends the halo exchange of its products through the second communicator and
                                 stream (pgd_comm_overlap) only where the ranks own at least this many rows on average (default 6 000 000;
                                 environment: PGD_HALO_OVERLAP_MIN_ROWS; a property of the current binding).  The second stream costs two event

@@ -635,6 +635,21 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
             total += np;
             return PGD_OK;
         };
+        // the exchange in stream order and the operator one stencil whose ghost planes are data planes (k_stencil_ghost): ALL owned
+        // planes in one march - no boundary launch (7 us + a launch gap per iteration on the slab of an 8-GPU rank)
+        if (folded && !async && c->shard_one_march && (glo || ghi) && !S.poisoned() && stencil_row_range(c, m, op, own0, own1)) {
+            auto whole = [&]() -> int {
+                int np = 0;
+                c->partials_off = 0;
+                PGD_TRY(launch_spmv_op(c, m, op, ud, wdst, ud, own0, own1, true, true, c->flags, &np));
+                total = np;
+                return PGD_OK;
+            };
+            SH_LOCAL(S, whole());
+            mark(1); mark(2); mark(3);
+            if (np_total) *np_total = total;
+            return PGD_OK;
+        }
         SH_LOCAL(S, range(0));
         mark(1);
         PGD_TRY(comm_halo_wait(c, lo_g, hi_g, async));

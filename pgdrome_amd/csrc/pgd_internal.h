@@ -129,6 +129,7 @@ struct Csr : Obj {
     bool st_ok = false;
     int st_ident = -1, st_z0 = 0, st_z1 = 0, st_zm0 = 0, st_zm1 = 0;   // (st_zm0 .. st_zm1: the run of planes with identical codes; the rest of the verified planes hold identity rows only)
     double st_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool st_g_lo = false, st_g_hi = false;   // the plane below st_z0 / above st_z1 - 1 is a ghost DATA plane of a sharded slab (k_stencil_ghost)
     bool st_virtual = false;       // st_c holds the couplings of D^-1/2 A D^-1/2 while slots, table and CSR values hold A (pgd_pcg_solve)
     bool cls_tried = false;        // atoms: the dictionary was looked for once for the current slot values (atom_fast_form)
     bool immutable = false;        // an ATOM (assembled / uploaded / embedded): its values change only through pgd_atom_embed(dst)
@@ -268,6 +269,7 @@ struct Ctx {
     int spmv_unit_diag = 1;       // scaled recurrence on structured grids: the unit diagonal is set to exactly 1 and not loaded
     int pcg_defer_x = 1;          // scaled recurrence, large systems: x += alpha p in the p kernel (8 vector passes per iteration, not 9)
     int pcg_scaled = 1;           // pgd_pcg_solve on the symmetrically scaled system (no dinv / z passes) when the symmetric storage applies
+    int shard_one_march = 1;      // pgd_pcg_solve_sharded, exchange in stream order: all owned planes in one stencil march, ghost planes as data (PGD_TUNE_SHARD_ONE_MARCH)
     int pcg_derive_scaled = 1;    // ... whose stencil couplings are DERIVED from the verified stencil of A where that exists (PGD_TUNE_PCG_DERIVE_SCALED)
     int spmv_combine_dia = 1;     // structured grids: op_combine also forms the diagonal form from the atoms' diagonal forms
     int spmv_sym = 1;             // PCG products from the symmetric half storage when the mesh qualifies
@@ -341,6 +343,7 @@ int ensure_vals(Ctx *c, const Mesh *m, Csr *a);                 // pgd_pcg.hip: 
 bool atom_fast_form(Ctx *c, const Mesh *m, Csr *a, int64_t r0, int64_t r1);   // pgd_spmv.hip
 // pgd_spmv.hip: row-class dictionary of the current slot values (+ its stencil form, verified on the planes [zlo, zhi) - whole grid: -1)
 int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo = -1, int zrange_hi = -1);
+bool stencil_row_range(const Ctx *c, const Mesh *m, const Csr *a, int64_t r0, int64_t r1);   // ... over the whole planes [r0, r1) of a slab
 bool stencil_whole_grid(const Ctx *c, const Mesh *m, const Csr *a);   // pgd_spmv.hip: a product over all rows would run in k_spmv_stencil_march
 int launch_stencil_pass(Ctx *c, const uint8_t *cls, int ident, const double cst[8], int nx, int ny, int nz, int zm0, int zm1,
                         const double *x, const double *b, double *y, double w, int epi, bool dot, int *nparts);      // pgd_spmv.hip

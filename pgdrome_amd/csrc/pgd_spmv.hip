@@ -1122,6 +1122,8 @@ struct StencilArgs {
     int nx, ny, nz;
     int zv0, zv1;           // planes the form was verified on (the grid, or the owned planes of a sharded slab)
     int zm0, zm1;           // the main run within them; the other planes of [zv0, zv1) hold identity rows only
+    int zs0, zs1;           // planes whose x is fetched and staged like a main plane's: the main run, and a GHOST plane next to it whose
+                            // eliminated nodes are the main planes' (a sharded slab: the neighbour rank's boundary plane - data, not rim)
     int z0, z1, zchunk, tiles_x, tiles_y;
     int qq;
     int whatif;             // instrumented builds only (PGD_STENCIL_TIMING): 1 no y stores, 2 no x fetches, 4 no LDS reads / FMAs
@@ -1210,7 +1212,8 @@ __global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) 
             v[q] = __builtin_bit_cast(double, t);
         }
     };
-    auto fetch_live = [&](int z) { return z >= A.zv0 && z < A.zv1 && z <= zb; };      // (planes behind the march's upper halo plane: no records)
+    const int zd0 = min(A.zv0, A.zs0), zd1 = max(A.zv1, A.zs1);             // planes that hold data: the verified ones and such ghost planes
+    auto fetch_live = [&](int z) { return z >= zd0 && z < zd1 && z <= zb; };          // (planes behind the march's upper halo plane: no records)
     // stage plane zz (values fetched D + 2 steps ago): the masked values for the neighbours, the raw own values into `own`
     auto stage_main = [&](int zz, const double (&v)[NQ], double (&own)[RW]) {
         double *dst = s_x + (zz & 3) * SLOT;
@@ -1219,7 +1222,7 @@ __global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) 
         dst[cell4] = v[RW];
     };
     auto stage = [&](int zz, const double (&v)[NQ], double (&own)[RW]) {
-        if (zz >= A.zm0 && zz < A.zm1) { stage_main(zz, v, own); return; }  // uniform
+        if (zz >= A.zs0 && zz < A.zs1) { stage_main(zz, v, own); return; }  // uniform
         // identity rows only (or outside the verified planes: nothing was fetched): zeros for the neighbours
         double *dst = s_x + (zz & 3) * SLOT;
 #pragma unroll
@@ -1335,7 +1338,7 @@ __global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) 
         }
     };
     // PURE: every plane the march touches - its own, its two halo planes - is a main plane: no plane tests in the steps
-    const bool pure = za - 1 >= A.zm0 && zb < A.zm1;
+    const bool pure = za - 1 >= A.zs0 && zb < A.zs1;                         // (zs = zm + at most one ghost plane either side: [za, zb) lies in the main run)
     int z = za;
     if (pure) {
 #pragma clang loop unroll(disable)
@@ -1393,7 +1396,7 @@ __global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) 
 // gives those rows a class id of their own (same tuple, a duplicate table row: the dictionary product does not care), so that
 // "class == identity class" means an eliminated node: every coupling TO it is zero as well.  k_stencil_verify: every row of those
 // planes, every slot, bit for bit.
-struct StencilInfo { int ok, ident, base, split; double c[8]; int zm0, zm1, pad0, pad1; };
+struct StencilInfo { int ok, ident, base, split; double c[8]; int zm0, zm1, g_lo, g_hi; };     // g_lo / g_hi: the plane below / above the verified planes is a ghost DATA plane (k_stencil_ghost)
 
 __global__ void k_stencil_pick(const uint8_t *__restrict__ cls, double *__restrict__ table, const int *__restrict__ info,
                                int nx, int ny, int z_lo, int z_hi, StencilInfo *S) {
@@ -1481,6 +1484,24 @@ __global__ void k_stencil_planes(const int *__restrict__ same, const int *__rest
     if (!simple) S->ok = 0;
 }
 
+// A sharded slab's ghost planes: the plane below z_lo (above z_hi - 1) lies inside the array, next to a main plane, and its
+// eliminated nodes are exactly those of the main planes - then the march may stage it like a main plane (its rows hold the
+// neighbour rank's x; couplings to its eliminated nodes are the exact zeros k_stencil_verify found in the owned rows next to it)
+__global__ void k_stencil_ghost_init(StencilInfo *S, int z_lo, int z_hi, int nz, int zm0, int zm1) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (zm0 < 0) { zm0 = S->zm0; zm1 = S->zm1; }
+    S->g_lo = (S->ok && z_lo > 0 && zm0 == z_lo && zm1 > zm0) ? 1 : 0;
+    S->g_hi = (S->ok && z_hi < nz && zm1 == z_hi && zm1 > zm0) ? 1 : 0;
+}
+__global__ __launch_bounds__(TPB) void k_stencil_ghost(const uint8_t *__restrict__ cls, int64_t plane, int z_lo, int z_hi, int zm0, StencilInfo *S) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= plane || !S->ok) return;
+    if (zm0 < 0) zm0 = S->zm0;
+    const bool id = (int)cls[plane * zm0 + i] == S->ident;
+    if (S->g_lo && ((int)cls[plane * (z_lo - 1) + i] == S->ident) != id) S->g_lo = 0;
+    if (S->g_hi && ((int)cls[plane * z_hi + i] == S->ident) != id) S->g_hi = 0;
+}
+
 __global__ __launch_bounds__(TPB) void k_stencil_verify(const uint8_t *__restrict__ cls, const double *__restrict__ table, int nx, int ny,
                                                         int nz, int z_lo, int z_hi, StencilInfo *S) {
     if (!S->ok) return;
@@ -1512,7 +1533,7 @@ int launch_stencil_pass(Ctx *c, const uint8_t *cls, int ident, const double cst[
     StencilArgs F;
     F.cls = cls; F.ident = ident; F.x = x; F.y = y; F.b = b; F.w = w; F.flags = c->flags;
     for (int s2 = 0; s2 < 8; ++s2) F.c[s2] = cst[s2];
-    F.nx = nx; F.ny = ny; F.nz = nz; F.zv0 = 0; F.zv1 = nz; F.zm0 = zm0; F.zm1 = zm1; F.z0 = 0; F.z1 = nz;
+    F.nx = nx; F.ny = ny; F.nz = nz; F.zv0 = 0; F.zv1 = nz; F.zm0 = zm0; F.zm1 = zm1; F.zs0 = zm0; F.zs1 = zm1; F.z0 = 0; F.z1 = nz;
     F.tiles_x = (nx + 63) / 64; F.tiles_y = (ny + 15) / 16;
     F.qq = 0; F.whatif = 0;
     const int64_t tiles = (int64_t)F.tiles_x * F.tiles_y, slots = (int64_t)c->stencil_wg_per_cu * c->num_cu;
@@ -1721,6 +1742,7 @@ __global__ __launch_bounds__(TPB) void k_cls_reps(const uint8_t *__restrict__ cl
 int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
     a->cls_count = 0;
     a->st_ok = false;
+    a->st_g_lo = a->st_g_hi = false;
     if (!c->spmv_classes || m->sym_nx <= 0 || !(a->uvals && a->uvals_valid) || m->nv >= ((int64_t)1 << 31)) return PGD_OK;
     const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
     if (m->nv / plane < 3 || plane * 64 < c->spmv_grid_min_plane_bytes) return PGD_OK;          // no march on this grid anyway
@@ -1760,6 +1782,8 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
                 ZeroPat zp;
                 memcpy(zp.b, E.zero_pat, sizeof zp.b);
                 k_stencil_known<<<1, 256, 0, st>>>(a->cls_table, E.ncls, E.ident, E.base, zp, SI);
+                k_stencil_ghost_init<<<1, 1, 0, st>>>(SI, z_lo, z_hi, nzp, E.zm0, E.zm1);
+                if (z_lo > 0 || z_hi < nzp) k_stencil_ghost<<<(int)((plane + TPB - 1) / TPB), TPB, 0, st>>>(a->cls, plane, z_lo, z_hi, E.zm0, SI);
             }
             host.info[1] = 1;
             PGD_HIP(c, hipMemcpyAsync(host.info, S->info, sizeof host.info, hipMemcpyDeviceToHost, st));
@@ -1778,6 +1802,7 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
                 a->st_ok = true;
                 a->st_ident = E.ident;
                 a->st_z0 = z_lo; a->st_z1 = z_hi; a->st_zm0 = E.zm0; a->st_zm1 = E.zm1;
+                a->st_g_lo = host.si.g_lo != 0; a->st_g_hi = host.si.g_hi != 0;
                 for (int s2 = 0; s2 < 8; ++s2) a->st_c[s2] = host.si.c[s2];
             }
             return PGD_OK;
@@ -1804,6 +1829,8 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
         int *allid = reinterpret_cast<int *>(SI + 1);
         k_stencil_allid<<<nzp, TPB, 0, st>>>(a->cls, plane, SI, allid, allid + 65536);
         k_stencil_planes<<<1, 64, 0, st>>>(allid + 65536, allid, z_lo, z_hi, SI);
+        k_stencil_ghost_init<<<1, 1, 0, st>>>(SI, z_lo, z_hi, nzp, -1, -1);
+        if (z_lo > 0 || z_hi < nzp) k_stencil_ghost<<<(int)((plane + TPB - 1) / TPB), TPB, 0, st>>>(a->cls, plane, z_lo, z_hi, -1, SI);
     }
     host.info[0] = 0; host.info[1] = 1; host.si.ok = 0;
     PGD_HIP(c, hipMemcpyAsync(host.info, S->info, sizeof host.info, hipMemcpyDeviceToHost, st));
@@ -1824,6 +1851,7 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
         a->st_ident = host.si.ident;
         a->st_z0 = z_lo; a->st_z1 = z_hi;
         a->st_zm0 = host.si.zm0; a->st_zm1 = host.si.zm1;
+        a->st_g_lo = host.si.g_lo != 0; a->st_g_hi = host.si.g_hi != 0;
         for (int s2 = 0; s2 < 8; ++s2) a->st_c[s2] = host.si.c[s2];
     }
     // ---- remember the structure for the next operator with this signature (at most four per mesh, least recently used out)
@@ -2202,6 +2230,21 @@ bool stencil_whole_grid(const Ctx *c, const Mesh *m, const Csr *a) {
            a->st_z0 == 0 && a->st_z1 == nz && plane < ((int64_t)1 << 26);
 }
 
+// ... and over the whole planes [r0, r1) of a sharded slab, ghost planes as halo included
+bool stencil_row_range(const Ctx *c, const Mesh *m, const Csr *a, int64_t r0, int64_t r1) {
+    if (!(c->spmv_sym && m->sym_w && a->uvals_valid && a->uvals) || m->sym_nx <= 0) return false;
+    const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
+    if (r0 < 0 || r1 <= r0 || r1 > m->nv || r0 % plane != 0 || r1 % plane != 0) return false;
+    const int nz = (int)(m->nv / plane), z0 = (int)(r0 / plane), z1 = (int)(r1 / plane);
+    int zchunk = 0;
+    if (dia_march_chunks(c, m, z0, z1, c->spmv_variant <= 1 ? 8 : 4, &zchunk) <= 0) return false;
+    const bool coded = c->spmv_variant == 0 && c->spmv_classes && a->cls_count > 0;
+    const bool st_lower = z0 == 0 ? a->st_z0 == 0 : (z0 - 1 >= a->st_z0 || (z0 == a->st_z0 && a->st_g_lo));
+    const bool st_upper = z1 == nz ? a->st_z1 == nz : (z1 + 1 <= a->st_z1 || (z1 == a->st_z1 && a->st_g_hi));
+    return coded && c->spmv_stencil && a->st_ok && (c->spmv_zchunk_force <= 0 || c->spmv_zchunk_stencil > 0) && st_lower && st_upper &&
+           plane < ((int64_t)1 << 26);
+}
+
 int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double *y, const double *w, int64_t r0,
                    int64_t r1, bool dot, bool store, const int *flags, int *nparts_out) {
     // (st_virtual: the stencil couplings describe D^-1/2 A D^-1/2 while the slot arrays and the CSR values hold A - inside
@@ -2292,13 +2335,15 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
             // Every plane the launch READS - its own and one halo plane either way - must be a verified plane or lie outside the grid
             // (the kernel stages what is outside the verified planes as zeros: right for the rim of the grid, wrong for a ghost plane
             // of a sharded slab, whose rows hold the neighbour rank's x)
-            const bool st_lower = D.z0 == 0 ? a->st_z0 == 0 : D.z0 - 1 >= a->st_z0;
-            const bool st_upper = D.z1 == D.nz ? a->st_z1 == D.nz : D.z1 + 1 <= a->st_z1;
+            // (... or a ghost plane whose eliminated nodes are the main planes': staged as data, k_stencil_ghost)
+            const bool st_lower = D.z0 == 0 ? a->st_z0 == 0 : (D.z0 - 1 >= a->st_z0 || (D.z0 == a->st_z0 && a->st_g_lo));
+            const bool st_upper = D.z1 == D.nz ? a->st_z1 == D.nz : (D.z1 + 1 <= a->st_z1 || (D.z1 == a->st_z1 && a->st_g_hi));
             if (coded && c->spmv_stencil && a->st_ok && (c->spmv_zchunk_force <= 0 || c->spmv_zchunk_stencil > 0) && st_lower && st_upper &&
                 plane < ((int64_t)1 << 26)) {
                 StencilArgs F;
                 F.cls = a->cls; F.ident = a->st_ident; F.x = x; F.y = y; F.flags = flags;
                 F.zv0 = a->st_z0; F.zv1 = a->st_z1; F.zm0 = a->st_zm0; F.zm1 = a->st_zm1;
+                F.zs0 = a->st_zm0 - (a->st_g_lo ? 1 : 0); F.zs1 = a->st_zm1 + (a->st_g_hi ? 1 : 0);
                 for (int s2 = 0; s2 < 8; ++s2) F.c[s2] = a->st_c[s2];
                 F.nx = D.nx; F.ny = D.ny; F.nz = D.nz; F.z0 = D.z0; F.z1 = D.z1; F.tiles_x = D.tiles_x; F.tiles_y = (D.ny + 15) / 16;
                 F.qq = D.qq;
@@ -2632,6 +2677,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_PCG_DERIVE_SCALED && value >= 0 && value <= 1) { c->pcg_derive_scaled = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_COMM_SELF_PERIODIC && value >= 0 && value <= 1) { c->comm.self_periodic = value != 0; return PGD_OK; }
     if (knob == PGD_TUNE_HALO_OVERLAP_MIN_ROWS && value >= 0) { c->comm.overlap_min_rows = value; return PGD_OK; }
+    if (knob == PGD_TUNE_SHARD_ONE_MARCH && value >= 0 && value <= 1) { c->shard_one_march = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_MG_CHUNK && value >= 2 && value <= 16 && value % 2 == 0) { c->mg_chunk = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_MG_MARCH_MIN && value >= 0 && value <= 1 << 20) { c->mg_march_min = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);

@@ -46,6 +46,7 @@ for variant in ("rccl", "rccl+overlap"):
     ctx.comm_bind_rccl(ctx.comm_unique_id(), 0, 1)
     ctx.comm_overlap(1 if variant == "rccl+overlap" else 0)
     ctx.tune(44, 1)
+    ctx.tune(45, 0)          # the second stream whatever the slab's size
     for rep in range(2):
         xv = ctx.vec_alloc(n)
         if rep:
