@@ -299,6 +299,8 @@ def main():
         general = general_paths(be, spec, settings)
         out["config"]["general_paths"] = general
         out["config"]["multigrid_preconditioner"] = multigrid_path(be, spec, settings, modes_ref)
+    if rank == 0 and world == 1 and not sharded and not args.no_general_paths and n == 256:
+        out["config"]["rank_with_ghost_planes"] = ghost_rank_rehearsal()
     pmc = pmc_traffic(own, upd_bytes) if rank == 0 and world == 1 and n == 256 and sym["nx"] and not args.no_pmc else {}
     out["roofline"].update(pmc.get("product", {}))
     if upd_n and upd_avg > avg:
@@ -339,6 +341,29 @@ def main():
         if args.watchdog_seconds > 0:
             import faulthandler
             faulthandler.cancel_dump_traceback_later()
+
+
+def ghost_rank_rehearsal():
+    """The sharded iteration of a rank WITH ghost planes, on this one GPU (a child process: it needs a process group of its own):
+    tools/bench_self_periodic.py makes ONE rank its own neighbour on both sides (PGD_TUNE_COMM_SELF_PERIODIC), so the solve has
+    real ghost planes and RCCL send / receive inside its loop - everything of an N > 1 iteration but the wire and the other ranks -
+    on the slab an 8-GPU rank of this workload owns (256 x 256 x 32).  None if the child could not run."""
+    import subprocess
+    try:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        env.pop("PGD_TUNE", None)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_self_periodic.py"), "--json"], capture_output=True,
+                           timeout=240, env=env, cwd=ROOT)
+        line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return None
+        res = json.loads(line[-1])
+        res["note"] = ("one rank as its own neighbour on both sides (a problem periodic in z): real ghost planes, the halo exchange as RCCL "
+                       "send / receive inside the iteration loop; microseconds per iteration over whole solves (setup included), best of two; "
+                       "no wire, no other ranks - a lower bound of the time a rank of an 8-GPU run needs per iteration")
+        return res
+    except Exception:      # noqa: BLE001 - a side section must not take the line with it
+        return None
 
 
 def csr_section(be, prob, n_sp, nnz):

@@ -69,3 +69,20 @@ def test_bench_line_of_the_sharded_driver_has_the_phase_timings():
         assert ph[k]["max"] >= ph[k]["min"] >= 0.0, k
     assert ph["samples"]["min"] >= 10 and ph["product_interior_us"]["max"] > 1.0 and ph["update_us"]["max"] > 1.0
     assert ph["allreduce_us"]["max"] > 0.0
+
+
+def test_rank_with_ghost_planes_rehearsal():
+    """bench.py's side section config.rank_with_ghost_planes (attached at the metric's size): tools/bench_self_periodic.py --json -
+    one rank as its own neighbour, real RCCL send / receive inside the sharded loop, three ways of running the iteration."""
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "bench_self_periodic.py"), "--json"]
+    res = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29549"))
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["owned_planes"] == 32 and d["rows"] == 256 * 256 * 32
+    one, split, over = (d[k] for k in ("stream_ordered_one_march", "stream_ordered_interior_plus_boundary", "overlapped_on_the_halo_stream"))
+    assert not one["second_stream_used"] and not split["second_stream_used"] and over["second_stream_used"] and over["second_stream_available"]
+    assert one["iterations"] == split["iterations"] > 100 and abs(over["iterations"] - one["iterations"]) <= 1
+    assert 10.0 < one["us_per_iteration"] <= 1.05 * split["us_per_iteration"]

@@ -19,7 +19,14 @@ from pgdrome_amd.hip_backend import HipBackend
 ap = argparse.ArgumentParser()
 ap.add_argument("--planes", type=int, default=32, help="owned planes (256 / 8 = the slab of an 8-GPU rank at 256^3)")
 ap.add_argument("--nxy", type=int, default=256)
+ap.add_argument("--json", action="store_true", help="one JSON line on stdout: microseconds per iteration of whole solves (bench.py's side section)")
 args = ap.parse_args()
+if args.json:                      # RCCL prints its banner to stdout: the result line goes to the saved descriptor
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+import json
+import time
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 os.environ.setdefault("MASTER_PORT", "29541")
 torch.cuda.set_device(0)
@@ -41,6 +48,34 @@ op = ctx.op_combine(h, [ak, am], [1.0, 3.0], hull)
 b = np.random.default_rng(9).uniform(-1, 1, n)
 b[hull] = 0.0
 bv = ctx.vec_from(b)
+if args.json:
+    res = {"owned_planes": args.planes, "plane": [nx, ny], "rows": int(own1 - own0)}
+    for variant, tune in (("stream_ordered_one_march", ((45, 1 << 40), (46, 1))), ("stream_ordered_interior_plus_boundary", ((45, 1 << 40), (46, 0))),
+                          ("overlapped_on_the_halo_stream", ((45, 0), (46, 1)))):
+        ctx.comm_unbind()
+        ctx.comm_bind_rccl(ctx.comm_unique_id(), 0, 1)
+        ok = ctx.comm_overlap(1)
+        ctx.tune(44, 1)
+        for knob, value in tune:
+            ctx.tune(knob, value)
+        best = None
+        for rep in range(3):
+            o2 = ctx.op_combine(h, [ak, am], [1.0, 3.0], hull)      # a fresh operator per solve, as the fixed-point loop has
+            xv = ctx.vec_alloc(n)
+            be.sync()
+            t0 = time.perf_counter()
+            it, rel = ctx.pcg_solve_sharded(o2, bv, xv, own0, own1, plane, plane, 1e-10, 0.0, 10000)
+            be.sync()
+            dt = time.perf_counter() - t0
+            ctx.vec_free(xv)
+            ctx.atom_free(o2)
+            if rep and (best is None or dt < best):
+                best = dt
+        res[variant] = {"us_per_iteration": 1e6 * best / max(it, 1), "iterations": it, "second_stream_used": bool(ctx.comm_overlap(-2)),
+                        "second_stream_available": bool(ok)}
+    os.write(result_fd, (json.dumps(res) + "\n").encode())
+    dist.destroy_process_group()
+    sys.exit(0)
 for variant in ("rccl", "rccl+overlap"):
     ctx.comm_unbind()
     ctx.comm_bind_rccl(ctx.comm_unique_id(), 0, 1)
