@@ -256,7 +256,7 @@ int pgd_comm_bind_rccl(pgd_handle ctx, const uint8_t *id128, int rank, int world
  * mode 1: try to enable - COLLECTIVE, call on every rank after all ranks bound successfully; the ranks must then
  * agree (e.g. MIN all-reduce of *state) and call mode 0 everywhere if any rank reports 0.  mode 0: disable.
  * mode -1: query.  *state: 1 = the sharded solve CAN overlap, 0 = the exchange stays on the compute stream.  A solve uses the
- * second stream only above PGD_TUNE_HALO_OVERLAP_MIN_ROWS rows per rank; mode -2: *state = did the last solve.            */
+ * second stream only above PGD_TUNE_HALO_OVERLAP_MIN_ROWS rows per rank (default: never); mode -2: *state = did the last solve. */
 int pgd_comm_overlap(pgd_handle ctx, int mode, int *state);
 int pgd_comm_unbind(pgd_handle ctx);
 /* Deadline of the host-side waits inside pgd_pcg_solve_sharded (the look at the flags after every chunk of iterations, the
@@ -311,10 +311,11 @@ enum {
                                 over all owned planes with the ghost planes staged as data; 0: interior march + the boundary planes in row
                                 order (what the overlapped exchange always does).  The same y; the fused dots are grouped differently. */
     PGD_TUNE_HALO_OVERLAP_MIN_ROWS = 45, /* pgd_pcg_solve_sharded sends the halo exchange of its products through the second communicator and
-                                stream (pgd_comm_overlap) only where the ranks own at least this many rows on average (default 6 000 000;
-                                environment: PGD_HALO_OVERLAP_MIN_ROWS; a property of the current binding).  The second stream costs two event
-                                hand-overs per iteration - 10 to 14 us measured - and hides at most the interior rows' product: 17 us on the
-                                slab of an 8-GPU rank at 256^3.  Decided from the all-reduced row count: the same on every rank. */
+                                stream (pgd_comm_overlap) only where the ranks own at least this many rows on average (default 2^40: never;
+                                environment: PGD_HALO_OVERLAP_MIN_ROWS; a property of the current binding).  Measured with one rank as its own
+                                neighbour: the second stream loses 15 - 19 us per iteration against the exchange in stream order + one march
+                                over all owned planes on the slabs of 8-, 4- and 2-GPU ranks of the 256^3 grid; it pays only where the wire
+                                adds more than that.  Decided from the all-reduced row count: the same on every rank. */
     PGD_TUNE_COMM_SELF_PERIODIC = 44, /* tests only: with ONE rank, pgd_pcg_solve_sharded and pgd_comm_halo accept ghost planes on both sides
                                 and the rank is its own neighbour - the ghost plane below receives the rank's top plane, the one above its
                                 bottom plane (a problem periodic in z): the halo communicator, its stream and events, the overlap with the

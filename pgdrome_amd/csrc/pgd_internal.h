@@ -165,11 +165,13 @@ struct Comm {
     hipStream_t halo_stream = nullptr;
     hipEvent_t ev_ready = nullptr, ev_halo = nullptr;
     bool overlap = false;         // the halo exchange CAN run concurrently with the interior rows' product (second communicator + stream, self-test passed)
-    // ... and does, in a solve whose ranks own at least this many rows on average: the second stream costs two event hand-overs per
-    // iteration (10 - 14 us measured, tools/bench_self_periodic.py) and can hide no more than the interior rows' product takes
-    // (17 us on the slab of an 8-GPU rank at 256^3, 35 us on a 4-GPU one, 65 us on half the grid).  PGD_HALO_OVERLAP_MIN_ROWS /
-    // PGD_TUNE_HALO_OVERLAP_MIN_ROWS; decided from the all-reduced row count of the setup vote: the same on every rank
-    int64_t overlap_min_rows = 6000000;
+    // ... and does, in a solve whose ranks own at least this many rows on average.  Measured (tools/bench_self_periodic.py, one rank as
+    // its own neighbour): the second stream costs two event hand-overs per iteration and LOSES 15 - 19 us against the exchange in
+    // stream order + one march over all owned planes on the slabs of 8-, 4- and 2-GPU ranks of the 256^3 grid alike (72 / 92 / 130
+    // against 54 / 75 / 114 us); what it can hide - a wire latency above that - is unknown here, so the default is "never" and
+    // PGD_HALO_OVERLAP_MIN_ROWS / PGD_TUNE_HALO_OVERLAP_MIN_ROWS switch it on.  Decided from the all-reduced row count of the
+    // setup vote: the same on every rank
+    int64_t overlap_min_rows = (int64_t)1 << 40;
     bool overlap_used = false;    // what the last solve did
     bool self_periodic = false;   // tests only (PGD_TUNE_COMM_SELF_PERIODIC): ONE rank whose ghost planes are its own far boundary planes
     pgd_handle work[7] = {0, 0, 0, 0, 0, 0, 0};   // r, u, w, p, s, q, dinv of the sharded PCG

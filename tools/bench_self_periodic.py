@@ -36,22 +36,27 @@ torch.cuda.set_stream(tstream)
 be = fem.set_backend(HipBackend(0, tstream.cuda_stream))
 ctx = be.ctx
 nx = ny = args.nxy
-nzl = args.planes + 2
-mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, (nzl - 1) / (nx - 1.0)), nx - 1, ny - 1, nzl - 1)
-coords = mesh.coordinates()
-h = ctx.mesh_upload(coords, mesh.cells())
-n, plane = coords.shape[0], nx * ny
-own0, own1 = plane, n - plane
-ak, am = ctx.atom_assemble(h, 1), ctx.atom_assemble(h, 0)
-hull = np.where((coords[:, 0] <= 1e-12) | (coords[:, 0] >= 1 - 1e-12) | (coords[:, 1] <= 1e-12) | (coords[:, 1] >= 1 - 1e-12))[0].astype(np.int32)
-op = ctx.op_combine(h, [ak, am], [1.0, 3.0], hull)
-b = np.random.default_rng(9).uniform(-1, 1, n)
-b[hull] = 0.0
-bv = ctx.vec_from(b)
-if args.json:
-    res = {"owned_planes": args.planes, "plane": [nx, ny], "rows": int(own1 - own0)}
-    for variant, tune in (("stream_ordered_one_march", ((45, 1 << 40), (46, 1))), ("stream_ordered_interior_plus_boundary", ((45, 1 << 40), (46, 0))),
-                          ("overlapped_on_the_halo_stream", ((45, 0), (46, 1)))):
+VARIANTS = (("stream_ordered_one_march", ((45, 1 << 40), (46, 1))), ("stream_ordered_interior_plus_boundary", ((45, 1 << 40), (46, 0))),
+            ("overlapped_on_the_halo_stream", ((45, 0), (46, 1))))
+
+
+def slab(planes):
+    nzl = planes + 2
+    mesh = fem.BoxMesh(fem.Point(0, 0, 0), fem.Point(1, 1, (nzl - 1) / (nx - 1.0)), nx - 1, ny - 1, nzl - 1)
+    coords = mesh.coordinates()
+    h = ctx.mesh_upload(coords, mesh.cells())
+    n, plane = coords.shape[0], nx * ny
+    ak, am = ctx.atom_assemble(h, 1), ctx.atom_assemble(h, 0)
+    hull = np.where((coords[:, 0] <= 1e-12) | (coords[:, 0] >= 1 - 1e-12) | (coords[:, 1] <= 1e-12) | (coords[:, 1] >= 1 - 1e-12))[0].astype(np.int32)
+    b = np.random.default_rng(9).uniform(-1, 1, n)
+    b[hull] = 0.0
+    return h, n, plane, plane, n - plane, ak, am, hull, ctx.vec_from(b)
+
+
+def timed(S, variants):
+    h, n, plane, own0, own1, ak, am, hull, bv = S
+    res = {}
+    for variant, tune in variants:
         ctx.comm_unbind()
         ctx.comm_bind_rccl(ctx.comm_unique_id(), 0, 1)
         ok = ctx.comm_overlap(1)
@@ -73,9 +78,36 @@ if args.json:
                 best = dt
         res[variant] = {"us_per_iteration": 1e6 * best / max(it, 1), "iterations": it, "second_stream_used": bool(ctx.comm_overlap(-2)),
                         "second_stream_available": bool(ok)}
+    return res
+
+
+def release(S):
+    h, n, plane, own0, own1, ak, am, hull, bv = S
+    ctx.comm_unbind()
+    ctx.vec_free(bv)
+    for a in (ak, am):
+        ctx.atom_free(a)
+    ctx.mesh_free(h)
+
+
+if args.json:
+    S = slab(args.planes)
+    res = {"owned_planes": args.planes, "plane": [nx, ny], "rows": int(S[4] - S[3])}
+    res.update(timed(S, VARIANTS))
+    release(S)
+    if args.planes == 32 and nx == 256:
+        # the slabs of a 4- and a 2-GPU rank of the same grid: what the iteration costs there (one march / second stream)
+        res["larger_slabs"] = {}
+        for planes in (64, 128):
+            S = slab(planes)
+            res["larger_slabs"][str(planes)] = {k: v["us_per_iteration"] for k, v in timed(S, (VARIANTS[0], VARIANTS[2])).items()}
+            release(S)
     os.write(result_fd, (json.dumps(res) + "\n").encode())
     dist.destroy_process_group()
     sys.exit(0)
+S = slab(args.planes)
+h, n, plane, own0, own1, ak, am, hull, bv = S
+op = ctx.op_combine(h, [ak, am], [1.0, 3.0], hull)
 for variant in ("rccl", "rccl+overlap"):
     ctx.comm_unbind()
     ctx.comm_bind_rccl(ctx.comm_unique_id(), 0, 1)
