@@ -98,8 +98,13 @@ class TorchComm:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if float(flag.item()) == 1.0:
             self.in_library = "rccl"
-            # halo exchange concurrent with the interior rows' product: every rank tries (collective inside the library),
-            # all ranks must agree, else it stays off everywhere
+            # halo exchange concurrent with the interior rows' product (a second communicator + stream): opt-in - it measured
+            # slower than the exchange in stream order at every slab size - with PGD_HALO_OVERLAP_MIN_ROWS
+            # (the rows per rank from which a solve uses it) or PGD_HALO_OVERLAP=1.  Every rank tries (collective inside the
+            # library), all ranks must agree, else it stays off everywhere
+            if os.environ.get("PGD_HALO_OVERLAP_MIN_ROWS") is None and os.environ.get("PGD_HALO_OVERLAP", "0") != "1":
+                self.halo_overlap = False
+                return
             ok = 0.0
             try:
                 ok = 1.0 if be.comm_overlap(1) else 0.0

@@ -70,6 +70,7 @@ def test_sharded_driver_world1_matches_library_pcg():
         torch.cuda.set_stream(tstream)
         be2 = fem.set_backend(HipBackend(0, tstream.cuda_stream))
         fem.clear_caches()
+        os.environ["PGD_HALO_OVERLAP"] = "1"        # (the second communicator is set up on request only)
         for in_library in (True, False):
             fem.clear_caches()
             comm = pdist.TorchComm(dist, be2, in_library=in_library)
@@ -101,6 +102,7 @@ def test_sharded_driver_world1_matches_library_pcg():
         torch.cuda.synchronize()
         assert np.array_equal(be2.vec_to_host(v), np.arange(5.0) + 1.0)
     finally:
+        os.environ.pop("PGD_HALO_OVERLAP", None)
         torch.cuda.set_stream(torch.cuda.default_stream(0))
         fem.set_backend(old)
         fem.clear_caches()
