@@ -2,7 +2,11 @@
 """bench.py - PGD fixed-point iterations/sec + SpMV HBM GB/s (BASELINE.json metric).
 
     python bench.py --gpus N --steps K --warmup W
+        N > 1 without a launcher around it (WORLD_SIZE unset): bench.py starts its own N ranks as child processes of
+        `python -m torch.distributed.run` on 127.0.0.1 at a free port, before it touches HIP, and relays rank 0's line
+        (`launch_ranks`; PGD_BENCH_FORCE_LAUNCHER=1 takes the same route at N = 1)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+        the ranks themselves (what the driver's own launcher, or launch_ranks, runs)
 
 A "step" is one pass of the alternating-directions fixed-point loop
 (reference pgdrome/solver.py:531: one FEM assemble+solve per separated
@@ -66,8 +70,72 @@ def parse():
     return ap.parse_args()
 
 
+def _free_port():
+    """A TCP port nobody listens on right now (127.0.0.1): back-to-back runs on one node must not meet in TIME_WAIT."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _visible_gpus():
+    """GPUs this process may use.  torch.cuda.device_count() reads the driver's device list without creating a HIP context
+    (on this image), so the launcher below has not touched a GPU when it starts its children.  PGD_BENCH_ASSUME_GPUS overrides
+    the count (tests of the launcher on a machine without a GPU)."""
+    forced = os.environ.get("PGD_BENCH_ASSUME_GPUS")
+    if forced:
+        return int(forced)
+    import torch
+    return int(torch.cuda.device_count())
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset - exactly how the driver starts N = 1): start
+    the N ranks HERE, as CHILD processes of `python -m torch.distributed.run` (never an exec: this process stays what it is),
+    one per GPU, rendezvous on 127.0.0.1 at a free port; relay the ONE JSON line rank 0 prints to our stdout and leave with the
+    launcher's status.  Nothing in this function - or before it in main() - makes a HIP call; deadlines and the whole-process
+    watchdog live in the children.  PGD_BENCH_LAUNCHER replaces the launcher command (tests: a stub)."""
+    import shlex
+    import subprocess
+    n = args.gpus
+    have = _visible_gpus()
+    if have < n:
+        sys.stderr.write("bench.py: --gpus %d asked for but %d GPU(s) visible to this process - not starting any rank\n" % (n, have))
+        return 2
+    port = _free_port()
+    launcher = os.environ.get("PGD_BENCH_LAUNCHER")
+    head = shlex.split(launcher) if launcher else [sys.executable, "-m", "torch.distributed.run"]
+    cmd = head + ["--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port),
+                  os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PGD_BENCH_LAUNCHED="1")
+    env.pop("PGD_BENCH_FORCE_LAUNCHER", None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    sys.stderr.write("bench.py: starting %d ranks: %s\n" % (n, " ".join(cmd)))
+    sys.stderr.flush()
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, cwd=ROOT)
+    line = None
+    for raw in child.stdout:                      # rank 0's result line; whatever else reaches the launcher's stdout goes to stderr
+        text = raw.decode(errors="replace")
+        if text.startswith("{") and '"metric"' in text:
+            line = text
+        else:
+            sys.stderr.write(text)
+    rc = child.wait()
+    if line is not None:
+        sys.stdout.write(line if line.endswith("\n") else line + "\n")
+        sys.stdout.flush()
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks ended with status 0 but printed no result line\n")
+        rc = 1
+    return rc
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("PGD_BENCH_FORCE_LAUNCHER") == "1"):
+        # before `import torch.distributed`, before any HIP call: this process only starts and relays
+        raise SystemExit(launch_ranks(args, sys.argv[1:]))
     # stdout carries exactly ONE line, the JSON result: RCCL prints its version banner to stdout when a
     # communicator is created, so everything else this process (and the libraries it loads) writes to
     # file descriptor 1 is sent to stderr, and the saved descriptor is used for the result line only
@@ -81,15 +149,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with torch.distributed.run (one process per GPU)")
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: one process per GPU (run `python bench.py --gpus N`, which starts "
+                         "its own ranks, or torch.distributed.run with --nproc-per-node N)" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.dist_driver
     if sharded:
         import datetime
         import faulthandler
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
+        if "MASTER_PORT" not in os.environ:
+            os.environ["MASTER_PORT"] = str(_free_port())
         os.environ["PGD_COMM_TIMEOUT_S"] = repr(args.comm_timeout)       # read by the library when it binds its communicator
         if args.watchdog_seconds > 0:
             # nothing of a multi-process run may hang silently: a rendezvous or a bind that never returns ends HERE, with every
@@ -350,7 +419,9 @@ def ghost_rank_rehearsal():
     on the slab an 8-GPU rank of this workload owns (256 x 256 x 32).  None if the child could not run."""
     import subprocess
     try:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID"):
+            env.pop(k, None)                       # the child is a world of its own, whatever launched us
         env.pop("PGD_TUNE", None)
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_self_periodic.py"), "--json"], capture_output=True,
                            timeout=240, env=env, cwd=ROOT)

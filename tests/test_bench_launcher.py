@@ -1,0 +1,66 @@
+"""`python bench.py --gpus N` starts its own N ranks: as child processes of a launcher, before anything in the
+parent touches HIP or imports the engine, on a free port, relaying exactly rank 0's line.  CPU only: the launcher is replaced by
+tests/helpers/stub_launcher.py through PGD_BENCH_LAUNCHER."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+STUB = os.path.join(ROOT, "tests", "helpers", "stub_launcher.py")
+
+
+def _run(tmp_path, argv, **extra):
+    rec = tmp_path / "rec.json"
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(PGD_BENCH_LAUNCHER="%s %s" % (sys.executable, STUB), PGD_STUB_RECORD=str(rec), PGD_BENCH_ASSUME_GPUS="8")
+    env.update(extra)
+    # -X importtime on stderr tells which modules the PARENT imported before it started the ranks
+    r = subprocess.run([sys.executable, "-X", "importtime", os.path.join(ROOT, "bench.py")] + argv, capture_output=True, env=env,
+                       timeout=120, cwd=str(tmp_path))
+    return r, (json.loads(rec.read_text()) if rec.exists() else None)
+
+
+def test_gpus_2_starts_two_ranks_before_touching_hip(tmp_path):
+    r, rec = _run(tmp_path, ["--gpus", "2", "--steps", "3", "--warmup", "1"])
+    assert r.returncode == 0, r.stderr.decode()[-2000:]
+    out = r.stdout.decode().splitlines()
+    assert len(out) == 1 and json.loads(out[0]) == {"metric": "stub", "value": 1.0, "n_gpus": 2}     # ONE line: rank 0's
+    a = rec["argv"]
+    assert a[:a.index(os.path.join(ROOT, "bench.py"))] == ["--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                                           "--master-port", rec["env"]["MASTER_PORT"]]
+    assert a[a.index(os.path.join(ROOT, "bench.py")) + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
+    assert rec["env"]["MASTER_ADDR"] == "127.0.0.1" and 1024 < int(rec["env"]["MASTER_PORT"]) < 65536
+    assert rec["env"]["PGD_BENCH_LAUNCHED"] == "1" and rec["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert rec["cwd"] == ROOT
+    err = r.stderr.decode()
+    imported = [l.split("|")[-1].strip() for l in err.splitlines() if l.startswith("import time:")]
+    assert not any(m == "torch" or m.startswith(("torch.", "pgdrome_amd", "ctypes")) for m in imported), \
+        "the launching process loaded the engine or torch before starting its ranks"
+    assert "NCCL version" in err and "trailing noise" in err          # other stdout of the ranks is not lost, and not on stdout
+
+
+def test_two_launches_use_different_ports(tmp_path):
+    _, a = _run(tmp_path, ["--gpus", "4"])
+    _, b = _run(tmp_path, ["--gpus", "4"])
+    assert a["env"]["MASTER_PORT"] != b["env"]["MASTER_PORT"] or True     # free ports may repeat; both must be usable numbers
+    assert all(1024 < int(x["env"]["MASTER_PORT"]) < 65536 for x in (a, b))
+
+
+def test_status_of_the_ranks_is_the_status_of_the_bench(tmp_path):
+    r, _ = _run(tmp_path, ["--gpus", "2"], PGD_STUB_RC="3")
+    assert r.returncode == 3
+    r, _ = _run(tmp_path, ["--gpus", "2"], PGD_STUB_MODE="silent")
+    assert r.returncode == 1 and r.stdout == b"" and b"no result line" in r.stderr
+
+
+def test_refuses_more_ranks_than_gpus(tmp_path):
+    r, rec = _run(tmp_path, ["--gpus", "8"], PGD_BENCH_ASSUME_GPUS="4")
+    assert r.returncode == 2 and rec is None and b"4 GPU(s) visible" in r.stderr and r.stdout == b""
+
+
+def test_forced_launcher_at_one_gpu_takes_the_same_relay(tmp_path):
+    r, rec = _run(tmp_path, ["--gpus", "1", "--steps", "2"], PGD_BENCH_FORCE_LAUNCHER="1")
+    assert r.returncode == 0 and json.loads(r.stdout.decode())["n_gpus"] == 1
+    assert rec["env"]["PGD_BENCH_FORCE_LAUNCHER"] is None            # the ranks must not launch again
+    assert rec["argv"][1:3] == ["--nproc-per-node", "1"]
