@@ -101,6 +101,11 @@ static void comm_env_defaults(Comm &k) {
         const double v = strtod(env, &end);
         if (end != env) k.timeout_s = v;
     }
+    // PGD_HALO_OVERLAP=1 asks for the overlapped exchange in EVERY sharded solve (it used to set up the second
+    // communicator and then never use it); PGD_HALO_OVERLAP_MIN_ROWS names the rows per rank from which a solve takes it
+    if (const char *env = getenv("PGD_HALO_OVERLAP")) {
+        if (env[0] == '1') k.overlap_min_rows = 0;
+    }
     if (const char *env = getenv("PGD_HALO_OVERLAP_MIN_ROWS")) {
         char *end = nullptr;
         const long long v = strtoll(env, &end, 10);

@@ -1627,6 +1627,7 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
                 PGD_TRY(mg_vcycle(c, r, true, &np));
                 PGD_TRY(reduce_partials(c, c->partials, np, 1, out, -1, 0, 0));                // r.z over the r~.r~ the test has used
                 k_pcg_p<true><<<g2, TPB, 0, c->stream>>>(p, mg_result(c), 0, n, c->slots, out, rz_old, c->flags);
+                PGD_LAUNCH_CHECK(c);
                 continue;
             }
             // (pays only where the launches, not the bytes, set the pace: 256^2 rows +22 %, 128^3 +-0, 256^3 -2 %)

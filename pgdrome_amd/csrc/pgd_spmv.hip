@@ -1493,13 +1493,36 @@ __global__ void k_stencil_ghost_init(StencilInfo *S, int z_lo, int z_hi, int nz,
     S->g_lo = (S->ok && z_lo > 0 && zm0 == z_lo && zm1 > zm0) ? 1 : 0;
     S->g_hi = (S->ok && z_hi < nz && zm1 == z_hi && zm1 > zm0) ? 1 : 0;
 }
-__global__ __launch_bounds__(TPB) void k_stencil_ghost(const uint8_t *__restrict__ cls, int64_t plane, int z_lo, int z_hi, int zm0, StencilInfo *S) {
+// The couplings between the LOWER ghost plane and the first owned plane live in the ghost rows' dz = 1 slots (half storage: a
+// row holds its couplings to the rows behind it), which k_stencil_verify - owned rows only - never sees: they are compared here,
+// bitwise, with the stencil's couplings (exact zeros where the target is eliminated or outside), so that the march applies
+// c[s] to the neighbour rank's x on evidence, like everywhere else.  (The upper ghost plane is reached through
+// the owned rows' own dz = 1 slots, which k_stencil_verify has compared.)
+__global__ __launch_bounds__(TPB) void k_stencil_ghost(const uint8_t *__restrict__ cls, const double *__restrict__ table, int nx, int ny,
+                                                       int z_lo, int z_hi, int zm0, StencilInfo *S) {
+    const int64_t plane = (int64_t)nx * ny;
     const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (i >= plane || !S->ok) return;
     if (zm0 < 0) zm0 = S->zm0;
-    const bool id = (int)cls[plane * zm0 + i] == S->ident;
-    if (S->g_lo && ((int)cls[plane * (z_lo - 1) + i] == S->ident) != id) S->g_lo = 0;
-    if (S->g_hi && ((int)cls[plane * z_hi + i] == S->ident) != id) S->g_hi = 0;
+    const int ident = S->ident;
+    const bool id = (int)cls[plane * zm0 + i] == ident;
+    if (S->g_lo) {
+        const int k = cls[plane * (z_lo - 1) + i];
+        bool good = (k == ident) == id;
+        if (good && k != ident) {
+            const int y = (int)(i / nx), x = (int)(i - (int64_t)y * nx);
+            const double *t = table + k * 8;
+#pragma unroll
+            for (int s = 4; s < 8; ++s) {
+                const int dx = s & 1, dy = (s >> 1) & 1;
+                const bool live = x + dx < nx && y + dy < ny && (int)cls[plane * z_lo + i + dx + (int64_t)nx * dy] != ident;
+                const double v = t[cls_pos(s)];
+                good = good && (live ? __double_as_longlong(v) == __double_as_longlong(S->c[s]) : v == 0.0);
+            }
+        }
+        if (!good) S->g_lo = 0;
+    }
+    if (S->g_hi && ((int)cls[plane * z_hi + i] == ident) != id) S->g_hi = 0;
 }
 
 __global__ __launch_bounds__(TPB) void k_stencil_verify(const uint8_t *__restrict__ cls, const double *__restrict__ table, int nx, int ny,
@@ -1783,7 +1806,7 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
                 memcpy(zp.b, E.zero_pat, sizeof zp.b);
                 k_stencil_known<<<1, 256, 0, st>>>(a->cls_table, E.ncls, E.ident, E.base, zp, SI);
                 k_stencil_ghost_init<<<1, 1, 0, st>>>(SI, z_lo, z_hi, nzp, E.zm0, E.zm1);
-                if (z_lo > 0 || z_hi < nzp) k_stencil_ghost<<<(int)((plane + TPB - 1) / TPB), TPB, 0, st>>>(a->cls, plane, z_lo, z_hi, E.zm0, SI);
+                if (z_lo > 0 || z_hi < nzp) k_stencil_ghost<<<(int)((plane + TPB - 1) / TPB), TPB, 0, st>>>(a->cls, a->cls_table, m->sym_nx, m->sym_ny, z_lo, z_hi, E.zm0, SI);
             }
             host.info[1] = 1;
             PGD_HIP(c, hipMemcpyAsync(host.info, S->info, sizeof host.info, hipMemcpyDeviceToHost, st));
@@ -1830,7 +1853,7 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
         k_stencil_allid<<<nzp, TPB, 0, st>>>(a->cls, plane, SI, allid, allid + 65536);
         k_stencil_planes<<<1, 64, 0, st>>>(allid + 65536, allid, z_lo, z_hi, SI);
         k_stencil_ghost_init<<<1, 1, 0, st>>>(SI, z_lo, z_hi, nzp, -1, -1);
-        if (z_lo > 0 || z_hi < nzp) k_stencil_ghost<<<(int)((plane + TPB - 1) / TPB), TPB, 0, st>>>(a->cls, plane, z_lo, z_hi, -1, SI);
+        if (z_lo > 0 || z_hi < nzp) k_stencil_ghost<<<(int)((plane + TPB - 1) / TPB), TPB, 0, st>>>(a->cls, a->cls_table, m->sym_nx, m->sym_ny, z_lo, z_hi, -1, SI);
     }
     host.info[0] = 0; host.info[1] = 1; host.si.ok = 0;
     PGD_HIP(c, hipMemcpyAsync(host.info, S->info, sizeof host.info, hipMemcpyDeviceToHost, st));

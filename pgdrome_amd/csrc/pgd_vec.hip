@@ -373,6 +373,10 @@ int pgd_vec_set(pgd_handle h, pgd_handle vh, const int32_t *idx, const double *v
         *cap = n;
         return PGD_OK;
     };
+    // The kept lists count as "on the device" only once the copies AND the launch that follow have completed without error
+    // (ADVICE r03): until then both flags are down, so a call that fails half way leaves nothing behind that the next call
+    // with the same lists would trust - it checks, uploads and synchronises again.
+    const bool had_idx = same_idx, had_val_flag = c->set_val_on_dev;
     if (!same_idx) {
         for (int64_t i = 0; i < n; ++i)
             if (idx[i] < 0 || idx[i] >= v->n) return fail(c, PGD_ERR_INVALID, "vec_set: index %d out of range", idx[i]);
@@ -382,24 +386,26 @@ int pgd_vec_set(pgd_handle h, pgd_handle vh, const int32_t *idx, const double *v
         c->set_idx_host.assign(idx, idx + n);
         c->set_idx_max = 0;
         for (int64_t i = 0; i < n; ++i) if (idx[i] > c->set_idx_max) c->set_idx_max = idx[i];
-        c->set_idx_on_dev = true;
         uploaded = true;
     } else if (c->set_idx_max >= v->n) {
         return fail(c, PGD_ERR_INVALID, "vec_set: index %d out of range", (int)c->set_idx_max);
     }
-    const bool same_val = c->set_val_on_dev && c->set_val_host.size() == (size_t)n &&
+    const bool same_val = had_val_flag && c->set_val_host.size() == (size_t)n &&
                           std::memcmp(c->set_val_host.data(), val, (size_t)n * sizeof(double)) == 0;
+    c->set_idx_on_dev = false;
+    c->set_val_on_dev = false;
     if (!same_val) {
-        c->set_val_on_dev = false;
         PGD_TRY(grow(reinterpret_cast<void **>(&c->set_vals), &c->set_vals_cap, sizeof(double)));
         PGD_HIP(c, hipMemcpyAsync(c->set_vals, val, n * sizeof(double), hipMemcpyHostToDevice, c->stream));
         c->set_val_host.assign(val, val + n);
-        c->set_val_on_dev = true;
         uploaded = true;
     }
     k_set<<<grid_for(n), TPB, 0, c->stream>>>(v->d, c->set_idx, c->set_vals, n);
     PGD_LAUNCH_CHECK(c);
     if (uploaded) PGD_HIP(c, hipStreamSynchronize(c->stream));   // host buffers are caller-owned
+    (void)had_idx;
+    c->set_idx_on_dev = true;
+    c->set_val_on_dev = true;
     return PGD_OK;
 }
 

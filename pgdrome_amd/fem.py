@@ -2284,12 +2284,21 @@ class functional_scope:
         if PREFETCH_FUNCTIONALS:
             plan = _FUNCTIONAL_PLANS.get(self.tag)
             if plan:
-                reqs = []
+                # A row-sharded layout takes part in ONE fixed-length all-reduce per entry of the scope.  Whether a rank issues it
+                # must not depend on anything rank-local (memo hits, weak references that died, what the product caches hold:
+                # ADVICE r03) - it depends on the recorded plan alone, which every rank records from the same sequence of
+                # assemble() calls: a layout's requests are numbered by their position in the plan (the SLOT of the message
+                # a value travels in), and the collective is issued whenever the plan names 2 ... _PREFETCH_MAX of them.
+                reqs, slots = [], {}
                 for lay, atom, fr, gr, sym in plan:
+                    slot = None
+                    if lay.part is not None:
+                        ent = slots.setdefault(id(lay), [lay, 0])
+                        slot, ent[1] = ent[1], ent[1] + 1
                     f, g = self._deref(fr), self._deref(gr)
                     if f is not None and g is not None:
-                        reqs.append((lay, atom, f, g, sym))
-                _prefetch_functionals(reqs)
+                        reqs.append((lay, atom, f, g, sym, slot))
+                _prefetch_functionals(reqs, [tuple(e) for e in slots.values()])
             _RECORDING = self
         return self
 
@@ -2302,10 +2311,17 @@ class functional_scope:
         return False
 
 
-def _prefetch_functionals(reqs):
+def _prefetch_functionals(reqs, sharded_plan=()):
+    """`reqs`: (layout, atom, f, g, symmetric, slot) of the requests to compute ahead; `sharded_plan`: (layout, number of
+    requests the PLAN holds for it) of every row-sharded layout of the plan, in plan order - the same on every rank."""
     be = get_backend()
     todo = {}
-    for lay, atom, f, g, sym in reqs:
+    for lay, n_slots in sharded_plan:
+        if 2 <= n_slots <= _PREFETCH_MAX:
+            todo[id(lay)] = (lay, [])                    # takes part in the collective even with nothing to bring
+    for lay, atom, f, g, sym, slot in reqs:
+        if lay.part is not None and id(lay) not in todo:
+            continue                                     # (a plan with 1 or too many requests on this layout: no batch, on any rank)
         key = (atom, id(f), f.version, id(g), g.version)
         hit = _SCALAR_MEMO.get(key)
         if hit is not None and hit[1]() is f and hit[2]() is g:
@@ -2327,9 +2343,9 @@ def _prefetch_functionals(reqs):
             if lay.part is None and not (KEEP_FUNCTIONAL_PRODUCTS and be.atom_product_form(atom) > 0):
                 continue                                 # the fused product-dot over the CSR atom stays the cheaper way
             ways.append((f, _matvec_cached(lay, atom, g)))
-        todo.setdefault(id(lay), (lay, []))[1].append((key, f, g, ways))
+        todo.setdefault(id(lay), (lay, []))[1].append((key, f, g, ways, slot))
     for lay, requests in todo.values():
-        if len(requests) < 2 or len(requests) > _PREFETCH_MAX:
+        if lay.part is None and (len(requests) < 2 or len(requests) > _PREFETCH_MAX):
             continue
         lo, hi = lay.owned_range()
         vals, order = [], []
@@ -2361,19 +2377,19 @@ def _prefetch_functionals(reqs):
                 pos = {id(r): i for i, r in enumerate(rl)}
                 for rq, left, other in covered:
                     vals.append(float(a[left][pos[id(other)]]))
-                    order.append((rq[0], rq[1], rq[2], other, None))
+                    order.append((rq[0], rq[1], rq[2], other, None, rq[4]))
                 STATS_PREFETCH["pair_values"] = STATS_PREFETCH.get("pair_values", 0) + len(covered)
             if order:
                 taken = {id(it[0]) for it in order}
                 requests = [rq for rq in requests if id(rq[0]) not in taken]
         shared = {}
-        for _key, _f, _g, ways in requests:
+        for _key, _f, _g, ways, _slot in requests:
             for other, _prod in ways:
                 shared[id(other)] = shared.get(id(other), 0) + 1
         items = []
-        for key, f, g, ways in requests:
+        for key, f, g, ways, slot in requests:
             other, prod = max(ways, key=lambda w: shared[id(w[0])])      # (ties: the first way, as before)
-            items.append((key, f, g, other, prod))
+            items.append((key, f, g, other, prod, slot))
         groups = {}
         for it in items:
             groups.setdefault(id(it[3]), (it[3], []))[1].append(it)
@@ -2383,16 +2399,24 @@ def _prefetch_functionals(reqs):
             vals.extend(float(v) for v in local)
             order.extend(its)
         if lay.part is not None:
-            k = len(vals)
-            msg = np.zeros(_PREFETCH_MAX + 2)
-            msg[0], msg[1], msg[2:2 + k] = k, k * k, vals
+            # a value travels in the slot of its request's position in the plan, its presence count in the second half: a
+            # functional is kept only where EVERY rank has brought its share (a rank whose memo already holds one, or whose
+            # weak reference has died, brings nothing for that slot - on any rank the ordinary path then answers the request)
+            msg = np.zeros(2 * _PREFETCH_MAX)
+            for it, val in zip(order, vals):
+                msg[it[5]] += val
+                msg[_PREFETCH_MAX + it[5]] += 1.0
             msg = lay.part.comm.allreduce_array(msg)
-            if lay.part.comm.world * msg[1] != msg[0] * msg[0]:      # the ranks' plans differ in length: nobody keeps anything
-                LOG.warning("prefetched functionals: the ranks hold different plans; ordinary path")
+            world = float(lay.part.comm.world)
+            kept = [(it, msg[it[5]]) for it in order if msg[_PREFETCH_MAX + it[5]] == world]
+            if len(kept) != len(order):
+                LOG.debug("prefetched functionals: %d of %d values not brought by every rank; ordinary path for those",
+                          len(order) - len(kept), len(order))
+            order, vals = [it for it, _ in kept], [v for _, v in kept]
+            if not order:
                 continue
-            vals = msg[2:2 + k]
         _memo_make_room(len(order))
-        for (key, f, g, _o, _a), val in zip(order, vals):
+        for (key, f, g, _o, _a, _s), val in zip(order, vals):
             _SCALAR_MEMO[key] = (float(val), weakref.ref(f), weakref.ref(g))
         STATS_PREFETCH["batches"] += 1
         STATS_PREFETCH["values"] += len(order)

@@ -211,8 +211,19 @@ class _Writer:
         sb += struct.pack("<QQII", 0, root_addr, 1, 0) + struct.pack("<QQ", btree, heap)
         assert len(sb) == 96
         self.buf[0:96] = sb
-        with open(self.path, "wb") as f:
-            f.write(bytes(self.buf))
+        # through a temporary file in the same directory + os.replace: a failure while writing leaves the old file as it was
+        import os
+        tmp = "%s.h5lite-tmp-%d" % (self.path, os.getpid())
+        try:
+            with open(tmp, "wb") as f:
+                f.write(bytes(self.buf))
+            os.replace(tmp, self.path)
+        except BaseException:
+            try:
+                os.unlink(tmp)
+            except OSError:
+                pass
+            raise
 
     def _alloc(self, blob: bytes) -> int:
         self.buf.extend(b"\x00" * ((-len(self.buf)) % 8))
@@ -753,6 +764,7 @@ class File(Group):
     def __init__(self, path, mode="r", **_ignored):
         self.filename, self.mode = str(path), mode
         self._writer = None
+        self._open = False          # armed only when construction has succeeded: close() / __del__ of a half-built object write nothing
         if mode == "r":
             try:
                 rd = _Reader(self.filename)
@@ -765,10 +777,16 @@ class File(Group):
             Group.__init__(self, self, "/", node=self._writer.root)
             if mode in ("a", "r+") and os.path.exists(self.filename):
                 # APPEND: what the file holds is read into the writer's tree (groups, datasets, attributes) and goes out again,
-                # together with what is added, when the file is closed - the writer builds files whole
-                self._open = True
-                with File(self.filename, "r") as old:
-                    self._adopt(old, self)
+                # together with what is added, when the file is closed - the writer builds files whole.  The writer is armed
+                # only after ALL of it has been adopted: if the reader cannot represent something (a dtype or layout
+                # of a file written by libhdf5 / dolfin, a truncated file) the open fails and the file stays byte-identical.
+                try:
+                    with File(self.filename, "r") as old:
+                        self._adopt(old, self)
+                except BaseException:
+                    self._writer = None
+                    self._node = None
+                    raise
             elif mode == "r+":
                 raise OSError("unable to open %s: no such file" % self.filename)
         else:
@@ -781,11 +799,14 @@ class File(Group):
             dst.attrs[k] = v
         for k in src.keys():
             c = src._child(k)
+            if c is None:
+                raise H5Error("cannot append to %s: link %r of %s cannot be read, and rewriting the file would drop it"
+                              % (src.file.filename, k, src.name))
             if isinstance(c, Dataset):
                 d = dst.create_dataset(k, data=np.array(c))
                 for ak, av in c.attrs.items():
                     d.attrs[ak] = av
-            elif c is not None:
+            else:
                 File._adopt(c, dst.create_group(k))
 
     def _root(self):

@@ -93,6 +93,10 @@ def test_sharded_driver_world1_matches_library_pcg():
             assert fem.STATS["pcg_iterations"] > 100
             if not in_library:
                 assert comm.stats["allreduce"] > 100
+            else:
+                # PGD_HALO_OVERLAP=1 is an opt-in that takes effect (it used to set up the second communicator and
+                # leave the threshold at 2^40 rows): the last sharded solve took the second stream
+                assert be2.comm_overlap(-2) is True
         be2.comm_unbind()
         assert be2.comm_info()["kind"] == "none"
         # zero-copy view really aliases the library's memory

@@ -159,7 +159,8 @@ def test_host_round_trips_around_a_pcg_solve(hip_backend):
 
 SETTINGS = {"linear_solver": "cg", "preconditioner": "jacobi", "relative_tolerance": 1e-10}
 # pass counts of the committed full-size runs (profiles/r01k_configs_full_size_n1.jsonl, profiles/r02*)
-FULL_SIZE = {"cfg2": [3, 2, 2, 2, 2, 2, 2], "cfg3": [3, 3, 3, 3] + [2] * 16, "cfg5_first3": [4, 6, 5]}
+FULL_SIZE = {"cfg2": [3, 2, 2, 2, 2, 2, 2], "cfg3": [3, 3, 3, 3] + [2] * 16, "cfg5_first3": [4, 6, 5], "cfg4_first3": [3, 3, 3]}
+CFG4_AMPLITUDE = [1.0, 0.0, 0.0]          # (filled from the committed run: profiles/r04_cfg4_full_size.txt)
 
 
 def _resolve_first_spatial_system(p, spec, hip_backend):
@@ -347,6 +348,58 @@ def test_cfg5_full_size_twelve_modes(hip_backend):
     assert exact and rel <= 1e-8
     assert hip_backend.ctx.kernel_counts()["stencil_march"] > 0               # (the spatial operator: one stencil + the Dirichlet hull)
     print("cfg5, 12 modes:", counts, "stalled", stalled)
+    fem.clear_caches()
+
+
+def test_cfg4_full_size(hip_backend):
+    """BASELINE config 4 - the workload the metric is quoted on (256^3 P1 x 128 P1, bench.py's problem) - at FULL size,
+    3 modes, asserted like cfg5's run: the committed pass counts and amplitudes, every loop converged, Dirichlet rows EXACT in
+    every stored mode, the first spatial system re-solved and checked to 1e-8 through the plain CSR kernel, the stencil march
+    counted as the product that ran; then the SAME three modes under settings["preconditioner"] = "amg" (the V-cycle): same
+    pass counts, amplitudes to 1e-7, every mode within the north star's 1e-6 (missing 5)."""
+    from pgdrome_amd import problems as P
+    spec = P.CONFIGS["cfg4"][0]()
+    spec["PGD_nmax"] = 3
+    k0 = hip_backend.ctx.kernel_counts()
+    p = PGDProblem(**spec)
+    p.solve_PGD(_problem="linear", settings=SETTINGS)
+    k1 = hip_backend.ctx.kernel_counts()
+    counts = [int(k) for k in p.num_fp_it]
+    print("cfg4, 3 modes (Jacobi):", counts, [float(a) for a in p.amplitude], [float(a) for a in p.alpha])
+    assert p.PGD_modes == 3 and counts == FULL_SIZE["cfg4_first3"]
+    assert p.simulation_info.count("NOT converged") == 0 and all(e < p.tol_fp_it for e in p.err_fp_it)
+    np.testing.assert_allclose(p.amplitude, CFG4_AMPLITUDE, rtol=1e-6)
+    assert k1["stencil_march"] - k0["stencil_march"] > 1000 and k1["csr"] == k0["csr"] and k1["dia_march"] == k0["dia_march"]
+    V = spec["Vs"][0]
+    bverts = np.where(V.mesh().vertex_on_boundary())[0]
+    modes = [[np.asarray(p.PGD_func[d][m].compute_vertex_values()).copy() for m in range(3)] for d in range(2)]
+    for m in range(3):
+        assert np.all(modes[0][m][bverts] == 0.0) and np.isfinite(modes[0][m]).all() and np.isfinite(modes[1][m]).all()
+    # the load is 1 and the domain the unit cube: the first spatial mode is positive inside and the 6-tetrahedra mesh keeps
+    # the point reflection x -> 1 - x
+    x0 = modes[0][0].reshape(256, 256, 256) * np.sign(modes[0][0][256 * 256 * 128 + 256 * 128 + 128])
+    assert x0[1:-1, 1:-1, 1:-1].min() > 0.0
+    assert np.abs(x0 - x0[::-1, ::-1, ::-1]).max() <= 1e-6 * np.abs(x0).max()
+    del x0
+    rel, exact = _resolve_first_spatial_system(p, spec, hip_backend)
+    assert exact and rel <= 1e-8
+    amp, alpha = [float(a) for a in p.amplitude], [float(a) for a in p.alpha]
+    del p
+    fem.clear_caches()
+    # ... and with the multigrid preconditioner
+    s0 = hip_backend.ctx.mg_stats()
+    q = PGDProblem(**spec)
+    q.solve_PGD(_problem="linear", settings=dict(SETTINGS, preconditioner="amg"))
+    s1 = hip_backend.ctx.mg_stats()
+    assert s1["solves"] - s0["solves"] >= sum(counts) and s1["fallbacks"] == s0["fallbacks"]
+    assert q.PGD_modes == 3 and [int(k) for k in q.num_fp_it] == counts
+    np.testing.assert_allclose(q.amplitude, amp, rtol=1e-7)
+    np.testing.assert_allclose(q.alpha, alpha, rtol=1e-7)
+    for d in range(2):
+        for m in range(3):
+            got = np.asarray(q.PGD_func[d][m].compute_vertex_values())
+            sgn = 1.0 if float(got @ modes[d][m]) >= 0 else -1.0
+            assert np.linalg.norm(sgn * got - modes[d][m]) <= 1e-6 * np.linalg.norm(modes[d][m]), (d, m)
     fem.clear_caches()
 
 
