@@ -288,6 +288,12 @@ int pgd_pcg_solve_sharded(pgd_handle ctx, pgd_handle A, pgd_handle b, pgd_handle
  * the device, ONE host synchronisation; a sharded caller all-reduces `out` once.                        */
 int pgd_start_gram(pgd_handle ctx, pgd_handle A, const pgd_handle *vecs, int k, pgd_handle b, int64_t r0,
                    int64_t r1, double *out);
+/* r = b - sum_j coefs[j] (A v_j), j < k, from the products A v_j the library still holds from the pgd_start_gram call
+ * that came right before (same operator, all rows, k <= 9): the residual of the Galerkin start x0 = sum_j coefs[j] v_j
+ * without another product - input of the second level of the start over the spectral vectors
+ * (pgdrome_amd/spectral.py; the solve it prepares replaces solver.py:636,716).  PGD_ERR_INVALID if the products are
+ * not held.                                                                                               */
+int pgd_start_residual(pgd_handle ctx, pgd_handle A, int k, const double *coefs, pgd_handle b, pgd_handle r);
 
 /* out[j] = x . y_j over entries [lo, hi) for k <= 256 vectors: ceil(k / 17) passes over x and ONE host
  * synchronisation.  Serves the functionals of one iterate against all stored modes of its dimension

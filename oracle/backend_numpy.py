@@ -203,11 +203,19 @@ class NumpyBackend:
         n = A.shape[0]
         r1 = n if r1 < 0 else r1
         V = [self._obj[v] for v in vecs]
-        W = [(A @ v)[r0:r1] for v in V]
+        full = [A @ v for v in V]
+        W = [w[r0:r1] for w in full]
         G = np.array([[float(vi[r0:r1] @ wj) for wj in W] for vi in V])
         G = 0.5 * (G + G.T)
         g = np.array([float(v[r0:r1] @ self._obj[b][r0:r1]) for v in V])
+        self._gram = (op, full) if (r0 == 0 and r1 == n and len(V) <= 9) else None
         return G, g
+
+    def start_residual(self, op, coefs, b, r):
+        held = getattr(self, "_gram", None)
+        if held is None or held[0] != op or len(held[1]) != len(coefs):
+            raise RuntimeError("start_residual: the products of this operator are not held")
+        self._obj[r][:] = self._obj[b] - sum(float(c) * w for c, w in zip(coefs, held[1]))
 
     def pcg(self, op, b, x, rtol, atol, maxit):
         A = self._obj[op][1]

@@ -66,6 +66,7 @@ SIGNATURES = {
     "pgd_bilinear": (C.c_int, [H, H, H, H, I64, I64, PD]),
     "pgd_bilinear_many": (C.c_int, [H, H, H, PH, C.c_int, I64, I64, PD]),
     "pgd_start_gram": (C.c_int, [H, H, PH, C.c_int, H, I64, I64, PD]),
+    "pgd_start_residual": (C.c_int, [H, H, C.c_int, PD, H, H]),
     "pgd_atom_product_form": (C.c_int, [H, H, C.POINTER(C.c_int)]),
     "pgd_vec_multidot": (C.c_int, [H, H, PH, C.c_int, I64, I64, PD]),
     "pgd_vec_multidot_pair": (C.c_int, [H, H, H, PH, C.c_int, I64, I64, PD]),
@@ -404,6 +405,11 @@ class Context:
         out = np.zeros(k * k + k, dtype=np.float64)
         self._ck(self.lib.pgd_start_gram(self.h, A, arr, k, b, int(r0), int(r1), dptr(out)))
         return out[:k * k].reshape(k, k).copy(), out[k * k:].copy()
+
+    def start_residual(self, A, coefs, b, r):
+        """r = b - sum_j coefs[j] (A v_j) from the products the start_gram call right before has left in the library."""
+        cf = np.ascontiguousarray(coefs, dtype=np.float64)
+        self._ck(self.lib.pgd_start_residual(self.h, A, int(cf.size), dptr(cf), b, r))
 
     def pcg_solve(self, op, b, x, rtol=1e-10, atol=0.0, maxit=10000):
         it = C.c_int()

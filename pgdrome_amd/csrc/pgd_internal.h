@@ -263,6 +263,9 @@ struct Ctx {
     void *cls_scratch = nullptr;  // hash slots of dia_classify
     double *gram_w = nullptr;     // pgd_start_gram: the products A v_j, one vector each
     size_t gram_w_bytes = 0;
+    pgd_handle gram_op = 0;       // ... of this operator, gram_k of them, each gram_n long (pgd_start_residual reads them; 0: none held)
+    int gram_k = 0;
+    int64_t gram_n = 0;
     int spmv_variant = 0;         // z-march: 0 = k_spmv_dia_march2 (64 x 8 patch, two rows per thread), 1 = 64 x 8 / 512 threads, 2 = 64 x 4 / 256 threads
     int spmv_zchunk = 8;          // k_spmv_dia_march: most planes a workgroup marches through (0: never use that kernel)
     int pcg_fold_reduce = 1;      // scaled recurrence: final reduction passes folded into the vector kernels (3 launches / iteration)

@@ -2905,6 +2905,7 @@ int pgd_start_gram(pgd_handle h, pgd_handle ah, const pgd_handle *vhs, int k, pg
         v[j] = x->d;
     }
     for (int q = 0; q < k * k + k; ++q) out[q] = 0.0;
+    c->gram_op = 0; c->gram_k = 0; c->gram_n = 0;       // (the products of an earlier call are about to be overwritten)
     if (r1 == r0) return PGD_OK;
     bool sym = false;
     PGD_TRY(ensure_sym(c, m, a, &sym));                 // the SPD solve that follows reads the same copy
@@ -2949,6 +2950,7 @@ int pgd_start_gram(pgd_handle h, pgd_handle ah, const pgd_handle *vhs, int k, pg
             for (int i = 0; i <= j; ++i) out[i * k + j] = out[j * k + i] = host[(size_t)(j * (j + 1) / 2 + i)];
             out[k * k + j] = host[(size_t)(k * (k + 1) / 2 + j)];
         }
+        if (r0 == 0 && r1 == m->nv) { c->gram_op = ah; c->gram_k = k; c->gram_n = m->nv; }     // whole products, kept for pgd_start_residual
         return PGD_OK;
     }
     const int g = grid_for(r1 - r0);

@@ -340,6 +340,31 @@ int pgd_vec_lincomb(pgd_handle h, pgd_handle yh, const pgd_handle *xs, const dou
     return PGD_OK;
 }
 
+int pgd_start_residual(pgd_handle h, pgd_handle ah, int k, const double *coefs, pgd_handle bh, pgd_handle rh) {
+    PGD_CTX(c, h);
+    Vec *b = get_vec(c, bh), *r = get_vec(c, rh);
+    if (!b || !r || b == r || !coefs || k < 1) return fail(c, PGD_ERR_INVALID, "start_residual: bad arguments");
+    if (!c->gram_op || c->gram_op != ah || c->gram_k != k || c->gram_n != b->n || r->n != b->n || !c->gram_w)
+        return fail(c, PGD_ERR_INVALID, "start_residual: the library does not hold the %d products of this operator "
+                                        "(pgd_start_gram over all rows with at most 9 vectors must come right before)", k);
+    // r = b - sum_j coefs[j] (A v_j): 8 terms per pass, b is the first term of the first pass
+    int done = 0;
+    bool first = true;
+    while (done < k || first) {
+        LincombArgs A;
+        int t = 0;
+        if (first) { A.x[0] = b->d; A.c[0] = 1.0; t = 1; }
+        for (; t < 8 && done < k; ++t, ++done) { A.x[t] = c->gram_w + (size_t)done * (size_t)c->gram_n; A.c[t] = -coefs[done]; }
+        A.k = t;
+        A.accumulate = first ? 0 : 1;
+        for (; t < 8; ++t) { A.x[t] = A.x[0]; A.c[t] = 0.0; }
+        k_lincomb<<<grid_for(r->n), TPB, 0, c->stream>>>(r->d, A, r->n);
+        first = false;
+    }
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
 int pgd_vec_set(pgd_handle h, pgd_handle vh, const int32_t *idx, const double *val, int64_t n) {
     PGD_CTX(c, h);
     Vec *v = get_vec(c, vh);

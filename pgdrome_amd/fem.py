@@ -2996,7 +2996,9 @@ def _rescale_start(lay, op, b, x):
     When the caller names further vectors (``x._start_space``: the stored modes of this dimension - the right-hand side
     of an enrichment step is the load minus the operator applied to them) the start is the Galerkin projection onto
     span{x, v_1, ..., v_k}: k + 1 products, (k + 1)(k + 4) / 2 dots and a (k + 1) x (k + 1) solve on the host; it is
-    never worse than the scaled x in the energy norm."""
+    never worse than the scaled x in the energy norm.
+
+    Returns the coefficients of the start in [x (as it came), v_1 ... v_k], or None where x was left as it was."""
     be = get_backend()
     lo, hi = lay.owned_range()
     extras = [v for v in getattr(x, "_start_space", ()) if v is not x][-START_SPACE_MAX:]
@@ -3012,7 +3014,7 @@ def _rescale_start(lay, op, b, x):
         packed = lay.part.comm.allreduce_array(np.concatenate([G.ravel(), g]))
         G, g = packed[:k * k].reshape(k, k), packed[k * k:]
     if not (np.all(np.isfinite(G)) and np.all(np.isfinite(g)) and G[0, 0] > 0.0):
-        return
+        return None
     if k == 1:
         coef = np.array([g[0] / G[0, 0]])
     else:
@@ -3020,7 +3022,7 @@ def _rescale_start(lay, op, b, x):
         d[d == 0.0] = 1.0
         coef = np.linalg.lstsq(G / np.outer(d, d), g / d, rcond=1e-10)[0] / d        # equilibrated, rank-revealing
     if not np.all(np.isfinite(coef)) or not np.any(coef):
-        return
+        return None
     if k == 1:
         be.vec_scale(x.dev(), float(coef[0]))
     else:
@@ -3031,6 +3033,7 @@ def _rescale_start(lay, op, b, x):
     x.touched_dev()
     if lay.part is not None:
         x._halo_version = x.version        # a combination of vectors with current ghost planes
+    return coef
 
 
 def _solve_linear(A, b, x, prm):
@@ -3061,10 +3064,11 @@ def _solve_linear(A, b, x, prm):
             k_spec = spectral.requested(prm) if n >= spectral.MIN_ROWS else 0
             spec = spectral.get(sys.modules[__name__], A, b, k_spec, prm) if k_spec > 0 else None
             t_solve = time.perf_counter()
+            start_coefs = None
             if WARM_START_RESCALE and not x._zero:
-                _rescale_start(A.lay, op, b, x)
+                start_coefs = _rescale_start(A.lay, op, b, x)
             if spec is not None:
-                spec.correct(sys.modules[__name__], A, op, b, x)
+                spec.correct(sys.modules[__name__], A, op, b, x, start_coefs)
             # settings["preconditioner"] (forwarded to PETSc by the reference, solver.py:593-594): the multigrid family asks for
             # the V-cycle of pgd_mg.hip, which the library uses where the operator has the structure for it and says so in its
             # counters; every other value is the Jacobi-PCG.  The row-sharded solve has the Jacobi form only.

@@ -631,6 +631,25 @@ def test_start_gram_matches_oracle(ctx, name):
     from pgdrome_amd._lib import PgdError
     with pytest.raises(PgdError):
         ctx.start_gram(op, vs + [bv], bv)                          # more than 17 vectors
+    # pgd_start_residual: b - sum_j c_j (A v_j) from the products the call right before left in the library (k <= 9, all rows)
+    rv = ctx.vec_alloc(n)
+    for k in (1, 5, 9):
+        ctx.start_gram(op, vs[:k], bv, 0, n)
+        cf = rng.uniform(-1, 1, k)
+        ctx.start_residual(op, cf, bv, rv)
+        ref = b - (A @ V[:k].T) @ cf
+        assert np.abs(ctx.vec_download(rv) - ref).max() <= 1e-13 * (np.abs(b) + np.abs(A) @ np.abs(V[:k].T) @ np.abs(cf)).max()
+    with pytest.raises(PgdError):
+        ctx.start_residual(op, np.ones(4), bv, rv)                 # not the number of products held
+    with pytest.raises(PgdError):
+        ctx.start_residual(am, np.ones(9), bv, rv)                 # not the operator they belong to
+    ctx.start_gram(op, vs[:12], bv, 0, n)
+    with pytest.raises(PgdError):
+        ctx.start_residual(op, np.ones(12), bv, rv)                # more than 9 vectors: the products are not kept
+    ctx.start_gram(op, vs[:3], bv, n // 4, n // 2)
+    with pytest.raises(PgdError):
+        ctx.start_residual(op, np.ones(3), bv, rv)                 # products over a row range only
+    ctx.vec_free(rv)
     for v in vs + [bv]:
         ctx.vec_free(v)
     for a in (op, ak, am):
