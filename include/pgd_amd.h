@@ -282,6 +282,13 @@ int pgd_pcg_solve_sharded(pgd_handle ctx, pgd_handle A, pgd_handle b, pgd_handle
                           int64_t own1, int64_t lo_ghost, int64_t hi_ghost, double rtol, double atol,
                           int maxit, int *iters, double *rel_res);
 
+/* BiCGStab with Jacobi scaling on the CSR product, for operators that are NOT symmetric (a convection atom
+ * u.dx(a) * v * dx on a 2-D / 3-D space, or a 1-D system too long for pgd_band_solve): replaces the MUMPS solve of
+ * LinearVariationalSolver for such systems (solver.py:627-636, 704-716).  x holds the start value; stop test
+ * ||b - A x|| <= max(rtol ||b||, atol), confirmed on the true residual; PGD_ERR_SINGULAR on repeated breakdown.  */
+int pgd_bicgstab_solve(pgd_handle ctx, pgd_handle A, pgd_handle b, pgd_handle x, double rtol, double atol,
+                       int maxit, int *iters, double *rel_res);
+
 /* Gram data of the Galerkin start of a PCG solve (the warm start x0 = sum_j c_j v_j with G c = g; this library's
  * addition in front of the solve that replaces solver.py:636,716): out[i*k + j] = v_i . (A v_j) over rows
  * [r0, r1), out[k*k + j] = v_j . b, k <= 17.  k products from the operator's fastest storage form, every dot on

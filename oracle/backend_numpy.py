@@ -228,6 +228,14 @@ class NumpyBackend:
         self._obj[x][:] = sol
         return it, rel
 
+    def bicgstab(self, op, b, x, rtol, atol, maxit):
+        """The oracle of the non-symmetric solve is the sparse DIRECT solve (SuperLU), like the reference's MUMPS."""
+        A = self._obj[op][1]
+        self._obj[x][:] = F.direct_solve(A, self._obj[b])
+        r = self._obj[b] - A @ self._obj[x]
+        bn = np.linalg.norm(self._obj[b])
+        return 1, float(np.linalg.norm(r) / bn) if bn > 0 else 0.0
+
     def band_solve(self, op, b, x):
         self._obj[x][:] = F.direct_solve(self._obj[op][1], self._obj[b])
 

@@ -67,6 +67,7 @@ SIGNATURES = {
     "pgd_bilinear_many": (C.c_int, [H, H, H, PH, C.c_int, I64, I64, PD]),
     "pgd_start_gram": (C.c_int, [H, H, PH, C.c_int, H, I64, I64, PD]),
     "pgd_start_residual": (C.c_int, [H, H, C.c_int, PD, H, H]),
+    "pgd_bicgstab_solve": (C.c_int, [H, H, H, H, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), PD]),
     "pgd_atom_product_form": (C.c_int, [H, H, C.POINTER(C.c_int)]),
     "pgd_vec_multidot": (C.c_int, [H, H, PH, C.c_int, I64, I64, PD]),
     "pgd_vec_multidot_pair": (C.c_int, [H, H, H, PH, C.c_int, I64, I64, PD]),
@@ -416,6 +417,12 @@ class Context:
         rel = F64()
         self._ck(self.lib.pgd_pcg_solve(self.h, op, b, x, float(rtol), float(atol), int(maxit),
                                         C.byref(it), C.byref(rel)))
+        return it.value, rel.value
+
+    def bicgstab(self, op, b, x, rtol=1e-10, atol=0.0, maxit=10000):
+        it = C.c_int()
+        rel = F64()
+        self._ck(self.lib.pgd_bicgstab_solve(self.h, op, b, x, float(rtol), float(atol), int(maxit), C.byref(it), C.byref(rel)))
         return it.value, rel.value
 
     def band_solve(self, op, b, x):

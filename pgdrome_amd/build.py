@@ -17,7 +17,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIBDIR = HERE / "lib"
 LIB = LIBDIR / "libpgd_amd.so"
-SOURCES = ["pgd_ctx.hip", "pgd_vec.hip", "pgd_mesh.hip", "pgd_spmv.hip", "pgd_pcg.hip", "pgd_comm.hip", "pgd_mg.hip"]
+SOURCES = ["pgd_ctx.hip", "pgd_vec.hip", "pgd_mesh.hip", "pgd_spmv.hip", "pgd_pcg.hip", "pgd_comm.hip", "pgd_mg.hip", "pgd_krylov.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-result",
          "-fno-gpu-rdc"]
 
@@ -54,7 +54,7 @@ def build(force: bool = False, verbose: bool = True) -> Path:
         subprocess.run(cmd, check=True)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(6, len(SOURCES))) as ex:
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(compile_one, SOURCES))
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
     if verbose:

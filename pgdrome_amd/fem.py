@@ -3049,12 +3049,32 @@ def _solve_linear(A, b, x, prm):
     info = {}
     try:
         use_direct = mesh.topology().dim() == 1 and n <= SMALL_DIRECT_N and mesh.part is None
-        if not use_direct and not A.is_symmetric():
-            raise NotImplementedError("non-symmetric operator on a large mesh: only SPD systems go to PCG")
+        nonsym = not use_direct and not A.is_symmetric()
+        if nonsym and mesh.part is not None:
+            raise NotImplementedError("non-symmetric operator on a row-sharded mesh: the sharded solve is the SPD Jacobi-PCG")
         if use_direct:
             be.band_solve(op, b.dev(), x.dev_for_write())
             x.touched_dev()
             info.update(method="band_lu", iterations=1)
+        elif nonsym:
+            # a convection atom on a 2-D / 3-D space (or a 1-D system beyond the banded LU): BiCGStab with Jacobi scaling on the
+            # CSR product (csrc/pgd_krylov.hip) where the reference's MUMPS solves whatever the callbacks produce
+            # (solver.py:627-636); same relative_tolerance / maximum_iterations / error_on_nonconvergence semantics as the PCG
+            rtol = float(prm.get("relative_tolerance", 1e-10)) if not isinstance(prm.get("relative_tolerance"), _Params) else 1e-10
+            atol = float(prm.get("absolute_tolerance", 0.0)) if not isinstance(prm.get("absolute_tolerance"), _Params) else 0.0
+            maxit = int(prm.get("maximum_iterations", 20000)) if not isinstance(prm.get("maximum_iterations"), _Params) else 20000
+            t_solve = time.perf_counter()
+            it, rel = be.bicgstab(op, b.dev(), x.dev(), rtol, atol, maxit)
+            x.touched_dev()
+            STATS["bicgstab_seconds"] = STATS.get("bicgstab_seconds", 0.0) + time.perf_counter() - t_solve
+            STATS["bicgstab_iterations"] = STATS.get("bicgstab_iterations", 0) + it
+            info.update(method="jacobi_bicgstab", iterations=it, relres=rel)
+            if rel > max(rtol, 1e-14) * 1.0001 and (atol <= 0.0 or it >= maxit):
+                msg = "BiCGStab did not reach rtol %g in %d iterations (relres %g)" % (rtol, it, rel)
+                eon = prm.get("error_on_nonconvergence", True)
+                if isinstance(eon, _Params) or eon:
+                    raise RuntimeError(msg)
+                LOG.error(msg)
         else:
             rtol = float(prm.get("relative_tolerance", 1e-10)) if not isinstance(prm.get("relative_tolerance"), _Params) else 1e-10
             atol = float(prm.get("absolute_tolerance", 0.0)) if not isinstance(prm.get("absolute_tolerance"), _Params) else 0.0

@@ -235,6 +235,72 @@ def transient_heat(space_mesh, n_t=256, n_p=0, rho_c=1.0, k=0.1, p_range=(0.5, 2
                 PGD_nmax=PGD_nmax, PGD_tol=PGD_tol)
 
 
+# ----------------- a CONVECTIVE spatial term: - kappa Laplace(u) + w beta . grad(u) + u = 1, u = sum X(x) K(kappa) W(w)
+def convection_diffusion(space_mesh, n_k=9, n_w=9, beta=(12.0, -5.0, 3.0), k_range=(0.5, 2.0), w_range=(0.0, 1.0), PGD_nmax=6,
+                         PGD_tol=1e-8):
+    """Space (2-D or 3-D, P1) x diffusivity kappa x velocity scale w (three-way separated).  The spatial operator
+    a_K K_x + a_C sum_a beta_a C_{x,a} + a_M M_x  carries convection atoms u.dx(a) * v * dx - the atom the reference uses on its
+    time axis (/root/reference/tests/integration/test_heat1D.py:80) - on a 2-D / 3-D space: NOT symmetric, solved by the
+    reference's MUMPS (solver.py:627-636) and by BiCGStab here (csrc/pgd_krylov.hip)."""
+    gdim = space_mesh.geometry().dim() if hasattr(space_mesh, "geometry") else space_mesh.coordinates().shape[1]
+    meshes = [space_mesh, fem.IntervalMesh(n_k - 1, k_range[0], k_range[1]), fem.IntervalMesh(n_w - 1, w_range[0], w_range[1])]
+    Vs = [fem.FunctionSpace(m, "CG", 1) for m in meshes]
+    load = [[fem.interpolate(fem.Expression("1.0", degree=1), V)] for V in Vs]
+    param = {"kappa": fem.interpolate(fem.Expression("x[0]", degree=1), Vs[1]),
+             "w": fem.interpolate(fem.Expression("x[0]", degree=1), Vs[2]), "beta": tuple(beta[:gdim])}
+    probs = ["x", "k", "w"]
+
+    def bc_fct(Vs, dom, param):
+        return [fem.DirichletBC(Vs[0], 0, _on_boundary), 0, 0]
+
+    # term t of the operator = product over the dimensions of these bilinear forms (f, g: trial / test or two Functions)
+    def own(term, d, f, g, meshes, param):
+        m = meshes[d]
+        if d == 0:
+            if term == 0:
+                return fem.inner(fem.grad(f), fem.grad(g)) * fem.dx(m)
+            if term == 1:
+                form = 0
+                for a, b_a in enumerate(param["beta"]):
+                    form = form + fem.Constant(b_a) * f.dx(a) * g * fem.dx(m)
+                return form
+            return f * g * fem.dx(m)
+        weight = param["kappa"] if (d == 1 and term == 0) else (param["w"] if (d == 2 and term == 1) else None)
+        return weight * f * g * fem.dx(m) if weight is not None else f * g * fem.dx(m)
+
+    def lhs_fct(u, v, Fs, meshes, dom, param, typ, dim):
+        d = probs.index(typ)
+        a = 0
+        for term in range(3):
+            c = 1.0
+            for j in range(3):
+                if j != d:
+                    c *= fem.assemble(own(term, j, Fs[j], Fs[j], meshes, param))
+            a = a + fem.Constant(c) * own(term, d, u, v, meshes, param)
+        return a
+
+    def rhs_fct(u, v, Fs, meshes, dom, param, Q, PGD_func, typ, nE, dim):
+        d = probs.index(typ)
+        c = 1.0
+        for j in range(3):
+            if j != d:
+                c *= fem.assemble(Q[j][0] * Fs[j] * fem.dx(meshes[j]))
+        l = fem.Constant(c) * Q[d][0] * v * fem.dx(meshes[d])
+        for old in range(nE):
+            for term in range(3):
+                c = 1.0
+                for j in range(3):
+                    if j != d:
+                        # (trial slot = the stored mode, test slot = the iterate: the convection form is not symmetric)
+                        c *= fem.assemble(own(term, j, PGD_func[j][old], Fs[j], meshes, param))
+                l = l + fem.Constant(-c) * own(term, d, PGD_func[d][old], v, meshes, param)
+        return l
+
+    return dict(name="convection_diffusion", name_coord=["X", "kappa", "w"], modes_info=["U", "Node", "Scalar"], Vs=Vs,
+                bc_fct=bc_fct, load=load, param=param, rhs_fct=rhs_fct, lhs_fct=lhs_fct, probs=probs,
+                PGD_nmax=PGD_nmax, PGD_tol=PGD_tol)
+
+
 def make_problem(spec, cls):
     """PGDProblem(**spec) for either implementation of the class."""
     return cls(**spec)
