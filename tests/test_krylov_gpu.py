@@ -28,13 +28,11 @@ def _boundary(coords):
     return np.where(np.any((coords <= lo + 1e-12) | (coords >= hi - 1e-12), axis=1))[0].astype(np.int32)
 
 
-@pytest.mark.parametrize("name", ["rect96", "box28", "interval30000"])
+@pytest.mark.parametrize("name", ["rect96", "box28"])
 def test_bicgstab_against_superlu(ctx, name):
-    """2-D and 3-D convection-diffusion-reaction (cell Peclet numbers up to ~0.5) and a 1-D system beyond the banded LU's size:
-    pgd_bicgstab_solve against SuperLU on the oracle's matrix to 1e-8, from a zero and from a non-zero start; an exhausted
+    """2-D and 3-D convection-diffusion-reaction (cell Peclet numbers up to ~0.5): pgd_bicgstab_solve against SuperLU on the oracle's matrix to 1e-8, from a zero and from a non-zero start; an exhausted
     iteration budget reports its residual instead of failing; a zero right-hand side gives zero."""
-    coords, cells = {"rect96": lambda: F.rectangle_mesh((0, 0), (1, 1), 95, 95), "box28": lambda: F.box_mesh((0, 0, 0), (1, 1, 1), 27, 27, 27),
-                     "interval30000": lambda: F.interval_mesh(29999, 0.0, 1.0)}[name]()
+    coords, cells = {"rect96": lambda: F.rectangle_mesh((0, 0), (1, 1), 95, 95), "box28": lambda: F.box_mesh((0, 0, 0), (1, 1, 1), 27, 27, 27)}[name]()
     gdim = coords.shape[1]
     n = coords.shape[0]
     beta = (30.0, -12.0, 7.0)[:gdim]
