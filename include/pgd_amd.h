@@ -473,6 +473,21 @@ int pgd_classify_counts(pgd_handle ctx, int64_t *full, int64_t *cached);
 /* Solves that asked for the multigrid preconditioner (PGD_TUNE_PCG_PRECOND = 1) since the context was created: preconditioned by
  * the V-cycle / fallen back to Jacobi because the operator is not one stencil with an eliminated hull.                  */
 int pgd_mg_counts(pgd_handle ctx, int64_t *solves, int64_t *fallbacks);
+/* The V-cycle of the multigrid preconditioner on a z-slab of a ROW-SHARDED lattice: settings["preconditioner"] = "amg"
+ * (forwarded by the reference into its solver, solver.py:593-594, 634-635) on a sharded spatial dimension.  Level 0 stays
+ * with the rows (this rank's planes + one ghost plane per side), levels >= 1 are whole on every rank.  The caller owns the
+ * PCG loop and the collectives: per cycle  halo(r) -> pgd_mg_slab_down(r, t) -> halo(t) -> pgd_mg_slab_restrict(t, b1) ->
+ * all-reduce(b1) -> pgd_mg_coarse(b1, x1) -> pgd_mg_slab_up(r, x1, t, z, &dot) with dot = r . z over the owned rows.
+ *   setup: A (unscaled) must be one stencil + eliminated nodes on the owned planes [own0, own1) of the local array (whole planes),
+ *   the eliminated nodes exactly the hull of the global lattice of nz_global planes, local plane 0 = global plane z_first;
+ *   *applies = 0 where it is not (the caller keeps Jacobi), *n_coarse = entries of a level-1 vector.                      */
+int pgd_mg_slab_setup(pgd_handle ctx, pgd_handle A, int nz_global, int z_first, int64_t own0, int64_t own1,
+                      int64_t *n_coarse, int *applies);
+int pgd_mg_slab_fix_start(pgd_handle ctx, pgd_handle A, pgd_handle b, pgd_handle x, int64_t own0, int64_t own1);   /* x = b on eliminated owned rows */
+int pgd_mg_slab_down(pgd_handle ctx, pgd_handle r, pgd_handle t);
+int pgd_mg_slab_restrict(pgd_handle ctx, pgd_handle t, pgd_handle b1);
+int pgd_mg_coarse(pgd_handle ctx, pgd_handle b1, pgd_handle x1);
+int pgd_mg_slab_up(pgd_handle ctx, pgd_handle r, pgd_handle x1, pgd_handle t, pgd_handle z, double *dot);
 /* One HIP-event stopwatch on the context's stream (bench.py's micro-sections: N launches between start
  * and stop; stop synchronises on its event).                                                        */
 /* Calibration of the PMC byte model: one pass over `vec` with 8- or 16-byte loads (store = 0) or stores (store = 1)

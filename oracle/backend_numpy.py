@@ -228,6 +228,63 @@ class NumpyBackend:
         self._obj[x][:] = sol
         return it, rel
 
+    # ---- the V-cycle on a z-slab of a row-sharded lattice (oracle/mg_numpy.py::Slab restates pgd_mg_slab_*)
+    def mg_slab_setup(self, op, nz_global, z_first, own0, own1):
+        from . import mg_numpy as MG
+        mh, A = self._obj[op]
+        m = self._obj[mh]
+        xs, ys = np.unique(np.round(m.coords[:, 0], 12)), np.unique(np.round(m.coords[:, 1], 12))
+        nx, ny = xs.size, ys.size
+        P = nx * ny
+        if m.coords.shape[1] != 3 or m.n % P or own0 % P or own1 % P or min(nx, ny, nz_global) < 8:
+            return 0
+        nzloc, lz0, lz1 = m.n // P, own0 // P, own1 // P
+        # the stencil of an interior owned row, then every owned row checked against it (eliminated rows = the global hull)
+        zi = min(max(lz0, 1 if z_first == 0 else lz0), lz1 - 1)
+        i0 = zi * P + (ny // 2) * nx + nx // 2
+        c = np.array([A[i0, i0 + dx + nx * dy + P * dz] if i0 + dx + nx * dy + P * dz < m.n else 0.0 for dx, dy, dz in MG.OFFS])
+        if not c[0] > 0.0:
+            return 0
+        sl = MG.Slab((nz_global, ny, nx), c, z_first, nzloc, lz0, lz1)
+        probe = np.random.default_rng(3).uniform(-1, 1, (nzloc, ny, nx)) * sl.mask
+        want = (MG.apply(sl.levels[0].S, probe) * sl.mask + probe * (1.0 - sl.mask)).ravel()
+        got = A @ (probe.ravel() + 0.0)
+        if np.abs(want - got)[own0:own1].max() > 1e-12 * np.abs(want).max():
+            return 0
+        diag = A.diagonal()[own0:own1].reshape(lz1 - lz0, ny, nx)
+        offd = np.asarray(abs(A[own0:own1]).sum(axis=1)).ravel().reshape(lz1 - lz0, ny, nx) - np.abs(diag)
+        ident = (diag == 1.0) & (offd == 0.0)
+        if not np.array_equal(ident, sl.mask[lz0:lz1] == 0.0):
+            return 0
+        self._mg_slab = sl
+        return sl.n_coarse
+
+    def _slab3(self, v):
+        sl = self._mg_slab
+        return self._obj[v].reshape(sl.nzloc, sl.mask.shape[1], sl.mask.shape[2])
+
+    def mg_slab_fix_start(self, op, b, x, own0, own1):
+        elim = (self._mg_slab.mask == 0.0).ravel()
+        elim[:own0] = False
+        elim[own1:] = False
+        self._obj[x][elim] = self._obj[b][elim]
+
+    def mg_slab_down(self, r, t):
+        self._obj[t][:] = self._mg_slab.down(self._slab3(r)).ravel()
+
+    def mg_slab_restrict(self, t, b1):
+        self._obj[b1][:] = self._mg_slab.restrict(self._slab3(t)).ravel()
+
+    def mg_coarse(self, b1, x1):
+        sl = self._mg_slab
+        self._obj[x1][:] = sl.coarse(self._obj[b1].reshape(sl.levels[1].shape)).ravel()
+
+    def mg_slab_up(self, r, x1, t, z):
+        sl = self._mg_slab
+        zz, dot = sl.up(self._slab3(r), self._obj[x1].reshape(sl.levels[1].shape))
+        self._obj[z][:] = zz.ravel()
+        return dot
+
     def bicgstab(self, op, b, x, rtol, atol, maxit):
         """The oracle of the non-symmetric solve is the sparse DIRECT solve (SuperLU), like the reference's MUMPS."""
         A = self._obj[op][1]

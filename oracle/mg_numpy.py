@@ -153,3 +153,45 @@ def pcg(shape, c, b, x0=None, rtol=1e-10, maxit=200, multigrid=True):
         p = z + (rz2 / rz) * p
         rz = rz2
     return x, it, (rr / bb) ** 0.5 if bb > 0 else 0.0
+
+
+# ---- the same cycle on a z-slab of a row-sharded lattice (pgd_mg_slab_* of pgdrome_amd/csrc/pgd_mg.hip) -------------------
+# Level 0 stays with the rows: a rank holds the local planes [0, nzloc) = global planes [zoff, zoff + nzloc), owns [lz0, lz1) of
+# them, the others are ghost planes the caller's halo exchange fills.  Levels >= 1 are whole on every rank: each rank restricts
+# into the coarse planes its slab covers (coarse plane Z belongs to the owner of fine plane 2 Z), zero elsewhere; the sum over the
+# ranks is the whole coarse right-hand side.  Array operation by array operation what the kernels do, so a sharded run makes the
+# same iterates as `pcg` above.
+class Slab:
+    def __init__(self, shape_global, c, zoff, nzloc, lz0, lz1):
+        self.levels = build_levels(shape_global, c)
+        self.zoff, self.nzloc, self.lz0, self.lz1 = zoff, nzloc, lz0, lz1
+        L = self.levels[0]
+        self.mask = L.mask[zoff:zoff + nzloc]                      # free nodes of the local planes (global hull = eliminated)
+        self.own = np.zeros((nzloc, 1, 1))
+        self.own[lz0:lz1] = 1.0
+        self.n_coarse = int(np.prod(self.levels[1].shape))
+
+    def down(self, r):
+        """t = r - w A r on the owned planes (r: local array with current ghost planes); 0 on the other planes."""
+        L = self.levels[0]
+        return (r - L.w * apply(L.S, r)) * self.mask * self.own
+
+    def restrict(self, t):
+        """This rank's part of the level-1 right-hand side (t: local array with current ghost planes)."""
+        C = self.levels[1]
+        full = apply(interpolation_stencil(), t)
+        b1 = np.zeros(C.shape)
+        g0, g1 = self.zoff + self.lz0, self.zoff + self.lz1
+        for Z in range((g0 + 1) // 2, (g1 + 1) // 2):
+            b1[Z] = full[2 * Z - self.zoff, 0:2 * C.shape[1]:2, 0:2 * C.shape[2]:2] * C.mask[Z]
+        return b1
+
+    def coarse(self, b1):
+        return vcycle(self.levels, 1, b1)
+
+    def up(self, r, x1):
+        """z = t + w (r - A t) with t = w r + P x1: t on all local planes (no exchange), z on the owned ones; (z, r . z owned)."""
+        L = self.levels[0]
+        t = (L.w * r + prolong(x1, L.shape)[self.zoff:self.zoff + self.nzloc]) * self.mask
+        z = (t + L.w * (r - apply(L.S, t))) * self.mask * self.own
+        return z, float((r * z).sum())

@@ -67,6 +67,12 @@ SIGNATURES = {
     "pgd_bilinear_many": (C.c_int, [H, H, H, PH, C.c_int, I64, I64, PD]),
     "pgd_start_gram": (C.c_int, [H, H, PH, C.c_int, H, I64, I64, PD]),
     "pgd_start_residual": (C.c_int, [H, H, C.c_int, PD, H, H]),
+    "pgd_mg_slab_setup": (C.c_int, [H, H, C.c_int, C.c_int, I64, I64, C.POINTER(I64), C.POINTER(C.c_int)]),
+    "pgd_mg_slab_fix_start": (C.c_int, [H, H, H, H, I64, I64]),
+    "pgd_mg_slab_down": (C.c_int, [H, H, H]),
+    "pgd_mg_slab_restrict": (C.c_int, [H, H, H]),
+    "pgd_mg_coarse": (C.c_int, [H, H, H]),
+    "pgd_mg_slab_up": (C.c_int, [H, H, H, H, H, PD]),
     "pgd_bicgstab_solve": (C.c_int, [H, H, H, H, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), PD]),
     "pgd_atom_product_form": (C.c_int, [H, H, C.POINTER(C.c_int)]),
     "pgd_vec_multidot": (C.c_int, [H, H, PH, C.c_int, I64, I64, PD]),
@@ -418,6 +424,30 @@ class Context:
         self._ck(self.lib.pgd_pcg_solve(self.h, op, b, x, float(rtol), float(atol), int(maxit),
                                         C.byref(it), C.byref(rel)))
         return it.value, rel.value
+
+    # ---- the V-cycle on a z-slab of a row-sharded lattice (levels >= 1 whole on every rank)
+    def mg_slab_setup(self, op, nz_global, z_first, own0, own1):
+        """Entries of a level-1 vector where the slab V-cycle applies to this operator, else 0."""
+        n1, ok = I64(0), C.c_int(0)
+        self._ck(self.lib.pgd_mg_slab_setup(self.h, op, int(nz_global), int(z_first), int(own0), int(own1), C.byref(n1), C.byref(ok)))
+        return int(n1.value) if ok.value else 0
+
+    def mg_slab_fix_start(self, op, b, x, own0, own1):
+        self._ck(self.lib.pgd_mg_slab_fix_start(self.h, op, b, x, int(own0), int(own1)))
+
+    def mg_slab_down(self, r, t):
+        self._ck(self.lib.pgd_mg_slab_down(self.h, r, t))
+
+    def mg_slab_restrict(self, t, b1):
+        self._ck(self.lib.pgd_mg_slab_restrict(self.h, t, b1))
+
+    def mg_coarse(self, b1, x1):
+        self._ck(self.lib.pgd_mg_coarse(self.h, b1, x1))
+
+    def mg_slab_up(self, r, x1, t, z):
+        out = F64()
+        self._ck(self.lib.pgd_mg_slab_up(self.h, r, x1, t, z, C.byref(out)))
+        return out.value
 
     def bicgstab(self, op, b, x, rtol=1e-10, atol=0.0, maxit=10000):
         it = C.c_int()

@@ -250,6 +250,7 @@ struct Ctx {
     int pcg_precond = 0;          // pgd_pcg_solve: 0 = Jacobi (the diagonal scaling), 1 = geometric multigrid V-cycle where the scaled operator is one
                                   // stencil on a lattice whose eliminated nodes are exactly its hull (pgd_mg.hip); anything else falls back to 0
     struct Mg *mg = nullptr;      // its levels and work vectors, kept across solves on the same lattice
+    struct Mg *mg_slab = nullptr; // the same for a z-slab of a row-sharded lattice (pgd_mg_slab_*: levels >= 1 are whole and replicated)
     int64_t mg_solves = 0, mg_fallbacks = 0;
     int mg_chunk = 2;             // iterations queued between two looks at the flags when the multigrid preconditioner is on (even: the slot parity of a replayed chunk)
     int mg_march_min = 64;        // levels with at least this many nodes along x and y run their stencil passes in k_spmv_stencil_march

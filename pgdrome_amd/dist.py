@@ -32,10 +32,13 @@ from __future__ import annotations
 
 import os
 
+import logging
+
 import numpy as np
 
 from . import fem
 
+LOG = logging.getLogger("pgdrome_amd.dist")
 CHECK_EVERY = 16
 # slots of the device scalar bank (shared convention with csrc/pgd_pcg.hip)
 S_PQ, S_TOL2, S_FINAL_RR, S_INIT, S_PAIR = 2, 5, 6, 20, 16
@@ -320,6 +323,85 @@ class TorchComm:
             raise err
         os._exit(3)
 
+    def pcg_mg(self, mesh, op, b, x, rtol, atol, maxit):
+        """PCG preconditioned by the V-cycle on a row-sharded lattice (settings["preconditioner"] = "amg" on a sharded mesh):
+        level 0 of the hierarchy stays with the rows - every rank runs the level's stencil passes, restriction and prolongation
+        on its own z-slab - and levels >= 1 are whole on every rank (pgd_mg_slab_*, csrc/pgd_mg.hip; oracle/mg_numpy.py::Slab).
+        Per iteration: halo(p) + the product, and inside the cycle halo(r), halo(t) and ONE all-reduce of the level-1 right-hand
+        side (n / 8 doubles, every entry with a single non-zero contribution: exact); two small all-reduces for the scalars.
+        The textbook recurrence with the stop test of the Jacobi form, driven from the host (a solve takes ~20 iterations).
+        Returns None - on EVERY rank, decided by an all-reduce - where the cycle does not apply to this operator on some rank;
+        the caller then takes the Jacobi-PCG."""
+        be, part = self.be, mesh.part
+        plane = int(getattr(part, "plane", 0) or 0)
+        n1 = 0
+        if plane and hasattr(be, "mg_slab_setup"):
+            try:
+                n1 = int(be.mg_slab_setup(op, part.n_global // plane, part.global_offset // plane, part.own0, part.own1))
+            except Exception as e:      # noqa: BLE001 - a rank-local failure must still reach the vote below
+                LOG.warning("slab V-cycle setup failed on rank %d: %s", self.rank, e)
+                n1 = 0
+        votes = self.allreduce_array([0.0 if n1 > 0 else 1.0, float(n1)])
+        if votes[0] > 0.0 or votes[1] != float(n1) * self.world:
+            return None
+        self._check_stream()
+        lo, hi, n = part.own0, part.own1, mesh.num_vertices()
+        r, z, p, q, t = (self._workvec(n, k) for k in ("r", "z", "p", "q", "mg_t"))
+        b1, x1 = self._workvec(n1, "mg_b1"), self._workvec(n1, "mg_x1")
+        xh, bh = x.dev(), b.dev()
+        b1_t = be.vec_tensor(b1)
+
+        def cycle():
+            """z = M r (r: owned rows current); returns the local r . z"""
+            self.halo_exchange_raw(mesh, r, cache_view=True)
+            be.mg_slab_down(r, t)
+            self.halo_exchange_raw(mesh, t, cache_view=True)
+            be.mg_slab_restrict(t, b1)
+            if self.world > 1:
+                if self._staged(b1_t):
+                    hst = b1_t.cpu()
+                    self.dist.all_reduce(hst)
+                    b1_t.copy_(hst)
+                else:
+                    self.dist.all_reduce(b1_t)
+                self.stats["allreduce"] += 1
+            be.mg_coarse(b1, x1)
+            return be.mg_slab_up(r, x1, t, z)
+
+        be.mg_slab_fix_start(op, bh, xh, lo, hi)
+        self.halo_exchange_raw(mesh, xh)
+        be.spmv(op, xh, q, lo, hi)
+        be.vec_copy(r, bh)
+        be.vec_axpy(r, -1.0, q)
+        rr_l, bb_l = be.vec_dot(r, r, lo, hi), be.vec_dot(bh, bh, lo, hi)
+        rz_l = cycle()
+        rr, bb, rz = self.allreduce_array([rr_l, bb_l, rz_l])
+        tol2 = max(rtol * rtol * bb, atol * atol)
+        it = 0
+        be.vec_copy(p, z)
+        while it < maxit and rr > tol2:
+            if not (np.isfinite(rr) and np.isfinite(rz)):
+                raise RuntimeError("sharded multigrid PCG breakdown (NaN) after %d iterations" % it)
+            self.halo_exchange_raw(mesh, p, cache_view=True)
+            be.spmv(op, p, q, lo, hi)
+            pq = float(self.allreduce_array([be.vec_dot(p, q, lo, hi)])[0])
+            alpha = rz / pq
+            be.vec_axpy(xh, alpha, p)
+            be.vec_axpy(r, -alpha, q)
+            it += 1
+            rr_l = be.vec_dot(r, r, lo, hi)
+            rz_l = cycle()
+            rr, rz_new = self.allreduce_array([rr_l, rz_l])
+            if rr <= tol2:
+                break
+            be.vec_scale(p, rz_new / rz)
+            be.vec_axpy(p, 1.0, z)
+            rz = rz_new
+        self.stats["sharded_mg_solves"] = self.stats.get("sharded_mg_solves", 0) + 1
+        x.touched_dev()
+        self.halo_exchange(mesh, x)
+        return it, (float(np.sqrt(rr / bb)) if bb > 0 else 0.0)
+
     def pcg(self, mesh, op, b, x, rtol, atol, maxit):
         if self.in_library:
             part = mesh.part
@@ -402,6 +484,7 @@ def sharded_box_mesh(comm, p0, p1, nx, ny, nz):
     own0 = lo_g
     own1 = own0 + (z1 - z0) * plane
     part = fem.Partition(comm, own0, own1, plane * (nz + 1), lo_g, hi_g, zf * plane)
+    part.plane = plane                                         # vertices per z-plane (the slab V-cycle needs the lattice)
     mesh = fem.Mesh(coords, cells, part)
     mesh._on_boundary = fem.box_hull_mask(nx, ny, nz, zf, zl)
     assert mesh.num_vertices() == own1 + hi_g

@@ -3093,13 +3093,22 @@ def _solve_linear(A, b, x, prm):
             # the V-cycle of pgd_mg.hip, which the library uses where the operator has the structure for it and says so in its
             # counters; every other value is the Jacobi-PCG.  The row-sharded solve has the Jacobi form only.
             prec = prm.get("preconditioner", "default")
-            want_mg = (not isinstance(prec, _Params)) and str(prec).lower() in MULTIGRID_NAMES and mesh.part is None
+            asks_mg = (not isinstance(prec, _Params)) and str(prec).lower() in MULTIGRID_NAMES
+            want_mg = asks_mg and mesh.part is None
             mg0 = None
+            used = 0
             if want_mg and hasattr(be, "precondition"):
                 mg0 = be.precondition(1)
             try:
                 if mesh.part is not None:
-                    it, rel = mesh.part.comm.pcg(mesh, op, b, x, rtol, atol, maxit)
+                    # a row-sharded lattice: the V-cycle with level 0 on the slabs and levels >= 1 replicated (dist.pcg_mg);
+                    # where it does not apply on some rank every rank takes the Jacobi-PCG (decided by an all-reduce)
+                    got = mesh.part.comm.pcg_mg(mesh, op, b, x, rtol, atol, maxit) if asks_mg and hasattr(mesh.part.comm, "pcg_mg") else None
+                    if got is not None:
+                        it, rel = got
+                        used = 1
+                    else:
+                        it, rel = mesh.part.comm.pcg(mesh, op, b, x, rtol, atol, maxit)
                 else:
                     it, rel = be.pcg(op, b.dev(), x.dev(), rtol, atol, maxit)
                     x.touched_dev()
@@ -3107,8 +3116,8 @@ def _solve_linear(A, b, x, prm):
                 if mg0 is not None:
                     used = be.precondition(0) - mg0
             STATS["pcg_seconds"] += time.perf_counter() - t_solve      # the solve returns synchronised
-            info.update(method="mg_pcg" if mg0 is not None and used > 0 else "jacobi_pcg", iterations=it, relres=rel)
-            if mg0 is not None and used > 0:
+            info.update(method="mg_pcg" if used > 0 else "jacobi_pcg", iterations=it, relres=rel)
+            if used > 0:
                 STATS["mg_solves"] = STATS.get("mg_solves", 0) + 1
             if rel > max(rtol, 1e-14) * 1.0001 and it >= maxit:
                 # dolfin's Krylov solvers raise on non-convergence unless told otherwise (error_on_nonconvergence,

@@ -233,3 +233,97 @@ def test_the_deadline_ends_the_process_with_a_diagnosis():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
     assert r.returncode == 3
     assert "no progress" in r.stderr and "rank 1/2" in r.stderr and "not reached" not in r.stdout
+
+
+def _mg_worker(rank, world, port, shape, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.backend_numpy import NumpyBackend
+        from pgdrome_amd import dist as pdist, fem
+        from pgdrome_amd.solver import PGDProblem
+        be = fem.set_backend(NumpyBackend())
+        comm = pdist.TorchComm(dist, be, True)
+        P = fem.Point
+        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+        # (1) one system: the first spatial system of the problem, from a zero start
+        spec = _problem(mesh)
+        p = PGDProblem(**spec)
+        V = p.V[0]
+        Fs = p.get_Fsinit(p.V, p.bc, None)
+        u, v = fem.TrialFunction(V), fem.TestFunction(V)
+        a = spec["lhs_fct"](u, v, Fs, p.meshes, p.dom, p.param, spec["probs"][0], 0)
+        l = spec["rhs_fct"](u, v, Fs, p.meshes, p.dom, p.param, spec["load"], [[] for _ in Fs], spec["probs"][0], 0, 0)
+        A, b = fem.assemble(a), fem.assemble(l)
+        fem._apply_bcs_system(A, b, p.bc[0])
+        x = fem.Vector(V)
+        op = A.op()
+        got = comm.pcg_mg(mesh, op, b, x, 1e-10, 0.0, 200)
+        assert got is not None, "the slab V-cycle must apply to the reaction-diffusion operator on the box"
+        xs = pdist.gather_owned(comm, mesh, x.host())
+        bs = pdist.gather_owned(comm, mesh, b.host())
+        coef = [fem.assemble(Fs[1] * Fs[1] * fem.dx(p.meshes[1])), fem.assemble(p.param["mu"] * Fs[1] * Fs[1] * fem.dx(p.meshes[1]))]
+        # (2) the whole PGD run with settings["preconditioner"] = "amg" on the sharded mesh
+        fem.clear_caches()
+        s0 = dict(comm.stats)
+        p2 = PGDProblem(**_problem(mesh))
+        p2.solve_PGD(_problem="linear", settings={"linear_solver": "cg", "preconditioner": "amg", "relative_tolerance": 1e-10})
+        modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values()) for f in p2.PGD_func[0]]
+        if rank == 0:
+            q.put(dict(one=dict(iters=got[0], rel=got[1], x=xs, b=bs, coef=coef), num_fp_it=p2.num_fp_it, amplitude=p2.amplitude,
+                       modes_x=modes_x, mg_solves=comm.stats.get("sharded_mg_solves", 0) - s0.get("sharded_mg_solves", 0),
+                       pcg_iterations=fem.STATS["pcg_iterations"]))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape", [(2, (9, 8, 10)), (3, (8, 9, 11)), (4, (9, 9, 15))])
+def test_sharded_v_cycle_makes_the_iterates_of_the_unsharded_one(world, shape):
+    """settings["preconditioner"] = "amg" on a row-sharded mesh (VERDICT r03 "missing 2"): level 0 of the V-cycle on the z-slabs,
+    levels >= 1 replicated behind one all-reduce.  (1) One system: the SAME iteration count and the same solution as the
+    unsharded multigrid PCG of oracle/mg_numpy.py (the restatement the GPU's pgd_pcg_solve is tested against); (2) the PGD run:
+    pass counts, amplitudes and modes of the unsharded Jacobi run, every spatial solve preconditioned by the cycle."""
+    from oracle import fem_numpy as F, mg_numpy as MG
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mg_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    out = q.get(timeout=300)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    # (1) the unsharded restatement on the global lattice
+    nx, ny, nz = (s + 1 for s in shape)
+    c, e = F.box_mesh((0, 0, 0), (1, 1, 1), *shape)
+    A = (out["one"]["coef"][0] * F.assemble_atom(c, e, F.STIFF) + out["one"]["coef"][1] * F.assemble_atom(c, e, F.MASS)).tocsr()
+    i0 = (nz // 2) * nx * ny + (ny // 2) * nx + nx // 2
+    cst = np.array([A[i0, i0 + dx + nx * dy + nx * ny * dz] for dx, dy, dz in MG.OFFS])
+    b3 = out["one"]["b"].reshape(nz, ny, nx)
+    xr, itr, relr = MG.pcg((nz, ny, nx), cst, b3, rtol=1e-10, maxit=200)
+    assert out["one"]["iters"] == itr and 10 <= itr <= 30, (out["one"]["iters"], itr)
+    assert out["one"]["rel"] <= 1e-10
+    assert np.abs(out["one"]["x"].reshape(nz, ny, nx) - xr).max() <= 1e-11 * np.abs(xr).max()
+    # (2) the run against the unsharded Jacobi run of the same host code
+    from oracle.backend_numpy import NumpyBackend
+    from pgdrome_amd import fem
+    from pgdrome_amd.solver import PGDProblem
+    old = fem._backend
+    try:
+        fem.set_backend(NumpyBackend())
+        fem.clear_caches()
+        P = fem.Point
+        ref = PGDProblem(**_problem(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape)))
+        ref.solve_PGD(_problem="linear")
+        ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
+    finally:
+        fem.set_backend(old) if old is not None else None
+        fem.clear_caches()
+    assert out["num_fp_it"] == ref.num_fp_it and out["mg_solves"] == sum(ref.num_fp_it)
+    np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
+    for m in range(len(ref_x)):
+        assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])

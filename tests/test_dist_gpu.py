@@ -468,3 +468,72 @@ def test_a_stream_without_progress_runs_into_the_deadline():
     msg, dt = _collect([pr], q, 1, 300)[0]
     assert "code -7" in msg and "no progress" in msg and "rank 0/1" in msg and "last collective issued" in msg, msg
     assert 0.9 < dt < 30, dt
+
+
+def _shared_gpu_mg_worker(rank, world, port, shape, q):
+    """Ranks sharing GPU 0, settings["preconditioner"] = "amg" on the sharded mesh: the slab pieces of the V-cycle are the HIP
+    kernels (pgd_mg_slab_*), halos and the level-1 all-reduce go through gloo (staged through the host)."""
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pgdrome_amd import dist as pdist, fem, problems
+        from pgdrome_amd.hip_backend import HipBackend
+        from pgdrome_amd.solver import PGDProblem
+        torch.cuda.set_device(0)
+        tstream = torch.cuda.Stream(device=0)
+        torch.cuda.set_stream(tstream)
+        be = fem.set_backend(HipBackend(0, tstream.cuda_stream))
+        comm = pdist.TorchComm(dist, be, in_library=False)
+        P = fem.Point
+        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+        p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=3))
+        i0 = fem.STATS["pcg_iterations"]
+        p.solve_PGD(_problem="linear", settings={"linear_solver": "cg", "preconditioner": "amg", "relative_tolerance": 1e-10})
+        modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values()) for f in p.PGD_func[0]]
+        if rank == 0:
+            q.put(dict(num_fp_it=p.num_fp_it, amplitude=p.amplitude, modes_x=modes_x, stats=dict(comm.stats),
+                       pcg_iterations=fem.STATS["pcg_iterations"] - i0, mg_solves=fem.STATS.get("mg_solves", 0)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,shape", [(2, (40, 36, 45)), (3, (31, 33, 38))])
+def test_sharded_v_cycle_on_one_gpu(world, shape):
+    """The V-cycle on a row-sharded lattice with the HIP kernels and real exchanges (`world` processes share GPU 0): the PGD run
+    under settings["preconditioner"] = "amg" reproduces the UNSHARDED run under the same setting - pass counts, amplitudes,
+    modes to 1e-7 - with the same number of PCG iterations (+-1 per solve: the dots are grouped by rank), every spatial solve
+    preconditioned by the cycle."""
+    import torch.multiprocessing as mp
+    from pgdrome_amd import fem, problems
+    from pgdrome_amd.hip_backend import HipBackend
+    from pgdrome_amd.solver import PGDProblem
+    old = fem._backend
+    be = fem.set_backend(HipBackend(0))
+    fem.clear_caches()
+    try:
+        P = fem.Point
+        ref = PGDProblem(**problems.reaction_diffusion(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape), 17, PGD_nmax=3))
+        i0, m0 = fem.STATS["pcg_iterations"], be.ctx.mg_stats()
+        ref.solve_PGD(_problem="linear", settings={"linear_solver": "cg", "preconditioner": "amg", "relative_tolerance": 1e-10})
+        its_ref, m1 = fem.STATS["pcg_iterations"] - i0, be.ctx.mg_stats()
+        ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
+        solves = sum(int(v) for v in ref.num_fp_it)
+        assert m1["solves"] - m0["solves"] == solves and m1["fallbacks"] == m0["fallbacks"]
+    finally:
+        fem.set_backend(old)
+        fem.clear_caches()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_gpu_mg_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    out = _collect(procs, q, 1, 300)[0]
+    assert out["num_fp_it"] == ref.num_fp_it and out["stats"].get("sharded_mg_solves", 0) == solves
+    assert abs(out["pcg_iterations"] - its_ref) <= solves, (out["pcg_iterations"], its_ref)
+    assert out["pcg_iterations"] <= 25 * solves
+    np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
+    for m in range(ref.PGD_modes):
+        assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
