@@ -49,6 +49,9 @@ def parse():
     ap.add_argument("--spectral-start", type=int, default=16,
                     help='settings["spectral_start"]: Ritz vectors in the second level of the Galerkin start of the spatial solves '
                          "(pgdrome_amd/spectral.py; harvested once, outside the timed region, reported in config.spectral_start); 0: off")
+    ap.add_argument("--preconditioner", default="jacobi",
+                    help='settings["preconditioner"] of the timed run: "jacobi" (the metric\'s Jacobi-PCG) or "amg" (the V-cycle of pgd_mg.hip; '
+                         "on a sharded run the slab form of it, dist.pcg_mg) - a side measurement, never the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-reduction", action="store_true",
                     help="with --dist-driver: force the Chronopoulos-Gear recurrence that N > 1 uses")
@@ -204,7 +207,7 @@ def main():
         space = fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), n - 1, n - 1, n - 1)
     spec = problems.reaction_diffusion(space, args.n_mu, PGD_nmax=50, PGD_tol=1e-12)
     prob = PGDProblem(**spec)
-    settings = {"linear_solver": "cg", "preconditioner": "jacobi", "relative_tolerance": args.rtol}
+    settings = {"linear_solver": "cg", "preconditioner": args.preconditioner, "relative_tolerance": args.rtol}
     # one-time work outside the timed region: mesh upload + topology, the four atoms
     space.atom(fem.STIFF)
     space.atom(fem.MASS)
@@ -213,7 +216,7 @@ def main():
     # ... and, on request, the spectral start space of the spatial solves: Ritz vectors of the first spatial operator, harvested
     # once per space and Dirichlet set (one-time work like the atoms; its seconds are reported on their own)
     spectral_info = None
-    if args.spectral_start > 0 and not sharded:
+    if args.spectral_start > 0 and not sharded and args.preconditioner == "jacobi":
         from pgdrome_amd import spectral
         settings["spectral_start"] = args.spectral_start
         t_h = time.time()
@@ -347,8 +350,10 @@ def main():
         "config": {"workload": "cfg4: 3D-space %d^3 P1 (BoxMesh, 6 tets/cube) x 1D-parameter %d P1, "
                                "-Laplace(u)+mu*u=1, Jacobi-PCG rtol %g" % (n, args.n_mu, args.rtol),
                    "spatial_dofs": n_sp, "nnz": nnz, "parallelism": "z-slab row sharding x%d" % world if sharded else "single GPU",
+                   "preconditioner": args.preconditioner,
                    "sharded_pcg_driver": (("in-library loop, RCCL" if comm.in_library == "rccl" else
                                            "python loop, torch.distributed") if sharded else None),
+                   "sharded_v_cycle_solves": (comm.stats.get("sharded_mg_solves", 0) if sharded else None),
                    "halo_overlap": (bool(be.comm_overlap(-2)) if sharded and getattr(comm, "in_library", None) == "rccl" else (False if sharded else None)),
                    "halo_overlap_available": (bool(getattr(comm, "halo_overlap", False)) if sharded else None),
                    "rccl_world": (be.comm_info()["world"] if sharded and comm.in_library == "rccl" else
@@ -396,6 +401,7 @@ def main():
             out["config"]["without_spectral_start"] = plain_start_path(be, spec, dict(settings, spectral_start=0), W, K)
     if rank == 0 and world == 1 and not sharded and not args.no_general_paths and n == 256:
         out["config"]["rank_with_ghost_planes"] = ghost_rank_rehearsal()
+        out["config"]["sharded_v_cycle_one_rank"] = sharded_v_cycle_rank(args)
     pmc = pmc_traffic(own, upd_bytes) if rank == 0 and world == 1 and n == 256 and sym["nx"] and not args.no_pmc else {}
     out["roofline"].update(pmc.get("product", {}))
     if upd_n and upd_avg > avg:
@@ -461,6 +467,32 @@ def ghost_rank_rehearsal():
                        "send / receive inside the iteration loop; microseconds per iteration over whole solves (setup included), best of two; "
                        "no wire, no other ranks - a lower bound of the time a rank of an 8-GPU run needs per iteration")
         return res
+    except Exception:      # noqa: BLE001 - a side section must not take the line with it
+        return None
+
+
+def sharded_v_cycle_rank(args):
+    """settings["preconditioner"] = "amg" through the SHARDED solver path (dist.pcg_mg: level 0 of the V-cycle on the rank's slab,
+    levels >= 1 replicated behind an all-reduce, the PCG driven from the host over torch.distributed) with ONE rank, in a child
+    process (a process group of its own): what a rank of an N-GPU run executes per iteration but the wire, the other ranks and the
+    ghost planes.  None if the child could not run."""
+    import subprocess
+    try:
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID", "PGD_TUNE"):
+            env.pop(k, None)
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dist-driver", "--python-driver", "--preconditioner", "amg",
+                            "--steps", "6", "--warmup", "2", "--n", str(args.n), "--n-mu", str(args.n_mu), "--no-cpu-baseline", "--no-pmc",
+                            "--no-csr-section", "--no-general-paths"], capture_output=True, timeout=300, env=env, cwd=ROOT)
+        line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        if r.returncode != 0 or not line:
+            return None
+        d = json.loads(line[-1])
+        c = d["config"]
+        return {"passes_per_s": d["value"], "ms_per_pass": d["ms_per_step"], "pcg_iterations_per_pass": c["pcg_iterations_per_step"],
+                "us_per_pcg_iteration": c["us_per_pcg_iteration"], "solves_preconditioned_by_the_slab_v_cycle": c["sharded_v_cycle_solves"],
+                "note": "one rank, no ghost planes; level 0 in the plain slab kernels (not yet the stencil march), the product from the CSR "
+                        "values; compare config.multigrid_preconditioner (the unsharded in-library loop)"}
     except Exception:      # noqa: BLE001 - a side section must not take the line with it
         return None
 
