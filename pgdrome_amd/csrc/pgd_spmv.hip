@@ -872,6 +872,184 @@ __global__ __launch_bounds__(256) void k_spmv_dia_march2(DiaArgs A) {
     }
 }
 
+// The same march with the r03 techniques of the stencil kernel (round 4, VERDICT r03 "next" #4): every slot value, every x cell
+// and every y row goes through a BUFFER descriptor with a 32-bit byte offset per lane that never changes during the march - the
+// plane is carried by the scalar offset (slot s of plane z: 8 (s n + P z)) or by a per-plane descriptor built from scalars - and
+// a lane that must not read (outside the grid, no neighbour on that side, not a border lane) carries an offset beyond the buffer:
+// the range check returns 0.0 / drops the store, so there are no exec masks, no selects and no 64-bit address arithmetic in the
+// step.  The registers that frees hold the NEXT plane's slot values: the loads of plane z + 1 are issued before plane z is
+// multiplied (two register sets that swap roles, the loop is unrolled by two), so a wave always has a plane of slot loads in
+// flight behind the one it is consuming.  Same values, same 15 fused multiply-adds per row in the same order: bit-identical to
+// k_spmv_dia_march2.  Needs 64 n < 2^31 (one descriptor over the eight slot arrays) and P < 2^27.
+typedef int dm_v2i __attribute__((ext_vector_type(2)));
+struct Dm3Plane { double u0[8], u1[8], t1a, t2a, t3a, t1b, t3b, g5a, g5b, g6a, g7a, g7b; };
+
+template <bool DOT, bool STORE>
+__global__ __launch_bounds__(256) void k_spmv_dia_march3(DiaArgs A) {
+    constexpr int NT = 256, PY = 8, HY = PY + 2, SLICE = DM_HX * HY;        // 660 cells per plane
+    constexpr int OOB = (int)0x80000000;                                    // byte offset beyond every buffer of the kernel
+    __shared__ double s_x[3 * SLICE];
+    __shared__ double s_lo[2 * 4 * NT];                     // [row of the pair][slot 4..7][thread]
+    __shared__ double s_red[4];
+    if (A.flags && A.flags[0]) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int b = xcd_remap(blockIdx.x, gridDim.x);
+    const int per_chunk = A.tiles_x * A.tiles_y;
+    const int chunk = b / per_chunk, tile = b - chunk * per_chunk;
+    const int ty = tile / A.tiles_x, tx = tile - ty * A.tiles_x;
+    const int x0 = tx * 64, y0 = ty * PY;
+    const int x = x0 + lane, ya = y0 + 2 * wv;
+    const bool live0 = x < A.nx && ya < A.ny, live1 = x < A.nx && ya + 1 < A.ny;
+    const bool inx0 = live0 && x > 0, inx1 = live1 && x > 0;
+    const bool iny0 = live0 && ya > 0;
+    const bool ldx = lane > 0, ldy = wv > 0;
+    const int nx = A.nx, P = A.nx * A.ny;
+    const int P8 = 8 * P, n8 = (int)(8 * A.n);
+    const int base0 = x + nx * ya, base1 = base0 + nx;
+    const int centre = (2 * wv + 1) * DM_HX + lane + 1;
+    const int za = A.z0 + chunk * A.zchunk, zb = min(A.z1, za + A.zchunk);
+    // lane offsets, fixed for the whole march
+    const int o0 = live0 ? 8 * base0 : OOB, o1 = live1 ? 8 * base1 : OOB;
+    const int o1a = inx0 ? 8 * (base0 - 1) : OOB, o2a = iny0 ? 8 * (base0 - nx) : OOB, o3a = (inx0 && iny0) ? 8 * (base0 - nx - 1) : OOB;
+    const int o1b = inx1 ? 8 * (base1 - 1) : OOB, o3b = inx1 ? 8 * (base1 - nx - 1) : OOB;
+    // plane-below couplings of the patch's low-x lane / low-y wave belong to the neighbouring patch: only those lanes load
+    const int q5a = (inx0 && !ldx) ? 8 * (base0 - 1) : OOB, q5b = (inx1 && !ldx) ? 8 * (base1 - 1) : OOB;
+    const int q6a = (iny0 && !ldy) ? 8 * (base0 - nx) : OOB;
+    const int q7a = (inx0 && iny0 && !(ldx && ldy)) ? 8 * (base0 - nx - 1) : OOB, q7b = (inx1 && !ldx) ? 8 * (base1 - nx - 1) : OOB;
+    int gv[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+        const int i = tid + q * NT;
+        const int ly = i / DM_HX, lx = i - ly * DM_HX;
+        const int gx = x0 - 1 + lx, gy = y0 - 1 + ly;
+        gv[q] = (i < SLICE && gx >= 0 && gx < A.nx && gy >= 0 && gy < A.ny) ? 8 * (gx + nx * gy) : OOB;
+    }
+    const auto rsU = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.uvals), 0, 8 * n8, 0x00020000);
+    auto ldu = [&](int voff, int soff) { return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsU, voff, soff, 0)); };
+    auto fetch = [&](int z, double (&v)[3]) {
+        const bool zok = z >= 0 && z < A.nz;
+        const auto r = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(A.x + (int64_t)P * (zok ? z : 0)), 0, zok ? P8 : 0, 0x00020000);
+#pragma unroll
+        for (int q = 0; q < 3; ++q) v[q] = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, gv[q], 0, 0));
+    };
+    auto put = [&](int z, const double (&v)[3]) {
+        const int sl = ((z % 3) + 3) % 3;
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (tid + q * NT < SLICE) s_x[sl * SLICE + tid + q * NT] = v[q];
+    };
+    // all vector-memory reads of plane z (and, for its border lanes, of the couplings up from plane z - 1)
+    auto load_plane = [&](int z, Dm3Plane &R) {
+        const int zo = P8 * z;
+        R.u0[0] = R.u1[0] = 1.0;
+        if (!A.unit_diag) { R.u0[0] = ldu(o0, zo); R.u1[0] = ldu(o1, zo); }
+#pragma unroll
+        for (int s = 1; s < 8; ++s) { R.u0[s] = ldu(o0, s * n8 + zo); R.u1[s] = ldu(o1, s * n8 + zo); }
+        R.t1a = ldu(o1a, 1 * n8 + zo); R.t2a = ldu(o2a, 2 * n8 + zo); R.t3a = ldu(o3a, 3 * n8 + zo);
+        R.t1b = ldu(o1b, 1 * n8 + zo); R.t3b = ldu(o3b, 3 * n8 + zo);
+        R.g5a = R.g5b = R.g6a = R.g7a = R.g7b = 0.0;
+        if (z > 0) {                                        // uniform
+            const int zm = zo - P8;
+            R.g5a = ldu(q5a, 5 * n8 + zm); R.g5b = ldu(q5b, 5 * n8 + zm); R.g6a = ldu(q6a, 6 * n8 + zm);
+            R.g7a = ldu(q7a, 7 * n8 + zm); R.g7b = ldu(q7b, 7 * n8 + zm);
+        }
+    };
+    double dot = 0.0, dot2 = 0.0;
+    Dm3Plane Ra, Rb;
+    if (za < zb) {
+        double v[3];
+        for (int z = za - 1; z <= za + 1; ++z) { fetch(z, v); put(z, v); }
+        if (za > 0) {
+            const int zm = P8 * (za - 1);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                s_lo[s * NT + tid] = ldu(o0, (4 + s) * n8 + zm);
+                s_lo[(4 + s) * NT + tid] = ldu(o1, (4 + s) * n8 + zm);
+            }
+        }
+        load_plane(za, Ra);
+    }
+    __syncthreads();
+    auto step = [&](int z, Dm3Plane &C, Dm3Plane &N) {
+        double vn[3] = {0.0, 0.0, 0.0};
+        if (z + 2 <= zb) fetch(z + 2, vn);                  // plane zb + 1 is never read
+        if (z + 1 < zb) load_plane(z + 1, N);               // the next plane's slot values travel while this one is multiplied
+        double a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0, b4 = 0.0, b5 = 0.0, b6 = 0.0, b7 = 0.0;
+        if (z > 0) {                                        // uniform
+            a4 = live0 ? s_lo[tid] : 0.0;
+            b4 = live1 ? s_lo[4 * NT + tid] : 0.0;
+            if (inx0) a5 = ldx ? s_lo[NT + tid - 1] : C.g5a;
+            if (inx1) b5 = ldx ? s_lo[5 * NT + tid - 1] : C.g5b;
+            if (iny0) a6 = ldy ? s_lo[6 * NT + tid - 64] : C.g6a;
+            if (live1) b6 = s_lo[2 * NT + tid];
+            if (inx0 && iny0) a7 = (ldx && ldy) ? s_lo[7 * NT + tid - 65] : C.g7a;
+            if (inx1) b7 = ldx ? s_lo[3 * NT + tid - 1] : C.g7b;
+        }
+        const double a1 = C.t1a, a2 = C.t2a, a3 = C.t3a;    // (0.0 where there is no such neighbour: the range check)
+        const double b1 = C.t1b, b2 = live1 ? C.u0[2] : 0.0, b3 = C.t3b;
+        const int sl0 = ((z - 1) % 3 + 3) % 3;
+        const double *xm = s_x + sl0 * SLICE + centre;
+        const double *xc = s_x + ((sl0 + 1) % 3) * SLICE + centre;
+        const double *xp = s_x + ((sl0 + 2) % 3) * SLICE + centre;
+        const double xa = xc[0], xb = xc[DM_HX];
+        double acc0 = a7 * xm[-DM_HX - 1];
+        acc0 = fma(a6, xm[-DM_HX], acc0);
+        acc0 = fma(a5, xm[-1], acc0);
+        acc0 = fma(a4, xm[0], acc0);
+        acc0 = fma(a3, xc[-DM_HX - 1], acc0);
+        acc0 = fma(a2, xc[-DM_HX], acc0);
+        acc0 = fma(a1, xc[-1], acc0);
+        acc0 = fma(C.u0[0], xa, acc0);
+        acc0 = fma(C.u0[1], xc[1], acc0);
+        acc0 = fma(C.u0[2], xc[DM_HX], acc0);
+        acc0 = fma(C.u0[3], xc[DM_HX + 1], acc0);
+        acc0 = fma(C.u0[4], xp[0], acc0);
+        acc0 = fma(C.u0[5], xp[1], acc0);
+        acc0 = fma(C.u0[6], xp[DM_HX], acc0);
+        acc0 = fma(C.u0[7], xp[DM_HX + 1], acc0);
+        double acc1 = b7 * xm[-1];
+        acc1 = fma(b6, xm[0], acc1);
+        acc1 = fma(b5, xm[DM_HX - 1], acc1);
+        acc1 = fma(b4, xm[DM_HX], acc1);
+        acc1 = fma(b3, xc[-1], acc1);
+        acc1 = fma(b2, xc[0], acc1);
+        acc1 = fma(b1, xc[DM_HX - 1], acc1);
+        acc1 = fma(C.u1[0], xb, acc1);
+        acc1 = fma(C.u1[1], xc[DM_HX + 1], acc1);
+        acc1 = fma(C.u1[2], xc[2 * DM_HX], acc1);
+        acc1 = fma(C.u1[3], xc[2 * DM_HX + 1], acc1);
+        acc1 = fma(C.u1[4], xp[DM_HX], acc1);
+        acc1 = fma(C.u1[5], xp[DM_HX + 1], acc1);
+        acc1 = fma(C.u1[6], xp[2 * DM_HX], acc1);
+        acc1 = fma(C.u1[7], xp[2 * DM_HX + 1], acc1);
+        if (STORE) {
+            const auto ry = __builtin_amdgcn_make_buffer_rsrc(A.y + (int64_t)P * z, 0, P8, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(dm_v2i, acc0), ry, o0, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(dm_v2i, acc1), ry, o1, 0, 0);
+        }
+        if (DOT && live0) { dot = fma(acc0, xa, dot); dot2 = fma(acc0, acc0, dot2); }
+        if (DOT && live1) { dot = fma(acc1, xb, dot); dot2 = fma(acc1, acc1, dot2); }
+        lds_barrier();
+        put(z + 2, vn);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) { s_lo[s * NT + tid] = C.u0[4 + s]; s_lo[(4 + s) * NT + tid] = C.u1[4 + s]; }
+        lds_barrier();
+    };
+    for (int z = za; z < zb; z += 2) {
+        step(z, Ra, Rb);
+        if (z + 1 < zb) step(z + 1, Rb, Ra);
+    }
+    if (DOT) {
+        for (int pass = 0; pass < (A.qq ? 2 : 1); ++pass) {
+            const double sum = wave_sum(pass ? dot2 : dot);
+            __syncthreads();
+            if (lane == 0) s_red[wv] = sum;
+            __syncthreads();
+            if (tid == 0) A.partials[A.qq ? 2 * b + pass : b] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        }
+    }
+}
+
 // ------------------------------------------------------------------ diagonal form with a row-class dictionary
 // On a uniform grid with piecewise-constant coefficients the rows of the (scaled) operator repeat a few 8-tuples of slot
 // values: every interior row carries the same one, the rows next to a face, an edge, a corner or a Dirichlet row a few dozen
@@ -2432,7 +2610,11 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
                 PGD_LAUNCH_CHECK(c);
                 return PGD_OK;
             }
-            if (c->spmv_variant == 0) {
+            if (c->spmv_variant == 0 && c->dia_march3 && (int64_t)64 * D.n < ((int64_t)1 << 31) && plane < ((int64_t)1 << 27)) {
+                if (dot && store) k_spmv_dia_march3<true, true><<<wgs, 256, 0, c->stream>>>(D);
+                else if (dot) k_spmv_dia_march3<true, false><<<wgs, 256, 0, c->stream>>>(D);
+                else k_spmv_dia_march3<false, true><<<wgs, 256, 0, c->stream>>>(D);
+            } else if (c->spmv_variant == 0) {
                 if (dot && store) k_spmv_dia_march2<true, true><<<wgs, 256, 0, c->stream>>>(D);
                 else if (dot) k_spmv_dia_march2<true, false><<<wgs, 256, 0, c->stream>>>(D);
                 else k_spmv_dia_march2<false, true><<<wgs, 256, 0, c->stream>>>(D);
@@ -2701,6 +2883,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_COMM_SELF_PERIODIC && value >= 0 && value <= 1) { c->comm.self_periodic = value != 0; return PGD_OK; }
     if (knob == PGD_TUNE_HALO_OVERLAP_MIN_ROWS && value >= 0) { c->comm.overlap_min_rows = value; return PGD_OK; }
     if (knob == PGD_TUNE_SHARD_ONE_MARCH && value >= 0 && value <= 1) { c->shard_one_march = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_DIA_MARCH3 && value >= 0 && value <= 1) { c->dia_march3 = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_MG_CHUNK && value >= 2 && value <= 16 && value % 2 == 0) { c->mg_chunk = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_MG_MARCH_MIN && value >= 0 && value <= 1 << 20) { c->mg_march_min = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);

@@ -518,14 +518,17 @@ def test_products_agree_at_bench_size(ctx, npts):
             ys[name] = (ctx.vec_download(yv), ctx.slots_download(30, 1)[0])
         ctx.tune(3, 1)
         assert ctx.op_symmetrize(op) is True
-        for name, knobs in (("dia_march", [(6, 8)]), ("dia_rows", [(6, 0)])):
+        # (dia_march: k_spmv_dia_march3 - buffer addressing, the next plane's slots prefetched; dia_march2: the r02 form of it)
+        for name, knobs in (("dia_march", [(6, 8), (47, 1)]), ("dia_march2", [(6, 8), (47, 0)]), ("dia_rows", [(6, 0)])):
             for k, v in knobs:
                 ctx.tune(k, v)
             c0 = ctx.kernel_counts()
             ctx.vec_fill(yv, -1.0)
             ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
-            assert ctx.kernel_counts()[name] == c0[name] + 1
+            counter = "dia_march" if name == "dia_march2" else name
+            assert ctx.kernel_counts()[counter] == c0[counter] + 1
             ys[name] = (ctx.vec_download(yv), ctx.slots_download(30, 1)[0])
+        ctx.tune(47, 1)
         # ... and the march on the row-class dictionary (one code byte per row), several chunk lengths
         assert 1 <= ctx.op_classify(op) <= 64
         ctx.tune(6, 8)

@@ -14,10 +14,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pgdrome_amd import _lib, fem
 from pgdrome_amd import sizes as psizes
 
-MODES = [  # name, sym, dict, zchunk knob, zchunk force, variant
-    ("csr", 0, 0, 8, 0, 0), ("csr_dict16", 0, 1, 8, 0, 0), ("dia_rows", 1, 1, 0, 0, 0),
-    ("march2 adaptive", 1, 1, 8, 0, 0), ("march<8> adaptive", 1, 1, 8, 0, 1), ("march<4> adaptive", 1, 1, 8, 0, 2),
-    ("march2 z4", 1, 1, 8, 4, 0), ("march2 z16", 1, 1, 16, 16, 0),
+MODES = [  # name, sym, dict, zchunk knob, zchunk force, variant, k_spmv_dia_march3 (knob 47)
+    ("csr", 0, 0, 8, 0, 0, 0), ("csr_dict16", 0, 1, 8, 0, 0, 0), ("dia_rows", 1, 1, 0, 0, 0, 0),
+    ("march2 adaptive", 1, 1, 8, 0, 0, 0), ("march3 adaptive", 1, 1, 8, 0, 0, 1),
+    ("march<8> adaptive", 1, 1, 8, 0, 1, 0), ("march<4> adaptive", 1, 1, 8, 0, 2, 0),
+    ("march2 z4", 1, 1, 8, 4, 0, 0), ("march2 z16", 1, 1, 16, 16, 0, 0), ("march3 z16", 1, 1, 16, 16, 0, 1), ("march3 z32", 1, 1, 32, 32, 0, 1),
+    ("march3 z64", 1, 1, 64, 64, 0, 1),
 ]
 
 
@@ -40,8 +42,8 @@ def main():
         print(f"n={n}^3 nv={nv} nnz={nnz}: symmetric storage usable: {used}", flush=True)
         ctx.flags_reset()
         for rnd in range(2):
-            for name, sym, dct, zk, zf, var in MODES:
-                ctx.tune(3, sym); ctx.tune(2, dct); ctx.tune(6, zk); ctx.tune(7, zf); ctx.tune(13, var)
+            for name, sym, dct, zk, zf, var, m3 in MODES:
+                ctx.tune(3, sym); ctx.tune(2, dct); ctx.tune(6, zk); ctx.tune(7, zf); ctx.tune(13, var); ctx.tune(47, m3)
                 for _ in range(3):
                     ctx.spmv_dot_slot(op, x, y, x, 0, nv, 30)
                 reps = 40
@@ -53,7 +55,7 @@ def main():
                 print(f"  round {rnd} {name:20s}: {t*1e6:7.1f} us per product+reduce; CSR formula {alg/t/1e9:6.0f} GB/s; own minimum "
                       f"{mine/1e9:.3f} GB -> {mine/t/1e9:5.0f} GB/s = {mine/t/8e12*100:4.1f}% of 8 TB/s; p.q = {ctx.slots_download(30, 1)[0]:.12e}",
                       flush=True)
-        ctx.tune(3, 1); ctx.tune(2, 1); ctx.tune(6, 8); ctx.tune(7, 0); ctx.tune(13, 0)
+        ctx.tune(3, 1); ctx.tune(2, 1); ctx.tune(6, 8); ctx.tune(7, 0); ctx.tune(13, 0); ctx.tune(47, 1)
         for v in (x, y):
             ctx.vec_free(v)
         for a in (ak, am, op):
