@@ -321,7 +321,9 @@ int pgd_vec_multidot_pair(pgd_handle ctx, pgd_handle x0, pgd_handle x1, const pg
 enum {
     PGD_TUNE_DIA_MARCH3 = 47, /* 1: the plain z-march of the diagonal form (variant 0: no row classes - variable coefficients, graded meshes) runs
                                * in k_spmv_dia_march3: buffer addressing with lane offsets that never change, the next plane's slot values
-                               * loaded while the current plane is multiplied; bit-identical to k_spmv_dia_march2 (0).                     */
+                               * loaded while the current plane is multiplied; bit-identical to k_spmv_dia_march2 (0, the default: half the vector
+                               * instructions, no faster - the march runs at 0.86-0.92 of what the memory system gives ANY kernel for its nine
+                               * streams, profiles/r04_dia_march_counters.txt).                                                            */
     PGD_TUNE_SHARD_ONE_MARCH = 46, /* 1 (default): where the halo exchange of pgd_pcg_solve_sharded runs in stream order and the rank's operator is one
                                 stencil whose ghost planes hold the same eliminated nodes as its own (checked per solve), the product is ONE march
                                 over all owned planes with the ghost planes staged as data; 0: interior march + the boundary planes in row

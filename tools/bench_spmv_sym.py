@@ -55,7 +55,7 @@ def main():
                 print(f"  round {rnd} {name:20s}: {t*1e6:7.1f} us per product+reduce; CSR formula {alg/t/1e9:6.0f} GB/s; own minimum "
                       f"{mine/1e9:.3f} GB -> {mine/t/1e9:5.0f} GB/s = {mine/t/8e12*100:4.1f}% of 8 TB/s; p.q = {ctx.slots_download(30, 1)[0]:.12e}",
                       flush=True)
-        ctx.tune(3, 1); ctx.tune(2, 1); ctx.tune(6, 8); ctx.tune(7, 0); ctx.tune(13, 0); ctx.tune(47, 1)
+        ctx.tune(3, 1); ctx.tune(2, 1); ctx.tune(6, 8); ctx.tune(7, 0); ctx.tune(13, 0); ctx.tune(47, 0)
         for v in (x, y):
             ctx.vec_free(v)
         for a in (ak, am, op):

@@ -16,6 +16,9 @@ mode = sys.argv[2] if len(sys.argv) > 2 else "grid"
 zchunk = int(sys.argv[3]) if len(sys.argv) > 3 else 0      # 0: the adaptive march length the solves use
 variant = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 ctx = _lib.Context(0)
+for item in filter(None, os.environ.get("PGD_TUNE", "").split(",")):       # e.g. PGD_TUNE=19=0,47=0: the plain march, r02 form
+    knob, value = (int(t) for t in item.split("="))
+    ctx.tune(knob, value)
 coords, cells = fem.box_mesh_arrays((0, 0, 0), (1, 1, 1), n - 1, n - 1, n - 1)
 mesh = ctx.mesh_upload(coords, cells)
 # the bench's operator: homogeneous Dirichlet conditions on the whole hull (PMC_NATURAL=1: natural boundaries, 27 row classes, no stencil form)
