@@ -2897,6 +2897,15 @@ int pgd_spmv(pgd_handle h, pgd_handle ah, pgd_handle xh, pgd_handle yh, int64_t 
     if (!a || !m || !x || !y || x->n != m->nv || y->n != m->nv || x == y)
         return fail(c, PGD_ERR_INVALID, "spmv: invalid handles, size mismatch or x aliases y");
     if (atom_fast_form(c, m, a, r0, r1)) return launch_spmv_op(c, m, a, x->d, y->d, nullptr, r0, r1, false, true, nullptr, nullptr);
+    // an OPERATOR that holds its (unscaled) diagonal form - pgd_op_combine made it, nothing has formed its CSR values yet: the
+    // product from that form (bit-identical y) instead of 8 nnz (T + 1) bytes of forming the CSR values first (r04: the residual
+    // of the spectral start, the host-driven sharded loops)
+    if (c->spmv_sym && c->atom_fast && m->sym_nx > 0 && !a->immutable && a->uvals && a->uvals_valid && !a->uvals_scaled && !a->st_virtual) {
+        const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
+        const int64_t q0 = r0 < 0 ? 0 : r0, q1 = r1 < 0 ? m->nv : r1;
+        if (q0 >= 0 && q1 <= m->nv && q0 <= q1 && q0 % plane == 0 && q1 % plane == 0)
+            return launch_spmv_op(c, m, a, x->d, y->d, nullptr, q0, q1, false, true, nullptr, nullptr);
+    }
     PGD_TRY(ensure_vals(c, m, a));
     return launch_spmv(c, m, a->vals, x->d, y->d, nullptr, r0, r1, false, true, nullptr, nullptr);
 }

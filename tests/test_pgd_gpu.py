@@ -182,12 +182,14 @@ def _resolve_first_spatial_system(p, spec, hip_backend):
     ctx = hip_backend.ctx
     r = fem.Vector(V)
     try:
-        ctx.tune(2, 0)                                        # plain CSR kernel: column ids streamed, no dictionary
+        ctx.tune(2, 0)                                        # plain CSR kernel: column ids streamed, no dictionary ...
+        ctx.tune(3, 0)                                        # ... and not the operator's diagonal form
         k0 = ctx.kernel_counts()
         hip_backend.spmv(op, x.vector().dev(), r.dev_for_write())
         assert ctx.kernel_counts()["csr"] == k0["csr"] + 1
     finally:
         ctx.tune(2, 1)
+        ctx.tune(3, 1)
     r.touched_dev()
     r.axpy(-1.0, b)
     hip_backend.atom_free(op)
