@@ -353,7 +353,7 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo = -1, int zrange_h
 bool stencil_row_range(const Ctx *c, const Mesh *m, const Csr *a, int64_t r0, int64_t r1);   // ... over the whole planes [r0, r1) of a slab
 bool stencil_whole_grid(const Ctx *c, const Mesh *m, const Csr *a);   // pgd_spmv.hip: a product over all rows would run in k_spmv_stencil_march
 int launch_stencil_pass(Ctx *c, const uint8_t *cls, int ident, const double cst[8], int nx, int ny, int nz, int zm0, int zm1,
-                        const double *x, const double *b, double *y, double w, int epi, bool dot, int *nparts);      // pgd_spmv.hip
+                        const double *x, const double *b, double *y, double w, int epi, bool dot, int *nparts, int z0 = 0, int z1 = -1);      // pgd_spmv.hip
 // pgd_mg.hip: multigrid preconditioner of the scaled stencil operator
 bool mg_prepare(Ctx *c, const Mesh *m, const Csr *a);                          // true: usable for this operator (levels built, buffers there)
 int mg_fix_start(Ctx *c, const Csr *a, const double *b, double *x, int64_t n);    // x = b on the eliminated rows

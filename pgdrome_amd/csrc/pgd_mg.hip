@@ -56,6 +56,9 @@ struct Mg {
     // [0, nzloc) = global planes [zoff, zoff + nzloc), owns [lz0, lz1) of them; level 0 has no buffers of its own
     bool slab = false;
     int zoff = 0, nzloc = 0, lz0 = 0, lz1 = 0;
+    uint8_t *cls_slab = nullptr;                        // code byte per LOCAL node (1 = eliminated: the global hull) for the march kernel
+    size_t cls_slab_bytes = 0;
+    int cls_zoff = -1, cls_nzloc = -1;
 };
 
 struct MgSlab { int zoff, zl0, nzloc; };                // kernels: blockIdx.z = local plane - zl0; global z = local + zoff
@@ -204,6 +207,14 @@ __global__ __launch_bounds__(TPB) void k_mg_codes(MgGrid g, uint8_t *__restrict_
     cls[i] = mg_is_free(g, x, y, z) ? 0 : 1;
 }
 
+__global__ __launch_bounds__(TPB) void k_mg_codes_slab(MgGrid g, int zoff, int nzloc, uint8_t *__restrict__ cls) {
+    const int64_t P = (int64_t)g.nx * g.ny, n = P * nzloc;
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const int zl = (int)(i / P), rem = (int)(i - (int64_t)zl * P), y = rem / g.nx, x = rem - y * g.nx;
+    cls[i] = mg_is_free(g, x, y, zl + zoff) ? 0 : 1;
+}
+
 __global__ __launch_bounds__(TPB) void k_mg_fix_start(const uint8_t *__restrict__ cls, int ident, const double *__restrict__ b,
                                                       double *__restrict__ x, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
@@ -258,6 +269,7 @@ static void mg_free(Mg *&M) {
         if (L.cls) (void)hipFree(L.cls);
     }
     if (M->bad) (void)hipFree(M->bad);
+    if (M->cls_slab) (void)hipFree(M->cls_slab);
     delete M;
     M = nullptr;
 }
@@ -544,11 +556,32 @@ int pgd_mg_slab_setup(pgd_handle h, pgd_handle oh, int nz_global, int z_first, i
         M->have_key = true;
     }
     M->zoff = z_first; M->nzloc = nzloc; M->lz0 = lz0; M->lz1 = lz1;
+    if (M->cls_zoff != z_first || M->cls_nzloc != nzloc || M->cls_slab_bytes < (size_t)m->nv) {
+        if (M->cls_slab && M->cls_slab_bytes < (size_t)m->nv) { (void)hipFree(M->cls_slab); M->cls_slab = nullptr; M->cls_slab_bytes = 0; }
+        if (!M->cls_slab) {
+            void *q = nullptr;
+            PGD_HIP(c, hipMalloc(&q, (size_t)m->nv + PAD_BYTES));
+            M->cls_slab = (uint8_t *)q; M->cls_slab_bytes = (size_t)m->nv;
+        }
+        k_mg_codes_slab<<<(unsigned)((m->nv + TPB - 1) / TPB), TPB, 0, c->stream>>>(M->lv[0].g, z_first, nzloc, M->cls_slab);
+        PGD_LAUNCH_CHECK(c);
+        M->cls_zoff = z_first; M->cls_nzloc = nzloc;
+    }
     const int64_t np = (int64_t)((nx + 63) / 64) * ((ny + 3) / 4) * (lz1 - lz0);
     PGD_TRY(ensure_partials(c, std::max<int64_t>(np + 64, 4 * (int64_t)MAX_VEC_BLOCKS)));
     *n_coarse = M->lv[1].n;
     *applies = 1;
     return PGD_OK;
+}
+
+// level 0 of a slab in the march kernel of the product: wide planes, at least three owned planes; the main run = the local planes
+// that are not hull planes of the global lattice (ghost planes included: they hold the neighbour ranks' data)
+static bool mg_slab_march(const Ctx *c, const Mg *M, int *zm0, int *zm1) {
+    const MgGrid &g = M->lv[0].g;
+    *zm0 = std::max(0, 1 - M->zoff);
+    *zm1 = std::min(M->nzloc, g.nz - 1 - M->zoff);
+    return c->mg_march_min > 0 && g.nx >= c->mg_march_min && g.ny >= c->mg_march_min && M->lz1 - M->lz0 >= 3 && M->cls_slab &&
+           (int64_t)g.nx * g.ny < ((int64_t)1 << 26) && *zm1 > *zm0;
 }
 
 #define PGD_MG_SLAB(M, what)                                                                                           \
@@ -576,6 +609,11 @@ int pgd_mg_slab_down(pgd_handle h, pgd_handle rh, pgd_handle th) {
     const MgLevel &L = M->lv[0];
     const int64_t nloc = (int64_t)L.g.nx * L.g.ny * M->nzloc;
     if (!r || !t || r == t || r->n != nloc || t->n != nloc) return fail(c, PGD_ERR_INVALID, "mg_slab_down: vectors of the local slab expected");
+    int zm0 = 0, zm1 = 0;
+    if (mg_slab_march(c, M, &zm0, &zm1)) {
+        PGD_HIP(c, hipMemsetAsync(c->flags, 0, 8 * sizeof(int), c->stream));
+        return launch_stencil_pass(c, M->cls_slab, 1, L.s.c, L.g.nx, L.g.ny, M->nzloc, zm0, zm1, r->d, nullptr, t->d, L.s.w, 1, false, nullptr, M->lz0, M->lz1);
+    }
     const dim3 grid((unsigned)((L.g.nx + 63) / 64), (unsigned)((L.g.ny + 3) / 4), (unsigned)(M->lz1 - M->lz0));
     k_mg_pass<0, false><<<grid, dim3(256, 1, 1), 0, c->stream>>>(L.g, L.s, MgSlab{M->zoff, M->lz0, M->nzloc}, r->d, nullptr, t->d, nullptr, nullptr);
     PGD_LAUNCH_CHECK(c);
@@ -623,12 +661,22 @@ int pgd_mg_slab_up(pgd_handle h, pgd_handle rh, pgd_handle xh, pgd_handle th, pg
     k_mg_prolong<<<gall, blk, 0, c->stream>>>(L.g, C.g, MgSlab{M->zoff, 0, M->nzloc}, L.s.w, r->d, x1->d, t->d, nullptr);
     // z = t + w (r - A t) on the owned planes, partial sums of r . z
     const dim3 gown(gall.x, gall.y, (unsigned)(M->lz1 - M->lz0));
-    const int np = (int)((int64_t)gown.x * gown.y * gown.z);
-    PGD_TRY(ensure_partials(c, std::max<int64_t>(np + 64, 4 * (int64_t)MAX_VEC_BLOCKS)));
-    k_mg_pass<1, true><<<gown, blk, 0, c->stream>>>(L.g, L.s, MgSlab{M->zoff, M->lz0, M->nzloc}, t->d, r->d, z->d, c->partials, nullptr);
-    PGD_LAUNCH_CHECK(c);
+    int np = (int)((int64_t)gown.x * gown.y * gown.z);
+    int zm0 = 0, zm1 = 0;
+    const double *parts = c->partials;
+    if (mg_slab_march(c, M, &zm0, &zm1)) {
+        PGD_LAUNCH_CHECK(c);
+        PGD_HIP(c, hipMemsetAsync(c->flags, 0, 8 * sizeof(int), c->stream));
+        PGD_TRY(launch_stencil_pass(c, M->cls_slab, 1, L.s.c, L.g.nx, L.g.ny, M->nzloc, zm0, zm1, t->d, r->d, z->d, L.s.w, 2, true, &np, M->lz0, M->lz1));
+        parts = c->partials + c->partials_off;
+    } else {
+        PGD_TRY(ensure_partials(c, std::max<int64_t>(np + 64, 4 * (int64_t)MAX_VEC_BLOCKS)));
+        parts = c->partials;
+        k_mg_pass<1, true><<<gown, blk, 0, c->stream>>>(L.g, L.s, MgSlab{M->zoff, M->lz0, M->nzloc}, t->d, r->d, z->d, c->partials, nullptr);
+        PGD_LAUNCH_CHECK(c);
+    }
     PGD_TRY(ensure_work(c, 6, 256));
-    PGD_TRY(reduce_partials_to(c, c->partials, np, 1, c->work[6]));
+    PGD_TRY(reduce_partials_to(c, parts, np, 1, c->work[6]));
     PGD_HIP(c, hipMemcpyAsync(dot, c->work[6], sizeof(double), hipMemcpyDeviceToHost, c->stream));
     PGD_HIP(c, hipStreamSynchronize(c->stream));
     return PGD_OK;

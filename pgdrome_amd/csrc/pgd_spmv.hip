@@ -1729,19 +1729,22 @@ __global__ __launch_bounds__(TPB) void k_stencil_verify(const uint8_t *__restric
 //   epi 1: y = x - w A x;   epi 2: y = x + w (b - A x), dot: partial sums of b . y (one per workgroup, *nparts of them in c->partials).
 // cls / ident as in the product: code byte per node, `ident` marks eliminated nodes; planes [zm0, zm1) share one pattern of
 // eliminated nodes, the planes outside hold eliminated nodes only.  x must vanish on eliminated nodes (then y does).
+// [z0, z1): the planes the pass computes (default: all) - a z-slab of a row-sharded lattice computes its owned planes only; the planes
+// next to them inside the array (ghost planes, filled by the caller) are read like any other plane of the main run.
 int launch_stencil_pass(Ctx *c, const uint8_t *cls, int ident, const double cst[8], int nx, int ny, int nz, int zm0, int zm1,
-                        const double *x, const double *b, double *y, double w, int epi, bool dot, int *nparts) {
+                        const double *x, const double *b, double *y, double w, int epi, bool dot, int *nparts, int z0, int z1) {
+    if (z1 < 0) { z0 = 0; z1 = nz; }
     StencilArgs F;
     F.cls = cls; F.ident = ident; F.x = x; F.y = y; F.b = b; F.w = w; F.flags = c->flags;
     for (int s2 = 0; s2 < 8; ++s2) F.c[s2] = cst[s2];
-    F.nx = nx; F.ny = ny; F.nz = nz; F.zv0 = 0; F.zv1 = nz; F.zm0 = zm0; F.zm1 = zm1; F.zs0 = zm0; F.zs1 = zm1; F.z0 = 0; F.z1 = nz;
+    F.nx = nx; F.ny = ny; F.nz = nz; F.zv0 = 0; F.zv1 = nz; F.zm0 = zm0; F.zm1 = zm1; F.zs0 = zm0; F.zs1 = zm1; F.z0 = z0; F.z1 = z1;
     F.tiles_x = (nx + 63) / 64; F.tiles_y = (ny + 15) / 16;
     F.qq = 0; F.whatif = 0;
     const int64_t tiles = (int64_t)F.tiles_x * F.tiles_y, slots = (int64_t)c->stencil_wg_per_cu * c->num_cu;
     const int64_t marches = std::max<int64_t>(1, slots / tiles);
-    const int zc = std::max(3, (int)((nz + marches - 1) / marches));
+    const int zc = std::max(3, (int)((z1 - z0 + marches - 1) / marches));
     F.zchunk = zc;
-    const int wgs = (int)(((nz + zc - 1) / zc) * tiles);
+    const int wgs = (int)(((z1 - z0 + zc - 1) / zc) * tiles);
     if (nparts) *nparts = wgs;
     if (dot) PGD_TRY(ensure_partials(c, std::max<int64_t>(c->partials_off + (int64_t)wgs, 4 * MAX_VEC_BLOCKS)));
     F.partials = c->partials + c->partials_off;
