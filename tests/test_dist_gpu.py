@@ -495,18 +495,20 @@ def _shared_gpu_mg_worker(rank, world, port, shape, q):
         modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values()) for f in p.PGD_func[0]]
         if rank == 0:
             q.put(dict(num_fp_it=p.num_fp_it, amplitude=p.amplitude, modes_x=modes_x, stats=dict(comm.stats),
-                       pcg_iterations=fem.STATS["pcg_iterations"] - i0, mg_solves=fem.STATS.get("mg_solves", 0)))
+                       pcg_iterations=fem.STATS["pcg_iterations"] - i0, mg_solves=fem.STATS.get("mg_solves", 0),
+                       kernels=be.ctx.kernel_counts()))
     finally:
         dist.barrier()
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,shape", [(2, (40, 36, 45)), (3, (31, 33, 38))])
-def test_sharded_v_cycle_on_one_gpu(world, shape):
+@pytest.mark.parametrize("world,shape,tune", [(2, (40, 36, 45), ""), (3, (31, 33, 38), ""), (2, (40, 36, 45), "42=16"), (3, (70, 65, 40), "")])
+def test_sharded_v_cycle_on_one_gpu(world, shape, tune):
     """The V-cycle on a row-sharded lattice with the HIP kernels and real exchanges (`world` processes share GPU 0): the PGD run
     under settings["preconditioner"] = "amg" reproduces the UNSHARDED run under the same setting - pass counts, amplitudes,
     modes to 1e-7 - with the same number of PCG iterations (+-1 per solve: the dots are grouped by rank), every spatial solve
-    preconditioned by the cycle."""
+    preconditioned by the cycle.  (tune "42=16" / the 71 x 66 planes: level 0 of the slabs in the stencil march of the product -
+    ghost planes staged as data - instead of the plain slab kernels.)"""
     import torch.multiprocessing as mp
     from pgdrome_amd import fem, problems
     from pgdrome_amd.hip_backend import HipBackend
@@ -529,9 +531,20 @@ def test_sharded_v_cycle_on_one_gpu(world, shape):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_shared_gpu_mg_worker, args=(r, world, port, shape, q)) for r in range(world)]
-    out = _collect(procs, q, 1, 300)[0]
+    saved = os.environ.get("PGD_TUNE")
+    try:
+        if tune:
+            os.environ["PGD_TUNE"] = tune
+        procs = [ctx.Process(target=_shared_gpu_mg_worker, args=(r, world, port, shape, q)) for r in range(world)]
+        out = _collect(procs, q, 1, 300)[0]
+    finally:
+        if saved is None:
+            os.environ.pop("PGD_TUNE", None)
+        else:
+            os.environ["PGD_TUNE"] = saved
     assert out["num_fp_it"] == ref.num_fp_it and out["stats"].get("sharded_mg_solves", 0) == solves
+    if tune or min(shape[0], shape[1]) >= 63:
+        assert out["kernels"]["stencil_march"] > 2 * out["pcg_iterations"]        # two level-0 passes per cycle in the march
     assert abs(out["pcg_iterations"] - its_ref) <= solves, (out["pcg_iterations"], its_ref)
     assert out["pcg_iterations"] <= 25 * solves
     np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
