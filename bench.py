@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--spectral-start", type=int, default=16,
                     help='settings["spectral_start"]: Ritz vectors in the second level of the Galerkin start of the spatial solves '
                          "(pgdrome_amd/spectral.py; harvested once, outside the timed region, reported in config.spectral_start); 0: off")
+    ap.add_argument("--spectral-sharded", action="store_true",
+                    help="N > 1 (or --dist-driver): harvest and use the spectral start space on the row-sharded mesh too (the harvest's solves "
+                         "run through the sharded V-cycle, dist.pcg_mg, driven from the host); off by default - the first contact with N GPUs "
+                         "runs the plain sharded Jacobi-PCG")
     ap.add_argument("--preconditioner", default="jacobi",
                     help='settings["preconditioner"] of the timed run: "jacobi" (the metric\'s Jacobi-PCG) or "amg" (the V-cycle of pgd_mg.hip; '
                          "on a sharded run the slab form of it, dist.pcg_mg) - a side measurement, never the headline")
@@ -216,7 +220,7 @@ def main():
     # ... and, on request, the spectral start space of the spatial solves: Ritz vectors of the first spatial operator, harvested
     # once per space and Dirichlet set (one-time work like the atoms; its seconds are reported on their own)
     spectral_info = None
-    if args.spectral_start > 0 and not sharded and args.preconditioner == "jacobi":
+    if args.spectral_start > 0 and (not sharded or args.spectral_sharded) and args.preconditioner == "jacobi":
         from pgdrome_amd import spectral
         settings["spectral_start"] = args.spectral_start
         t_h = time.time()

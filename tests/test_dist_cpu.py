@@ -327,3 +327,57 @@ def test_sharded_v_cycle_makes_the_iterates_of_the_unsharded_one(world, shape):
     np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
     for m in range(len(ref_x)):
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
+
+
+def _spectral_worker(rank, world, port, shape, q, k):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.backend_numpy import NumpyBackend
+        from pgdrome_amd import dist as pdist, fem, spectral
+        from pgdrome_amd.solver import PGDProblem
+        spectral.MIN_ROWS = 100
+        be = fem.set_backend(NumpyBackend())
+        comm = pdist.TorchComm(dist, be, True)
+        P = fem.Point
+        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+        p = PGDProblem(**_problem(mesh))
+        settings = {"linear_solver": "cg", "relative_tolerance": 1e-10}
+        if k:
+            settings["spectral_start"] = k
+        p.solve_PGD(_problem="linear", settings=settings)
+        sp = [v for v in spectral._SPACES.values() if v is not None]
+        inner = sum(v.info["inner_pcg_iterations"] for v in sp)
+        modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values()) for f in p.PGD_func[0]]
+        if rank == 0:
+            q.put(dict(num_fp_it=p.num_fp_it, amplitude=p.amplitude, modes_x=modes_x, iterations=fem.STATS["pcg_iterations"] - inner,
+                       vectors=[v.k for v in sp], stats=dict(spectral.STATS), mg=comm.stats.get("sharded_mg_solves", 0)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_spectral_start_on_a_sharded_mesh():
+    """settings["spectral_start"] on a row-sharded dimension: the harvest's inverse-Lanczos solves run through the sharded V-cycle
+    (dist.pcg_mg), the Ritz vectors are slab vectors with ghost planes, their dots are all-reduced - fewer Jacobi-PCG iterations,
+    the same run as without it."""
+    ctx = mp.get_context("spawn")
+    outs = {}
+    for k in (0, 6):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_spectral_worker, args=(r, 2, port, (9, 8, 11), q, k)) for r in range(2)]
+        for pr in procs:
+            pr.start()
+        outs[k] = q.get(timeout=300)
+        for pr in procs:
+            pr.join(timeout=120)
+            assert pr.exitcode == 0
+    a, b = outs[6], outs[0]
+    assert a["stats"]["harvests"] == 1 and a["vectors"] and 1 <= a["vectors"][0] <= 6 and a["mg"] == 15      # 15 Lanczos steps = 15 V-cycle solves
+    assert a["num_fp_it"] == b["num_fp_it"] and a["iterations"] < 0.95 * b["iterations"], (a["iterations"], b["iterations"])
+    np.testing.assert_allclose(a["amplitude"], b["amplitude"], rtol=1e-7)
+    for m in range(len(b["modes_x"])):
+        assert np.linalg.norm(a["modes_x"][m] - b["modes_x"][m]) <= 1e-6 * np.linalg.norm(b["modes_x"][m])
