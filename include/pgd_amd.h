@@ -319,6 +319,8 @@ int pgd_vec_multidot_pair(pgd_handle ctx, pgd_handle x0, pgd_handle x1, const pg
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
+    PGD_TUNE_STENCIL_ROWS = 48, /* rows per thread of k_spmv_stencil_march: 4 (64 x 16 patches), 2 (64 x 8: twice the patches per plane, marches
+                                 * twice as long on thin z-slabs), 0 (default): 2 where four-row patches would march fewer than 8 planes.   */
     PGD_TUNE_DIA_MARCH3 = 47, /* 1: the plain z-march of the diagonal form (variant 0: no row classes - variable coefficients, graded meshes) runs
                                * in k_spmv_dia_march3: buffer addressing with lane offsets that never change, the next plane's slot values
                                * loaded while the current plane is multiplied; bit-identical to k_spmv_dia_march2 (0, the default: half the vector

@@ -275,6 +275,7 @@ struct Ctx {
     int spmv_unit_diag = 1;       // scaled recurrence on structured grids: the unit diagonal is set to exactly 1 and not loaded
     int pcg_defer_x = 1;          // scaled recurrence, large systems: x += alpha p in the p kernel (8 vector passes per iteration, not 9)
     int pcg_scaled = 1;           // pgd_pcg_solve on the symmetrically scaled system (no dinv / z passes) when the symmetric storage applies
+    int stencil_rows = 0;         // rows per thread of k_spmv_stencil_march: 0 = by the launch's shape (2 for thin slabs), 2, 4 (PGD_TUNE_STENCIL_ROWS)
     int dia_march3 = 0;           // 1: variant 0 of the plain z-march in k_spmv_dia_march3 (PGD_TUNE_DIA_MARCH3; bit-identical, measured 2 - 5 % slower at 256^3)
     int shard_one_march = 1;      // pgd_pcg_solve_sharded, exchange in stream order: all owned planes in one stencil march, ghost planes as data (PGD_TUNE_SHARD_ONE_MARCH)
     int pcg_derive_scaled = 1;    // ... whose stencil couplings are DERIVED from the verified stencil of A where that exists (PGD_TUNE_PCG_DERIVE_SCALED)

@@ -1317,11 +1317,14 @@ struct StencilArgs {
 
 typedef int st_v2i __attribute__((ext_vector_type(2)));
 
-template <bool DOT, bool STORE, int D, bool NTY, int OCC, int EPI = 0>
+// RWT rows per thread: 4 (a 64 x 16 patch) or 2 (64 x 8: twice the patches per plane - thin z-slabs of a sharded solve then fill the
+// chip with marches twice as long: a 256 x 256 x 32 slab is 4 marches of 8 planes instead of 8 of 4, r04)
+template <bool DOT, bool STORE, int D, bool NTY, int OCC, int EPI = 0, int RWT = 4>
 __global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) {
-    constexpr int NT = 256, PY = 16, HY = PY + 2, RW = 4;                   // 64 x 16 patch, four rows per thread
-    constexpr int NQ = 5;                                                   // cells a thread stages per plane: its own four + one halo cell
-    constexpr int SLOT = NQ * NT;                                           // 1280 >= 66 * 18 = 1188 cells (+ dump cells of idle stagers)
+    static_assert(RWT == 4 || RWT == 2, "rows per thread");
+    constexpr int NT = 256, RW = RWT, PY = 4 * RW, HY = PY + 2;             // 64 x 16 patch, four rows per thread (64 x 8, two)
+    constexpr int NQ = RW + 1;                                              // cells a thread stages per plane: its own rows + one halo cell
+    constexpr int SLOT = NQ * NT;                                           // 1280 >= 66 * 18 = 1188 cells (768 >= 66 * 10 = 660) + dump cells of idle stagers
     constexpr int OOB = (int)0x40000000;                                    // byte offset no plane reaches (planes < 2^27 rows: launcher)
     constexpr int AUX_ST = NTY ? 2 : 0;                                     // nt
     __shared__ double s_x[4 * SLOT];
@@ -1372,7 +1375,9 @@ __global__ __launch_bounds__(256, OCC) void k_spmv_stencil_march(StencilArgs A) 
             }
         }
     }
-    const bool fixr[RW] = {(fix & 1u) != 0, (fix & 2u) != 0, (fix & 4u) != 0, (fix & 8u) != 0};
+    bool fixr[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) fixr[r] = ((fix >> r) & 1u) != 0;
     const double c0 = A.c[0], c1 = A.c[1], c2 = A.c[2], c3 = A.c[3], c4 = A.c[4], c5 = A.c[5], c6 = A.c[6], c7 = A.c[7];
     double dot = 0.0, dot2 = 0.0;
     // A plane is read and written through a descriptor of its own - base + one plane of records, none at all where the plane
@@ -2550,6 +2555,16 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
                 F.zs0 = a->st_zm0 - (a->st_g_lo ? 1 : 0); F.zs1 = a->st_zm1 + (a->st_g_hi ? 1 : 0);
                 for (int s2 = 0; s2 < 8; ++s2) F.c[s2] = a->st_c[s2];
                 F.nx = D.nx; F.ny = D.ny; F.nz = D.nz; F.z0 = D.z0; F.z1 = D.z1; F.tiles_x = D.tiles_x; F.tiles_y = (D.ny + 15) / 16;
+                // rows per thread: four; two where the launch is so thin that marches of four-row patches would be shorter than 8
+                // planes (a z-slab of a sharded solve: 256 x 256 x 32 = 8 marches of 4 planes against 4 of 8) - PGD_TUNE_STENCIL_ROWS
+                int rows_per_thread = 4;
+                {
+                    const int64_t slots4 = (int64_t)c->stencil_wg_per_cu * c->num_cu, tiles4 = (int64_t)F.tiles_x * F.tiles_y;
+                    const int64_t marches4 = std::max<int64_t>(1, slots4 / tiles4);
+                    const int zc4 = (int)((D.z1 - D.z0 + marches4 - 1) / marches4);
+                    if (c->stencil_rows == 2 || (c->stencil_rows == 0 && zc4 < 8 && D.ny >= 16 && c->spmv_zchunk_stencil <= 0 && c->stencil_depth != 6)) rows_per_thread = 2;
+                }
+                if (rows_per_thread == 2) F.tiles_y = (D.ny + 7) / 8;
                 F.qq = D.qq;
                 F.whatif = 0;
                 F.b = nullptr; F.w = 0.0;
@@ -2578,7 +2593,12 @@ int launch_spmv_op(Ctx *c, const Mesh *m, const Csr *a, const double *x, double 
         else if (dot) k_spmv_stencil_march<true, false, DD, false, OC><<<wgs_s, 256, 0, c->stream>>>(F);               \
         else k_spmv_stencil_march<false, true, DD, false, OC><<<wgs_s, 256, 0, c->stream>>>(F);                        \
     } while (0)
-                if (depth == 6) PGD_STENCIL(6, 2); else PGD_STENCIL(3, 2);
+                if (rows_per_thread == 2 && depth != 6) {
+                    if (dot && store && nty) k_spmv_stencil_march<true, true, 3, true, 2, 0, 2><<<wgs_s, 256, 0, c->stream>>>(F);
+                    else if (dot && store) k_spmv_stencil_march<true, true, 3, false, 2, 0, 2><<<wgs_s, 256, 0, c->stream>>>(F);
+                    else if (dot) k_spmv_stencil_march<true, false, 3, false, 2, 0, 2><<<wgs_s, 256, 0, c->stream>>>(F);
+                    else k_spmv_stencil_march<false, true, 3, false, 2, 0, 2><<<wgs_s, 256, 0, c->stream>>>(F);
+                } else if (depth == 6) PGD_STENCIL(6, 2); else PGD_STENCIL(3, 2);
 #undef PGD_STENCIL
                 c->kcount[KC_STENCIL_MARCH] += 1;
                 if (timed2) PGD_TRY(prof_end(c, m, nrows, 16.0));
@@ -2887,6 +2907,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_HALO_OVERLAP_MIN_ROWS && value >= 0) { c->comm.overlap_min_rows = value; return PGD_OK; }
     if (knob == PGD_TUNE_SHARD_ONE_MARCH && value >= 0 && value <= 1) { c->shard_one_march = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_DIA_MARCH3 && value >= 0 && value <= 1) { c->dia_march3 = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_STENCIL_ROWS && (value == 0 || value == 2 || value == 4)) { c->stencil_rows = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_MG_CHUNK && value >= 2 && value <= 16 && value % 2 == 0) { c->mg_chunk = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_MG_MARCH_MIN && value >= 0 && value <= 1 << 20) { c->mg_march_min = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);

@@ -543,6 +543,17 @@ def test_products_agree_at_bench_size(ctx, npts):
             assert ctx.kernel_counts()["stencil_march"] == c0["stencil_march"] + 1
             ys["stencil_march_%d" % L] = (ctx.vec_download(yv), ctx.slots_download(30, 1)[0])
         ctx.tune(36, 0)
+        # (s2) ... and with TWO rows per thread (64 x 8 patches: what a thin z-slab of a sharded solve takes), default march and 9 planes
+        ctx.tune(48, 2)
+        for L in (0, 9):
+            ctx.tune(36, L)
+            c0 = ctx.kernel_counts()
+            ctx.vec_fill(yv, -1.0)
+            ctx.spmv_dot_slot(op, xv, yv, xv, 0, n, 30)
+            assert ctx.kernel_counts()["stencil_march"] == c0["stencil_march"] + 1
+            ys["stencil_march_rows2_%d" % L] = (ctx.vec_download(yv), ctx.slots_download(30, 1)[0])
+        ctx.tune(36, 0)
+        ctx.tune(48, 0)
         ctx.tune(35, 0)                               # ... and the dictionary form of the same classes from here on
         # (a) the launch shape the solves take by DEFAULT: as many planes per march as fill every resident workgroup slot exactly
         # once (PGD_TUNE_SPMV_ZCHUNK_CODED2 = 96: 256^3 -> 4 marches of 66 planes, 128^3 -> marches of 9) ...
@@ -568,10 +579,11 @@ def test_products_agree_at_bench_size(ctx, npts):
         ctx.tune(32, 96)
         ctx.tune(35, 1)
         ctx.tune(36, 0)
+        ctx.tune(48, 0)
     base = ys["csr"][0]
     # (the dot's partial sums are grouped per workgroup: different march lengths give different last bits of the DOT, never of y)
     assert len({ys["diac_march_%d" % zc][1] for zc in (24, 12, 5)} | {ys["diac_march_default_rule"][1]}) >= 2
-    for name in ("csr_dict", "dia_march", "dia_march2", "dia_rows", "stencil_march_0", "stencil_march_7", "stencil_march_33", "diac_march_default_rule",
+    for name in ("csr_dict", "dia_march", "dia_march2", "dia_rows", "stencil_march_0", "stencil_march_7", "stencil_march_33", "stencil_march_rows2_0", "stencil_march_rows2_9", "diac_march_default_rule",
                  "diac_march_24", "diac_march_12", "diac_march_5"):
         assert np.array_equal(ys[name][0], base), (name, np.abs(ys[name][0] - base).max())
         assert abs(ys[name][1] - ys["csr"][1]) <= 1e-12 * np.abs(x) @ np.abs(base)
