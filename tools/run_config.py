@@ -19,6 +19,7 @@ ap.add_argument("--modes", type=int, default=0)
 ap.add_argument("--problem", default="linear")
 ap.add_argument("--rtol", type=float, default=1e-10)
 ap.add_argument("--preconditioner", default="jacobi", help='settings["preconditioner"]: "jacobi" (default) or a multigrid name ("amg")')
+ap.add_argument("--spectral-start", type=int, default=0, help='settings["spectral_start"]: Ritz vectors in the second level of the Galerkin start (0: off)')
 ap.add_argument("--trace", action="store_true", help="one line per enrichment step on stderr: seconds, passes, PCG iterations")
 args = ap.parse_args()
 
@@ -45,8 +46,10 @@ if args.trace:
                  1e3 * (dt - (fem.STATS["pcg_seconds"] - s0)) / max(passes, 1)), file=sys.stderr, flush=True)
         return out
     p.FP_solve = _timed
-p.solve_PGD(_problem=args.problem, settings={"linear_solver": "cg", "preconditioner": args.preconditioner,
-                                             "relative_tolerance": args.rtol})
+settings = {"linear_solver": "cg", "preconditioner": args.preconditioner, "relative_tolerance": args.rtol}
+if args.spectral_start:
+    settings["spectral_start"] = args.spectral_start
+p.solve_PGD(_problem=args.problem, settings=settings)
 be.sync()
 t2 = time.time()
 print(json.dumps({
@@ -57,4 +60,5 @@ print(json.dumps({
     "linear_solves": fem.STATS["linear_solves"], "pcg_iterations": fem.STATS["pcg_iterations"],
     "not_converged": p.simulation_info.count("NOT converged"), "pcg_seconds": fem.STATS["pcg_seconds"],
     "product_launches_by_kernel": be.ctx.kernel_counts(), "preconditioner": args.preconditioner,
+    "spectral_start": args.spectral_start, "spectral_harvest_seconds_inside_solve_s": __import__("pgdrome_amd.spectral", fromlist=["STATS"]).STATS["harvest_seconds"],
     "solves_preconditioned_by_the_v_cycle": be.ctx.mg_stats()["solves"], "multigrid_fallbacks_to_jacobi": be.ctx.mg_stats()["fallbacks"]}))
