@@ -71,6 +71,7 @@ struct Mesh : Obj {
     // the vertices sit on a uniform lattice origin + index * lat_h (checked at upload, pgd_mesh.hip): the P1 assembly takes
     // edge vectors as whole lattice steps, so congruent cells get identical local matrices
     bool lattice = false;
+    bool lattice_unit = false;    // ... and every cell spans at most one step per axis: edge vectors from the vertex indices (k_lattice_cells_verify)
     double lat_h[3] = {0.0, 0.0, 0.0};
     // What dia_classify learned about operators on this mesh (pgd_spmv.hip): the class CODES of an operator depend on its atoms'
     // structure and its Dirichlet set, not on the coefficients it is combined with - every solve of a fixed-point pass classifies

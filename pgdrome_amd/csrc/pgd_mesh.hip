@@ -153,8 +153,28 @@ __global__ __launch_bounds__(TPB) void k_lattice_verify(const double *__restrict
     if (!ok) flag[0] = 1;
 }
 
+// every cell of a lattice mesh joins vertices that differ by at most one lattice step along every axis: then a cell's edge vectors
+// follow from its vertex INDICES alone (k_assemble_p1<3>: no coordinate is read)
+__global__ __launch_bounds__(TPB) void k_lattice_cells_verify(const int4 *__restrict__ cells, int64_t nc, int nx, int ny, int *__restrict__ flag) {
+    const int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (k >= nc) return;
+    const int4 c4 = cells[k];
+    const int u[4] = {c4.x, c4.y, c4.z, c4.w};
+    const int P = nx * ny;
+    int lo[3], hi[3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int iz = u[t] / P, rem = u[t] - iz * P, iy = rem / nx, ix = rem - iy * nx;
+        const int id[3] = {ix, iy, iz};
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = t ? min(lo[a], id[a]) : id[a]; hi[a] = t ? max(hi[a], id[a]) : id[a]; }
+    }
+    if (hi[0] - lo[0] > 1 || hi[1] - lo[1] > 1 || hi[2] - lo[2] > 1) flag[0] = 1;
+}
+
 static int detect_lattice(Ctx *c, Mesh *m) {
     m->lattice = false;
+    m->lattice_unit = false;
     if (m->sym_nx <= 0 || m->gdim != 3 || m->ncomp != 1 || !m->coords || m->cellsN) return PGD_OK;
     const int64_t plane = (int64_t)m->sym_nx * m->sym_ny;
     const int nz = (int)(m->nv / plane);
@@ -175,6 +195,20 @@ static int detect_lattice(Ctx *c, Mesh *m) {
     if (bad == 0) {
         m->lattice = true;
         for (int k = 0; k < 3; ++k) m->lat_h[k] = host[k];
+        // ... and its cells are unit cells (P1 tetrahedra, int32 vertex ids, planes of at least 3 x 3 vertices)
+        if (m->cells && m->nvpc == 4 && m->sym_nx >= 3 && m->sym_ny >= 3 && m->nv < ((int64_t)1 << 31)) {
+            void *q;
+            PGD_TRY(dev_alloc(c, &q, sizeof(int)));
+            int *fl = (int *)q;
+            PGD_HIP(c, hipMemsetAsync(fl, 0, sizeof(int), c->stream));
+            k_lattice_cells_verify<<<(int)((m->nc + TPB - 1) / TPB), TPB, 0, c->stream>>>(m->cells, m->nc, m->sym_nx, m->sym_ny, fl);
+            int far = 1;
+            PGD_HIP(c, hipMemcpyAsync(&far, fl, sizeof far, hipMemcpyDeviceToHost, c->stream));
+            PGD_HIP(c, hipStreamSynchronize(c->stream));
+            (void)hipFree(fl);
+            PGD_LAUNCH_CHECK(c);
+            m->lattice_unit = far == 0;
+        }
     }
     return PGD_OK;
 }
@@ -190,7 +224,16 @@ struct AsmArgs {
     int kind, da, db;
     int lattice;                  // Mesh::lattice: edge vectors are whole lattice steps
     double lat_h[3], lat_inv[3];
+    int lat_unit, nx, ny;         // Mesh::lattice_unit: ... of at most one step per axis, taken from the vertex indices (row = x + nx y + nx ny z)
 };
+
+// lattice offset (dx, dy, dz), each in {-1, 0, 1}, of vertex v relative to vertex v0 (unit cells, nx, ny >= 3)
+__device__ __forceinline__ void lattice_step(int d, int nx, int P, int &dx, int &dy, int &dz) {
+    dz = d > P / 2 ? 1 : (d < -(P / 2) ? -1 : 0);
+    const int r = d - dz * P;
+    dy = 2 * r > nx ? 1 : (2 * r < -nx ? -1 : 0);
+    dx = r - dy * nx;
+}
 
 template <int D>
 __device__ __forceinline__ void p1_geometry(const AsmArgs &A, const int *u, double &vol, double g[D + 1][D]) {
@@ -210,11 +253,26 @@ __device__ __forceinline__ void p1_geometry(const AsmArgs &A, const int *u, doub
         g[0][0] = -(g[1][0] + g[2][0]);
         g[0][1] = -(g[1][1] + g[2][1]);
     } else {
-        const double x0 = A.cx[u[0]], y0 = A.cy[u[0]], z0 = A.cz[u[0]];
-        double ax = A.cx[u[1]] - x0, ay = A.cy[u[1]] - y0, az = A.cz[u[1]] - z0;
-        double bx = A.cx[u[2]] - x0, by = A.cy[u[2]] - y0, bz = A.cz[u[2]] - z0;
-        double cx = A.cx[u[3]] - x0, cy = A.cy[u[3]] - y0, cz = A.cz[u[3]] - z0;
-        if (A.lattice) {
+        double ax, ay, az, bx, by, bz, cx, cy, cz;
+        if (A.lat_unit) {
+            // unit cells of a uniform lattice: the edge vectors are (dx hx, dy hy, dz hz) with the steps read off the vertex INDICES -
+            // the very numbers the rounding below produces from the coordinates, without the twelve scattered coordinate reads per
+            // cell visit (r04: 63 KB pulled through the L1 per row against 400 B of unique data, profiles/r03_assembly_counters.txt)
+            const int P = A.nx * A.ny;
+            int i1, j1, k1, i2, j2, k2, i3, j3, k3;
+            lattice_step(u[1] - u[0], A.nx, P, i1, j1, k1);
+            lattice_step(u[2] - u[0], A.nx, P, i2, j2, k2);
+            lattice_step(u[3] - u[0], A.nx, P, i3, j3, k3);
+            ax = (double)i1 * A.lat_h[0]; ay = (double)j1 * A.lat_h[1]; az = (double)k1 * A.lat_h[2];
+            bx = (double)i2 * A.lat_h[0]; by = (double)j2 * A.lat_h[1]; bz = (double)k2 * A.lat_h[2];
+            cx = (double)i3 * A.lat_h[0]; cy = (double)j3 * A.lat_h[1]; cz = (double)k3 * A.lat_h[2];
+        } else {
+            const double x0 = A.cx[u[0]], y0 = A.cy[u[0]], z0 = A.cz[u[0]];
+            ax = A.cx[u[1]] - x0; ay = A.cy[u[1]] - y0; az = A.cz[u[1]] - z0;
+            bx = A.cx[u[2]] - x0; by = A.cy[u[2]] - y0; bz = A.cz[u[2]] - z0;
+            cx = A.cx[u[3]] - x0; cy = A.cy[u[3]] - y0; cz = A.cz[u[3]] - z0;
+        }
+        if (A.lattice && !A.lat_unit) {
             // vertices on a uniform lattice (to the rounding of their coordinates, checked at upload): every edge component
             // is a whole number of steps - taken as exactly that, so congruent cells get IDENTICAL local matrices and the
             // assembled rows of a uniform grid repeat bit for bit (what the row-class dictionary of the products lives on).
@@ -878,6 +936,8 @@ int pgd_atom_assemble(pgd_handle h, pgd_handle mh, int kind, int da, int db, pgd
     A.w = w; A.vals = a->vals; A.nv = m->nv; A.kind = kind; A.da = da; A.db = db;
     A.lattice = (m->lattice && c->asm_lattice) ? 1 : 0;
     for (int k = 0; k < 3; ++k) { A.lat_h[k] = m->lat_h[k]; A.lat_inv[k] = m->lattice ? 1.0 / m->lat_h[k] : 0.0; }
+    A.lat_unit = (A.lattice && m->lattice_unit && c->asm_lattice >= 1 && c->asm_lattice != 2) ? 1 : 0;      // (PGD_TUNE_ASM_LATTICE = 2: steps from the coordinates, the r03 form)
+    A.nx = m->sym_nx; A.ny = m->sym_ny;
     const int gb = (int)((m->nv + TPB - 1) / TPB);
     if (m->cellsN && m->gdim == 2) k_assemble_p2_simplex<2><<<(int)((m->nv + 63) / 64), 64, 0, c->stream>>>(A, m->cellsN);
     else if (m->cellsN) k_assemble_p2_simplex<3><<<(int)((m->nv + 63) / 64), 64, 0, c->stream>>>(A, m->cellsN);

@@ -95,6 +95,36 @@ def test_atoms_match_oracle(ctx, mesh, kind):
         ctx.vec_free(wv)
 
 
+@pytest.mark.parametrize("shape", [(12, 9, 7), (5, 4, 3), (33, 20, 17)])
+def test_lattice_assembly_from_vertex_indices_is_the_one_from_coordinates(ctx, shape):
+    """On a uniform lattice whose cells span at most one step per axis k_assemble_p1<3> reads the edge vectors off the vertex
+    INDICES (no coordinate gather, r04): bit for bit the atoms of the r03 form, which rounds coordinate differences to whole steps
+    (PGD_TUNE_ASM_LATTICE = 2) - all seven kinds, different steps per axis, an origin that is not zero; and within the oracle's bar."""
+    coords, cells = F.box_mesh((0.25, -1.0, 3.0), (1.0, 1.5, 3.7), *shape)
+    h = ctx.mesh_upload(coords, cells)
+    assert ctx.mesh_lattice(h)[0]
+    nnz = ctx.mesh_info(h)["nnz"]
+    w = 1.0 + coords[:, 0] ** 2 + 0.5 * np.sin(coords.sum(axis=1))
+    wv = ctx.vec_from(w)
+    try:
+        for kind in range(7):
+            for da, db in ((0, 0), (2, 1)) if F.KIND_NAMES[kind] in ("dudv", "conv", "convt") else ((0, 0),):
+                weighted = F.KIND_NAMES[kind] in ("wmass", "wstiff")
+                got = {}
+                for knob in (1, 2):
+                    ctx.tune(20, knob)
+                    a = ctx.atom_assemble(h, kind, da, db, wv if weighted else 0)
+                    got[knob] = ctx.atom_download(a, nnz)
+                    ctx.atom_free(a)
+                assert np.array_equal(got[1], got[2]), (F.KIND_NAMES[kind], da, db, np.abs(got[1] - got[2]).max())
+                ref = F.assemble_atom(coords, cells, kind, da, db, w if weighted else None)
+                assert np.abs(got[1] - ref.data).max() <= 5e-14 * np.abs(ref.data).max()
+    finally:
+        ctx.tune(20, 1)
+        ctx.vec_free(wv)
+        ctx.mesh_free(h)
+
+
 def test_assembly_is_bitwise_reproducible(ctx, mesh):
     name, coords, cells, h = mesh
     nnz = ctx.mesh_info(h)["nnz"]
