@@ -72,11 +72,6 @@ struct Mesh : Obj {
     // edge vectors as whole lattice steps, so congruent cells get identical local matrices
     bool lattice = false;
     bool lattice_unit = false;    // ... and every cell spans at most one step per axis: edge vectors from the vertex indices (k_lattice_cells_verify)
-    // ... and its cells fall into a few congruence TYPES (step triples of the vertices 1, 2, 3 relative to vertex 0; the 6-tetrahedra box
-    // mesh: 6): one byte per cell, the unweighted P1 atoms take their local matrices from a table of n_types x 16 entries (k_assemble_p1_typed)
-    uint8_t *cell_type = nullptr;
-    int n_types = 0;
-    int type_code[64] = {0};
     double lat_h[3] = {0.0, 0.0, 0.0};
     // What dia_classify learned about operators on this mesh (pgd_spmv.hip): the class CODES of an operator depend on its atoms'
     // structure and its Dirichlet set, not on the coefficients it is combined with - every solve of a fixed-point pass classifies
@@ -103,7 +98,7 @@ struct Mesh : Obj {
     int dict_count = 0;          // 0: dictionary not available (irregular pattern) -> plain CSR kernel
     ~Mesh() override {
         for (void *p : {(void *)coords, (void *)cells, (void *)cellsN, (void *)v2c_ptr, (void *)v2c,
-                        (void *)row_ptr, (void *)cols, (void *)pids, (void *)dict_off, (void *)sym_tab, (void *)cell_type})
+                        (void *)row_ptr, (void *)cols, (void *)pids, (void *)dict_off, (void *)sym_tab})
             if (p) (void)hipFree(p);
         for (ClsCache &e : cls_cache) if (e.same) (void)hipFree(e.same);      // (the block starts at `same`)
         if (bc_dev) (void)hipFree(bc_dev);

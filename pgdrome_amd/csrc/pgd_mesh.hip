@@ -129,14 +129,6 @@ __global__ __launch_bounds__(NT) void k_pattern(const void *__restrict__ cells, 
     }
 }
 
-// lattice offset (dx, dy, dz), each in {-1, 0, 1}, of vertex v relative to vertex v0 (unit cells, nx, ny >= 3)
-__device__ __forceinline__ void lattice_step(int d, int nx, int P, int &dx, int &dy, int &dz) {
-    dz = d > P / 2 ? 1 : (d < -(P / 2) ? -1 : 0);
-    const int r = d - dz * P;
-    dy = 2 * r > nx ? 1 : (2 * r < -nx ? -1 : 0);
-    dx = r - dy * nx;
-}
-
 // -------------------------------------------------------------------- uniform lattices
 // A structured vertex grid (Mesh::sym_nx > 0: row = x + nx y + nx ny z) whose coordinates are origin + index * step per
 // axis to within the rounding of that formula: the assembly then takes edge vectors as whole steps (p1_geometry).
@@ -180,63 +172,6 @@ __global__ __launch_bounds__(TPB) void k_lattice_cells_verify(const int4 *__rest
     if (hi[0] - lo[0] > 1 || hi[1] - lo[1] > 1 || hi[2] - lo[2] > 1) flag[0] = 1;
 }
 
-// congruence type of a unit cell: the lattice steps of its vertices 1, 2, 3 relative to vertex 0, 27 values each
-constexpr int LAT_CODES = 27 * 27 * 27, LAT_MAX_TYPES = 64;
-__device__ __forceinline__ int lattice_cell_code(const int4 c4, int nx, int P) {
-    int code = 0;
-    const int u[4] = {c4.x, c4.y, c4.z, c4.w};
-#pragma unroll
-    for (int t = 1; t < 4; ++t) {
-        int dx, dy, dz;
-        lattice_step(u[t] - u[0], nx, P, dx, dy, dz);
-        code = 27 * code + (dx + 1) + 3 * (dy + 1) + 9 * (dz + 1);
-    }
-    return code;
-}
-__global__ __launch_bounds__(TPB) void k_lattice_codes_mark(const int4 *__restrict__ cells, int64_t nc, int nx, int ny, int *__restrict__ seen) {
-    const int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (k < nc) seen[lattice_cell_code(cells[k], nx, nx * ny)] = 1;
-}
-__global__ __launch_bounds__(TPB) void k_lattice_types(const int4 *__restrict__ cells, int64_t nc, int nx, int ny, const int *__restrict__ type_of,
-                                                       uint8_t *__restrict__ out) {
-    const int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (k < nc) out[k] = (uint8_t)type_of[lattice_cell_code(cells[k], nx, nx * ny)];
-}
-
-static int type_lattice_cells(Ctx *c, Mesh *m) {
-    m->n_types = 0;
-    void *q;
-    PGD_TRY(dev_alloc(c, &q, LAT_CODES * sizeof(int)));
-    int *seen = (int *)q;
-    struct Free { int *p; ~Free() { (void)hipFree(p); } } guard{seen};
-    PGD_HIP(c, hipMemsetAsync(seen, 0, LAT_CODES * sizeof(int), c->stream));
-    const int g = (int)((m->nc + TPB - 1) / TPB);
-    k_lattice_codes_mark<<<g, TPB, 0, c->stream>>>(m->cells, m->nc, m->sym_nx, m->sym_ny, seen);
-    std::vector<int> host((size_t)LAT_CODES);
-    PGD_HIP(c, hipMemcpyAsync(host.data(), seen, LAT_CODES * sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    PGD_HIP(c, hipStreamSynchronize(c->stream));
-    PGD_LAUNCH_CHECK(c);
-    int nt = 0;
-    for (int code = 0; code < LAT_CODES; ++code) {          // type ids in ascending order of the codes: the same on every run
-        if (!host[(size_t)code]) { host[(size_t)code] = 0; continue; }
-        if (nt == LAT_MAX_TYPES) return PGD_OK;              // too many shapes for the table: the general kernel
-        m->type_code[nt] = code;
-        host[(size_t)code] = nt++;
-    }
-    if (nt == 0) return PGD_OK;
-    if (!m->cell_type) {
-        void *t;
-        if (hipMalloc(&t, (size_t)m->nc + PAD_BYTES) != hipSuccess) { (void)hipGetLastError(); return PGD_OK; }      // (no room: the general kernel)
-        m->cell_type = (uint8_t *)t;
-    }
-    PGD_HIP(c, hipMemcpyAsync(seen, host.data(), LAT_CODES * sizeof(int), hipMemcpyHostToDevice, c->stream));
-    k_lattice_types<<<g, TPB, 0, c->stream>>>(m->cells, m->nc, m->sym_nx, m->sym_ny, seen, m->cell_type);
-    PGD_HIP(c, hipStreamSynchronize(c->stream));
-    PGD_LAUNCH_CHECK(c);
-    m->n_types = nt;
-    return PGD_OK;
-}
-
 static int detect_lattice(Ctx *c, Mesh *m) {
     m->lattice = false;
     m->lattice_unit = false;
@@ -273,7 +208,6 @@ static int detect_lattice(Ctx *c, Mesh *m) {
             (void)hipFree(fl);
             PGD_LAUNCH_CHECK(c);
             m->lattice_unit = far == 0;
-            if (m->lattice_unit) PGD_TRY(type_lattice_cells(c, m));
         }
     }
     return PGD_OK;
@@ -293,6 +227,13 @@ struct AsmArgs {
     int lat_unit, nx, ny;         // Mesh::lattice_unit: ... of at most one step per axis, taken from the vertex indices (row = x + nx y + nx ny z)
 };
 
+// lattice offset (dx, dy, dz), each in {-1, 0, 1}, of vertex v relative to vertex v0 (unit cells, nx, ny >= 3)
+__device__ __forceinline__ void lattice_step(int d, int nx, int P, int &dx, int &dy, int &dz) {
+    dz = d > P / 2 ? 1 : (d < -(P / 2) ? -1 : 0);
+    const int r = d - dz * P;
+    dy = 2 * r > nx ? 1 : (2 * r < -nx ? -1 : 0);
+    dx = r - dy * nx;
+}
 
 template <int D>
 __device__ __forceinline__ void p1_geometry(const AsmArgs &A, const int *u, double &vol, double g[D + 1][D]) {
@@ -457,81 +398,6 @@ __global__ __launch_bounds__(TPB) void k_assemble_p1(AsmArgs A) {
         for (int k = tid; k < e - s; k += TPB) A.vals[s + k] = s_acc[k];
 }
 
-
-// Unit-cell lattices (Mesh::n_types > 0), unweighted kinds: a cell's local matrix depends on its congruence TYPE alone - the 6-tetrahedra
-// box mesh has six of them - so every workgroup first computes the n_types x 16 local entries with the very arithmetic of the general
-// kernel (p1_geometry's lattice branch on the type's step triples, p1_entry) into LDS, and a cell visit is then the cell record, its
-// type byte and four table reads instead of three cross products, a division and four entry formulas (r04: the general kernel is
-// issue-bound at ~800 instructions per visit, profiles/r04_assembly.txt).  Same values, same order of summation: bit-identical rows.
-struct LatTypes { int n; int code[LAT_MAX_TYPES]; };
-
-__global__ __launch_bounds__(TPB) void k_assemble_p1_typed(AsmArgs A, const uint8_t *__restrict__ ctype, LatTypes T) {
-    __shared__ double s_acc[ASM_CAP];
-    __shared__ int s_cols[ASM_CAP];
-    __shared__ int s_rp[TPB + 1];
-    __shared__ double s_loc[LAT_MAX_TYPES * 16];
-    const int tid = threadIdx.x;
-    const int64_t r0 = (int64_t)blockIdx.x * TPB;
-    const int nr = (int)min((int64_t)TPB, A.nv - r0);
-    if (tid < nr) s_rp[tid] = A.row_ptr[r0 + tid];
-    if (tid == 0) s_rp[nr] = A.row_ptr[r0 + nr];
-    if (tid < T.n) {
-        // vertex ids with the type's steps relative to vertex 0 (an interior vertex of a fictitious lattice of the same nx, ny)
-        const int P = A.nx * A.ny;
-        int code = T.code[tid], st[3];
-        st[2] = code % 27; code /= 27; st[1] = code % 27; code /= 27; st[0] = code;
-        int u[4];
-        u[0] = 4 * P + 4 * A.nx + 4;
-#pragma unroll
-        for (int t = 0; t < 3; ++t) u[t + 1] = u[0] + (st[t] % 3 - 1) + A.nx * ((st[t] / 3) % 3 - 1) + P * (st[t] / 9 - 1);
-        double vol, g[4][3];
-        const double wl[4] = {0.0, 0.0, 0.0, 0.0};
-        p1_geometry<3>(A, u, vol, g);
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) s_loc[tid * 16 + i * 4 + j] = p1_entry<3>(A.kind, A.da, A.db, i, j, vol, g[i], g[j], wl);
-    }
-    __syncthreads();
-    const int s = s_rp[0], e = s_rp[nr];
-    const bool staged = (e - s) <= ASM_CAP;   // uniform
-    if (staged) {
-        for (int k = tid; k < e - s; k += TPB) { s_acc[k] = 0.0; s_cols[k] = A.cols[s + k]; }
-    } else if (tid < nr) {
-        for (int k = s_rp[tid]; k < s_rp[tid + 1]; ++k) A.vals[k] = 0.0;
-    }
-    __syncthreads();
-    if (tid < nr) {
-        const int r = (int)(r0 + tid);
-        const int ra = s_rp[tid], len = s_rp[tid + 1] - ra;
-        double *acc = staged ? (s_acc + (ra - s)) : (A.vals + ra);
-        const int *rc = staged ? (s_cols + (ra - s)) : (A.cols + ra);
-        const int ca = A.v2c_ptr[r], cb = A.v2c_ptr[r + 1];
-        for (int k = ca; k < cb; ++k) {
-            const int cell = A.v2c[k];
-            const int4 c4 = A.cells[cell];
-            const double *loc = s_loc + 16 * (int)ctype[cell];
-            const int u[4] = {c4.x, c4.y, c4.z, c4.w};
-            int i = 0;
-#pragma unroll
-            for (int t = 0; t < 4; ++t) if (u[t] == r) i = t;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const double val = loc[4 * i + j];
-                int pos = 0;
-                for (int nleft = len; nleft > 1;) {
-                    const int half = nleft >> 1;
-                    pos += rc[pos + half - 1] < u[j] ? half : 0;
-                    nleft -= half;
-                }
-                acc[pos] += val;
-            }
-        }
-    }
-    __syncthreads();
-    if (staged)
-        for (int k = tid; k < e - s; k += TPB) A.vals[s + k] = s_acc[k];
-}
 
 // Quadratic Lagrange elements on intervals (cell record = v0, v1, midpoint node): owner-computes like
 // the P1 kernel, local 3x3 entries by 4-point Gauss quadrature (exact to degree 7).  These systems are
@@ -1070,8 +936,7 @@ int pgd_atom_assemble(pgd_handle h, pgd_handle mh, int kind, int da, int db, pgd
     A.w = w; A.vals = a->vals; A.nv = m->nv; A.kind = kind; A.da = da; A.db = db;
     A.lattice = (m->lattice && c->asm_lattice) ? 1 : 0;
     for (int k = 0; k < 3; ++k) { A.lat_h[k] = m->lat_h[k]; A.lat_inv[k] = m->lattice ? 1.0 / m->lat_h[k] : 0.0; }
-    // (PGD_TUNE_ASM_LATTICE = 2: steps from the coordinates, the r03 form; 3: steps from the indices, but the general kernel)
-    A.lat_unit = (A.lattice && m->lattice_unit && (c->asm_lattice == 1 || c->asm_lattice == 3)) ? 1 : 0;
+    A.lat_unit = (A.lattice && m->lattice_unit && c->asm_lattice >= 1 && c->asm_lattice != 2) ? 1 : 0;      // (PGD_TUNE_ASM_LATTICE = 2: steps from the coordinates, the r03 form)
     A.nx = m->sym_nx; A.ny = m->sym_ny;
     const int gb = (int)((m->nv + TPB - 1) / TPB);
     if (m->cellsN && m->gdim == 2) k_assemble_p2_simplex<2><<<(int)((m->nv + 63) / 64), 64, 0, c->stream>>>(A, m->cellsN);
@@ -1079,12 +944,6 @@ int pgd_atom_assemble(pgd_handle h, pgd_handle mh, int kind, int da, int db, pgd
     else if (m->gdim == 1 && m->nvpc == 3) k_assemble_p2_interval<<<gb, TPB, 0, c->stream>>>(A);
     else if (m->gdim == 1) k_assemble_p1<1><<<gb, TPB, 0, c->stream>>>(A);
     else if (m->gdim == 2) k_assemble_p1<2><<<gb, TPB, 0, c->stream>>>(A);
-    else if (A.lat_unit && m->n_types > 0 && m->cell_type && !w && c->asm_lattice == 1) {
-        LatTypes T;
-        T.n = m->n_types;
-        for (int t = 0; t < LAT_MAX_TYPES; ++t) T.code[t] = t < m->n_types ? m->type_code[t] : 0;
-        k_assemble_p1_typed<<<gb, TPB, 0, c->stream>>>(A, m->cell_type, T);
-    }
     else k_assemble_p1<3><<<gb, TPB, 0, c->stream>>>(A);
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
