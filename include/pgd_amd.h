@@ -418,7 +418,9 @@ enum {
                                 checked at pgd_mesh_upload) the P1 assembly takes every edge component as a whole number of steps instead of
                                 the difference of two rounded coordinates: congruent cells get identical local matrices, the rows of a uniform
                                 grid repeat bit for bit (relative change of the entries ~ 1e-16) - read off the vertex INDICES where every cell spans at most
-                                one step per axis (no coordinate is gathered; the same numbers); 2: the steps from the rounded coordinates (r03);
+                                one step per axis (no coordinate is gathered; the same numbers), and where the cells are numbered regularly - cell 6 q + t =
+                                tetrahedron t of cube q - the unweighted atoms gather nothing at all (k_assemble_p1_regular); 3: index steps in the general
+                                kernel; 2: the steps from the rounded coordinates (r03);
                                 0: coordinate differences as they are */
     PGD_TUNE_SPMV_ROW_CLASSES = 19, /* 1 (default): after scaling, pgd_pcg_solve(_sharded) looks for a lossless ROW-CLASS dictionary of the
                                 operator's diagonal form (uniform grids repeat a few 8-tuples of slot values; every row verified bit by

@@ -72,6 +72,11 @@ struct Mesh : Obj {
     // edge vectors as whole lattice steps, so congruent cells get identical local matrices
     bool lattice = false;
     bool lattice_unit = false;    // ... and every cell spans at most one step per axis: edge vectors from the vertex indices (k_lattice_cells_verify)
+    // ... and the cells are numbered regularly: cell 6 q + t is tetrahedron t of cube q (cubes in vertex order), every cube cut the same way
+    // (k_lattice_regular_verify): the cells around a vertex follow from its position - k_assemble_p1_regular gathers nothing
+    bool lattice_regular = false;
+    int pat_off[6][4] = {{0}};    // vertex offsets of tetrahedron t relative to its cube's first vertex
+    int pat_loc[6][8] = {{0}};    // local index of cube corner (dx + 2 dy + 4 dz) in tetrahedron t, -1: not a vertex of it
     double lat_h[3] = {0.0, 0.0, 0.0};
     // What dia_classify learned about operators on this mesh (pgd_spmv.hip): the class CODES of an operator depend on its atoms'
     // structure and its Dirichlet set, not on the coefficients it is combined with - every solve of a fixed-point pass classifies

@@ -172,6 +172,58 @@ __global__ __launch_bounds__(TPB) void k_lattice_cells_verify(const int4 *__rest
     if (hi[0] - lo[0] > 1 || hi[1] - lo[1] > 1 || hi[2] - lo[2] > 1) flag[0] = 1;
 }
 
+// cell 6 q + t = (first vertex of cube q) + the offsets of cell t (cube 0): the 6-tetrahedra box mesh in its natural numbering
+struct RegPat { int off[6][4]; int loc[6][8]; };
+__global__ __launch_bounds__(TPB) void k_lattice_regular_verify(const int4 *__restrict__ cells, int64_t nc, int nx, int ny, RegPat R, int *__restrict__ flag) {
+    const int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (k >= nc) return;
+    const int64_t q = k / 6;
+    const int t = (int)(k - 6 * q), ncx = nx - 1, ncy = ny - 1;
+    const int cz = (int)(q / ((int64_t)ncx * ncy)), rem = (int)(q - (int64_t)cz * ncx * ncy), cy = rem / ncx, cx = rem - cy * ncx;
+    const int base = cx + nx * cy + nx * ny * cz;
+    const int4 c4 = cells[k];
+    if (c4.x != base + R.off[t][0] || c4.y != base + R.off[t][1] || c4.z != base + R.off[t][2] || c4.w != base + R.off[t][3]) flag[0] = 1;
+}
+
+static int detect_regular_cells(Ctx *c, Mesh *m) {
+    m->lattice_regular = false;
+    const int nx = m->sym_nx, ny = m->sym_ny;
+    const int64_t P = (int64_t)nx * ny;
+    const int nz = (int)(m->nv / P);
+    if (m->nc != (int64_t)6 * (nx - 1) * (ny - 1) * (nz - 1) || m->nc < 6) return PGD_OK;
+    int4 first[6];
+    PGD_HIP(c, hipMemcpyAsync(first, m->cells, sizeof first, hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    RegPat R;
+    for (int t = 0; t < 6; ++t) {
+        const int u[4] = {first[t].x, first[t].y, first[t].z, first[t].w};
+        for (int q = 0; q < 8; ++q) R.loc[t][q] = -1;
+        for (int a = 0; a < 4; ++a) {
+            if (u[a] < 0) return PGD_OK;
+            const int dz = (int)(u[a] / P), rem = (int)(u[a] - dz * P), dy = rem / nx, dx = rem - dy * nx;
+            if (dx > 1 || dy > 1 || dz > 1 || R.loc[t][dx + 2 * dy + 4 * dz] >= 0) return PGD_OK;      // not a corner of cube 0 (or twice the same)
+            R.off[t][a] = u[a];
+            R.loc[t][dx + 2 * dy + 4 * dz] = a;
+        }
+    }
+    void *q;
+    PGD_TRY(dev_alloc(c, &q, sizeof(int)));
+    int *fl = (int *)q;
+    PGD_HIP(c, hipMemsetAsync(fl, 0, sizeof(int), c->stream));
+    k_lattice_regular_verify<<<(int)((m->nc + TPB - 1) / TPB), TPB, 0, c->stream>>>(m->cells, m->nc, nx, ny, R, fl);
+    int bad = 1;
+    PGD_HIP(c, hipMemcpyAsync(&bad, fl, sizeof bad, hipMemcpyDeviceToHost, c->stream));
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    (void)hipFree(fl);
+    PGD_LAUNCH_CHECK(c);
+    if (bad == 0) {
+        m->lattice_regular = true;
+        memcpy(m->pat_off, R.off, sizeof R.off);
+        memcpy(m->pat_loc, R.loc, sizeof R.loc);
+    }
+    return PGD_OK;
+}
+
 static int detect_lattice(Ctx *c, Mesh *m) {
     m->lattice = false;
     m->lattice_unit = false;
@@ -208,6 +260,7 @@ static int detect_lattice(Ctx *c, Mesh *m) {
             (void)hipFree(fl);
             PGD_LAUNCH_CHECK(c);
             m->lattice_unit = far == 0;
+            if (m->lattice_unit) PGD_TRY(detect_regular_cells(c, m));
         }
     }
     return PGD_OK;
@@ -398,6 +451,81 @@ __global__ __launch_bounds__(TPB) void k_assemble_p1(AsmArgs A) {
         for (int k = tid; k < e - s; k += TPB) A.vals[s + k] = s_acc[k];
 }
 
+
+// Regularly numbered unit-cell lattices (Mesh::lattice_regular), unweighted kinds: NOTHING of the mesh is gathered.  The cells around
+// vertex (x, y, z) are the tetrahedra of its up to eight cubes that have it as a corner - known from the cutting pattern of cube 0,
+// verified for every cell at upload - visited in ascending cell number like the vertex->cell list of the general kernel; a cell's local
+// matrix depends on its type t alone and comes from a table of 6 x 16 entries that every workgroup computes first with the general
+// kernel's own arithmetic (p1_geometry on the type's steps, p1_entry).  Same values, same order of summation: bit-identical atoms.
+// (r04: the general kernel is bound by its gathers - a cell record per visit, 24 visits per row; a table behind one more gather, the
+// cell's type byte, was SLOWER: HISTORY.md.)  Reads the CSR pattern, writes the values: 3.1 GB at 256^3.
+__global__ __launch_bounds__(TPB) void k_assemble_p1_regular(AsmArgs A, RegPat R, int nz) {
+    __shared__ double s_acc[ASM_CAP];
+    __shared__ int s_cols[ASM_CAP];
+    __shared__ int s_rp[TPB + 1];
+    __shared__ double s_loc[6 * 16];
+    const int tid = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * TPB;
+    const int nr = (int)min((int64_t)TPB, A.nv - r0);
+    const int nx = A.nx, P = A.nx * A.ny;
+    if (tid < nr) s_rp[tid] = A.row_ptr[r0 + tid];
+    if (tid == 0) s_rp[nr] = A.row_ptr[r0 + nr];
+    if (tid < 6) {
+        int u[4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) u[a] = 4 * P + 4 * nx + 4 + R.off[tid][a];      // (the steps between them are all p1_geometry takes)
+        double vol, g[4][3];
+        const double wl[4] = {0.0, 0.0, 0.0, 0.0};
+        p1_geometry<3>(A, u, vol, g);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s_loc[tid * 16 + i * 4 + j] = p1_entry<3>(A.kind, A.da, A.db, i, j, vol, g[i], g[j], wl);
+    }
+    __syncthreads();
+    const int s = s_rp[0], e = s_rp[nr];
+    const bool staged = (e - s) <= ASM_CAP;   // uniform
+    if (staged) {
+        for (int k = tid; k < e - s; k += TPB) { s_acc[k] = 0.0; s_cols[k] = A.cols[s + k]; }
+    } else if (tid < nr) {
+        for (int k = s_rp[tid]; k < s_rp[tid + 1]; ++k) A.vals[k] = 0.0;
+    }
+    __syncthreads();
+    if (tid < nr) {
+        const int r = (int)(r0 + tid);
+        const int ra = s_rp[tid], len = s_rp[tid + 1] - ra;
+        double *acc = staged ? (s_acc + (ra - s)) : (A.vals + ra);
+        const int *rc = staged ? (s_cols + (ra - s)) : (A.cols + ra);
+        const int z = r / P, rem = r - z * P, y = rem / nx, x = rem - y * nx;
+#pragma unroll
+        for (int o = 7; o >= 0; --o) {                      // the vertex as corner o of the cube at (x - ox, y - oy, z - oz): ascending cube number
+            const int ox = o & 1, oy = (o >> 1) & 1, oz = o >> 2;
+            const int cx = x - ox, cy = y - oy, cz = z - oz;
+            if (cx < 0 || cy < 0 || cz < 0 || cx >= nx - 1 || cy >= A.ny - 1 || cz >= nz - 1) continue;
+            const int base = r - ox - nx * oy - P * oz;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) {
+                const int i = R.loc[t][o];                  // (uniform: a kernel argument at compile-time indices)
+                if (i < 0) continue;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const double val = s_loc[t * 16 + 4 * i + j];
+                    const int uj = base + R.off[t][j];
+                    int pos = 0;
+                    for (int nleft = len; nleft > 1;) {
+                        const int half = nleft >> 1;
+                        pos += rc[pos + half - 1] < uj ? half : 0;
+                        nleft -= half;
+                    }
+                    acc[pos] += val;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (staged)
+        for (int k = tid; k < e - s; k += TPB) A.vals[s + k] = s_acc[k];
+}
 
 // Quadratic Lagrange elements on intervals (cell record = v0, v1, midpoint node): owner-computes like
 // the P1 kernel, local 3x3 entries by 4-point Gauss quadrature (exact to degree 7).  These systems are
@@ -936,7 +1064,8 @@ int pgd_atom_assemble(pgd_handle h, pgd_handle mh, int kind, int da, int db, pgd
     A.w = w; A.vals = a->vals; A.nv = m->nv; A.kind = kind; A.da = da; A.db = db;
     A.lattice = (m->lattice && c->asm_lattice) ? 1 : 0;
     for (int k = 0; k < 3; ++k) { A.lat_h[k] = m->lat_h[k]; A.lat_inv[k] = m->lattice ? 1.0 / m->lat_h[k] : 0.0; }
-    A.lat_unit = (A.lattice && m->lattice_unit && c->asm_lattice >= 1 && c->asm_lattice != 2) ? 1 : 0;      // (PGD_TUNE_ASM_LATTICE = 2: steps from the coordinates, the r03 form)
+    // (PGD_TUNE_ASM_LATTICE = 2: steps from the coordinates, the r03 form; 3: steps from the indices, in the general kernel)
+    A.lat_unit = (A.lattice && m->lattice_unit && (c->asm_lattice == 1 || c->asm_lattice == 3)) ? 1 : 0;
     A.nx = m->sym_nx; A.ny = m->sym_ny;
     const int gb = (int)((m->nv + TPB - 1) / TPB);
     if (m->cellsN && m->gdim == 2) k_assemble_p2_simplex<2><<<(int)((m->nv + 63) / 64), 64, 0, c->stream>>>(A, m->cellsN);
@@ -944,6 +1073,12 @@ int pgd_atom_assemble(pgd_handle h, pgd_handle mh, int kind, int da, int db, pgd
     else if (m->gdim == 1 && m->nvpc == 3) k_assemble_p2_interval<<<gb, TPB, 0, c->stream>>>(A);
     else if (m->gdim == 1) k_assemble_p1<1><<<gb, TPB, 0, c->stream>>>(A);
     else if (m->gdim == 2) k_assemble_p1<2><<<gb, TPB, 0, c->stream>>>(A);
+    else if (A.lat_unit && m->lattice_regular && !w && c->asm_lattice == 1) {
+        RegPat R;
+        memcpy(R.off, m->pat_off, sizeof R.off);
+        memcpy(R.loc, m->pat_loc, sizeof R.loc);
+        k_assemble_p1_regular<<<gb, TPB, 0, c->stream>>>(A, R, (int)(m->nv / ((int64_t)m->sym_nx * m->sym_ny)));
+    }
     else k_assemble_p1<3><<<gb, TPB, 0, c->stream>>>(A);
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;

@@ -2888,7 +2888,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_COMBINE_DIA && value >= 0 && value <= 1) { c->spmv_combine_dia = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_VARIANT && value >= 0 && value <= 2) { c->spmv_variant = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_SPMV_ROW_CLASSES && value >= 0 && value <= 1) { c->spmv_classes = (int)value; return PGD_OK; }
-    if (knob == PGD_TUNE_ASM_LATTICE && value >= 0 && value <= 2) { c->asm_lattice = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_ASM_LATTICE && value >= 0 && value <= 3) { c->asm_lattice = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_LAG_X && value >= 0 && value <= 1) { c->pcg_lag_x = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_STREAM_HINTS && value >= 0 && value <= 1) { c->pcg_stream_hints = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_PCG_SMALL_SINGLE_SYNC && value >= 0 && value <= 1) { c->pcg_small_ss = (int)value; return PGD_OK; }

@@ -111,14 +111,30 @@ def test_lattice_assembly_from_vertex_indices_is_the_one_from_coordinates(ctx, s
             for da, db in ((0, 0), (2, 1)) if F.KIND_NAMES[kind] in ("dudv", "conv", "convt") else ((0, 0),):
                 weighted = F.KIND_NAMES[kind] in ("wmass", "wstiff")
                 got = {}
-                for knob in (1, 2):
+                for knob in (1, 3, 2):         # nothing gathered (regular numbering, unweighted kinds) / index steps in the general kernel / r03
                     ctx.tune(20, knob)
                     a = ctx.atom_assemble(h, kind, da, db, wv if weighted else 0)
                     got[knob] = ctx.atom_download(a, nnz)
                     ctx.atom_free(a)
                 assert np.array_equal(got[1], got[2]), (F.KIND_NAMES[kind], da, db, np.abs(got[1] - got[2]).max())
+                assert np.array_equal(got[3], got[2]), (F.KIND_NAMES[kind], da, db, np.abs(got[3] - got[2]).max())
                 ref = F.assemble_atom(coords, cells, kind, da, db, w if weighted else None)
                 assert np.abs(got[1] - ref.data).max() <= 5e-14 * np.abs(ref.data).max()
+        # the same lattice with its cells in another order (and their vertices rotated): not the regular numbering - the general
+        # kernel takes it, the atoms are those of the oracle
+        rng = np.random.default_rng(8)
+        perm = rng.permutation(cells.shape[0])
+        shuffled = np.roll(cells[perm], 1, axis=1).copy()
+        h2 = ctx.mesh_upload(coords, shuffled)
+        try:
+            assert ctx.mesh_lattice(h2)[0]
+            for kind in (F.STIFF, F.MASS):
+                a = ctx.atom_assemble(h2, kind)
+                ref = F.assemble_atom(coords, shuffled, kind)
+                assert np.abs(ctx.atom_download(a, nnz) - ref.data).max() <= 5e-14 * np.abs(ref.data).max()
+                ctx.atom_free(a)
+        finally:
+            ctx.mesh_free(h2)
     finally:
         ctx.tune(20, 1)
         ctx.vec_free(wv)
