@@ -172,6 +172,23 @@ __global__ __launch_bounds__(TPB) void k_lattice_cells_verify(const int4 *__rest
     if (hi[0] - lo[0] > 1 || hi[1] - lo[1] > 1 || hi[2] - lo[2] > 1) flag[0] = 1;
 }
 
+// cube corners v0..v7 = (dx, dy, dz) in {0, 1}^3, corner id = dx + 2 dy + 4 dz; tetrahedra of a cube in cell order:
+//   (v0, v1, v3, v7), (v0, v1, v7, v5), (v0, v5, v7, v4), (v0, v3, v2, v7), (v0, v6, v4, v7), (v0, v2, v6, v7)
+__host__ __device__ constexpr int box_corner(int t, int a) {
+    return t == 0 ? (a == 0 ? 0 : a == 1 ? 1 : a == 2 ? 3 : 7) : t == 1 ? (a == 0 ? 0 : a == 1 ? 1 : a == 2 ? 7 : 5) :
+           t == 2 ? (a == 0 ? 0 : a == 1 ? 5 : a == 2 ? 7 : 4) : t == 3 ? (a == 0 ? 0 : a == 1 ? 3 : a == 2 ? 2 : 7) :
+           t == 4 ? (a == 0 ? 0 : a == 1 ? 6 : a == 2 ? 4 : 7) : (a == 0 ? 0 : a == 1 ? 2 : a == 2 ? 6 : 7);
+}
+__host__ __device__ constexpr int box_local(int t, int corner) {      // local index of that corner in tetrahedron t, -1: not a vertex of it
+    return box_corner(t, 0) == corner ? 0 : box_corner(t, 1) == corner ? 1 : box_corner(t, 2) == corner ? 2 : box_corner(t, 3) == corner ? 3 : -1;
+}
+// slot of the neighbour at lattice offset (dx, dy, dz) in a row's ascending columns (all 15 present): -1 off the pattern
+__host__ __device__ constexpr int box_slot(int dx, int dy, int dz) {
+    return (dz == -1) ? ((dy == -1) ? (dx == -1 ? 0 : dx == 0 ? 1 : -1) : (dy == 0) ? (dx == -1 ? 2 : dx == 0 ? 3 : -1) : -1) :
+           (dz == 0) ? ((dy == -1) ? (dx == -1 ? 4 : dx == 0 ? 5 : -1) : (dy == 0) ? (dx == -1 ? 6 : dx == 0 ? 7 : 8) : (dx == 0 ? 9 : dx == 1 ? 10 : -1)) :
+           ((dy == 0) ? (dx == 0 ? 11 : dx == 1 ? 12 : -1) : (dy == 1) ? (dx == 0 ? 13 : dx == 1 ? 14 : -1) : -1);
+}
+
 // cell 6 q + t = (first vertex of cube q) + the offsets of cell t (cube 0): the 6-tetrahedra box mesh in its natural numbering
 struct RegPat { int off[6][4]; int loc[6][8]; };
 __global__ __launch_bounds__(TPB) void k_lattice_regular_verify(const int4 *__restrict__ cells, int64_t nc, int nx, int ny, RegPat R, int *__restrict__ flag) {
@@ -216,7 +233,10 @@ static int detect_regular_cells(Ctx *c, Mesh *m) {
     PGD_HIP(c, hipStreamSynchronize(c->stream));
     (void)hipFree(fl);
     PGD_LAUNCH_CHECK(c);
-    if (bad == 0) {
+    bool box = bad == 0;
+    for (int t = 0; t < 6 && box; ++t)
+        for (int q = 0; q < 8; ++q) box = box && R.loc[t][q] == box_local(t, q);      // ... cut like dolfin's BoxMesh (k_assemble_p1_regular's pattern)
+    if (box) {
         m->lattice_regular = true;
         memcpy(m->pat_off, R.off, sizeof R.off);
         memcpy(m->pat_loc, R.loc, sizeof R.loc);
@@ -452,16 +472,18 @@ __global__ __launch_bounds__(TPB) void k_assemble_p1(AsmArgs A) {
 }
 
 
-// Regularly numbered unit-cell lattices (Mesh::lattice_regular), unweighted kinds: NOTHING of the mesh is gathered.  The cells around
-// vertex (x, y, z) are the tetrahedra of its up to eight cubes that have it as a corner - known from the cutting pattern of cube 0,
-// verified for every cell at upload - visited in ascending cell number like the vertex->cell list of the general kernel; a cell's local
-// matrix depends on its type t alone and comes from a table of 6 x 16 entries that every workgroup computes first with the general
-// kernel's own arithmetic (p1_geometry on the type's steps, p1_entry).  Same values, same order of summation: bit-identical atoms.
-// (r04: the general kernel is bound by its gathers - a cell record per visit, 24 visits per row; a table behind one more gather, the
-// cell's type byte, was SLOWER: HISTORY.md.)  Reads the CSR pattern, writes the values: 3.1 GB at 256^3.
-__global__ __launch_bounds__(TPB) void k_assemble_p1_regular(AsmArgs A, RegPat R, int nz) {
-    __shared__ double s_acc[ASM_CAP];
-    __shared__ int s_cols[ASM_CAP];
+// Regularly numbered unit-cell lattices cut like dolfin's BoxMesh (Mesh::lattice_regular), unweighted kinds: NOTHING of the mesh is
+// read but the row pointers.  The cells around vertex (x, y, z) are the tetrahedra of its up to eight cubes that have it as a corner -
+// the cutting pattern below, verified for every cell at upload (k_lattice_regular_verify) - visited in ascending cell number like the
+// vertex->cell list of the general kernel; a cell's local matrix depends on its type t alone and comes from a table of 6 x 16 entries
+// that every workgroup computes first with the general kernel's own arithmetic (p1_geometry on the type's steps, p1_entry); with the
+// pattern known at compile time every contribution goes to one of the row's 15 stencil slots by a CONSTANT index - registers, no
+// search - and a slot belongs to the row's CSR entries iff one of the cubes that feed it exists (that is how the pattern was built).
+// Same values, same order of summation: bit-identical atoms.  (r04: the general kernel is bound by its gathers - a cell record per
+// visit, 24 visits per row; a table behind one more gather, the cell's type byte, was SLOWER; gather-free with the binary search into
+// the LDS image of the CSR rows: 5.6 ms at 256^3; HISTORY.md.)  Reads 4 B, writes 8 x 15 B per row.
+__global__ __launch_bounds__(TPB) void k_assemble_p1_regular(AsmArgs A, int nz) {
+    __shared__ double s_acc[TPB * 15];
     __shared__ int s_rp[TPB + 1];
     __shared__ double s_loc[6 * 16];
     const int tid = threadIdx.x;
@@ -473,7 +495,12 @@ __global__ __launch_bounds__(TPB) void k_assemble_p1_regular(AsmArgs A, RegPat R
     if (tid < 6) {
         int u[4];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) u[a] = 4 * P + 4 * nx + 4 + R.off[tid][a];      // (the steps between them are all p1_geometry takes)
+        for (int a = 0; a < 4; ++a) {                     // (the steps between the vertices are all p1_geometry takes)
+            int cn = 0;
+#pragma unroll
+            for (int t = 0; t < 6; ++t) if (t == tid) cn = box_corner(t, a);
+            u[a] = 4 * P + 4 * nx + 4 + (cn & 1) + nx * ((cn >> 1) & 1) + P * (cn >> 2);
+        }
         double vol, g[4][3];
         const double wl[4] = {0.0, 0.0, 0.0, 0.0};
         p1_geometry<3>(A, u, vol, g);
@@ -483,48 +510,42 @@ __global__ __launch_bounds__(TPB) void k_assemble_p1_regular(AsmArgs A, RegPat R
             for (int j = 0; j < 4; ++j) s_loc[tid * 16 + i * 4 + j] = p1_entry<3>(A.kind, A.da, A.db, i, j, vol, g[i], g[j], wl);
     }
     __syncthreads();
-    const int s = s_rp[0], e = s_rp[nr];
-    const bool staged = (e - s) <= ASM_CAP;   // uniform
-    if (staged) {
-        for (int k = tid; k < e - s; k += TPB) { s_acc[k] = 0.0; s_cols[k] = A.cols[s + k]; }
-    } else if (tid < nr) {
-        for (int k = s_rp[tid]; k < s_rp[tid + 1]; ++k) A.vals[k] = 0.0;
-    }
-    __syncthreads();
+    const int s = s_rp[0];
     if (tid < nr) {
         const int r = (int)(r0 + tid);
-        const int ra = s_rp[tid], len = s_rp[tid + 1] - ra;
-        double *acc = staged ? (s_acc + (ra - s)) : (A.vals + ra);
-        const int *rc = staged ? (s_cols + (ra - s)) : (A.cols + ra);
         const int z = r / P, rem = r - z * P, y = rem / nx, x = rem - y * nx;
+        double acc[15];
+        unsigned present = 0;
+#pragma unroll
+        for (int q = 0; q < 15; ++q) acc[q] = 0.0;
 #pragma unroll
         for (int o = 7; o >= 0; --o) {                      // the vertex as corner o of the cube at (x - ox, y - oy, z - oz): ascending cube number
             const int ox = o & 1, oy = (o >> 1) & 1, oz = o >> 2;
             const int cx = x - ox, cy = y - oy, cz = z - oz;
-            if (cx < 0 || cy < 0 || cz < 0 || cx >= nx - 1 || cy >= A.ny - 1 || cz >= nz - 1) continue;
-            const int base = r - ox - nx * oy - P * oz;
+            const bool have = cx >= 0 && cy >= 0 && cz >= 0 && cx < nx - 1 && cy < A.ny - 1 && cz < nz - 1;
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
-                const int i = R.loc[t][o];                  // (uniform: a kernel argument at compile-time indices)
-                if (i < 0) continue;
+                const int i = box_local(t, o);
+                if (i < 0) continue;                        // (compile time)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
+                    const int cj = box_corner(t, j);
+                    const int q = box_slot((cj & 1) - ox, ((cj >> 1) & 1) - oy, (cj >> 2) - oz);
                     const double val = s_loc[t * 16 + 4 * i + j];
-                    const int uj = base + R.off[t][j];
-                    int pos = 0;
-                    for (int nleft = len; nleft > 1;) {
-                        const int half = nleft >> 1;
-                        pos += rc[pos + half - 1] < uj ? half : 0;
-                        nleft -= half;
-                    }
-                    acc[pos] += val;
+                    if (have) { acc[q] += val; present |= 1u << q; }
                 }
             }
         }
+        // the row's CSR entries: the slots that got a contribution, in ascending column order
+        double *out = s_acc + (s_rp[tid] - s);
+        int k = 0;
+#pragma unroll
+        for (int q = 0; q < 15; ++q)
+            if (present & (1u << q)) out[k++] = acc[q];
     }
     __syncthreads();
-    if (staged)
-        for (int k = tid; k < e - s; k += TPB) A.vals[s + k] = s_acc[k];
+    const int e = s_rp[nr];
+    for (int k = tid; k < e - s; k += TPB) A.vals[s + k] = s_acc[k];
 }
 
 // Quadratic Lagrange elements on intervals (cell record = v0, v1, midpoint node): owner-computes like
@@ -1073,12 +1094,8 @@ int pgd_atom_assemble(pgd_handle h, pgd_handle mh, int kind, int da, int db, pgd
     else if (m->gdim == 1 && m->nvpc == 3) k_assemble_p2_interval<<<gb, TPB, 0, c->stream>>>(A);
     else if (m->gdim == 1) k_assemble_p1<1><<<gb, TPB, 0, c->stream>>>(A);
     else if (m->gdim == 2) k_assemble_p1<2><<<gb, TPB, 0, c->stream>>>(A);
-    else if (A.lat_unit && m->lattice_regular && !w && c->asm_lattice == 1) {
-        RegPat R;
-        memcpy(R.off, m->pat_off, sizeof R.off);
-        memcpy(R.loc, m->pat_loc, sizeof R.loc);
-        k_assemble_p1_regular<<<gb, TPB, 0, c->stream>>>(A, R, (int)(m->nv / ((int64_t)m->sym_nx * m->sym_ny)));
-    }
+    else if (A.lat_unit && m->lattice_regular && !w && c->asm_lattice == 1 && m->max_row <= 15)
+        k_assemble_p1_regular<<<gb, TPB, 0, c->stream>>>(A, (int)(m->nv / ((int64_t)m->sym_nx * m->sym_ny)));
     else k_assemble_p1<3><<<gb, TPB, 0, c->stream>>>(A);
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
