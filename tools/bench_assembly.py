@@ -33,7 +33,11 @@ for n in [int(a) for a in sys.argv[1:]] or [128, 256]:
     # read once: int4 cell records, 3 coordinate arrays, v2c_ptr + v2c (4 entries per cell), row_ptr + cols; written: values
     unique = 16 * nc + 24 * nv + 4 * (nv + 1) + 4 * 4 * nc + 4 * (nv + 1) + 4 * nnz + 8 * nnz
     gathered = nv and (24 * nc * 4 / nv) * (16 + 4 * 24)       # bytes a row's lane pulls through the L1: 24 cells x (record + 4 x 3 coordinates)
+    # k_assemble_p1_regular (r04: regularly numbered unit-cell lattices, unweighted kinds) reads the row pointers and writes the values - nothing else
+    own = 4 * (nv + 1) + 8 * nnz
+    regular = bool(ctx.mesh_lattice(mesh)[0])
     out = {"n": n, "rows": nv, "cells": nc, "nnz": nnz, "unique_bytes": unique,
+           "gather_free_kernel_bytes": own, "gather_free_kernel_frac_of_8TBps": {k: own / t / 8e12 for k, t in res.items()} if regular else None,
            "seconds": res, "unique_GBps": {k: unique / t / 1e9 for k, t in res.items()},
            "frac_of_8TBps": {k: unique / t / 8e12 for k, t in res.items()},
            "cell_visits": 4 * nc, "ns_per_cell_visit_per_CU": {k: 1e9 * t / (4 * nc / 256) for k, t in res.items()},
