@@ -488,7 +488,7 @@ int pgd_mg_counts(pgd_handle ctx, int64_t *solves, int64_t *fallbacks);
  * (forwarded by the reference into its solver, solver.py:593-594, 634-635) on a sharded spatial dimension.  Level 0 stays
  * with the rows (this rank's planes + one ghost plane per side), levels >= 1 are whole on every rank.  The caller owns the
  * PCG loop and the collectives: per cycle  halo(r) -> pgd_mg_slab_down(r, t) -> halo(t) -> pgd_mg_slab_restrict(t, b1) ->
- * all-reduce(b1) -> pgd_mg_coarse(b1, x1) -> pgd_mg_slab_up(r, x1, t, z, &dot) with dot = r . z over the owned rows.
+ * all-reduce(b1) -> pgd_mg_coarse(b1, x1) -> pgd_mg_slab_up(r, x1, t, z, slot, &dot) with r . z over the owned rows.
  *   setup: A (unscaled) must be one stencil + eliminated nodes on the owned planes [own0, own1) of the local array (whole planes),
  *   the eliminated nodes exactly the hull of the global lattice of nz_global planes, local plane 0 = global plane z_first;
  *   *applies = 0 where it is not (the caller keeps Jacobi), *n_coarse = entries of a level-1 vector.                      */
@@ -498,7 +498,7 @@ int pgd_mg_slab_fix_start(pgd_handle ctx, pgd_handle A, pgd_handle b, pgd_handle
 int pgd_mg_slab_down(pgd_handle ctx, pgd_handle r, pgd_handle t);
 int pgd_mg_slab_restrict(pgd_handle ctx, pgd_handle t, pgd_handle b1);
 int pgd_mg_coarse(pgd_handle ctx, pgd_handle b1, pgd_handle x1);
-int pgd_mg_slab_up(pgd_handle ctx, pgd_handle r, pgd_handle x1, pgd_handle t, pgd_handle z, double *dot);
+int pgd_mg_slab_up(pgd_handle ctx, pgd_handle r, pgd_handle x1, pgd_handle t, pgd_handle z, int slot, double *dot);   /* slot >= 0: r . z into that scalar slot, no host synchronisation (dot may be NULL) */
 /* One HIP-event stopwatch on the context's stream (bench.py's micro-sections: N launches between start
  * and stop; stop synchronises on its event).                                                        */
 /* Calibration of the PMC byte model: one pass over `vec` with 8- or 16-byte loads (store = 0) or stores (store = 1)

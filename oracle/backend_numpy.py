@@ -279,10 +279,13 @@ class NumpyBackend:
         sl = self._mg_slab
         self._obj[x1][:] = sl.coarse(self._obj[b1].reshape(sl.levels[1].shape)).ravel()
 
-    def mg_slab_up(self, r, x1, t, z):
+    def mg_slab_up(self, r, x1, t, z, slot=-1):
         sl = self._mg_slab
         zz, dot = sl.up(self._slab3(r), self._obj[x1].reshape(sl.levels[1].shape))
         self._obj[z][:] = zz.ravel()
+        if slot >= 0:
+            self.slots[slot] = dot
+            return None
         return dot
 
     def bicgstab(self, op, b, x, rtol, atol, maxit):

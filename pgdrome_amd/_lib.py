@@ -72,7 +72,7 @@ SIGNATURES = {
     "pgd_mg_slab_down": (C.c_int, [H, H, H]),
     "pgd_mg_slab_restrict": (C.c_int, [H, H, H]),
     "pgd_mg_coarse": (C.c_int, [H, H, H]),
-    "pgd_mg_slab_up": (C.c_int, [H, H, H, H, H, PD]),
+    "pgd_mg_slab_up": (C.c_int, [H, H, H, H, H, C.c_int, PD]),
     "pgd_bicgstab_solve": (C.c_int, [H, H, H, H, C.c_double, C.c_double, C.c_int, C.POINTER(C.c_int), PD]),
     "pgd_atom_product_form": (C.c_int, [H, H, C.POINTER(C.c_int)]),
     "pgd_vec_multidot": (C.c_int, [H, H, PH, C.c_int, I64, I64, PD]),
@@ -444,9 +444,13 @@ class Context:
     def mg_coarse(self, b1, x1):
         self._ck(self.lib.pgd_mg_coarse(self.h, b1, x1))
 
-    def mg_slab_up(self, r, x1, t, z):
+    def mg_slab_up(self, r, x1, t, z, slot=-1):
+        """z = M r on the owned planes; r . z to the host (slot < 0) or into that scalar slot without a host synchronisation."""
+        if slot >= 0:
+            self._ck(self.lib.pgd_mg_slab_up(self.h, r, x1, t, z, int(slot), None))
+            return None
         out = F64()
-        self._ck(self.lib.pgd_mg_slab_up(self.h, r, x1, t, z, C.byref(out)))
+        self._ck(self.lib.pgd_mg_slab_up(self.h, r, x1, t, z, -1, C.byref(out)))
         return out.value
 
     def bicgstab(self, op, b, x, rtol=1e-10, atol=0.0, maxit=10000):

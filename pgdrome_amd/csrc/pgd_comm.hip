@@ -92,7 +92,13 @@ void comm_release(Ctx *c) {
     for (auto &set : k.mark) for (hipEvent_t e : set) if (e) (void)hipEventDestroy(e);
     if (k.snap_flags) (void)hipHostFree(k.snap_flags);
     for (pgd_handle &wh : k.work) if (wh) { (void)free_obj(c, wh, Obj::VEC); wh = 0; }
+    // what pgd_tune / pgd_comm_timeout have set on this CONTEXT outlives a binding (PGD_TUNE=45=... given at context
+    // creation was wiped here, before the first bind); the environment defaults of the next bind still apply on top
+    const int64_t keep_rows = k.overlap_min_rows;
+    const double keep_timeout = k.timeout_s;
     k = Comm();
+    k.overlap_min_rows = keep_rows;
+    k.timeout_s = keep_timeout;
 }
 
 static void comm_env_defaults(Comm &k) {

@@ -611,7 +611,8 @@ int pgd_mg_slab_down(pgd_handle h, pgd_handle rh, pgd_handle th) {
     if (!r || !t || r == t || r->n != nloc || t->n != nloc) return fail(c, PGD_ERR_INVALID, "mg_slab_down: vectors of the local slab expected");
     int zm0 = 0, zm1 = 0;
     if (mg_slab_march(c, M, &zm0, &zm1)) {
-        PGD_HIP(c, hipMemsetAsync(c->flags, 0, 8 * sizeof(int), c->stream));
+        // (the kernels of the cycle leave at once where the context's "done" flag is up: the caller's loop - dist.pcg_mg - resets the
+        // flags at the start of a solve and stops calling when the flag rises)
         return launch_stencil_pass(c, M->cls_slab, 1, L.s.c, L.g.nx, L.g.ny, M->nzloc, zm0, zm1, r->d, nullptr, t->d, L.s.w, 1, false, nullptr, M->lz0, M->lz1);
     }
     const dim3 grid((unsigned)((L.g.nx + 63) / 64), (unsigned)((L.g.ny + 3) / 4), (unsigned)(M->lz1 - M->lz0));
@@ -643,18 +644,18 @@ int pgd_mg_coarse(pgd_handle h, pgd_handle bh, pgd_handle xh) {
     PGD_MG_SLAB(M, "mg_coarse");
     Vec *b1 = get_vec(c, bh), *x1 = get_vec(c, xh);
     if (!b1 || !x1 || b1 == x1 || b1->n != M->lv[1].n || x1->n != M->lv[1].n) return fail(c, PGD_ERR_INVALID, "mg_coarse: whole level-1 vectors expected");
-    PGD_HIP(c, hipMemsetAsync(c->flags, 0, 8 * sizeof(int), c->stream));
     return mg_cycle(c, M, 1, b1->d, false, nullptr, x1->d);
 }
 
-int pgd_mg_slab_up(pgd_handle h, pgd_handle rh, pgd_handle xh, pgd_handle th, pgd_handle zh, double *dot) {
+int pgd_mg_slab_up(pgd_handle h, pgd_handle rh, pgd_handle xh, pgd_handle th, pgd_handle zh, int slot, double *dot) {
     PGD_CTX(c, h);
     PGD_MG_SLAB(M, "mg_slab_up");
     Vec *r = get_vec(c, rh), *x1 = get_vec(c, xh), *t = get_vec(c, th), *z = get_vec(c, zh);
     const MgLevel &L = M->lv[0], &C = M->lv[1];
     const int64_t nloc = (int64_t)L.g.nx * L.g.ny * M->nzloc;
-    if (!r || !x1 || !t || !z || !dot || r->n != nloc || t->n != nloc || z->n != nloc || x1->n != C.n || t == r || z == r || z == t)
-        return fail(c, PGD_ERR_INVALID, "mg_slab_up: invalid vectors");
+    if (!r || !x1 || !t || !z || (!dot && slot < 0) || slot >= PGD_NSLOTS || r->n != nloc || t->n != nloc || z->n != nloc || x1->n != C.n ||
+        t == r || z == r || z == t)
+        return fail(c, PGD_ERR_INVALID, "mg_slab_up: invalid vectors or slot");
     const dim3 blk(256, 1, 1);
     // t = w r + P e on ALL local planes (the ghost planes of r are current and e is whole: no exchange of t is needed)
     const dim3 gall((unsigned)((L.g.nx + 63) / 64), (unsigned)((L.g.ny + 3) / 4), (unsigned)M->nzloc);
@@ -666,7 +667,6 @@ int pgd_mg_slab_up(pgd_handle h, pgd_handle rh, pgd_handle xh, pgd_handle th, pg
     const double *parts = c->partials;
     if (mg_slab_march(c, M, &zm0, &zm1)) {
         PGD_LAUNCH_CHECK(c);
-        PGD_HIP(c, hipMemsetAsync(c->flags, 0, 8 * sizeof(int), c->stream));
         PGD_TRY(launch_stencil_pass(c, M->cls_slab, 1, L.s.c, L.g.nx, L.g.ny, M->nzloc, zm0, zm1, t->d, r->d, z->d, L.s.w, 2, true, &np, M->lz0, M->lz1));
         parts = c->partials + c->partials_off;
     } else {
@@ -675,6 +675,7 @@ int pgd_mg_slab_up(pgd_handle h, pgd_handle rh, pgd_handle xh, pgd_handle th, pg
         k_mg_pass<1, true><<<gown, blk, 0, c->stream>>>(L.g, L.s, MgSlab{M->zoff, M->lz0, M->nzloc}, t->d, r->d, z->d, c->partials, nullptr);
         PGD_LAUNCH_CHECK(c);
     }
+    if (slot >= 0) return reduce_partials(c, parts, np, 1, slot, -1, 0, 0);      // r . z stays on the device (a host-driven loop on the slot bank)
     PGD_TRY(ensure_work(c, 6, 256));
     PGD_TRY(reduce_partials_to(c, parts, np, 1, c->work[6]));
     PGD_HIP(c, hipMemcpyAsync(dot, c->work[6], sizeof(double), hipMemcpyDeviceToHost, c->stream));

@@ -351,8 +351,8 @@ class TorchComm:
         xh, bh = x.dev(), b.dev()
         b1_t = be.vec_tensor(b1)
 
-        def cycle():
-            """z = M r (r: owned rows current); returns the local r . z"""
+        def cycle(slot):
+            """z = M r (r: owned rows current); the local r . z lands in scalar slot `slot` (no host synchronisation)"""
             self.halo_exchange_raw(mesh, r, cache_view=True)
             be.mg_slab_down(r, t)
             self.halo_exchange_raw(mesh, t, cache_view=True)
@@ -366,41 +366,48 @@ class TorchComm:
                     self.dist.all_reduce(b1_t)
                 self.stats["allreduce"] += 1
             be.mg_coarse(b1, x1)
-            return be.mg_slab_up(r, x1, t, z)
+            be.mg_slab_up(r, x1, t, z, slot)
 
+        # The recurrence of `pcg` below with z = M r in place of z = D^-1 r: scalars in the device slot bank, the rank sums
+        # all-reduced there, the stop test on the device - ONE host synchronisation per iteration (the look at the flags).
+        ones = self._work.get((n, "mg_ones"))
+        if ones is None:
+            ones = self._workvec(n, "mg_ones")
+            be.vec_fill(ones, 1.0)
+        be.flags_reset()
         be.mg_slab_fix_start(op, bh, xh, lo, hi)
         self.halo_exchange_raw(mesh, xh)
         be.spmv(op, xh, q, lo, hi)
-        be.vec_copy(r, bh)
-        be.vec_axpy(r, -1.0, q)
-        rr_l, bb_l = be.vec_dot(r, r, lo, hi), be.vec_dot(bh, bh, lo, hi)
-        rz_l = cycle()
-        rr, bb, rz = self.allreduce_array([rr_l, bb_l, rz_l])
-        tol2 = max(rtol * rtol * bb, atol * atol)
-        it = 0
+        be.pcg_init_slot(bh, q, ones, r, z, p, lo, hi, S_INIT)          # r = b - q; local (r.r as r.z, r.r, b.b)
+        cycle(S_INIT)                                                    # z = M r, the local r.z over the slot's r.r
         be.vec_copy(p, z)
-        while it < maxit and rr > tol2:
-            if not (np.isfinite(rr) and np.isfinite(rz)):
-                raise RuntimeError("sharded multigrid PCG breakdown (NaN) after %d iterations" % it)
-            self.halo_exchange_raw(mesh, p, cache_view=True)
-            be.spmv(op, p, q, lo, hi)
-            pq = float(self.allreduce_array([be.vec_dot(p, q, lo, hi)])[0])
-            alpha = rz / pq
-            be.vec_axpy(xh, alpha, p)
-            be.vec_axpy(r, -alpha, q)
-            it += 1
-            rr_l = be.vec_dot(r, r, lo, hi)
-            rz_l = cycle()
-            rr, rz_new = self.allreduce_array([rr_l, rz_l])
-            if rr <= tol2:
+        self.allreduce_slots(S_INIT, 3)
+        be.pcg_tol_slot(rtol, atol, S_INIT + 1, S_INIT + 2, S_TOL2)       # (raises the flag for a start that already meets the bar)
+        rz_old, k = S_INIT, 0
+        while True:
+            done, iters, status = be.flags()
+            if done or k >= maxit:
                 break
-            be.vec_scale(p, rz_new / rz)
-            be.vec_axpy(p, 1.0, z)
-            rz = rz_new
+            out = S_PAIR + 2 * (k & 1)
+            self.halo_exchange_raw(mesh, p, cache_view=True)
+            be.spmv_dot_slot(op, p, q, p, lo, hi, S_PQ)                  # q = A p, local p.q
+            self.allreduce_slots(S_PQ, 1)
+            be.pcg_xr_slot(xh, r, p, q, ones, z, lo, hi, rz_old, S_PQ, out)      # x += alpha p, r -= alpha q; local (.., r.r) in out, out + 1
+            cycle(out)                                                   # z = M r, the local r.z into `out`
+            self.allreduce_slots(out, 2)
+            be.pcg_check_slot(out + 1, S_TOL2)
+            be.pcg_p_slot(p, z, lo, hi, out, rz_old)
+            rz_old = out
+            k += 1
+        if status != 0:
+            raise RuntimeError("sharded multigrid PCG breakdown (NaN residual) after %d iterations" % iters)
+        sl = be.slots_get(0, 24)
+        bb = sl[S_INIT + 2]
+        rr = sl[S_FINAL_RR] if iters > 0 else sl[S_INIT + 1]
         self.stats["sharded_mg_solves"] = self.stats.get("sharded_mg_solves", 0) + 1
         x.touched_dev()
         self.halo_exchange(mesh, x)
-        return it, (float(np.sqrt(rr / bb)) if bb > 0 else 0.0)
+        return iters, (float(np.sqrt(rr / bb)) if bb > 0 else 0.0)
 
     def pcg(self, mesh, op, b, x, rtol, atol, maxit):
         if self.in_library:

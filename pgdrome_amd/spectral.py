@@ -168,6 +168,8 @@ def get(fem, A, b, k, prm):
         STATS["dropped_requests"] += 1
         LOG.warning("spectral start asked for but not available on this system: %s", e)
     _SPACES[key] = sp
+    if hit is False:
+        weakref.finalize(A.lay, _SPACES.pop, key, None)        # the k vectors (2 GB at 256^3) go with their layout
     return sp
 
 
