@@ -495,8 +495,8 @@ def sharded_v_cycle_rank(args):
         c = d["config"]
         return {"passes_per_s": d["value"], "ms_per_pass": d["ms_per_step"], "pcg_iterations_per_pass": c["pcg_iterations_per_step"],
                 "us_per_pcg_iteration": c["us_per_pcg_iteration"], "solves_preconditioned_by_the_slab_v_cycle": c["sharded_v_cycle_solves"],
-                "note": "one rank, no ghost planes; level 0 in the plain slab kernels (not yet the stencil march), the product from the CSR "
-                        "values; compare config.multigrid_preconditioner (the unsharded in-library loop)"}
+                "note": "one rank, no ghost planes; level 0 in the stencil march, the recurrence on the device slot bank driven from the host "
+                        "(one synchronisation per iteration); compare config.multigrid_preconditioner (the unsharded in-library loop)"}
     except Exception:      # noqa: BLE001 - a side section must not take the line with it
         return None
 
