@@ -182,7 +182,7 @@ def harvest(fem, A, b, k, steps=None):
     lay, V = A.lay, b.V
     t0 = time.perf_counter()
     m = int(steps) if steps else max(int(2.5 * k), k + 4)
-    prm = fem._Params(linear_solver="cg", preconditioner="amg", relative_tolerance=1e-11, spectral_start=0)
+    prm = fem._Params(linear_solver="cg", preconditioner="amg", relative_tolerance=1e-10, spectral_start=0)
     any_solver = os.environ.get("PGD_SPECTRAL_ANY_SOLVER") == "1"
     v = b.copy()
     if A.bc_vertices.size:
@@ -201,10 +201,12 @@ def harvest(fem, A, b, k, steps=None):
         if j == 0 and info.get("method") != "mg_pcg" and not any_solver:
             raise _Unavailable("the multigrid preconditioner does not apply here (%s): a harvest through Jacobi-PCG solves would "
                                "cost %d cold solves; PGD_SPECTRAL_ANY_SOLVER=1 accepts that" % (info.get("method"), m))
-        for _ in range(2):                                 # classical Gram-Schmidt, twice
+        for _ in range(2):                                 # classical Gram-Schmidt, twice: w -= Q (Q'w), eight vectors per pass
             h = _multidot(fem, lay, w, Q)
-            for hj, q in zip(h, Q):
-                w.axpy(-float(hj), q)
+            out = fem.Vector(V)
+            be.vec_lincomb(out.dev_for_write(), [w.dev()] + [q.dev() for q in Q], [1.0] + [-float(hj) for hj in h])
+            out.touched_dev()
+            w = out
         nw = w.norm("l2")
         if not nw > 1e-13:
             break
