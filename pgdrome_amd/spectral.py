@@ -12,12 +12,12 @@ along them out of every later start residual:
     per solve second level of the Galerkin start (fem._rescale_start is the first):  x0 = x1 + Y (Y'AY)^-1 Y'(b - A x1).
               Y'AY = sum_t c_t (Y'A_t Y) from Gram matrices kept per atom (Y vanishes on the eliminated nodes, so the
               operator's Dirichlet rows play no part): one product, one multi-dot over Y, one linear combination over Y -
-              about 1 ms at 256^3 with k = 16 against the 20 ms the iterations it saves would take.
+              about 1.5 ms at 256^3 with k = 16 (2.7 ms with 32) against the 20 - 37 ms the iterations it saves would take.
 
-Measured (tools/spectral_start_study.py, profiles/r04_spectral_start_study_*.jsonl; cfg4, 256^3): PCG iterations per pass
-551 -> 468 / 440 / 427 for k = 4 / 8 / 16; k = 32 gives nothing more (the Ritz pairs beyond the first ~16 of 40 steps have not
-converged).  That is what an exact deflation of the start can do here: the right-hand sides of later modes are spread over the
-whole spectrum and the first residual is only 1e-3 .. 1e-5 of |b| - see HISTORY.md (r04).
+Measured (tools/spectral_start_study.py, bench.py --spectral-start k, profiles/r04_spectral_start_study_*.jsonl; cfg4, 256^3): PCG
+iterations per pass 551 -> 425 / 338 / 303 / 298 for k = 16 / 32 / 48 / 64 (2.5 k Lanczos steps each: the accuracy of the Ritz pairs
+matters - 32 vectors out of 40 steps were WORSE than 16), 9.7 -> 12.2 / 14.6 / 15.7 / 15.6 passes/s.  Beyond that the right-hand sides
+of later modes are spread over the whole spectrum and the first residual stays at 1e-3 .. 1e-5 of |b| - HISTORY.md (r04) has the tables.
 
 Opt-in: ``settings["spectral_start"] = k`` (forwarded like every other key of the reference's ``settings``,
 solver.py:593-594) or PGD_SPECTRAL_START=k; off by default, so that a run without it is the run of the earlier rounds bit for
