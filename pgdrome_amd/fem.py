@@ -3082,7 +3082,7 @@ def _solve_linear(A, b, x, prm):
             # settings["spectral_start"] = k: the second level of the Galerkin start, over k Ritz vectors harvested once per space
             # and Dirichlet set (pgdrome_amd/spectral.py); the harvest itself is one-time work and stays out of the solve's clock
             k_spec = spectral.requested(prm) if n >= spectral.MIN_ROWS else 0
-            spec = spectral.get(sys.modules[__name__], A, b, k_spec, prm) if k_spec > 0 else None
+            spec = spectral.get(sys.modules[__name__], A, b, k_spec, prm) if k_spec != 0 else None
             t_solve = time.perf_counter()
             start_coefs = None
             if WARM_START_RESCALE and not x._zero:

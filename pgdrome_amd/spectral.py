@@ -20,7 +20,8 @@ matters - 32 vectors out of 40 steps were WORSE than 16), 9.7 -> 12.2 / 14.6 / 1
 of later modes are spread over the whole spectrum and the first residual stays at 1e-3 .. 1e-5 of |b| - HISTORY.md (r04) has the tables.
 
 Opt-in: ``settings["spectral_start"] = k`` (forwarded like every other key of the reference's ``settings``,
-solver.py:593-594) or PGD_SPECTRAL_START=k; off by default, so that a run without it is the run of the earlier rounds bit for
+solver.py:593-594) or PGD_SPECTRAL_START=k - or "auto": 32 vectors, harvested once a space has seen 48 large SPD solves (a run that
+short never pays the harvest back); off by default, so that a run without it is the run of the earlier rounds bit for
 bit.  The harvest needs the multigrid preconditioner to be cheap; where the operator has no structure for it (or the rows are
 sharded) the request is dropped with a log line unless PGD_SPECTRAL_ANY_SOLVER=1 accepts Jacobi-PCG solves (m cold solves).
 The reference has no counterpart (direct solves, solver.py:627-636); the iterates equal the ones without it to the solver's
@@ -35,18 +36,25 @@ import weakref
 import numpy as np
 
 LOG = logging.getLogger("pgdrome_amd.spectral")
-DEFAULT_K = int(os.environ.get("PGD_SPECTRAL_START", "0") or 0)
 MIN_ROWS = int(os.environ.get("PGD_SPECTRAL_MIN_ROWS", "200000"))         # smaller systems: the solves are launch-bound, nothing to win
 RESIDUAL_BAR = 1e-2                                                         # relative residual |A y - theta y| / (theta |y|) of a kept Ritz pair
 STATS = {"harvests": 0, "harvest_seconds": 0.0, "corrections": 0, "dropped_requests": 0}
 _SPACES = {}      # (id(layout), Dirichlet signature) -> SpectralStart | None (None: asked for, not available)
 
 
+AUTO_K = 32                 # settings["spectral_start"] = "auto": this many vectors ...
+AUTO_AFTER = 48             # ... harvested when a space has seen this many large SPD solves (the harvest pays back after ~65 passes: short runs never pay)
+_AUTO_SOLVES = {}
+
+
 def requested(prm):
-    """k of settings["spectral_start"] (an unset key of the nested parameter dictionary is an empty dictionary), else the default."""
+    """k of settings["spectral_start"] (an unset key of the nested parameter dictionary is an empty dictionary), else the default;
+    "auto": -AUTO_K (get() then waits for AUTO_AFTER solves on the space before it harvests)."""
     v = prm.get("spectral_start", None) if hasattr(prm, "get") else None
     if v is None or isinstance(v, dict):
-        return DEFAULT_K
+        v = os.environ.get("PGD_SPECTRAL_START", "0") or "0"
+    if isinstance(v, str) and v.strip().lower() == "auto":
+        return -AUTO_K
     try:
         return max(int(v), 0)
     except (TypeError, ValueError):
@@ -55,6 +63,7 @@ def requested(prm):
 
 def clear():
     _SPACES.clear()
+    _AUTO_SOLVES.clear()
 
 
 class SpectralStart:
@@ -161,6 +170,12 @@ def get(fem, A, b, k, prm):
     hit = _SPACES.get(key, False)
     if hit is not False and (hit is None or hit.lay() is A.lay):
         return hit
+    if k < 0:                                # "auto": not before the space has seen AUTO_AFTER solves
+        n = _AUTO_SOLVES.get(key, 0) + 1
+        _AUTO_SOLVES[key] = n
+        if n < AUTO_AFTER:
+            return None
+        k = -k
     sp = None
     try:
         sp = harvest(fem, A, b, k)

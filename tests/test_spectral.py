@@ -84,6 +84,18 @@ def test_spectral_start_on_the_oracle_backend(monkeypatch):
         A = (a_k * F.assemble_atom(c, e, F.STIFF) + a_m * F.assemble_atom(c, e, F.MASS)).tocsr()[free][:, free]
         w = spla.eigsh(A.tocsc(), k=1, sigma=0, which="LM")[0]
         assert abs(sp.theta[0] - w[0]) <= 1e-8 * w[0]
+        # (3) "auto": nothing before the space has seen AUTO_AFTER solves, then the harvest
+        monkeypatch.setattr(spectral, "AUTO_AFTER", 4)
+        monkeypatch.setattr(spectral, "AUTO_K", 5)
+        fem.clear_caches()
+        P = fem.Point
+        p3 = PGDProblem(**problems.reaction_diffusion(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), 19, 19, 19), 17, PGD_nmax=4, PGD_tol=1e-12))
+        s0 = dict(spectral.STATS)
+        p3.solve_PGD(_problem="linear", settings=dict(SET, spectral_start="auto"))
+        solves = sum(int(v) for v in p3.num_fp_it)
+        assert spectral.STATS["harvests"] - s0["harvests"] == 1 and spectral.STATS["corrections"] - s0["corrections"] == solves - 3
+        assert [int(v) for v in p3.num_fp_it] == [int(v) for v in p0.num_fp_it]
+        np.testing.assert_allclose(p3.amplitude, p0.amplitude, rtol=1e-7)
     finally:
         fem.set_backend(old) if old is not None else None
         fem.clear_caches()

@@ -19,7 +19,7 @@ ap.add_argument("--modes", type=int, default=0)
 ap.add_argument("--problem", default="linear")
 ap.add_argument("--rtol", type=float, default=1e-10)
 ap.add_argument("--preconditioner", default="jacobi", help='settings["preconditioner"]: "jacobi" (default) or a multigrid name ("amg")')
-ap.add_argument("--spectral-start", type=int, default=0, help='settings["spectral_start"]: Ritz vectors in the second level of the Galerkin start (0: off)')
+ap.add_argument("--spectral-start", default="0", help='settings["spectral_start"]: Ritz vectors in the second level of the Galerkin start (0: off; "auto")')
 ap.add_argument("--trace", action="store_true", help="one line per enrichment step on stderr: seconds, passes, PCG iterations")
 args = ap.parse_args()
 
@@ -47,8 +47,8 @@ if args.trace:
         return out
     p.FP_solve = _timed
 settings = {"linear_solver": "cg", "preconditioner": args.preconditioner, "relative_tolerance": args.rtol}
-if args.spectral_start:
-    settings["spectral_start"] = args.spectral_start
+if args.spectral_start not in ("0", ""):
+    settings["spectral_start"] = args.spectral_start if args.spectral_start == "auto" else int(args.spectral_start)
 p.solve_PGD(_problem=args.problem, settings=settings)
 be.sync()
 t2 = time.time()
