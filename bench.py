@@ -49,10 +49,10 @@ def parse():
     ap.add_argument("--spectral-start", type=int, default=32,
                     help='settings["spectral_start"]: Ritz vectors in the second level of the Galerkin start of the spatial solves '
                          "(pgdrome_amd/spectral.py; harvested once, outside the timed region, reported in config.spectral_start); 0: off")
-    ap.add_argument("--spectral-sharded", action="store_true",
-                    help="N > 1 (or --dist-driver): harvest and use the spectral start space on the row-sharded mesh too (the harvest's solves "
-                         "run through the sharded V-cycle, dist.pcg_mg, driven from the host); off by default - the first contact with N GPUs "
-                         "runs the plain sharded Jacobi-PCG")
+    ap.add_argument("--no-spectral-sharded", action="store_true",
+                    help="N > 1 (or --dist-driver): do NOT harvest / use the spectral start space on the row-sharded mesh (by default every N runs "
+                         "the same algorithm - the harvest's solves go through the sharded V-cycle, dist.pcg_mg, driven from the host; a harvest "
+                         "that fails on any rank switches it off on all of them and the run goes on as the plain sharded Jacobi-PCG)")
     ap.add_argument("--preconditioner", default="jacobi",
                     help='settings["preconditioner"] of the timed run: "jacobi" (the metric\'s Jacobi-PCG) or "amg" (the V-cycle of pgd_mg.hip; '
                          "on a sharded run the slab form of it, dist.pcg_mg) - a side measurement, never the headline")
@@ -220,14 +220,29 @@ def main():
     # ... and, on request, the spectral start space of the spatial solves: Ritz vectors of the first spatial operator, harvested
     # once per space and Dirichlet set (one-time work like the atoms; its seconds are reported on their own)
     spectral_info = None
-    if args.spectral_start > 0 and (not sharded or args.spectral_sharded) and args.preconditioner == "jacobi":
+    if args.spectral_start > 0 and (not sharded or not args.no_spectral_sharded) and args.preconditioner == "jacobi":
         from pgdrome_amd import spectral
         settings["spectral_start"] = args.spectral_start
         t_h = time.time()
-        A0, b0 = _first_spatial_system(prob)
-        sp = spectral.get(fem, A0, b0, args.spectral_start, fem._Params(settings))
-        be.sync()
-        del A0, b0
+        sp, why = None, None
+        try:
+            A0, b0 = _first_spatial_system(prob)
+            sp = spectral.get(fem, A0, b0, args.spectral_start, fem._Params(settings))
+            be.sync()
+            del A0, b0
+        except Exception as e:      # noqa: BLE001 - the run must go on without it (N > 1: the harvest is the only host-driven solver loop of the run)
+            if not sharded:
+                raise
+            why = repr(e)[:300]
+            sys.stderr.write("bench.py: rank %d: the spectral start space could not be harvested (%s): the run goes on without it\n" % (rank, why))
+        if sharded:
+            # every rank uses it or none does (a rank-local failure above must not leave the ranks with different start vectors:
+            # the iteration counts, and with them the collectives of the solves, would differ)
+            ok = comm.allreduce_array([0.0 if sp is not None else 1.0])[0] == 0.0
+            if not ok:
+                spectral.clear()
+                settings["spectral_start"] = 0
+                sp = None
         spectral_info = ({"vectors": sp.k, "asked": args.spectral_start, "lanczos_steps": sp.info["lanczos_steps"],
                           "inner_pcg_iterations_of_the_harvest": sp.info["inner_pcg_iterations"],
                           "harvest_seconds_untimed": time.time() - t_h, "hbm_bytes": 8.0 * sp.k * n ** 3,
@@ -236,7 +251,7 @@ def main():
                           "note": "settings[\"spectral_start\"]: second level of the Galerkin start of every spatial solve, x0 += Y (Y'AY)^-1 "
                                   "Y'(b - A x0) over Ritz vectors of the first spatial operator (inverse Lanczos from the first right-hand "
                                   "side through multigrid-PCG solves, once); config.without_spectral_start is the same workload without it"}
-                         if sp is not None else {"vectors": 0, "asked": args.spectral_start, "note": "not available on this system"})
+                         if sp is not None else {"vectors": 0, "asked": args.spectral_start, "note": "not available on this system", "error": why})
 
     def barrier():
         be.sync()
