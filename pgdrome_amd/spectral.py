@@ -197,8 +197,11 @@ def harvest(fem, A, b, k, steps=None):
     lay, V = A.lay, b.V
     t0 = time.perf_counter()
     m = int(steps) if steps else max(int(2.5 * k), k + 4)
-    prm = fem._Params(linear_solver="cg", preconditioner="amg", relative_tolerance=1e-10, spectral_start=0)
-    any_solver = os.environ.get("PGD_SPECTRAL_ANY_SOLVER") == "1"
+    # (PGD_SPECTRAL_HARVEST_PRECONDITIONER=jacobi: the inverse-Lanczos solves through the Jacobi-PCG even where the V-cycle applies - the
+    # price of a harvest without any multigrid, measured in HISTORY.md r04)
+    prec = os.environ.get("PGD_SPECTRAL_HARVEST_PRECONDITIONER", "amg")
+    prm = fem._Params(linear_solver="cg", preconditioner=prec, relative_tolerance=1e-10, spectral_start=0)
+    any_solver = os.environ.get("PGD_SPECTRAL_ANY_SOLVER") == "1" or prec not in fem.MULTIGRID_NAMES
     v = b.copy()
     if A.bc_vertices.size:
         be.vec_set(v.dev(), A.bc_vertices, 0.0)          # the whole Krylov space then vanishes on the eliminated nodes
