@@ -2255,6 +2255,12 @@ _RECORDING = None
 STATS_PREFETCH = {"batches": 0, "values": 0, "requests": 0, "hits": 0}
 
 
+def drop_functional_plans(scope_id):
+    """Forget the plans of the call sites tagged (.., scope_id, ..): their problem has died (solver.PGDProblem)."""
+    for tag in [t for t in _FUNCTIONAL_PLANS if isinstance(t, tuple) and len(t) > 1 and t[1] == scope_id]:
+        _FUNCTIONAL_PLANS.pop(tag, None)
+
+
 class functional_scope:
     """``with functional_scope(tag, iterates):`` around the evaluation of a call site's functionals.  `iterates`: the vectors
     that change from call to call (the current factors of all dimensions), in an order that is the same every time; every

@@ -23,7 +23,9 @@ reference discards the first result).
 """
 from __future__ import annotations
 
+import itertools
 import logging
+import weakref
 
 import numpy as np
 import scipy.sparse
@@ -32,11 +34,19 @@ import scipy.sparse.linalg
 from . import fem
 
 
+_SCOPE_IDS = itertools.count(1)
+
+
 class PGDProblem:
     def __init__(self, name=None, name_coord=[], modes_info=[], Vs=[], dom_fct=None, bc_fct=None,
                  load=[], param=None, rhs_fct=None, lhs_fct=None, probs=[], seq_fp=[], PGD_nmax=20,
                  PGD_tol=1e-10, num_elem=[], order=[], ranges=[], dims=[], *args, **kwargs):
         self.logger = logging.getLogger(__name__ + "." + self.__class__.__name__)
+        # the call sites of this problem's functionals (fem.functional_scope) are named by a number no other problem ever had - an
+        # id() is reused once its object has died, and a later problem at the same address would then be served the dead one's plan
+        # (its layouts, its atoms: r04, seen as "spmv: size mismatch" in a long test session); the plans go when the problem goes
+        self._scope_id = next(_SCOPE_IDS)
+        weakref.finalize(self, fem.drop_functional_plans, self._scope_id)
         self.name = name
         self.name_coord = name_coord
         self.modes_info = modes_info
@@ -300,7 +310,7 @@ class PGDProblem:
                 # |new - old|^2 of the rank-one tensors = nn + oo - 2 no, factor by factor
                 nn = no = oo = 1.0
                 its = [F.vector() for F in list(Fs) + list(Fs_init) if hasattr(F, "vector")]
-                with fem.functional_scope(("stop", id(self)), its):
+                with fem.functional_scope(("stop", self._scope_id), its):
                     for d in range(D):
                         if self._is_fd(solve_modes, d):
                             nn *= self._mm_quad(d, Fs[d], Fs[d])
@@ -339,7 +349,7 @@ class PGDProblem:
         def forms(u):
             # (the functionals the two callbacks evaluate - eagerly, one assemble() at a time - are learned per call site and
             # computed ahead in one batch the next time round: fem.functional_scope)
-            with fem.functional_scope(("solve", id(self), dim), [F.vector() for F in Fs if hasattr(F, "vector")]):
+            with fem.functional_scope(("solve", self._scope_id, dim), [F.vector() for F in Fs if hasattr(F, "vector")]):
                 a = self.lhs_fct(u, var_F, Fs, self.meshes, self.dom, self.param, self.prob[dim], dim)
                 l = self.rhs_fct(u, var_F, Fs, self.meshes, self.dom, self.param, self.load, self.PGD_func,
                                  self.prob[dim], n_enr, dim)
