@@ -28,7 +28,7 @@ def test_gpus_2_starts_two_ranks_before_touching_hip(tmp_path):
     assert len(out) == 1 and json.loads(out[0]) == {"metric": "stub", "value": 1.0, "n_gpus": 2}     # ONE line: rank 0's
     a = rec["argv"]
     assert a[:a.index(os.path.join(ROOT, "bench.py"))] == ["--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                                                           "--master-port", rec["env"]["MASTER_PORT"]]
+                                                           "--master-port", rec["env"]["MASTER_PORT"], "--"]
     assert a[a.index(os.path.join(ROOT, "bench.py")) + 1:] == ["--gpus", "2", "--steps", "3", "--warmup", "1"]
     assert rec["env"]["MASTER_ADDR"] == "127.0.0.1" and 1024 < int(rec["env"]["MASTER_PORT"]) < 65536
     assert rec["env"]["PGD_BENCH_LAUNCHED"] == "1" and rec["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
@@ -64,3 +64,22 @@ def test_forced_launcher_at_one_gpu_takes_the_same_relay(tmp_path):
     assert r.returncode == 0 and json.loads(r.stdout.decode())["n_gpus"] == 1
     assert rec["env"]["PGD_BENCH_FORCE_LAUNCHER"] is None            # the ranks must not launch again
     assert rec["argv"][1:3] == ["--nproc-per-node", "1"]
+
+
+def test_two_ranks_rehearsed_through_the_real_launcher(tmp_path):
+    """`python bench.py --gpus 2 --cpu-rehearsal`: the REAL launcher (torch.distributed.run), two gloo ranks, the sharded mesh, the
+    sharded solver driver, the spectral start harvested through the sharded V-cycle and agreed by the all-reduced vote, the timing
+    window between barriers, the maximum over the ranks, ONE line from rank 0 - everything of an N-rank run but the GPUs (the oracle
+    backend does the local arithmetic at a tiny size).  An argument of ours that abbreviates a launcher option (`--n`) must not
+    be read as that option (r04: it was, until the launcher line got its `--`)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PGD_BENCH_LAUNCHER")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-rehearsal", "--n", "12", "--n-mu", "9",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, env=env, timeout=600, cwd=str(tmp_path))
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = r.stdout.decode().splitlines()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["data"] == "cpu rehearsal" and d["value"] > 0
+    c = d["config"]
+    assert c["parallelism"] == "z-slab row sharding x2" and c["spectral_start"]["vectors"] >= 1 and c["spectral_start"]["error"] is None
+    assert c["sharded_v_cycle_solves"] >= 5 and c["pcg_iterations_per_step"] > 0
