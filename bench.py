@@ -56,10 +56,6 @@ def parse():
     ap.add_argument("--preconditioner", default="jacobi",
                     help='settings["preconditioner"] of the timed run: "jacobi" (the metric\'s Jacobi-PCG) or "amg" (the V-cycle of pgd_mg.hip; '
                          "on a sharded run the slab form of it, dist.pcg_mg) - a side measurement, never the headline")
-    ap.add_argument("--cpu-rehearsal", action="store_true",
-                    help="rehearse the PLUMBING of an N-rank run on a machine without GPUs (tests): the same launcher, rendezvous, sharded mesh, "
-                         "solver driver, timing window, max-over-ranks and result line - over gloo, with the oracle backend doing the local "
-                         "arithmetic at a small --n.  Its line says \"data\": \"cpu rehearsal\" and carries no roofline: never a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-reduction", action="store_true",
                     help="with --dist-driver: force the Chronopoulos-Gear recurrence that N > 1 uses")
@@ -103,7 +99,7 @@ def _visible_gpus():
     return int(torch.cuda.device_count())
 
 
-def launch_ranks(args, argv):
+def launch_ranks(args, argv, script=None, need_gpus=True):
     """`python bench.py --gpus N` without a launcher around it (WORLD_SIZE unset - exactly how the driver starts N = 1): start
     the N ranks HERE, as CHILD processes of `python -m torch.distributed.run` (never an exec: this process stays what it is),
     one per GPU, rendezvous on 127.0.0.1 at a free port; relay the ONE JSON line rank 0 prints to our stdout and leave with the
@@ -112,7 +108,7 @@ def launch_ranks(args, argv):
     import shlex
     import subprocess
     n = args.gpus
-    have = n if args.cpu_rehearsal else _visible_gpus()
+    have = _visible_gpus() if need_gpus else n          # (need_gpus False, another script: tests/helpers/bench_rehearsal.py)
     if have < n:
         sys.stderr.write("bench.py: --gpus %d asked for but %d GPU(s) visible to this process - not starting any rank\n" % (n, have))
         return 2
@@ -122,7 +118,7 @@ def launch_ranks(args, argv):
     # ("--": everything behind it is the script and ITS arguments - the launcher's parser would otherwise read an argument of ours
     # that abbreviates one of its own options, e.g. `--n`, as that option)
     cmd = head + ["--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(port), "--",
-                  os.path.abspath(__file__)] + list(argv)
+                  os.path.abspath(script or __file__)] + list(argv)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PGD_BENCH_LAUNCHED="1")
     env.pop("PGD_BENCH_FORCE_LAUNCHER", None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: RCCL between processes needs it on this driver
@@ -167,8 +163,6 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: one process per GPU (run `python bench.py --gpus N`, which starts "
                          "its own ranks, or torch.distributed.run with --nproc-per-node N)" % (args.gpus, world))
-    if args.cpu_rehearsal:
-        return cpu_rehearsal(args, world, rank, result_fd)
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.dist_driver
     if sharded:
@@ -473,95 +467,6 @@ def main():
         if args.watchdog_seconds > 0:
             import faulthandler
             faulthandler.cancel_dump_traceback_later()
-
-
-def cpu_rehearsal(args, world, rank, result_fd):
-    """The plumbing of an N-rank run without GPUs: what `main` does around the solves - process group, sharded mesh, the sharded
-    solver driver of pgdrome_amd/dist.py, the spectral start with its all-reduced vote, the timing window between barriers, the
-    maximum over the ranks, ONE line from rank 0 - over gloo with the oracle backend (test infrastructure: imported here and
-    nowhere in the product path).  Not a measurement."""
-    import datetime
-    import torch
-    import torch.distributed as dist
-    from oracle.backend_numpy import NumpyBackend
-    from pgdrome_amd import dist as pdist, fem, problems, spectral
-    from pgdrome_amd.solver import PGDProblem
-    sharded = world > 1 or args.dist_driver
-    if sharded:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if "MASTER_PORT" not in os.environ:
-            os.environ["MASTER_PORT"] = str(_free_port())
-        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
-    be = fem.set_backend(NumpyBackend())
-    n = min(args.n, 24)
-    P = fem.Point
-    if sharded:
-        comm = pdist.TorchComm(dist, be, True if args.single_reduction else None, in_library=False)
-        space = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), n - 1, n - 1, n - 1)
-    else:
-        space = fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), n - 1, n - 1, n - 1)
-    spec = problems.reaction_diffusion(space, min(args.n_mu, 17), PGD_nmax=50, PGD_tol=1e-12)
-    prob = PGDProblem(**spec)
-    settings = {"linear_solver": "cg", "preconditioner": args.preconditioner, "relative_tolerance": args.rtol}
-    spectral_info = None
-    if args.spectral_start > 0 and (not sharded or not args.no_spectral_sharded) and args.preconditioner == "jacobi":
-        spectral.MIN_ROWS = 0
-        settings["spectral_start"] = min(args.spectral_start, 6)
-        sp, why = None, None
-        try:
-            A0, b0 = _first_spatial_system(prob)
-            sp = spectral.get(fem, A0, b0, settings["spectral_start"], fem._Params(settings))
-        except Exception as e:      # noqa: BLE001
-            if not sharded:
-                raise
-            why = repr(e)[:300]
-        if sharded:
-            if not comm.allreduce_array([0.0 if sp is not None else 1.0])[0] == 0.0:
-                spectral.clear()
-                settings["spectral_start"] = 0
-                sp = None
-        spectral_info = {"vectors": sp.k if sp is not None else 0, "error": why}
-    W, K = args.warmup, args.steps
-    state = {"t0": None, "t1": None, "i0": 0, "i1": 0}
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    def hook(passes):
-        if passes == W:
-            barrier()
-            state["i0"], state["t0"] = fem.STATS["pcg_iterations"], time.perf_counter()
-        elif passes == W + K:
-            barrier()
-            state["t1"], state["i1"] = time.perf_counter(), fem.STATS["pcg_iterations"]
-            raise _Done()
-    prob.pass_hook = hook
-    if W == 0:
-        hook(0)
-    try:
-        for _ in range(1000):
-            prob.solve_PGD(_problem="linear", settings=settings)
-    except _Done:
-        pass
-    elapsed = state["t1"] - state["t0"]
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    out = {"metric": "PGD fixed-point iters/sec + SpMV HBM GB/s, 256^3 P1 space x 1D param", "value": K / elapsed,
-           "unit": "fixed-point iterations/s", "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": 1e3 * elapsed / K,
-           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "cpu rehearsal",
-           "config": {"workload": "REHEARSAL of the run's plumbing on the CPU (gloo, oracle backend), %d^3 x %d: not a measurement" % (n, min(args.n_mu, 17)),
-                      "parallelism": "z-slab row sharding x%d" % world if sharded else "single process",
-                      "pcg_iterations_per_step": (state["i1"] - state["i0"]) / K, "modes_completed": len(prob.num_fp_it),
-                      "spectral_start": spectral_info, "preconditioner": args.preconditioner,
-                      "sharded_v_cycle_solves": (comm.stats.get("sharded_mg_solves", 0) if sharded else None)}}
-    if rank == 0:
-        os.write(result_fd, (json.dumps(out) + "\n").encode())
-    if sharded:
-        dist.barrier()
-        dist.destroy_process_group()
 
 
 def ghost_rank_rehearsal():

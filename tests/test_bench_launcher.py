@@ -67,13 +67,13 @@ def test_forced_launcher_at_one_gpu_takes_the_same_relay(tmp_path):
 
 
 def test_two_ranks_rehearsed_through_the_real_launcher(tmp_path):
-    """`python bench.py --gpus 2 --cpu-rehearsal`: the REAL launcher (torch.distributed.run), two gloo ranks, the sharded mesh, the
+    """`python tests/helpers/bench_rehearsal.py --gpus 2`: bench.launch_ranks - the REAL launcher (torch.distributed.run) - two gloo ranks, the sharded mesh, the
     sharded solver driver, the spectral start harvested through the sharded V-cycle and agreed by the all-reduced vote, the timing
     window between barriers, the maximum over the ranks, ONE line from rank 0 - everything of an N-rank run but the GPUs (the oracle
     backend does the local arithmetic at a tiny size).  An argument of ours that abbreviates a launcher option (`--n`) must not
     be read as that option (r04: it was, until the launcher line got its `--`)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PGD_BENCH_LAUNCHER")}
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cpu-rehearsal", "--n", "12", "--n-mu", "9",
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "helpers", "bench_rehearsal.py"), "--gpus", "2", "--n", "12", "--n-mu", "9",
                         "--steps", "2", "--warmup", "1"], capture_output=True, env=env, timeout=600, cwd=str(tmp_path))
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     lines = r.stdout.decode().splitlines()
