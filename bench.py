@@ -80,6 +80,15 @@ def parse():
     return ap.parse_args()
 
 
+_T0 = time.time()
+
+
+def _note(what):
+    """One progress line on stderr (seconds since this process started): a long run shows where it is."""
+    sys.stderr.write("bench.py: [%6.1f s] %s\n" % (time.time() - _T0, what))
+    sys.stderr.flush()
+
+
 def _free_port():
     """A TCP port nobody listens on right now (127.0.0.1): back-to-back runs on one node must not meet in TIME_WAIT."""
     import socket
@@ -203,6 +212,7 @@ def main():
         be.ctx.tune(18, args.single_sync)
 
     n = args.n
+    _note("library bound; setup")
     t_setup = time.time()
     P = fem.Point
     if sharded:
@@ -226,6 +236,7 @@ def main():
         from pgdrome_amd import spectral
         settings["spectral_start"] = args.spectral_start
         t_h = time.time()
+        _note("harvest of the spectral start space")
         sp, why = None, None
         try:
             A0, b0 = _first_spatial_system(prob)
@@ -254,6 +265,8 @@ def main():
                                   "Y'(b - A x0) over Ritz vectors of the first spatial operator (inverse Lanczos from the first right-hand "
                                   "side through multigrid-PCG solves, once); config.without_spectral_start is the same workload without it"}
                          if sp is not None else {"vectors": 0, "asked": args.spectral_start, "note": "not available on this system", "error": why})
+
+    _note("warm-up and timed passes")
 
     def barrier():
         be.sync()
@@ -408,6 +421,7 @@ def main():
                      # not stream the CSR arrays) - the CSR kernels' own measurement is in csr_product below
                      "csr_formula_bytes_per_launch": alg, "csr_formula_equivalent_GBps": alg / avg / 1e9 if avg > 0 else 0.0},
     }
+    _note("timed region over: %.3f passes/s" % out["value"])
     if rank == 0 and world == 1 and not args.no_csr_section:
         out["roofline"]["csr_product"] = csr_section(be, prob, n_sp, nnz)
     general = None
@@ -417,14 +431,20 @@ def main():
         modes_ref = [[np.asarray(f[k].vector()[:]).copy() for f in prob.PGD_func] for k in range(n_done)]
         # (without the spectral start: its harvest leans on the multigrid structure, which the operators these paths stand for -
         # natural boundaries, variable coefficients, meshes without a lattice - do not have)
+        _note("side section: general paths")
         general = general_paths(be, spec, dict(settings, spectral_start=0))
         out["config"]["general_paths"] = general
+        _note("side section: multigrid preconditioner")
         out["config"]["multigrid_preconditioner"] = multigrid_path(be, spec, dict(settings, spectral_start=0), modes_ref)
         if settings.get("spectral_start"):
+            _note("side section: the same passes without the spectral start")
             out["config"]["without_spectral_start"] = plain_start_path(be, spec, dict(settings, spectral_start=0), W, K)
     if rank == 0 and world == 1 and not sharded and not args.no_general_paths and n == 256:
+        _note("side section: a rank with ghost planes (child process)")
         out["config"]["rank_with_ghost_planes"] = ghost_rank_rehearsal()
+        _note("side section: the sharded V-cycle on one rank (child process)")
         out["config"]["sharded_v_cycle_one_rank"] = sharded_v_cycle_rank(args)
+    _note("counters")
     pmc = pmc_traffic(own, upd_bytes) if rank == 0 and world == 1 and n == 256 and sym["nx"] and not args.no_pmc else {}
     out["roofline"].update(pmc.get("product", {}))
     if upd_n and upd_avg > avg:
@@ -457,7 +477,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         # (the CPU restatement has no spectral start: its pass is priced with the iteration count of the plain Galerkin start)
         plain = out["config"].get("without_spectral_start") or {}
+        _note("cpu_baseline")
         out["cpu_baseline"] = cpu_baseline(prob, spec, be, plain.get("pcg_iterations_per_pass", pcg_its / K), args)
+    _note("done")
     if rank == 0:
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(out) + "\n").encode())
@@ -469,6 +491,19 @@ def main():
             faulthandler.cancel_dump_traceback_later()
 
 
+def _own_world_env(**more):
+    """The environment of a child process that forms a process group of its OWN, whatever launched us: none of the launcher's rank
+    variables, and none of torch elastic's (TORCHELASTIC_USE_AGENT_STORE makes rank 0 a CLIENT of the agent's store at MASTER_PORT -
+    at a port of our own nobody listens, and the child would wait for its whole rendezvous timeout)."""
+    env = {k: v for k, v in os.environ.items()
+           if not k.startswith("TORCHELASTIC_") and k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK",
+                                                               "GROUP_WORLD_SIZE", "ROLE_RANK", "ROLE_WORLD_SIZE", "ROLE_NAME",
+                                                               "PGD_TUNE", "PGD_BENCH_LAUNCHED", "PGD_BENCH_FORCE_LAUNCHER")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    env.update(more)
+    return env
+
+
 def ghost_rank_rehearsal():
     """The sharded iteration of a rank WITH ghost planes, on this one GPU (a child process: it needs a process group of its own):
     tools/bench_self_periodic.py makes ONE rank its own neighbour on both sides (PGD_TUNE_COMM_SELF_PERIODIC), so the solve has
@@ -476,10 +511,7 @@ def ghost_rank_rehearsal():
     on the slab an 8-GPU rank of this workload owns (256 x 256 x 32).  None if the child could not run."""
     import subprocess
     try:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID"):
-            env.pop(k, None)                       # the child is a world of its own, whatever launched us
-        env.pop("PGD_TUNE", None)
+        env = _own_world_env()
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_self_periodic.py"), "--json"], capture_output=True,
                            timeout=240, env=env, cwd=ROOT)
         line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
@@ -501,9 +533,7 @@ def sharded_v_cycle_rank(args):
     ghost planes.  None if the child could not run."""
     import subprocess
     try:
-        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "TORCHELASTIC_RUN_ID", "PGD_TUNE"):
-            env.pop(k, None)
+        env = _own_world_env()
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dist-driver", "--python-driver", "--preconditioner", "amg",
                             "--steps", "6", "--warmup", "2", "--n", str(args.n), "--n-mu", str(args.n_mu), "--no-cpu-baseline", "--no-pmc",
                             "--no-csr-section", "--no-general-paths"], capture_output=True, timeout=300, env=env, cwd=ROOT)

@@ -83,3 +83,16 @@ def test_two_ranks_rehearsed_through_the_real_launcher(tmp_path):
     c = d["config"]
     assert c["parallelism"] == "z-slab row sharding x2" and c["spectral_start"]["vectors"] >= 1 and c["spectral_start"]["error"] is None
     assert c["sharded_v_cycle_solves"] >= 5 and c["pcg_iterations_per_step"] > 0
+
+
+def test_child_worlds_do_not_inherit_the_launchers_store(monkeypatch):
+    """A side section that forms a process group of its own (bench.ghost_rank_rehearsal, bench.sharded_v_cycle_rank) must not see the
+    launcher's rank variables nor torch elastic's: with TORCHELASTIC_USE_AGENT_STORE its rank 0 would wait for a store nobody serves."""
+    import bench
+    for k, v in (("RANK", "0"), ("WORLD_SIZE", "1"), ("LOCAL_RANK", "0"), ("TORCHELASTIC_USE_AGENT_STORE", "True"),
+                 ("TORCHELASTIC_RUN_ID", "none"), ("MASTER_PORT", "1"), ("PGD_TUNE", "3=0"), ("ROLE_RANK", "0")):
+        monkeypatch.setenv(k, v)
+    env = bench._own_world_env(EXTRA="1")
+    assert not [k for k in env if k.startswith("TORCHELASTIC_")]
+    assert not {"RANK", "WORLD_SIZE", "LOCAL_RANK", "ROLE_RANK", "PGD_TUNE"} & set(env)
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["MASTER_PORT"] != "1" and env["EXTRA"] == "1"
