@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--preconditioner", default="jacobi",
                     help='settings["preconditioner"] of the timed run: "jacobi" (the metric\'s Jacobi-PCG) or "amg" (the V-cycle of pgd_mg.hip; '
                          "on a sharded run the slab form of it, dist.pcg_mg) - a side measurement, never the headline")
+    ap.add_argument("--share-one-gpu", action="store_true",
+                    help="REHEARSAL on a one-GPU box, never a measurement: the N ranks all use GPU 0, the exchange steps go through gloo "
+                         "(RCCL refuses two ranks on one device) and the library's sharded loop through its callback binding; the "
+                         "line says so in `data`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--single-reduction", action="store_true",
                     help="with --dist-driver: force the Chronopoulos-Gear recurrence that N > 1 uses")
@@ -117,7 +121,7 @@ def launch_ranks(args, argv, script=None, need_gpus=True):
     import shlex
     import subprocess
     n = args.gpus
-    have = _visible_gpus() if need_gpus else n          # (need_gpus False, another script: tests/helpers/bench_rehearsal.py)
+    have = _visible_gpus() if need_gpus and not getattr(args, "share_one_gpu", False) else n          # (need_gpus False, another script: tests/helpers/bench_rehearsal.py)
     if have < n:
         sys.stderr.write("bench.py: --gpus %d asked for but %d GPU(s) visible to this process - not starting any rank\n" % (n, have))
         return 2
@@ -172,6 +176,8 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: one process per GPU (run `python bench.py --gpus N`, which starts "
                          "its own ranks, or torch.distributed.run with --nproc-per-node N)" % (args.gpus, world))
+    if args.share_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     sharded = world > 1 or args.dist_driver
     if sharded:
@@ -185,8 +191,11 @@ def main():
             # nothing of a multi-process run may hang silently: a rendezvous or a bind that never returns ends HERE, with every
             # thread's Python stack on stderr and a non-zero status (a fresh exit of this process; nothing is re-executed)
             faulthandler.dump_traceback_later(args.watchdog_seconds, exit=True)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
-                                timeout=datetime.timedelta(seconds=max(4.0 * args.comm_timeout, 120.0)))
+        if args.share_one_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=max(4.0 * args.comm_timeout, 120.0)))
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank),
+                                    timeout=datetime.timedelta(seconds=max(4.0 * args.comm_timeout, 120.0)))
 
     from pgdrome_amd import fem, problems
     from pgdrome_amd.hip_backend import HipBackend
@@ -380,12 +389,14 @@ def main():
         "metric": "PGD fixed-point iters/sec + SpMV HBM GB/s, 256^3 P1 space x 1D param",
         "value": K / elapsed, "unit": "fixed-point iterations/s", "n_gpus": world, "steps": K, "warmup": W,
         "ms_per_step": 1e3 * elapsed / K, "higher_is_better": True,
-        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic" if not args.share_one_gpu else "synthetic; REHEARSAL, not a measurement: %d ranks share ONE GPU over gloo" % world,
         "config": {"workload": "cfg4: 3D-space %d^3 P1 (BoxMesh, 6 tets/cube) x 1D-parameter %d P1, "
                                "-Laplace(u)+mu*u=1, Jacobi-PCG rtol %g" % (n, args.n_mu, args.rtol),
                    "spatial_dofs": n_sp, "nnz": nnz, "parallelism": "z-slab row sharding x%d" % world if sharded else "single GPU",
                    "preconditioner": args.preconditioner,
                    "sharded_pcg_driver": (("in-library loop, RCCL" if comm.in_library == "rccl" else
+                                           "in-library loop, exchange steps called back into torch.distributed" if comm.in_library == "callbacks" else
                                            "python loop, torch.distributed") if sharded else None),
                    "sharded_v_cycle_solves": (comm.stats.get("sharded_mg_solves", 0) if sharded else None),
                    "halo_overlap": (bool(be.comm_overlap(-2)) if sharded and getattr(comm, "in_library", None) == "rccl" else (False if sharded else None)),

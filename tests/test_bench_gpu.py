@@ -86,3 +86,27 @@ def test_rank_with_ghost_planes_rehearsal():
     assert not one["second_stream_used"] and not split["second_stream_used"] and over["second_stream_used"] and over["second_stream_available"]
     assert one["iterations"] == split["iterations"] > 100 and abs(over["iterations"] - one["iterations"]) <= 1
     assert 10.0 < one["us_per_iteration"] <= 1.05 * split["us_per_iteration"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("extra", [[], ["--preconditioner", "amg"]])
+def test_two_ranks_of_the_bench_on_one_gpu(extra):
+    """`python bench.py --gpus 2 --share-one-gpu`: bench.main's N > 1 code - the launcher, the sharded mesh, the spectral start's vote,
+    the timing window between barriers, the maximum over the ranks, the gathered phase timings - with the HIP kernels, two ranks on
+    GPU 0, the exchange steps over gloo.  A rehearsal (the line says so), at a small size."""
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-one-gpu", "--n", "64", "--n-mu", "33",
+                        "--steps", "4", "--warmup", "2"] + extra, capture_output=True, env=env, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and "REHEARSAL" in d["data"]
+    c = d["config"]
+    assert c["parallelism"].endswith("x2") and c["pcg_iterations_per_step"] > 3
+    if extra:
+        assert c["sharded_v_cycle_solves"] > 0
+    else:
+        assert c["spectral_start"]["vectors"] > 0 and c["sharded_iteration_phases"]
