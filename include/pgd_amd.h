@@ -275,6 +275,23 @@ int pgd_comm_info(pgd_handle ctx, int *kind /* 0 none, 1 callbacks, 2 rccl */, i
 int pgd_comm_halo(pgd_handle ctx, pgd_handle vec, int64_t own0, int64_t own1, int64_t lo_ghost,
                   int64_t hi_ghost);
 int pgd_comm_allreduce_slots(pgd_handle ctx, int first_slot, int count);
+
+/* DIRECT HALO of the sharded PCG loop (opt-in; no reference counterpart - /root/reference/pgdrome/solver.py:538-540 is serial).  The
+ * boundary planes of the search direction are stored straight into the neighbours' ghost planes through mapped device pointers
+ * (hipIpcMemHandle between processes; plain addresses inside one) with a sequence number posted behind them, and the product waits
+ * for the numbers of its own ghost planes: no RCCL send / receive kernel in the iteration (14 of 54 us on the slab of an 8-GPU rank).
+ * pgd_comm_push_export sizes the loop's work vectors for a vector of n rows partitioned [0, lo) ghost | [own0, own1) | ghost and
+ * writes PGD_PUSH_BLOB_BYTES describing them; the caller carries every rank's blob to its neighbours (any transport) and hands the
+ * lower / upper neighbour's blob (NULL where there is none) to pgd_comm_push_attach - collective over neighbours, ends with a
+ * checked exchange; *state = 1 if the direct halo is usable on this rank.  pgd_pcg_solve_sharded uses it when EVERY rank has it
+ * for exactly that partition (its setup vote) and the single-sync recurrence runs; otherwise the binding's exchange.  A number that
+ * does not arrive within pgd_comm_timeout ends the solve with PGD_ERR_TIMEOUT.  pgd_comm_push: mode 1 / 0 switch it on / off,
+ * -1 reads the state, -2 what the last solve did. */
+#define PGD_PUSH_BLOB_BYTES 256
+int pgd_comm_push_export(pgd_handle ctx, int64_t n, int64_t own0, int64_t own1, int64_t lo_ghost, int64_t hi_ghost,
+                         uint8_t *blob /* PGD_PUSH_BLOB_BYTES */);
+int pgd_comm_push_attach(pgd_handle ctx, const uint8_t *lower_blob, const uint8_t *upper_blob, int *state);
+int pgd_comm_push(pgd_handle ctx, int mode, int *state);
 /* Jacobi-PCG on the rows [own0, own1) of this rank's slab of A (replaces the KSP solve of
  * solver.py:636,716 for the row-partitioned spatial dimension); b, x are local slab vectors, x holds
  * the start value and returns with current ghost planes.  iters / rel_res are global.            */

@@ -104,6 +104,9 @@ SIGNATURES = {
     "pgd_comm_info": (C.c_int, [H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "pgd_comm_halo": (C.c_int, [H, H, I64, I64, I64, I64]),
     "pgd_comm_allreduce_slots": (C.c_int, [H, C.c_int, C.c_int]),
+    "pgd_comm_push_export": (C.c_int, [H, I64, I64, I64, I64, I64, PU8]),
+    "pgd_comm_push_attach": (C.c_int, [H, PU8, PU8, C.POINTER(C.c_int)]),
+    "pgd_comm_push": (C.c_int, [H, C.c_int, C.POINTER(C.c_int)]),
     "pgd_pcg_solve_sharded": (C.c_int, [H, H, H, H, I64, I64, I64, I64, F64, F64, C.c_int, C.POINTER(C.c_int), PD]),
     "pgd_op_symmetrize": (C.c_int, [H, H, C.POINTER(C.c_int)]),
     "pgd_op_classify": (C.c_int, [H, H, C.POINTER(C.c_int)]),
@@ -588,6 +591,31 @@ class Context:
 
     def comm_halo(self, vec, own0, own1, lo_g, hi_g):
         self._ck_cb(self.lib.pgd_comm_halo(self.h, vec, int(own0), int(own1), int(lo_g), int(hi_g)))
+
+    PUSH_BLOB_BYTES = 256
+
+    def comm_push_export(self, n, own0, own1, lo_g, hi_g):
+        """Direct halo, step 1: size the sharded loop's work vectors for this partition; returns the blob the neighbours need."""
+        buf = (C.c_uint8 * self.PUSH_BLOB_BYTES)()
+        self._ck(self.lib.pgd_comm_push_export(self.h, int(n), int(own0), int(own1), int(lo_g), int(hi_g), buf))
+        return bytes(buf)
+
+    def comm_push_attach(self, lower, upper):
+        """Direct halo, step 2 (collective over the neighbours): the lower / upper neighbour's blob or None.  True if usable here."""
+        def arr(b):
+            if b is None:
+                return None
+            if len(b) != self.PUSH_BLOB_BYTES:
+                raise ValueError("comm_push_attach: a blob has %d bytes" % self.PUSH_BLOB_BYTES)
+            return (C.c_uint8 * self.PUSH_BLOB_BYTES).from_buffer_copy(b)
+        st = C.c_int(0)
+        self._ck(self.lib.pgd_comm_push_attach(self.h, arr(lower), arr(upper), C.byref(st)))
+        return bool(st.value)
+
+    def comm_push(self, mode=-1):
+        st = C.c_int(0)
+        self._ck(self.lib.pgd_comm_push(self.h, int(mode), C.byref(st)))
+        return bool(st.value)
 
     def comm_allreduce_slots(self, first, count):
         self._ck_cb(self.lib.pgd_comm_allreduce_slots(self.h, int(first), int(count)))

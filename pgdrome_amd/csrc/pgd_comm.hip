@@ -16,6 +16,8 @@
 #include "pgd_internal.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
+#include <cstring>
 
 #include <algorithm>
 #include <chrono>
@@ -76,8 +78,21 @@ static RcclApi *rccl_api(std::string &why) {
         if (rc__ != 0) return fail((c), PGD_ERR_HIP, "%s: %s", #call, (api)->GetErrorString(rc__)); \
     } while (0)
 
+// the direct halo's mappings and flags (the work vectors stay: they belong to the binding)
+static void push_drop(Ctx *c) {
+    Comm &k = c->comm;
+    for (void *&m : k.push_mapped) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
+    if (k.push_flags) { (void)hipFree(k.push_flags); k.push_flags = nullptr; }
+    k.push = k.push_used = false;
+    k.push_peer[0] = k.push_peer[1] = nullptr;
+    k.push_peer_flags[0] = k.push_peer_flags[1] = nullptr;
+    k.push_n = 0;
+    (void)hipGetLastError();
+}
+
 void comm_release(Ctx *c) {
     Comm &k = c->comm;
+    push_drop(c);
     if (k.kind == 2 && k.nccl) {
         std::string why;
         if (RcclApi *api = rccl_api(why)) {
@@ -117,6 +132,80 @@ static void comm_env_defaults(Comm &k) {
         const long long v = strtoll(env, &end, 10);
         if (end != env && v >= 0) k.overlap_min_rows = v;
     }
+}
+
+// ---- direct halo (opt-in; pgd_comm_push_export / pgd_comm_push_attach)
+// k_halo_push: the two boundary planes of v go straight into the neighbours' ghost planes (dst_*: mapped addresses) as write-through
+// stores at system scope - nothing of them stays behind in this device's L2, so no cache write-back stands between the data and the
+// number posted behind it (a first version fenced every thread at system scope: 14 us for 1 MiB, as long as the RCCL kernel it
+// replaced).  Every workgroup waits for its stores to be acknowledged and takes a ticket; the LAST one posts the sequence number into
+// the neighbours' flag words (release, system scope) and then polls the flag words of THIS rank's ghost planes (acquire, system
+// scope) until they carry the number too: when the kernel ends, the planes of both neighbours have arrived, and the kernel boundary
+// orders the product's loads behind that.  Every rank posts before it waits, so nobody waits for somebody who waits.  A number that
+// does not come within the deadline flags the solve done with PGD_ERR_TIMEOUT, like a breakdown, and the host reports it.
+__device__ __forceinline__ void push_plane(const double *__restrict__ src, double *__restrict__ dst, int64_t n, int64_t t, int64_t step) {
+    for (int64_t i = t; i < n; i += step)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst) + i, (unsigned long long)__double_as_longlong(src[i]), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+__global__ __launch_bounds__(256) void k_halo_push(const double *__restrict__ src_lo, double *__restrict__ dst_lo, int64_t n_lo,
+                                                   const double *__restrict__ src_hi, double *__restrict__ dst_hi, int64_t n_hi,
+                                                   unsigned long long *post_lo, unsigned long long *post_hi,
+                                                   const unsigned long long *wait_a, const unsigned long long *wait_b,
+                                                   unsigned long long seq, unsigned long long *ticket, long long ticks, int *__restrict__ flags) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, step = (int64_t)gridDim.x * blockDim.x;
+    push_plane(src_lo, dst_lo, n_lo, t, step);
+    push_plane(src_hi, dst_hi, n_hi, t, step);
+    __builtin_amdgcn_s_waitcnt(0);                       // this wave's stores are acknowledged
+    __syncthreads();                                     // ... and those of the whole workgroup
+    if (threadIdx.x != 0) return;
+    const unsigned long long done = __hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (done + 1 != gridDim.x) return;
+    __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (post_lo) __hip_atomic_store(post_lo, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (post_hi) __hip_atomic_store(post_hi, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    const long long t0 = wall_clock64();
+    for (int which = 0; which < 2; ++which) {
+        const unsigned long long *f = which ? wait_b : wait_a;
+        if (!f) continue;
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < seq) {
+            if (wall_clock64() - t0 > ticks) {
+                if (flags) { flags[2] = PGD_ERR_TIMEOUT; flags[0] = 1; }
+                return;
+            }
+            __builtin_amdgcn_s_sleep(4);
+        }
+    }
+}
+
+static long long push_ticks(const Comm &k) {
+    const double s = k.timeout_s > 0.0 ? std::min(k.timeout_s, 3600.0) : 3600.0;
+    return (long long)(s * 1e8);                                       // wall_clock64: 100 MHz
+}
+
+// the exchange itself: v must be the vector the export was made for (the sharded loop's p).  Always issued by every rank of a solve
+// that voted for it - a rank that failed locally pushes whatever its p holds, so that nobody waits for a number that never comes.
+static int comm_push_halo(Ctx *c, double *v, int *flags) {
+    Comm &k = c->comm;
+    if (!k.push) return fail(c, PGD_ERR_INVALID, "direct halo: not attached");
+    const int64_t lo_g = k.push_lo_g, hi_g = k.push_hi_g, own0 = k.push_own0, own1 = k.push_own1;
+    if (!lo_g && !hi_g) return PGD_OK;
+    k.push_seq += 1;
+    const bool self = k.self_periodic && k.world == 1;
+    // to the LOWER neighbour: my bottom plane -> its ghost planes above (its last rows); to the UPPER one: my top plane -> its first rows.
+    // (a rank that is its own neighbour: the ghost plane above is fed by the bottom plane, the one below by the top plane)
+    const int64_t n_lo = self ? hi_g : lo_g, n_hi = self ? lo_g : hi_g;
+    const double *src_lo = v + own0, *src_hi = v + own1 - n_hi;
+    double *dst_lo = n_lo ? k.push_peer[0] + (k.push_peer_n[0] - n_lo) : nullptr;
+    double *dst_hi = n_hi ? k.push_peer[1] : nullptr;
+    const int64_t most = std::max(n_lo, n_hi);
+    const int grid = (int)std::min<int64_t>(std::max<int64_t>((most + 511) / 512, 1), 256);
+    k_halo_push<<<grid, 256, 0, c->stream>>>(src_lo, dst_lo, n_lo, src_hi, dst_hi, n_hi, n_lo ? k.push_peer_flags[0] + 1 : nullptr,
+                                             n_hi ? k.push_peer_flags[1] + 0 : nullptr, lo_g ? k.push_flags + 0 : nullptr,
+                                             hi_g ? k.push_flags + 1 : nullptr, k.push_seq, k.push_flags + 2, push_ticks(k), flags);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
 }
 
 // neighbour planes -> ghost planes of v (local numbering: [0, lo_g) ghost below, [own0, own1) owned,
@@ -356,6 +445,150 @@ int pgd_comm_allreduce_slots(pgd_handle h, int first, int count) {
     return comm_allreduce(c, first, count);
 }
 
+// ---- direct halo: export -> (the caller carries the blobs to the neighbours) -> attach
+struct PushBlob {
+    hipIpcMemHandle_t vec, flags;
+    int64_t n, own0, own1, lo_g, hi_g, pid;
+    uint64_t vec_ptr, flags_ptr;         // addresses in the exporting process (used when the neighbour is that process)
+};
+static_assert(sizeof(PushBlob) <= PGD_PUSH_BLOB_BYTES, "the blob must fit its public size");
+
+int pgd_comm_push_export(pgd_handle h, int64_t n, int64_t own0, int64_t own1, int64_t lo_g, int64_t hi_g, uint8_t *blob) {
+    PGD_CTX(c, h);
+    Comm &k = c->comm;
+    if (!blob || n < 1 || n > 0x7fffffff || own0 != lo_g || own0 > own1 || own1 + hi_g != n || lo_g < 0 || hi_g < 0)
+        return fail(c, PGD_ERR_INVALID, "comm_push_export: partition does not fit the vector");
+    if (k.kind == 0) return fail(c, PGD_ERR_INVALID, "comm_push_export: no communication binding");
+    push_drop(c);
+    if (k.work_n != n) {
+        for (pgd_handle &wh : k.work) { if (wh) (void)pgd_vec_free(h, wh); wh = 0; }
+        k.work_n = 0;
+        for (pgd_handle &wh : k.work) PGD_TRY(pgd_vec_alloc(h, n, &wh));
+        k.work_n = n;
+    }
+    void *fl = nullptr;
+    PGD_HIP(c, hipMalloc(&fl, 64));
+    k.push_flags = static_cast<unsigned long long *>(fl);
+    PGD_HIP(c, hipMemsetAsync(fl, 0, 64, c->stream));
+    double *pv = get_vec(c, k.work[3])->d;
+    // (the ghost planes start from a value no rank sends in the checked exchange of the attach step; set HERE, before any neighbour
+    // can have the blob: a neighbour's planes may arrive while this rank is still attaching)
+    k_comm_fill<<<(int)((n + 255) / 256), 256, 0, c->stream>>>(pv, (int)n, -1.0);
+    PGD_LAUNCH_CHECK(c);
+    PGD_HIP(c, hipStreamSynchronize(c->stream));
+    PushBlob b;
+    memset(&b, 0, sizeof b);
+    // (handles of memory another PROCESS will map; a neighbour inside this process takes the addresses - a failure here leaves the
+    // handles zero, which only matters to a neighbour in another process: its attach fails and the exchange stays with the binding)
+    if (hipIpcGetMemHandle(&b.vec, pv) != hipSuccess || hipIpcGetMemHandle(&b.flags, fl) != hipSuccess) {
+        (void)hipGetLastError();
+        memset(&b.vec, 0, sizeof b.vec);
+        memset(&b.flags, 0, sizeof b.flags);
+    }
+    b.n = n; b.own0 = own0; b.own1 = own1; b.lo_g = lo_g; b.hi_g = hi_g; b.pid = (int64_t)getpid();
+    b.vec_ptr = reinterpret_cast<uint64_t>(pv);
+    b.flags_ptr = reinterpret_cast<uint64_t>(fl);
+    memset(blob, 0, PGD_PUSH_BLOB_BYTES);
+    memcpy(blob, &b, sizeof b);
+    k.push_n = n; k.push_own0 = own0; k.push_own1 = own1; k.push_lo_g = lo_g; k.push_hi_g = hi_g;
+    k.push_seq = 0;
+    return PGD_OK;
+}
+
+// lower / upper: the blobs of the ranks below and above (NULL where there is none; with ONE self-periodic rank both are its own).
+// Collective over the neighbours: ends with a checked exchange - every rank pushes planes filled with 1000 + its rank and reads what
+// arrived.  On any failure the direct halo stays off (state 0) and the call still returns PGD_OK unless an argument was wrong: the
+// solves vote, so one rank without it switches it off for all.
+int pgd_comm_push_attach(pgd_handle h, const uint8_t *lower, const uint8_t *upper, int *state) {
+    PGD_CTX(c, h);
+    Comm &k = c->comm;
+    if (state) *state = 0;
+    if (!k.push_flags || !k.push_n) return fail(c, PGD_ERR_INVALID, "comm_push_attach: pgd_comm_push_export first");
+    const bool self = k.self_periodic && k.world == 1;
+    if ((k.push_lo_g > 0) != (lower != nullptr) || (k.push_hi_g > 0) != (upper != nullptr))
+        return fail(c, PGD_ERR_INVALID, "comm_push_attach: a blob for every side with ghost planes, and for no other");
+    const uint8_t *blobs[2] = {lower, upper};
+    bool ok = true;
+    int nmap = 0;
+    for (int side = 0; side < 2 && ok; ++side) {
+        if (!blobs[side]) continue;
+        PushBlob b;
+        memcpy(&b, blobs[side], sizeof b);
+        // the neighbour's ghost planes towards us must be as large as our boundary plane
+        const int64_t want = self ? (side == 0 ? k.push_hi_g : k.push_lo_g) : (side == 0 ? k.push_lo_g : k.push_hi_g);
+        const int64_t have = side == 0 ? b.hi_g : b.lo_g;
+        if (have != want || b.n < want) return fail(c, PGD_ERR_INVALID, "comm_push_attach: the neighbour's ghost planes do not match this rank's boundary planes");
+        if (b.pid == (int64_t)getpid()) {
+            k.push_peer[side] = reinterpret_cast<double *>(b.vec_ptr);
+            k.push_peer_flags[side] = reinterpret_cast<unsigned long long *>(b.flags_ptr);
+        } else {
+            void *pv = nullptr, *pf = nullptr;
+            if (hipIpcOpenMemHandle(&pv, b.vec, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { ok = false; break; }
+            k.push_mapped[nmap++] = pv;
+            if (hipIpcOpenMemHandle(&pf, b.flags, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { ok = false; break; }
+            k.push_mapped[nmap++] = pf;
+            k.push_peer[side] = static_cast<double *>(pv);
+            k.push_peer_flags[side] = static_cast<unsigned long long *>(pf);
+        }
+        k.push_peer_n[side] = b.n;
+    }
+    (void)hipGetLastError();
+    if (!ok) {
+        // (the neighbours still run the checked exchange below and would wait for this rank's number: it cannot be posted without a
+        // mapping, so they find out through their deadline-free test wait - bounded at 2 s - and switch off as well)
+        for (void *&m : k.push_mapped) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
+        k.push_peer[0] = k.push_peer[1] = nullptr;
+        (void)hipGetLastError();
+        return PGD_OK;
+    }
+    // checked exchange, exactly as a solve does it
+    double *pv = get_vec(c, k.work[3])->d;
+    const int64_t n = k.push_n;
+    if (k.push_own1 > k.push_own0) {      // the OWNED rows only: the ghost planes belong to the neighbours from the export on
+        const int64_t rows = k.push_own1 - k.push_own0;
+        k_comm_fill<<<(int)((rows + 255) / 256), 256, 0, c->stream>>>(pv + k.push_own0, (int)rows, 1000.0 + k.rank);
+        PGD_LAUNCH_CHECK(c);
+    }
+    k.push = true;
+    const double keep_timeout = k.timeout_s;
+    k.timeout_s = 2.0;
+    int *tflags = nullptr;
+    PGD_TRY(ensure_work(c, 5, 16));
+    tflags = reinterpret_cast<int *>(c->work[5]);
+    (void)hipMemsetAsync(tflags, 0, 4 * sizeof(int), c->stream);
+    int rc = comm_push_halo(c, pv, tflags);
+    k.timeout_s = keep_timeout;
+    double got[2] = {0.0, 0.0};
+    int tf[4] = {0, 0, 0, 0};
+    if (rc == PGD_OK && k.push_lo_g) rc = hipMemcpyAsync(&got[0], pv, sizeof(double), hipMemcpyDeviceToHost, c->stream) == hipSuccess ? PGD_OK : PGD_ERR_HIP;
+    if (rc == PGD_OK && k.push_hi_g) rc = hipMemcpyAsync(&got[1], pv + n - 1, sizeof(double), hipMemcpyDeviceToHost, c->stream) == hipSuccess ? PGD_OK : PGD_ERR_HIP;
+    if (rc == PGD_OK) rc = hipMemcpyAsync(tf, tflags, sizeof tf, hipMemcpyDeviceToHost, c->stream) == hipSuccess ? PGD_OK : PGD_ERR_HIP;
+    if (rc == PGD_OK) rc = hipStreamSynchronize(c->stream) == hipSuccess ? PGD_OK : PGD_ERR_HIP;
+    const double below = 1000.0 + (self ? k.rank : k.rank - 1), above = 1000.0 + (self ? k.rank : k.rank + 1);
+    const bool good = rc == PGD_OK && tf[0] == 0 && (!k.push_lo_g || got[0] == below) && (!k.push_hi_g || got[1] == above);
+    (void)hipGetLastError();
+    if (!good) {
+        for (void *&m : k.push_mapped) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
+        k.push = false;
+        k.push_peer[0] = k.push_peer[1] = nullptr;
+        (void)hipGetLastError();
+        return PGD_OK;
+    }
+    if (state) *state = 1;
+    return PGD_OK;
+}
+
+// mode -1: read; 0: off (the mappings stay); 1: on again if attached.  state: 1 = the next solves may use it; -2 reads what the LAST solve did
+int pgd_comm_push(pgd_handle h, int mode, int *state) {
+    PGD_CTX(c, h);
+    Comm &k = c->comm;
+    if (mode == 0) k.push = false;
+    else if (mode == 1) k.push = k.push_peer[0] != nullptr || k.push_peer[1] != nullptr || (k.push_n > 0 && !k.push_lo_g && !k.push_hi_g && k.push_flags);
+    else if (mode != -1 && mode != -2) return fail(c, PGD_ERR_INVALID, "comm_push: mode must be 1, 0, -1 (read) or -2 (what the last solve did)");
+    if (state) *state = mode == -2 ? (k.push_used ? 1 : 0) : (k.push ? 1 : 0);
+    return PGD_OK;
+}
+
 }  // extern "C"
 
 // ---- collective discipline of one sharded solve ------------------------------------------------------------------
@@ -528,11 +761,12 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     // ---- phase A: everything that can fail on ONE rank before the first collective (allocations, the symmetric copy), and
     // the choice of recurrence, are agreed on with one all-reduce: a rank whose operator did not qualify for the symmetric
     // storage must not take another branch (the scaled recurrence has one more halo exchange) than its neighbours.
-    bool sym = false, ss_all = false;
+    bool sym = false, ss_all = false, push_all = false;
     double rows_all = 0.0;
     auto setup = [&]() -> int {
         if (!m) return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: operator without a mesh");
         if (k.work_n != n) {      // r, u, w, p, s, q, dinv as library vectors (the slot kernels take handles)
+            push_drop(c);         // (the direct halo was exported for the old p: this rank votes it off below, for good)
             for (pgd_handle &wh : k.work) { if (wh) (void)pgd_vec_free(h, wh); wh = 0; }
             k.work_n = 0;
             for (pgd_handle &wh : k.work) PGD_TRY(pgd_vec_alloc(h, n, &wh));
@@ -553,18 +787,21 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         const bool can_ss = rc_setup == PGD_OK && sym && c->pcg_scaled && c->pcg_single_sync && m && m->sym_nx > 0;
         // (the fourth number: the rows this rank owns - their sum decides, identically everywhere, whether the halo exchange of the
         // products takes the second stream)
-        const double vote[4] = {rc_setup != PGD_OK ? 1.0 : 0.0, (rc_setup == PGD_OK && sym && c->pcg_scaled) ? 0.0 : 1.0, can_ss ? 0.0 : 1.0,
-                                (double)(own1 - own0)};
-        double got[4] = {1.0, 1.0, 1.0, 0.0};
-        int rc = pgd_slots_upload(h, vote, B, 4);
-        if (rc == PGD_OK) rc = comm_allreduce(c, B, 4);
-        if (rc == PGD_OK) rc = pgd_slots_download(h, got, B, 4);
+        // (the fifth: the direct halo is attached here for exactly this vector - used only if it is on every rank)
+        const bool can_push = k.push && k.push_n == n && k.push_own0 == own0 && k.push_own1 == own1 && k.push_lo_g == lo_g && k.push_hi_g == hi_g;
+        const double vote[5] = {rc_setup != PGD_OK ? 1.0 : 0.0, (rc_setup == PGD_OK && sym && c->pcg_scaled) ? 0.0 : 1.0, can_ss ? 0.0 : 1.0,
+                                (double)(own1 - own0), can_push ? 0.0 : 1.0};
+        double got[5] = {1.0, 1.0, 1.0, 0.0, 1.0};
+        int rc = pgd_slots_upload(h, vote, B, 5);
+        if (rc == PGD_OK) rc = comm_allreduce(c, B, 5);
+        if (rc == PGD_OK) rc = pgd_slots_download(h, got, B, 5);
         if (rc_setup != PGD_OK) { c->err = err_setup; return rc_setup; }
         if (rc != PGD_OK) return rc;
         if (got[0] != 0.0) return fail(c, PGD_ERR_PEER, "pcg_solve_sharded: the setup failed on another rank");
         sym = sym && got[1] == 0.0;                     // scaled only if EVERY rank can
         ss_all = got[2] == 0.0;                         // ... and the single-sync recurrence only if every rank's slab is a grid
         rows_all = got[3];
+        push_all = got[4] == 0.0;
     }
     const double dbg_t1 = dbg_now();
     const bool scaled = sym && c->pcg_scaled;
@@ -628,11 +865,19 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     // the SAME choice on every rank: the capability was agreed on at bind time, the row count is all-reduced
     const bool async = k.overlap && rows_all >= (double)k.overlap_min_rows * (double)k.world;
     k.overlap_used = async;
+    // the direct halo carries the search direction of the single-sync loop (one all-reduce between a product and the next update:
+    // nobody overwrites ghost planes that are still being read), in stream order
+    const bool pushing = push_all && ss && !async;
+    k.push_used = pushing;
     hipEvent_t *marks = nullptr;                                     // phase timing of the iteration being queued (or none)
     auto mark = [&](int i) { if (marks) (void)hipEventRecord(marks[i], c->stream); };
     auto product = [&](pgd_handle uh, double *ud, double *wdst, bool folded, int *np_total) -> int {
         mark(0);
-        PGD_TRY(sh_halo_begin(S, uh, ud, own0, own1, lo_g, hi_g, async, "halo exchange of the product"));
+        if (pushing && ud == pd) {
+            S.last = "direct halo of the product";
+            S.ncoll += 1;
+            PGD_TRY(comm_push_halo(c, ud, c->flags));
+        } else PGD_TRY(sh_halo_begin(S, uh, ud, own0, own1, lo_g, hi_g, async, "halo exchange of the product"));
         const int64_t lo[3] = {own0 + glo, own0, own1 - ghi}, hi[3] = {own1 - ghi, own0 + glo, own1};
         const int mult = c->spmv_qq ? 2 : 1;      // pairs (w.y, y.y) per workgroup in the single-sync form
         int total = 0;
@@ -833,6 +1078,9 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     prof_collect(c, 1);
     const int32_t it2 = f2[1], status2 = f2[2];
     (void)it;
+    if (status == PGD_ERR_TIMEOUT || status2 == PGD_ERR_TIMEOUT)
+        return fail(c, PGD_ERR_TIMEOUT, "pcg_solve_sharded: rank %d/%d: a neighbour's boundary planes did not arrive within the deadline (direct halo, "
+                    "iteration %d)", k.rank, k.world, it2);
     if (status != 0 || status2 != 0) return fail(c, PGD_ERR_SINGULAR, "sharded PCG breakdown (NaN) after %d iterations", it2);
     // ---- everybody is healthy and has left the loop at the same iteration
     if (ss && c->pcg_lag_x && it2 > 0 && ((it2 - 1) & 1) == 0)          // the last update had an even index: its term of x may be outstanding

@@ -192,6 +192,19 @@ struct Comm {
     hipEvent_t mark[2][7] = {{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}};
     bool mark_set[2] = {false, false};
     double prof_sum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // DIRECT halo of the sharded loop's search direction (pgd_comm_push_export / _attach; opt-in): the boundary planes of p are
+    // stored straight into the neighbours' ghost planes through mapped pointers (hipIpcMemHandle; the rank itself where it is its
+    // own neighbour) and a sequence number posted behind them; the product waits for the numbers of ITS ghost planes.  No RCCL
+    // kernel in the iteration.  Geometry of the vector the export was made for: a solve with another one votes the exchange off.
+    bool push = false;            // attached and self-tested
+    bool push_used = false;       // what the last solve did
+    int64_t push_n = 0, push_own0 = 0, push_own1 = 0, push_lo_g = 0, push_hi_g = 0;
+    double *push_peer[2] = {nullptr, nullptr};                 // lower / upper neighbour's p (its base address in THIS process)
+    int64_t push_peer_n[2] = {0, 0};                           // ... and its length: the upper ghost planes are its last rows
+    unsigned long long *push_flags = nullptr;                  // own: [0] posted by the lower neighbour, [1] by the upper one, [2] ticket
+    unsigned long long *push_peer_flags[2] = {nullptr, nullptr};
+    void *push_mapped[4] = {nullptr, nullptr, nullptr, nullptr};   // what hipIpcOpenMemHandle returned (to close)
+    unsigned long long push_seq = 0;
 };
 
 struct Ctx {

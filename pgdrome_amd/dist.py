@@ -123,6 +123,43 @@ class TorchComm:
             warnings.warn("in-library RCCL binding not available on every rank (%s): the sharded PCG is driven "
                           "through torch.distributed instead" % (why or "another rank failed"))
 
+    direct_halo = False
+
+    def enable_direct_halo(self, n, own0, own1, lo_g, hi_g):
+        """Direct halo of the in-library loop (opt-in: PGD_HALO_DIRECT=1, or called by hand): the boundary planes of the search
+        direction are stored straight into the neighbours' ghost planes through IPC-mapped pointers and the product waits for a
+        posted sequence number - no send / receive kernel in the iteration (include/pgd_amd.h, pgd_comm_push_*).  Collective:
+        every rank exports for ITS partition, the blobs travel through torch.distributed, neighbours attach and run a checked
+        exchange; all ranks must succeed, else it stays off everywhere (and the solves' own vote would keep it off anyway)."""
+        if self.in_library is None:
+            return False
+        be, dist = self.be, self.dist
+        blob, why = None, ""
+        try:
+            blob = be.comm_push_export(n, own0, own1, lo_g, hi_g)
+        except Exception as e:              # noqa: BLE001 - every rank must learn of it
+            why = str(e)
+        blobs = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(blobs, blob)
+        else:
+            blobs = [blob]
+        ok = 0.0
+        if all(b is not None for b in blobs):
+            try:
+                ok = 1.0 if be.comm_push_attach(blobs[self.rank - 1] if lo_g else None, blobs[self.rank + 1] if hi_g else None) else 0.0
+            except Exception as e:          # noqa: BLE001
+                why = str(e)
+        ok = float(self.allreduce_array([1.0 - ok])[0]) == 0.0
+        if not ok:
+            try:
+                be.comm_push(0)
+            except Exception:               # noqa: BLE001
+                pass
+            LOG.warning("direct halo not available on every rank (%s): the exchange stays with the binding", why or "another rank")
+        self.direct_halo = ok
+        return ok
+
     def _cb_halo(self, vec, own0, own1, lo_g, hi_g):
         from types import SimpleNamespace
         self.halo_exchange_raw(SimpleNamespace(part=SimpleNamespace(own0=own0, own1=own1, lo_ghost=lo_g, hi_ghost=hi_g)), vec)
@@ -492,6 +529,8 @@ def sharded_box_mesh(comm, p0, p1, nx, ny, nz):
     own1 = own0 + (z1 - z0) * plane
     part = fem.Partition(comm, own0, own1, plane * (nz + 1), lo_g, hi_g, zf * plane)
     part.plane = plane                                         # vertices per z-plane (the slab V-cycle needs the lattice)
+    if os.environ.get("PGD_HALO_DIRECT", "0") == "1" and hasattr(comm, "enable_direct_halo") and getattr(comm.be, "name", "") == "hip":
+        comm.enable_direct_halo(own1 + hi_g, own0, own1, lo_g, hi_g)
     mesh = fem.Mesh(coords, cells, part)
     mesh._on_boundary = fem.box_hull_mask(nx, ny, nz, zf, zl)
     assert mesh.num_vertices() == own1 + hi_g

@@ -229,7 +229,8 @@ def _shared_gpu_worker(rank, world, port, shape, q, in_library):
         modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values()) for f in p.PGD_func[0]]
         if rank == 0:
             q.put(dict(num_fp_it=p.num_fp_it, amplitude=p.amplitude, modes_x=modes_x, stats=dict(comm.stats),
-                       kernels=be.ctx.kernel_counts()))
+                       kernels=be.ctx.kernel_counts(), direct_halo=bool(comm.direct_halo),
+                       direct_halo_used=bool(be.comm_push(-2)) if comm.in_library else False))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -357,6 +358,37 @@ def test_sharded_solve_on_slabs_of_the_bench_plane():
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
 
 
+@pytest.mark.parametrize("world,shape", [(2, (127, 127, 99)), (3, (24, 20, 29))])
+def test_direct_halo_between_processes_on_one_gpu(world, shape):
+    """PGD_HALO_DIRECT=1: the boundary planes of the search direction go straight into the NEIGHBOUR PROCESS's ghost planes through
+    hipIpcMemHandle-mapped pointers, a sequence number is posted behind them and the product waits for its own (pgd_comm_push_*) -
+    `world` processes on GPU 0, everything else of the exchange over gloo as in the tests above.  Only the transport of the planes
+    differs: the run must be bit for bit the one with the binding's exchange."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    outs = {}
+    saved = os.environ.get("PGD_HALO_DIRECT")
+    try:
+        for direct in ("0", "1"):
+            os.environ["PGD_HALO_DIRECT"] = direct
+            q = ctx.Queue()
+            port = _free_port()
+            procs = [ctx.Process(target=_shared_gpu_worker, args=(r, world, port, shape, q, True)) for r in range(world)]
+            outs[direct] = _collect(procs, q, 1, 600)[0]
+    finally:
+        if saved is None:
+            os.environ.pop("PGD_HALO_DIRECT", None)
+        else:
+            os.environ["PGD_HALO_DIRECT"] = saved
+    a, b = outs["0"], outs["1"]
+    assert not a["direct_halo"] and not a["direct_halo_used"]
+    assert b["direct_halo"] and b["direct_halo_used"], b
+    assert b["stats"]["halo"] < a["stats"]["halo"] - 100           # the products' exchanges no longer come through the callback
+    assert a["num_fp_it"] == b["num_fp_it"] and a["amplitude"] == b["amplitude"]
+    for xa, xb in zip(a["modes_x"], b["modes_x"]):
+        assert np.array_equal(xa, xb)
+
+
 FAULT_CASES = (("iteration 7", 15, 7), ("stage 1", 33, 1), ("stage 2", 33, 2), ("stage 3", 33, 3), ("stage 4", 33, 4))
 
 
@@ -383,6 +415,7 @@ def _faulty_worker(rank, world, port, shape, q):
         be.comm_timeout(120.0)
         P = fem.Point
         mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+        assert comm.direct_halo == (os.environ.get("PGD_HALO_DIRECT") == "1")
         for name, knob, value in FAULT_CASES + (("none", 0, 0),):
             p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=2))
             if rank == 1 and knob:
@@ -400,12 +433,15 @@ def _faulty_worker(rank, world, port, shape, q):
         dist.destroy_process_group()
 
 
-def test_a_rank_failing_anywhere_in_a_solve_takes_the_others_out_with_an_error():
-    """A rank-local failure at ANY point of the in-library sharded solve after its setup vote must end the solve on EVERY rank
+@pytest.mark.parametrize("direct", ["0", "1"])
+def test_a_rank_failing_anywhere_in_a_solve_takes_the_others_out_with_an_error(direct, monkeypatch):
+    """(direct = "1": with the direct halo - a rank that failed locally still pushes its planes and posts its numbers.)
+    A rank-local failure at ANY point of the in-library sharded solve after its setup vote must end the solve on EVERY rank
     with an error, promptly: the failing rank keeps issuing the protocol's collectives (NaN payloads) and votes at the next
     agreement - before the first chunk, after every chunk, at the end - where all ranks leave together (PGD_ERR_PEER on the
     healthy ones), instead of leaving its neighbours blocked in a halo exchange or an all-reduce."""
     import torch.multiprocessing as mp
+    monkeypatch.setenv("PGD_HALO_DIRECT", direct)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()

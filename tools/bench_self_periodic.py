@@ -19,6 +19,7 @@ from pgdrome_amd.hip_backend import HipBackend
 ap = argparse.ArgumentParser()
 ap.add_argument("--planes", type=int, default=32, help="owned planes (256 / 8 = the slab of an 8-GPU rank at 256^3)")
 ap.add_argument("--nxy", type=int, default=256)
+ap.add_argument("--only", default="", help="with --json: just this variant (profiling)")
 ap.add_argument("--json", action="store_true", help="one JSON line on stdout: microseconds per iteration of whole solves (bench.py's side section)")
 args = ap.parse_args()
 if args.json:                      # RCCL prints its banner to stdout: the result line goes to the saved descriptor
@@ -37,7 +38,9 @@ be = fem.set_backend(HipBackend(0, tstream.cuda_stream))
 ctx = be.ctx
 nx = ny = args.nxy
 VARIANTS = (("stream_ordered_one_march", ((45, 1 << 40), (46, 1))), ("stream_ordered_interior_plus_boundary", ((45, 1 << 40), (46, 0))),
-            ("overlapped_on_the_halo_stream", ((45, 0), (46, 1))))
+            ("overlapped_on_the_halo_stream", ((45, 0), (46, 1))),
+            # the boundary planes stored straight into the ghost planes + a posted sequence number (pgd_comm_push_*): no RCCL kernel
+            ("direct_halo_one_march", ((45, 1 << 40), (46, 1), ("push", 1))))
 
 
 def slab(planes):
@@ -55,14 +58,19 @@ def slab(planes):
 
 def timed(S, variants):
     h, n, plane, own0, own1, ak, am, hull, bv = S
-    res = {}
+    res, xs = {}, {}
     for variant, tune in variants:
         ctx.comm_unbind()
         ctx.comm_bind_rccl(ctx.comm_unique_id(), 0, 1)
         ok = ctx.comm_overlap(1)
         ctx.tune(44, 1)
+        pushing = False
         for knob, value in tune:
-            ctx.tune(knob, value)
+            if knob == "push":
+                blob = ctx.comm_push_export(n, own0, own1, plane, plane)
+                pushing = ctx.comm_push_attach(blob, blob)
+            else:
+                ctx.tune(knob, value)
         best = None
         for rep in range(3):
             o2 = ctx.op_combine(h, [ak, am], [1.0, 3.0], hull)      # a fresh operator per solve, as the fixed-point loop has
@@ -72,12 +80,18 @@ def timed(S, variants):
             it, rel = ctx.pcg_solve_sharded(o2, bv, xv, own0, own1, plane, plane, 1e-10, 0.0, 10000)
             be.sync()
             dt = time.perf_counter() - t0
+            if rep == 2:
+                xs[variant] = ctx.vec_download(xv)
             ctx.vec_free(xv)
             ctx.atom_free(o2)
             if rep and (best is None or dt < best):
                 best = dt
         res[variant] = {"us_per_iteration": 1e6 * best / max(it, 1), "iterations": it, "second_stream_used": bool(ctx.comm_overlap(-2)),
                         "second_stream_available": bool(ok)}
+        if variant.startswith("direct_halo"):
+            res[variant].update(direct_halo_attached=bool(pushing), direct_halo_used=bool(ctx.comm_push(-2)),
+                                same_bits_as_the_rccl_exchange=bool("stream_ordered_one_march" in xs and
+                                                                    np.array_equal(xs[variant], xs["stream_ordered_one_march"])))
     return res
 
 
@@ -93,14 +107,14 @@ def release(S):
 if args.json:
     S = slab(args.planes)
     res = {"owned_planes": args.planes, "plane": [nx, ny], "rows": int(S[4] - S[3])}
-    res.update(timed(S, VARIANTS))
+    res.update(timed(S, [v for v in VARIANTS if not args.only or v[0] == args.only]))
     release(S)
-    if args.planes == 32 and nx == 256:
+    if args.planes == 32 and nx == 256 and not args.only:
         # the slabs of a 4- and a 2-GPU rank of the same grid: what the iteration costs there (one march / second stream)
         res["larger_slabs"] = {}
         for planes in (64, 128):
             S = slab(planes)
-            res["larger_slabs"][str(planes)] = {k: v["us_per_iteration"] for k, v in timed(S, (VARIANTS[0], VARIANTS[2])).items()}
+            res["larger_slabs"][str(planes)] = {k: v["us_per_iteration"] for k, v in timed(S, (VARIANTS[0], VARIANTS[2], VARIANTS[3])).items()}
             release(S)
     os.write(result_fd, (json.dumps(res) + "\n").encode())
     dist.destroy_process_group()
