@@ -56,6 +56,10 @@ def parse():
     ap.add_argument("--preconditioner", default="jacobi",
                     help='settings["preconditioner"] of the timed run: "jacobi" (the metric\'s Jacobi-PCG) or "amg" (the V-cycle of pgd_mg.hip; '
                          "on a sharded run the slab form of it, dist.pcg_mg) - a side measurement, never the headline")
+    ap.add_argument("--direct-halo", action="store_true",
+                    help="N > 1: the boundary planes of the PCG loop's search direction go straight into the neighbours' ghost planes "
+                         "through IPC-mapped pointers (PGD_HALO_DIRECT=1, pgd_comm_push_*) instead of RCCL send / receive; opt-in - "
+                         "never run between two different GPUs so far")
     ap.add_argument("--share-one-gpu", action="store_true",
                     help="REHEARSAL on a one-GPU box, never a measurement: the N ranks all use GPU 0, the exchange steps go through gloo "
                          "(RCCL refuses two ranks on one device) and the library's sharded loop through its callback binding; the "
@@ -226,6 +230,8 @@ def main():
     P = fem.Point
     if sharded:
         from pgdrome_amd import dist as pdist
+        if args.direct_halo:
+            os.environ["PGD_HALO_DIRECT"] = "1"         # read by pdist.sharded_box_mesh
         comm = pdist.TorchComm(dist, be, True if args.single_reduction else None, in_library=not args.python_driver)
         space = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), n - 1, n - 1, n - 1)
     else:
@@ -401,6 +407,8 @@ def main():
                    "sharded_v_cycle_solves": (comm.stats.get("sharded_mg_solves", 0) if sharded else None),
                    "halo_overlap": (bool(be.comm_overlap(-2)) if sharded and getattr(comm, "in_library", None) == "rccl" else (False if sharded else None)),
                    "halo_overlap_available": (bool(getattr(comm, "halo_overlap", False)) if sharded else None),
+                   "direct_halo": ({"attached_on_every_rank": bool(getattr(comm, "direct_halo", False)),
+                                    "used_by_the_last_solve": bool(be.comm_push(-2)) if comm.in_library else False} if sharded else None),
                    "rccl_world": (be.comm_info()["world"] if sharded and comm.in_library == "rccl" else
                                   (dist.get_world_size() if sharded else None)),
                    "pcg_iterations_per_step": pcg_its / K, "modes_completed": len(prob.num_fp_it),

@@ -89,7 +89,7 @@ def test_rank_with_ghost_planes_rehearsal():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--preconditioner", "amg"]])
+@pytest.mark.parametrize("extra", [[], ["--preconditioner", "amg"], ["--direct-halo"]])
 def test_two_ranks_of_the_bench_on_one_gpu(extra):
     """`python bench.py --gpus 2 --share-one-gpu`: bench.main's N > 1 code - the launcher, the sharded mesh, the spectral start's vote,
     the timing window between barriers, the maximum over the ranks, the gathered phase timings - with the HIP kernels, two ranks on
@@ -106,7 +106,9 @@ def test_two_ranks_of_the_bench_on_one_gpu(extra):
     assert d["n_gpus"] == 2 and d["steps"] == 4 and d["value"] > 0 and "REHEARSAL" in d["data"]
     c = d["config"]
     assert c["parallelism"].endswith("x2") and c["pcg_iterations_per_step"] > 3
-    if extra:
+    if "--direct-halo" in extra:
+        assert c["direct_halo"] == {"attached_on_every_rank": True, "used_by_the_last_solve": True}
+    elif extra:
         assert c["sharded_v_cycle_solves"] > 0
     else:
         assert c["spectral_start"]["vectors"] > 0 and c["sharded_iteration_phases"]
