@@ -109,6 +109,8 @@ int pgd_vec_ptr(pgd_handle ctx, pgd_handle vec, void **device_ptr);
 int pgd_vec_fill(pgd_handle ctx, pgd_handle vec, double value);
 int pgd_vec_copy(pgd_handle ctx, pgd_handle dst, pgd_handle src);
 int pgd_vec_scale(pgd_handle ctx, pgd_handle vec, double a);                 /* v *= a      */
+int pgd_vec_mul(pgd_handle ctx, pgd_handle y, pgd_handle a, pgd_handle x);   /* y = a .* x entry by entry (y may be x or a): the Jacobi
+                                                                               * scaling of the sharded BiCGStab, pgdrome_amd/dist.py */
 int pgd_vec_axpy(pgd_handle ctx, pgd_handle y, double a, pgd_handle x);      /* y += a x    */
 int pgd_vec_set(pgd_handle ctx, pgd_handle vec, const int32_t *idx, const double *val, int64_t n);
 /* y = sum_k coefs[k] * xs[k]: the online reconstruction u = sum_k c_k F^k of a PGD solution

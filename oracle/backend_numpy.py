@@ -113,6 +113,9 @@ class NumpyBackend:
     def vec_scale(self, v, a):
         self._obj[v] *= a
 
+    def vec_mul(self, y, a, x):
+        self._obj[y][:] = self._obj[a] * self._obj[x]
+
     def vec_axpy(self, y, a, x):
         self._obj[y] += a * self._obj[x]
 

@@ -53,6 +53,7 @@ SIGNATURES = {
     "pgd_vec_fill": (C.c_int, [H, H, F64]),
     "pgd_vec_copy": (C.c_int, [H, H, H]),
     "pgd_vec_scale": (C.c_int, [H, H, F64]),
+    "pgd_vec_mul": (C.c_int, [H, H, H, H]),
     "pgd_vec_axpy": (C.c_int, [H, H, F64, H]),
     "pgd_vec_set": (C.c_int, [H, H, PI32, PD, I64]),
     "pgd_vec_lincomb": (C.c_int, [H, H, PH, PD, C.c_int]),
@@ -321,6 +322,9 @@ class Context:
 
     def vec_scale(self, v, a):
         self._ck(self.lib.pgd_vec_scale(self.h, v, float(a)))
+
+    def vec_mul(self, y, a, x):
+        self._ck(self.lib.pgd_vec_mul(self.h, y, a, x))
 
     def vec_axpy(self, y, a, x):
         self._ck(self.lib.pgd_vec_axpy(self.h, y, float(a), x))

@@ -303,6 +303,21 @@ int pgd_vec_scale(pgd_handle h, pgd_handle vh, double a) {
     return PGD_OK;
 }
 
+// y = a .* x, entry by entry (y may be x or a)
+__global__ __launch_bounds__(TPB) void k_vec_mul(double *y, const double *a, const double *x, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (int64_t)gridDim.x * TPB) y[i] = a[i] * x[i];
+}
+
+int pgd_vec_mul(pgd_handle h, pgd_handle yh, pgd_handle ah, pgd_handle xh) {
+    PGD_CTX(c, h);
+    Vec *y = get_vec(c, yh), *a = get_vec(c, ah), *x = get_vec(c, xh);
+    if (!x || !y || !a || x->n != y->n || a->n != y->n) return fail(c, PGD_ERR_INVALID, "vec_mul: invalid handles or size mismatch");
+    if (y->n == 0) return PGD_OK;
+    k_vec_mul<<<grid_for(y->n), TPB, 0, c->stream>>>(y->d, a->d, x->d, y->n);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
 int pgd_vec_axpy(pgd_handle h, pgd_handle yh, double a, pgd_handle xh) {
     PGD_CTX(c, h);
     Vec *y = get_vec(c, yh), *x = get_vec(c, xh);

@@ -360,6 +360,106 @@ class TorchComm:
             raise err
         os._exit(3)
 
+    def bicgstab(self, mesh, op, b, x, rtol, atol, maxit):
+        """BiCGStab with right Jacobi preconditioning for a NON-symmetric operator on a row-sharded mesh (a convection atom on
+        the spatial dimension; the reference's MUMPS solves whatever the callbacks produce, solver.py:627-636): the recurrence of
+        csrc/pgd_krylov.hip driven from the host over the backend's vector primitives - every product behind a halo exchange of
+        its argument, every group of dots one all-reduce, all decisions (stop test, breakdown restarts) taken on all-reduced
+        numbers, hence the same on every rank.  Host-synchronised three times per iteration like the unsharded loop.  Ends with the
+        TRUE residual; returns (iterations, relative residual); x comes back with current ghost planes."""
+        be, part = self.be, mesh.part
+        self._check_stream()
+        lo, hi, n = part.own0, part.own1, mesh.num_vertices()
+        xh, bh = x.dev(), b.dev()
+        r, rhat, p, v, y, z, t, dinv = (self._workvec(n, k) for k in ("bi_r", "bi_rhat", "bi_p", "bi_v", "bi_y", "bi_z", "bi_t", "bi_dinv"))
+        be.op_diag_inv(op, dinv)
+
+        def sums(pairs):
+            """all-reduced dots over the owned rows: [(a, b), ...] -> [a . b, ...]"""
+            loc = [be.vec_dot(a, c, lo, hi) for a, c in pairs]
+            return [float(t_) for t_ in self.allreduce_array(loc)]
+
+        def product(src, dst):
+            self.halo_exchange_raw(mesh, src)
+            be.spmv(op, src, dst, lo, hi)
+
+        def residual():
+            product(xh, v)
+            be.vec_copy(r, bh)
+            be.vec_axpy(r, -1.0, v)
+            return sums([(r, r), (bh, bh)])
+
+        rr, bb = residual()
+        bnorm = float(np.sqrt(bb))
+        tol = max(rtol * bnorm, atol)
+        if not np.isfinite(rr):
+            raise RuntimeError("sharded BiCGStab: the start residual is not finite")
+        it, restarts, fresh = 0, 0, True
+        rho = alpha = omega = 1.0
+        rho_new = rr
+
+        def restart(what):
+            nonlocal restarts, fresh, rr
+            restarts += 1
+            if restarts > 4:
+                raise RuntimeError("sharded BiCGStab: breakdown (%s) after %d iterations" % (what, it))
+            rr = residual()[0]
+            fresh = True
+
+        for leg in range(4):                       # the recurrence, then up to three short legs from the true residual
+            it_leg = 0
+            while np.sqrt(rr) > tol and it < maxit and (leg == 0 or it_leg < 50):
+                if fresh:
+                    be.vec_copy(rhat, r)
+                    be.vec_fill(p, 0.0)
+                    be.vec_fill(v, 0.0)
+                    rho = alpha = omega = 1.0
+                    rho_new = rr
+                    fresh = False
+                beta = (rho_new / rho) * (alpha / omega)
+                be.vec_axpy(p, -omega, v)          # p = r + beta (p - omega v)
+                be.vec_scale(p, beta)
+                be.vec_axpy(p, 1.0, r)
+                be.vec_mul(y, dinv, p)
+                product(y, v)
+                hv, = sums([(rhat, v)])
+                if hv == 0.0 or not np.isfinite(hv):
+                    restart("rhat . v = 0")
+                    continue
+                alpha = rho_new / hv
+                be.vec_axpy(r, -alpha, v)          # r now holds s
+                be.vec_mul(z, dinv, r)
+                it += 1
+                it_leg += 1
+                product(z, t)
+                ss, ts, tt = sums([(r, r), (t, r), (t, t)])
+                if np.sqrt(ss) <= tol:             # converged in the half step
+                    be.vec_axpy(xh, alpha, y)
+                    rr = ss
+                    break
+                if tt == 0.0 or not np.isfinite(tt):
+                    be.vec_axpy(xh, alpha, y)
+                    restart("t . t = 0")
+                    continue
+                omega = ts / tt
+                be.vec_axpy(xh, alpha, y)
+                be.vec_axpy(xh, omega, z)
+                be.vec_axpy(r, -omega, t)
+                rr, hr = sums([(r, r), (rhat, r)])
+                rho, rho_new = rho_new, hr
+                if not np.isfinite(rr):
+                    raise RuntimeError("sharded BiCGStab: the residual is not finite after %d iterations" % it)
+                if omega == 0.0 or rho_new == 0.0:
+                    if np.sqrt(rr) <= tol:
+                        break
+                    restart("omega or rho = 0")
+            rr = residual()[0]                      # the recurrence residual drifts from the true one: confirm on b - A x
+            if np.sqrt(rr) <= tol * 1.0000001 or it >= maxit:
+                break
+            fresh = True
+        self.halo_exchange_raw(mesh, xh)
+        return it, (float(np.sqrt(rr)) / bnorm if bnorm > 0.0 else float(np.sqrt(rr)))
+
     def pcg_mg(self, mesh, op, b, x, rtol, atol, maxit):
         """PCG preconditioned by the V-cycle on a row-sharded lattice (settings["preconditioner"] = "amg" on a sharded mesh):
         level 0 of the hierarchy stays with the rows - every rank runs the level's stencil passes, restriction and prolongation

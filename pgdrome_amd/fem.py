@@ -3056,8 +3056,6 @@ def _solve_linear(A, b, x, prm):
     try:
         use_direct = mesh.topology().dim() == 1 and n <= SMALL_DIRECT_N and mesh.part is None
         nonsym = not use_direct and not A.is_symmetric()
-        if nonsym and mesh.part is not None:
-            raise NotImplementedError("non-symmetric operator on a row-sharded mesh: the sharded solve is the SPD Jacobi-PCG")
         if use_direct:
             be.band_solve(op, b.dev(), x.dev_for_write())
             x.touched_dev()
@@ -3070,7 +3068,12 @@ def _solve_linear(A, b, x, prm):
             atol = float(prm.get("absolute_tolerance", 0.0)) if not isinstance(prm.get("absolute_tolerance"), _Params) else 0.0
             maxit = int(prm.get("maximum_iterations", 20000)) if not isinstance(prm.get("maximum_iterations"), _Params) else 20000
             t_solve = time.perf_counter()
-            it, rel = be.bicgstab(op, b.dev(), x.dev(), rtol, atol, maxit)
+            if mesh.part is not None:
+                # (row-sharded: the same recurrence driven over the communicator - pgdrome_amd/dist.py::TorchComm.bicgstab;
+                # is_symmetric() reads the forms' coefficients, which are all-reduced numbers: every rank takes this branch or none)
+                it, rel = mesh.part.comm.bicgstab(mesh, op, b, x, rtol, atol, maxit)
+            else:
+                it, rel = be.bicgstab(op, b.dev(), x.dev(), rtol, atol, maxit)
             x.touched_dev()
             STATS["bicgstab_seconds"] = STATS.get("bicgstab_seconds", 0.0) + time.perf_counter() - t_solve
             STATS["bicgstab_iterations"] = STATS.get("bicgstab_iterations", 0) + it

@@ -381,3 +381,64 @@ def test_spectral_start_on_a_sharded_mesh():
     np.testing.assert_allclose(a["amplitude"], b["amplitude"], rtol=1e-7)
     for m in range(len(b["modes_x"])):
         assert np.linalg.norm(a["modes_x"][m] - b["modes_x"][m]) <= 1e-6 * np.linalg.norm(b["modes_x"][m])
+
+
+def _convection_worker(rank, world, port, shape, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.backend_numpy import NumpyBackend
+        from pgdrome_amd import dist as pdist, fem, problems
+        from pgdrome_amd.solver import PGDProblem
+        be = fem.set_backend(NumpyBackend())
+        comm = pdist.TorchComm(dist, be, True)
+        P = fem.Point
+        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+        p = PGDProblem(**problems.convection_diffusion(mesh, 7, 6, PGD_nmax=3))
+        p.solve_PGD(_problem="linear", settings={"relative_tolerance": 1e-11})
+        modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values()) for f in p.PGD_func[0]]
+        if rank == 0:
+            q.put(dict(num_fp_it=p.num_fp_it, amplitude=p.amplitude, modes_x=modes_x, its=fem.STATS.get("bicgstab_iterations", 0)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_nonsymmetric_spatial_systems_on_a_sharded_mesh(world):
+    """A convective term on a row-sharded spatial dimension (problems.convection_diffusion, three-way separated): the systems are
+    not symmetric and go through the BiCGStab of pgdrome_amd/dist.py - products behind halo exchanges, dots all-reduced - where the
+    reference's MUMPS solves whatever the callbacks produce (solver.py:627-636).  Must reproduce the unsharded run, whose systems
+    the oracle backend solves DIRECTLY (SuperLU)."""
+    from oracle.backend_numpy import NumpyBackend
+    from pgdrome_amd import fem, problems
+    from pgdrome_amd.solver import PGDProblem
+    shape = (7, 6, 10)
+    old = fem._backend
+    fem.set_backend(NumpyBackend())
+    fem.clear_caches()
+    try:
+        P = fem.Point
+        ref = PGDProblem(**problems.convection_diffusion(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape), 7, 6, PGD_nmax=3))
+        ref.solve_PGD(_problem="linear", settings={"relative_tolerance": 1e-11})
+        ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
+    finally:
+        fem.set_backend(old)
+        fem.clear_caches()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_convection_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    out = q.get(timeout=600)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert out["its"] > 10                                   # the Krylov loop ran (the unsharded oracle solves directly)
+    assert out["num_fp_it"] == ref.num_fp_it
+    np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-7)
+    for m in range(ref.PGD_modes):
+        assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-6 * np.linalg.norm(ref_x[m])

@@ -204,7 +204,7 @@ def test_halo_exchange_with_itself_overlapped_or_not_is_the_same_solve():
         dist.destroy_process_group()
 
 
-def _shared_gpu_worker(rank, world, port, shape, q, in_library):
+def _shared_gpu_worker(rank, world, port, shape, q, in_library, problem="reaction"):
     """One of several ranks that all use GPU 0: HIP kernels for the local arithmetic, gloo (staged
     through the host) for the exchange steps."""
     import torch
@@ -224,11 +224,14 @@ def _shared_gpu_worker(rank, world, port, shape, q, in_library):
         assert comm.in_library == ("callbacks" if in_library else None)
         P = fem.Point
         mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
-        p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=3))
+        if problem == "convection":
+            p = PGDProblem(**problems.convection_diffusion(mesh, 7, 6, PGD_nmax=3))
+        else:
+            p = PGDProblem(**problems.reaction_diffusion(mesh, 17, PGD_nmax=3))
         p.solve_PGD(_problem="linear")
         modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values()) for f in p.PGD_func[0]]
         if rank == 0:
-            q.put(dict(num_fp_it=p.num_fp_it, amplitude=p.amplitude, modes_x=modes_x, stats=dict(comm.stats),
+            q.put(dict(num_fp_it=p.num_fp_it, bicgstab_iterations=fem.STATS.get("bicgstab_iterations", 0), amplitude=p.amplitude, modes_x=modes_x, stats=dict(comm.stats),
                        kernels=be.ctx.kernel_counts(), direct_halo=bool(comm.direct_halo),
                        direct_halo_used=bool(be.comm_push(-2)) if comm.in_library else False))
     finally:
@@ -356,6 +359,37 @@ def test_sharded_solve_on_slabs_of_the_bench_plane():
     np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
     for m in range(ref.PGD_modes):
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
+
+
+def test_nonsymmetric_spatial_systems_on_a_sharded_mesh_on_the_gpu():
+    """A convective term on the row-sharded spatial dimension with the HIP kernels (two processes on GPU 0): TorchComm.bicgstab over
+    the library's vector primitives and CSR product must reproduce the unsharded run (in-library BiCGStab, csrc/pgd_krylov.hip)."""
+    import torch.multiprocessing as mp
+    from pgdrome_amd import fem, problems
+    from pgdrome_amd.hip_backend import HipBackend
+    from pgdrome_amd.solver import PGDProblem
+    shape = (20, 18, 23)
+    old = fem._backend
+    fem.set_backend(HipBackend(0))
+    fem.clear_caches()
+    try:
+        P = fem.Point
+        ref = PGDProblem(**problems.convection_diffusion(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape), 7, 6, PGD_nmax=3))
+        ref.solve_PGD(_problem="linear")
+        ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
+    finally:
+        fem.set_backend(old)
+        fem.clear_caches()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, 2, port, shape, q, True, "convection")) for r in range(2)]
+    out = _collect(procs, q, 1, 600)[0]
+    assert out["bicgstab_iterations"] > 10
+    assert out["num_fp_it"] == ref.num_fp_it
+    np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-7)
+    for m in range(ref.PGD_modes):
+        assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-6 * np.linalg.norm(ref_x[m])
 
 
 @pytest.mark.parametrize("world,shape", [(2, (127, 127, 99)), (3, (24, 20, 29))])
