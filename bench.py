@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--n", type=int, default=256, help="spatial dofs per axis (256 = the metric's config)")
     ap.add_argument("--n-mu", type=int, default=128)
     ap.add_argument("--rtol", type=float, default=1e-10)
-    ap.add_argument("--spectral-start", type=int, default=32,
+    ap.add_argument("--spectral-start", type=int, default=48,
                     help='settings["spectral_start"]: Ritz vectors in the second level of the Galerkin start of the spatial solves '
                          "(pgdrome_amd/spectral.py; harvested once, outside the timed region, reported in config.spectral_start); 0: off")
     ap.add_argument("--no-spectral-sharded", action="store_true",
