@@ -63,6 +63,50 @@ __global__ __launch_bounds__(256) void k_linear16(const double *__restrict__ u, 
     }
 }
 
+// ---- the SAME bytes with the S slot values of 64 consecutive rows side by side ([group of 64 rows][S][64]: one stream of S x 512 B
+// pieces instead of S streams of 512 B pieces) - would the march be faster on such a layout?
+template <int S>
+__global__ __launch_bounds__(256) void k_patch8_blocked(const double *__restrict__ u, const double *__restrict__ x, double *__restrict__ y, int nx, int ny, int nz, int zchunk) {
+    const int tiles_x = nx / 64, tiles_y = ny / 8, per = tiles_x * tiles_y;
+    const int chunk = blockIdx.x / per, tile = blockIdx.x - chunk * per, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t P = (int64_t)nx * ny, b0 = tx * 64 + (int64_t)nx * (ty * 8 + 2 * wv), b1 = b0 + nx;      // first row of the wave's two 64-row segments
+    for (int z = chunk * zchunk; z < min(nz, (chunk + 1) * zchunk); ++z) {
+        const int64_t r0 = b0 + P * z, r1 = b1 + P * z;
+        double a0 = x[r0 + lane], a1 = x[r1 + lane];
+        const double *u0 = u + (r0 / 64) * (S * 64) + lane, *u1 = u + (r1 / 64) * (S * 64) + lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) { a0 += u0[s * 64]; a1 += u1[s * 64]; }
+        y[r0 + lane] = a0; y[r1 + lane] = a1;
+    }
+}
+// ... and with 16 B per lane: [group of 128 rows][S][128], 128 x 8 patch (two rows per thread)
+template <int S>
+__global__ __launch_bounds__(256) void k_patch16x2_blocked(const double *__restrict__ u, const double *__restrict__ x, double *__restrict__ y, int nx, int ny, int nz, int zchunk) {
+    const int tiles_x = nx / 128, tiles_y = ny / 8, per = tiles_x * tiles_y;
+    const int chunk = blockIdx.x / per, tile = blockIdx.x - chunk * per, ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t P = (int64_t)nx * ny, b0 = tx * 128 + (int64_t)nx * (ty * 8 + 2 * wv), b1 = b0 + nx;
+    for (int z = chunk * zchunk; z < min(nz, (chunk + 1) * zchunk); ++z) {
+        const int64_t r0 = b0 + P * z, r1 = b1 + P * z;
+        d2 a0 = *reinterpret_cast<const d2 *>(x + r0 + 2 * lane), a1 = *reinterpret_cast<const d2 *>(x + r1 + 2 * lane);
+        const double *u0 = u + (r0 / 128) * (S * 128) + 2 * lane, *u1 = u + (r1 / 128) * (S * 128) + 2 * lane;
+#pragma unroll
+        for (int s = 0; s < S; ++s) { a0 += *reinterpret_cast<const d2 *>(u0 + s * 128); a1 += *reinterpret_cast<const d2 *>(u1 + s * 128); }
+        *reinterpret_cast<d2 *>(y + r0 + 2 * lane) = a0; *reinterpret_cast<d2 *>(y + r1 + 2 * lane) = a1;
+    }
+}
+template <int S>
+__global__ __launch_bounds__(256) void k_linear16_blocked(const double *__restrict__ u, const double *__restrict__ x, double *__restrict__ y, int64_t n) {
+    for (int64_t i = 2 * ((int64_t)blockIdx.x * 256 + threadIdx.x); i < n; i += 2 * (int64_t)gridDim.x * 256) {
+        d2 a = *reinterpret_cast<const d2 *>(x + i);
+        const double *ub = u + (i / 128) * (S * 128) + (i & 127);
+#pragma unroll
+        for (int s = 0; s < S; ++s) a += *reinterpret_cast<const d2 *>(ub + s * 128);
+        *reinterpret_cast<d2 *>(y + i) = a;
+    }
+}
+
 int main(int argc, char **argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 256;
     const int64_t n = (int64_t)N * N * N;
@@ -93,6 +137,15 @@ int main(int argc, char **argv) {
         snprintf(nm, sizeof nm, "128 x 8 patch, 16 B/lane x 2 rows, march %d", zc);
         run(nm, [&] { k_patch16x2<S><<<(N / 128) * (N / 8) * ((N + zc - 1) / zc), 256>>>(u, x, y, stride, N, N, N, zc); });
     }
+    for (int zc : {8, 16, 32, 64}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "BLOCKED [64 rows][7][64]: 64 x 8 patch, march %d", zc);
+        run(nm, [&] { k_patch8_blocked<S><<<(N / 64) * (N / 8) * ((N + zc - 1) / zc), 256>>>(u, x, y, N, N, N, zc); });
+        snprintf(nm, sizeof nm, "BLOCKED [128][7][128]: 128 x 8 patch 16 B, march %d", zc);
+        run(nm, [&] { k_patch16x2_blocked<S><<<(N / 128) * (N / 8) * ((N + zc - 1) / zc), 256>>>(u, x, y, N, N, N, zc); });
+    }
+    run("BLOCKED linear, 16 B/lane, 2048 workgroups", [&] { k_linear16_blocked<S><<<2048, 256>>>(u, x, y, n); });
+    run("BLOCKED linear, 16 B/lane, 8192 workgroups", [&] { k_linear16_blocked<S><<<8192, 256>>>(u, x, y, n); });
     run("linear, 16 B/lane, 2048 workgroups", [&] { k_linear16<S><<<2048, 256>>>(u, x, y, stride, n); });
     run("linear, 16 B/lane, 8192 workgroups", [&] { k_linear16<S><<<8192, 256>>>(u, x, y, stride, n); });
     run("linear, 16 B/lane, 3 slot arrays (but priced as 7)", [&] { k_linear16<3><<<4096, 256>>>(u, x, y, stride, n); });
