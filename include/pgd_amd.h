@@ -338,6 +338,9 @@ int pgd_vec_multidot_pair(pgd_handle ctx, pgd_handle x0, pgd_handle x1, const pg
 /* Launch-shape knobs; they change speed (and the order of the dot's partial
  * sums), never which result is computed (PGD_TUNE_FAULT_ITERATION excepted: a test hook).  */
 enum {
+    PGD_TUNE_PUSH_IN_UPDATE = 49, /* direct halo (pgd_comm_push_*): 1 (default) the boundary planes of the new search direction leave from the
+                                update kernel of the iteration itself - no launch for the exchange at all; 0: k_halo_push in front of
+                                every product.  Same stores, same iterates. */
     PGD_TUNE_STENCIL_ROWS = 48, /* rows per thread of k_spmv_stencil_march: 4 (64 x 16 patches), 2 (64 x 8: twice the patches per plane, marches
                                  * twice as long on thin z-slabs), 0 (default): 2 where four-row patches would march fewer than 8 planes.   */
     PGD_TUNE_DIA_MARCH3 = 47, /* 1: the plain z-march of the diagonal form (variant 0: no row classes - variable coefficients, graded meshes) runs

@@ -186,26 +186,40 @@ static long long push_ticks(const Comm &k) {
 
 // the exchange itself: v must be the vector the export was made for (the sharded loop's p).  Always issued by every rank of a solve
 // that voted for it - a rank that failed locally pushes whatever its p holds, so that nobody waits for a number that never comes.
+// where this rank's boundary planes go.  To the LOWER neighbour: my bottom plane -> its ghost planes above (its last rows); to the UPPER
+// one: my top plane -> its first rows.  (A rank that is its own neighbour: the ghost plane above is fed by the bottom plane, the one
+// below by the top plane.)
+struct PushTargets { int64_t n_lo, n_hi; double *dst_lo, *dst_hi; unsigned long long *post_lo, *post_hi, *wait_a, *wait_b; };
+static PushTargets push_targets(const Comm &k) {
+    const bool self = k.self_periodic && k.world == 1;
+    PushTargets T;
+    T.n_lo = self ? k.push_hi_g : k.push_lo_g;
+    T.n_hi = self ? k.push_lo_g : k.push_hi_g;
+    T.dst_lo = T.n_lo ? k.push_peer[0] + (k.push_peer_n[0] - T.n_lo) : nullptr;
+    T.dst_hi = T.n_hi ? k.push_peer[1] : nullptr;
+    T.post_lo = T.n_lo ? k.push_peer_flags[0] + 1 : nullptr;
+    T.post_hi = T.n_hi ? k.push_peer_flags[1] + 0 : nullptr;
+    T.wait_a = k.push_lo_g ? k.push_flags + 0 : nullptr;
+    T.wait_b = k.push_hi_g ? k.push_flags + 1 : nullptr;
+    return T;
+}
+
 static int comm_push_halo(Ctx *c, double *v, int *flags) {
     Comm &k = c->comm;
     if (!k.push) return fail(c, PGD_ERR_INVALID, "direct halo: not attached");
     const int64_t lo_g = k.push_lo_g, hi_g = k.push_hi_g, own0 = k.push_own0, own1 = k.push_own1;
     if (!lo_g && !hi_g) return PGD_OK;
     k.push_seq += 1;
-    const bool self = k.self_periodic && k.world == 1;
-    // to the LOWER neighbour: my bottom plane -> its ghost planes above (its last rows); to the UPPER one: my top plane -> its first rows.
-    // (a rank that is its own neighbour: the ghost plane above is fed by the bottom plane, the one below by the top plane)
-    const int64_t n_lo = self ? hi_g : lo_g, n_hi = self ? lo_g : hi_g;
+    const PushTargets T = push_targets(k);
+    const int64_t n_lo = T.n_lo, n_hi = T.n_hi;
     const double *src_lo = v + own0, *src_hi = v + own1 - n_hi;
-    double *dst_lo = n_lo ? k.push_peer[0] + (k.push_peer_n[0] - n_lo) : nullptr;
-    double *dst_hi = n_hi ? k.push_peer[1] : nullptr;
+    double *dst_lo = T.dst_lo, *dst_hi = T.dst_hi;
     const int64_t most = std::max(n_lo, n_hi);
     // (workgroups: enough write-through stores in flight for 2 x 512 KiB, few enough tickets on one address - measured on the
     // 256 x 256 plane: 16 / 32 / 64 / 128 / 256 workgroups = 50.4 / 45.0 / 40.9 / 40.8 / 41.9 us per iteration)
     const int grid = (int)std::min<int64_t>(std::max<int64_t>((most + 511) / 512, 1), 128);
-    k_halo_push<<<grid, 256, 0, c->stream>>>(src_lo, dst_lo, n_lo, src_hi, dst_hi, n_hi, n_lo ? k.push_peer_flags[0] + 1 : nullptr,
-                                             n_hi ? k.push_peer_flags[1] + 0 : nullptr, lo_g ? k.push_flags + 0 : nullptr,
-                                             hi_g ? k.push_flags + 1 : nullptr, k.push_seq, k.push_flags + 2, push_ticks(k), flags);
+    k_halo_push<<<grid, 256, 0, c->stream>>>(src_lo, dst_lo, n_lo, src_hi, dst_hi, n_hi, T.post_lo, T.post_hi, T.wait_a, T.wait_b, k.push_seq,
+                                             k.push_flags + 2, push_ticks(k), flags);
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
 }
@@ -873,12 +887,17 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     k.push_used = pushing;
     hipEvent_t *marks = nullptr;                                     // phase timing of the iteration being queued (or none)
     auto mark = [&](int i) { if (marks) (void)hipEventRecord(marks[i], c->stream); };
+    // ... and leaves from the update kernel of the iteration before where that launch can carry it (fold, even rows and plane sizes):
+    // `p_sent` says whether the planes of the CURRENT p are already on their way (else the product sends them itself - the first
+    // iteration, a rank that skipped its update after a local failure)
+    bool p_sent = false;
     auto product = [&](pgd_handle uh, double *ud, double *wdst, bool folded, int *np_total) -> int {
         mark(0);
         if (pushing && ud == pd) {
             S.last = "direct halo of the product";
             S.ncoll += 1;
-            PGD_TRY(comm_push_halo(c, ud, c->flags));
+            if (!p_sent) PGD_TRY(comm_push_halo(c, ud, c->flags));
+            p_sent = false;
         } else PGD_TRY(sh_halo_begin(S, uh, ud, own0, own1, lo_g, hi_g, async, "halo exchange of the product"));
         const int64_t lo[3] = {own0 + glo, own0, own1 - ghi}, hi[3] = {own1 - ghi, own0 + glo, own1};
         const int mult = c->spmv_qq ? 2 : 1;      // pairs (w.y, y.y) per workgroup in the single-sync form
@@ -978,6 +997,23 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     // an empty slab has no update launch to fold the scalar step into; every rank must take the same form (collective-free: the
     // decision depends on nothing rank-local but that, and a rank without rows runs k_pcg1_finish for its own books instead)
     const bool fold = ss && c->pcg_fold_finish != 0 && own1 > own0;
+    // the direct halo inside the update launch (every rank decides from its own slab: a rank that cannot sends from k_halo_push, the
+    // sequence numbers advance alike)
+    PushArgs push_proto;
+    bool push_fused = false;
+    if (pushing && fold && c->push_in_update && (lo_g || hi_g)) {
+        const PushTargets T = push_targets(k);
+        const bool even = !(own0 & 1) && !((own1 - own0) & 1) && !(T.n_lo & 1) && !(T.n_hi & 1) && T.n_lo <= own1 - own0 && T.n_hi <= own1 - own0;
+        if (even) {
+            push_proto.dst_lo = T.dst_lo; push_proto.dst_hi = T.dst_hi;
+            push_proto.lo_end = own0 + T.n_lo; push_proto.hi_begin = own1 - T.n_hi;
+            push_proto.post_lo = T.post_lo; push_proto.post_hi = T.post_hi; push_proto.wait_a = T.wait_a; push_proto.wait_b = T.wait_b;
+            push_proto.ticket = k.push_flags + 2;
+            push_proto.ticks = push_ticks(k);
+            push_proto.nblocks = pcg1_update_push_blocks(gvec, own0, own1, push_proto.lo_end, push_proto.hi_begin);
+            push_fused = push_proto.nblocks > 0;
+        }
+    }
     // One iteration.  Returns an error only for what ends the protocol.
     auto iterate = [&](int kidx) -> int {
         S.iter = kidx;
@@ -1000,6 +1036,13 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
             // stop test, alpha, beta: by every workgroup of the update (fold), or by k_pcg1_finish in a launch of its own
             if (!fold) SH_LOCAL(S, pcg1_finish_slots(c, B));
             // (x is updated every other iteration, two terms at a time: k_pcg1_update; every rank reads the same beta)
+            if (push_fused && !S.poisoned()) {
+                PushArgs P = push_proto;
+                P.seq = k.push_seq + 1;
+                const int rc_u = pcg1_update(c, xd, rd, pd, qd, scp, own0, own1, B, &nb, c->pcg_lag_x ? 1 + (kidx & 1) : 0, kidx & 1, &P);
+                if (rc_u == PGD_OK) { k.push_seq += 1; p_sent = true; }
+                else S.local(rc_u);                                  // (nothing was launched: the next product sends the planes itself)
+            } else
             SH_LOCAL(S, pcg1_update(c, xd, rd, pd, qd, scp, own0, own1, B, &nb, c->pcg_lag_x ? 1 + (kidx & 1) : 0, fold ? (kidx & 1) : -1));
             mark(6);
             return PGD_OK;

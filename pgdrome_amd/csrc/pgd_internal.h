@@ -296,6 +296,7 @@ struct Ctx {
     int pcg_scaled = 1;           // pgd_pcg_solve on the symmetrically scaled system (no dinv / z passes) when the symmetric storage applies
     int stencil_rows = 0;         // rows per thread of k_spmv_stencil_march: 0 = by the launch's shape (2 for thin slabs), 2, 4 (PGD_TUNE_STENCIL_ROWS)
     int dia_march3 = 0;           // 1: variant 0 of the plain z-march in k_spmv_dia_march3 (PGD_TUNE_DIA_MARCH3; bit-identical, measured 2 - 5 % slower at 256^3)
+    int push_in_update = 1;       // direct halo: the boundary planes leave from the update kernel itself (PGD_TUNE_PUSH_IN_UPDATE); 0: k_halo_push
     int shard_one_march = 1;      // pgd_pcg_solve_sharded, exchange in stream order: all owned planes in one stencil march, ghost planes as data (PGD_TUNE_SHARD_ONE_MARCH)
     int pcg_derive_scaled = 1;    // ... whose stencil couplings are DERIVED from the verified stencil of A where that exists (PGD_TUNE_PCG_DERIVE_SCALED)
     int spmv_combine_dia = 1;     // structured grids: op_combine also forms the diagonal form from the atoms' diagonal forms
@@ -361,8 +362,20 @@ int pcg1_tol(Ctx *c, int base, double rtol, double atol, int slot_p8);
 int pcg1_aux(Ctx *c, const double *s, const double *r, int64_t lo, int64_t hi, int slot);
 int pcg1_sums(Ctx *c, int nprod, int nvec, int base);
 int pcg1_finish_slots(Ctx *c, int base);
+// direct halo folded into the update (pgd_comm.hip): the rows [lo, lo_end) and [hi_begin, hi) of the new p also go - as write-through
+// stores at system scope - to dst_lo / dst_hi, the workgroups that hold such rows take a ticket, the last one posts `seq` and polls
+struct PushArgs {
+    double *dst_lo = nullptr, *dst_hi = nullptr;
+    int64_t lo_end = 0, hi_begin = 0;
+    unsigned long long *post_lo = nullptr, *post_hi = nullptr;
+    const unsigned long long *wait_a = nullptr, *wait_b = nullptr;
+    unsigned long long seq = 0, *ticket = nullptr;
+    unsigned int nblocks = 0;          // filled by pcg1_update: workgroups that take a ticket
+    long long ticks = 0;
+};
+unsigned int pcg1_update_push_blocks(int g, int64_t lo, int64_t hi, int64_t lo_end, int64_t hi_begin);
 int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const double *sc, int64_t lo, int64_t hi, int base,
-                int *nblocks, int lag, int fold_par);
+                int *nblocks, int lag, int fold_par, const PushArgs *push = nullptr);
 int pcg1_flush_x(Ctx *c, double *x, const double *p, const double *r, int64_t lo, int64_t hi, int base, int fold_par);
 int vec_sqrt(Ctx *c, double *v, int64_t n);
 int vec_div_mul(Ctx *c, double *x, const double *sc, int64_t n, int mul);

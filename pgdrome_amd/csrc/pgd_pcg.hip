@@ -755,13 +755,29 @@ __global__ __launch_bounds__(TPB) void k_pcg1_aux(const double *__restrict__ s, 
 // previous pair), the sums are rewritten by the NEXT iteration's k_pcg1_sums, and the sharded form is in its exact phase
 // (flags[3] = 1, the true r.r in every iteration) from the start.  A workgroup that starts late and finds the done flag set by
 // workgroup 0 returns - what its own test would have told it.
-template <bool NT, bool FOLD>
+// PUSH (the direct halo of the sharded loop, pgd_comm.hip; FOLD launches with an even first row and even plane sizes): the boundary
+// planes of the NEW p go straight into the neighbours' ghost planes as well - write-through stores at system scope - and the last of
+// the workgroups that hold such rows (a ticket) posts the sequence number and polls this rank's own: k_halo_push without its launch.
+// A launch that returns early (the solve is done - on every rank alike) still posts, so that a neighbour which failed locally and
+// keeps pushing from launches of its own is never left waiting; it does not wait itself.
+__device__ __forceinline__ void push_store(double *dst, double v) {
+    __hip_atomic_store(reinterpret_cast<unsigned long long *>(dst), (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void push_post(const PushArgs &P) {
+    if (P.post_lo) __hip_atomic_store(P.post_lo, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (P.post_hi) __hip_atomic_store(P.post_hi, P.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+template <bool NT, bool FOLD, bool PUSH = false>
 __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, double *__restrict__ r, double *__restrict__ p,
                                                      const double *__restrict__ q, const double *__restrict__ s, int64_t lo,
                                                      int64_t hi, double *__restrict__ slots, int slot_alpha, int slot_beta,
                                                      double *__restrict__ partials, int *__restrict__ flags, int lag,
-                                                     int fold_base, int par) {
-    if (flags[0]) return;
+                                                     int fold_base, int par, PushArgs P) {
+    if (flags[0]) {
+        if (PUSH && blockIdx.x == 0 && threadIdx.x == 0) push_post(P);
+        return;
+    }
     __shared__ double s_red[4];
     typedef double d2 __attribute__((ext_vector_type(2)));
     double alpha, beta;
@@ -781,7 +797,7 @@ __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, dou
         }
         if (lead) { slots[S1F_EXACT + par] = fold_exact ? 1.0 : 0.0; flags[3] = fold_exact ? 1 : 0; }
         if (done) {
-            if (lead) { if (status) flags[2] = status; flags[0] = 1; }
+            if (lead) { if (status) flags[2] = status; flags[0] = 1; if (PUSH) push_post(P); }
             return;                                                // uniform over the whole launch
         }
         alpha = rz0 / pq;
@@ -799,6 +815,7 @@ __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, dou
     const double alpha_p = two ? slots[FOLD ? S1F_ALPHA + (par ^ 1) : S1_ALPHA_PREV] : 0.0;
     const double ibeta_p = two ? 1.0 / slots[FOLD ? S1F_BETA + (par ^ 1) : S1_BETA_PREV] : 0.0;
     double rz = 0.0, rr = 0.0;
+    int pushed = 0;
     if ((lo & 1) == 0) {                                  // 16-byte accesses (row ranges of the sharded solve may start odd)
         const int64_t npair = (hi - lo) >> 1;
         for (int64_t k = (int64_t)blockIdx.x * TPB + threadIdx.x; k < npair; k += (int64_t)gridDim.x * TPB) {
@@ -816,6 +833,10 @@ __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, dou
             pi.x = fma(beta, pi.x, ri.x); pi.y = fma(beta, pi.y, ri.y);
             if (NT) __builtin_nontemporal_store(ri, reinterpret_cast<d2 *>(r + i)); else *reinterpret_cast<d2 *>(r + i) = ri;
             *reinterpret_cast<d2 *>(p + i) = pi;
+            if (PUSH) {                                   // (even plane sizes: a pair never straddles a range)
+                if (i < P.lo_end) { push_store(P.dst_lo + (i - lo), pi.x); push_store(P.dst_lo + (i - lo) + 1, pi.y); pushed = 1; }
+                if (i >= P.hi_begin) { push_store(P.dst_hi + (i - P.hi_begin), pi.x); push_store(P.dst_hi + (i - P.hi_begin) + 1, pi.y); pushed = 1; }
+            }
             rz = fma(ri.x, ri.x, rz); rz = fma(ri.y, ri.y, rz);
             if (exact) {
                 const d2 si = *reinterpret_cast<const d2 *>(s + i);
@@ -842,6 +863,24 @@ __global__ __launch_bounds__(TPB) void k_pcg1_update(double *__restrict__ x, dou
     rr = block_sum(rr, s_red);
     if (threadIdx.x == 0) { partials[2 * blockIdx.x] = rz; partials[2 * blockIdx.x + 1] = exact ? rr : rz; }
     if (lag == 1 && blockIdx.x == 0 && threadIdx.x == 0) slots[S1_PEND] = skip_x ? 1.0 : 0.0;
+    if (PUSH) {
+        __builtin_amdgcn_s_waitcnt(0);                    // this wave's pushed rows are acknowledged
+        if (!__syncthreads_or(pushed)) return;            // a workgroup without boundary rows (uniform)
+        if (threadIdx.x != 0) return;
+        const unsigned long long t = __hip_atomic_fetch_add(P.ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t + 1 != P.nblocks) return;
+        __hip_atomic_store(P.ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        push_post(P);
+        const long long t0 = wall_clock64();
+        for (int which = 0; which < 2; ++which) {
+            const unsigned long long *f = which ? P.wait_b : P.wait_a;
+            if (!f) continue;
+            while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < P.seq) {
+                if (wall_clock64() - t0 > P.ticks) { flags[2] = PGD_ERR_TIMEOUT; flags[0] = 1; return; }
+                __builtin_amdgcn_s_sleep(4);
+            }
+        }
+    }
 }
 
 // ---- small systems (up to 2^20 rows): the scalar step folded into the vector update, 2 launches per iteration.
@@ -1260,11 +1299,31 @@ int pcg1_finish_slots(Ctx *c, int base) {
     return PGD_OK;
 }
 
+// the workgroups of a k_pcg1_update launch over [lo, hi) that hold a row of [lo, lo_end) or [hi_begin, hi): the kernel's own loop
+unsigned int pcg1_update_push_blocks(int g, int64_t lo, int64_t hi, int64_t lo_end, int64_t hi_begin) {
+    const int64_t npair = (hi - lo) >> 1, a1 = (lo_end - lo) >> 1, b0 = (hi_begin - lo) >> 1;
+    unsigned int count = 0;
+    for (int b = 0; b < g; ++b) {
+        bool any = false;
+        for (int64_t k0 = (int64_t)b * TPB; k0 < npair && !any; k0 += (int64_t)g * TPB) {
+            const int64_t k1 = std::min<int64_t>(k0 + TPB, npair);
+            any = k0 < a1 || k1 > b0;
+        }
+        count += any ? 1u : 0u;
+    }
+    return count;
+}
+
 int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const double *sc, int64_t lo, int64_t hi, int base,
-                int *nblocks, int lag, int fold_par) {       // fold_par >= 0: the scalar step in every workgroup (parity of the iteration)
+                int *nblocks, int lag, int fold_par, const PushArgs *push) {       // fold_par >= 0: the scalar step in every workgroup (parity of the iteration)
     *nblocks = 0;
-    if (hi == lo) return PGD_OK;
+    if (hi == lo) return push ? fail(c, PGD_ERR_INVALID, "pcg1_update: a push from an empty slab") : PGD_OK;
     const int g = grid_for((hi - lo + 1) / 2);
+    if (push) {
+        // the caller has checked: fold, lo even, (hi - lo), (lo_end - lo), (hi - hi_begin) even
+        if (fold_par < 0 || (lo & 1) || ((hi - lo) & 1) || ((push->lo_end - lo) & 1) || ((hi - push->hi_begin) & 1))
+            return fail(c, PGD_ERR_INVALID, "pcg1_update: this launch cannot carry the direct halo");
+    }
     PGD_TRY(ensure_work(c, 6, 2 * (int64_t)MAX_VEC_BLOCKS));
     const bool timed_u = c->prof && ((c->prof_upd_seen++ % 3) == 0);      // launch timing, as in pgd_pcg_solve
     if (timed_u) {
@@ -1272,11 +1331,16 @@ int pcg1_update(Ctx *c, double *x, double *r, double *p, const double *q, const 
         c->ev_rec[c->ev_used / 2] = Ctx::ProfRec{1, c->prof_iter, 0.0, 0.0, 0.0};
         PGD_HIP(c, hipEventRecord(c->ev[c->ev_used], c->stream));
     }
-    if (fold_par >= 0) {
-        if (c->pcg_stream_hints) k_pcg1_update<true, true><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, 0, 0, c->work[6], c->flags, lag, base, fold_par);
-        else k_pcg1_update<false, true><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, 0, 0, c->work[6], c->flags, lag, base, fold_par);
-    } else if (c->pcg_stream_hints) k_pcg1_update<true, false><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, lag, 0, 0);
-    else k_pcg1_update<false, false><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, lag, 0, 0);
+    if (push) {
+        PushArgs P = *push;
+        if (!P.nblocks) P.nblocks = pcg1_update_push_blocks(g, lo, hi, P.lo_end, P.hi_begin);
+        if (c->pcg_stream_hints) k_pcg1_update<true, true, true><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, 0, 0, c->work[6], c->flags, lag, base, fold_par, P);
+        else k_pcg1_update<false, true, true><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, 0, 0, c->work[6], c->flags, lag, base, fold_par, P);
+    } else if (fold_par >= 0) {
+        if (c->pcg_stream_hints) k_pcg1_update<true, true><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, 0, 0, c->work[6], c->flags, lag, base, fold_par, PushArgs());
+        else k_pcg1_update<false, true><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, 0, 0, c->work[6], c->flags, lag, base, fold_par, PushArgs());
+    } else if (c->pcg_stream_hints) k_pcg1_update<true, false><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, lag, 0, 0, PushArgs());
+    else k_pcg1_update<false, false><<<g, TPB, 0, c->stream>>>(x, r, p, q, sc, lo, hi, c->slots, base + 5, base + 6, c->work[6], c->flags, lag, 0, 0, PushArgs());
     if (timed_u) {
         PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
         // (outside the exact phase - all but the last few dozen iterations - the kernel does not read s; the host cannot see the flag)
@@ -1605,8 +1669,8 @@ int pgd_pcg_solve(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle xh, dou
                     const int par = (start + k) & 1;
                     k_pcg1_step<<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, n, prod, nparts, par ? part2 : part2b, g2v, par ? part2b : part2,
                                                             c->slots, c->flags, par, lag);
-                } else if (c->pcg_stream_hints) k_pcg1_update<true, false><<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags, lag, 0, 0);
-                else k_pcg1_update<false, false><<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags, lag, 0, 0);
+                } else if (c->pcg_stream_hints) k_pcg1_update<true, false><<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags, lag, 0, 0, PushArgs());
+                else k_pcg1_update<false, false><<<g2v, TPB, 0, c->stream>>>(x->d, r, p, q, sc, 0, n, c->slots, S1_ALPHA, S1_BETA, part2, c->flags, lag, 0, 0, PushArgs());
                 if (timed_u) {
                     PGD_HIP(c, hipEventRecord(c->ev[c->ev_used + 1], c->stream));
                     c->ev_rec[c->ev_used / 2].bytes = (lag == 1 ? 40.0 : 56.0) * (double)n;      // (a lag = 1 launch that meets beta < 0.01 moves 56)

@@ -2908,6 +2908,7 @@ int pgd_tune(pgd_handle h, int knob, int64_t value) {
     if (knob == PGD_TUNE_SHARD_ONE_MARCH && value >= 0 && value <= 1) { c->shard_one_march = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_DIA_MARCH3 && value >= 0 && value <= 1) { c->dia_march3 = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_STENCIL_ROWS && (value == 0 || value == 2 || value == 4)) { c->stencil_rows = (int)value; return PGD_OK; }
+    if (knob == PGD_TUNE_PUSH_IN_UPDATE && (value == 0 || value == 1)) { c->push_in_update = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_MG_CHUNK && value >= 2 && value <= 16 && value % 2 == 0) { c->mg_chunk = (int)value; return PGD_OK; }
     if (knob == PGD_TUNE_MG_MARCH_MIN && value >= 0 && value <= 1 << 20) { c->mg_march_min = (int)value; return PGD_OK; }
     return fail(c, PGD_ERR_INVALID, "tune: unknown knob %d or value out of range", knob);

@@ -392,13 +392,16 @@ def test_nonsymmetric_spatial_systems_on_a_sharded_mesh_on_the_gpu():
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-6 * np.linalg.norm(ref_x[m])
 
 
-@pytest.mark.parametrize("world,shape", [(2, (127, 127, 99)), (3, (24, 20, 29))])
-def test_direct_halo_between_processes_on_one_gpu(world, shape):
+@pytest.mark.parametrize("world,shape,tune", [(2, (127, 127, 99), ""), (2, (127, 127, 99), "49=0"), (3, (24, 20, 29), "")])
+def test_direct_halo_between_processes_on_one_gpu(world, shape, tune, monkeypatch):
     """PGD_HALO_DIRECT=1: the boundary planes of the search direction go straight into the NEIGHBOUR PROCESS's ghost planes through
     hipIpcMemHandle-mapped pointers, a sequence number is posted behind them and the product waits for its own (pgd_comm_push_*) -
     `world` processes on GPU 0, everything else of the exchange over gloo as in the tests above.  Only the transport of the planes
-    differs: the run must be bit for bit the one with the binding's exchange."""
+    differs: the run must be bit for bit the one with the binding's exchange.  (Planes with an even number of rows - the first
+    shape - send from the update kernel itself, PGD_TUNE_PUSH_IN_UPDATE; "49=0" and odd planes from k_halo_push.)"""
     import torch.multiprocessing as mp
+    if tune:
+        monkeypatch.setenv("PGD_TUNE", tune)
     ctx = mp.get_context("spawn")
     outs = {}
     saved = os.environ.get("PGD_HALO_DIRECT")

@@ -40,7 +40,9 @@ nx = ny = args.nxy
 VARIANTS = (("stream_ordered_one_march", ((45, 1 << 40), (46, 1))), ("stream_ordered_interior_plus_boundary", ((45, 1 << 40), (46, 0))),
             ("overlapped_on_the_halo_stream", ((45, 0), (46, 1))),
             # the boundary planes stored straight into the ghost planes + a posted sequence number (pgd_comm_push_*): no RCCL kernel
-            ("direct_halo_one_march", ((45, 1 << 40), (46, 1), ("push", 1))))
+            ("direct_halo_one_march", ((45, 1 << 40), (46, 1), (49, 1), ("push", 1))),
+            # (49 = 0: the planes leave from a launch of their own, k_halo_push, instead of the update kernel)
+            ("direct_halo_push_kernel", ((45, 1 << 40), (46, 1), (49, 0), ("push", 1))))
 
 
 def slab(planes):
