@@ -295,6 +295,9 @@ class DofLayout:
     def owned_range(self):
         return self.mesh.owned_range() if self.degree == 1 else (0, self.n)
 
+    def shard_view(self):
+        return self.mesh
+
     def on_boundary(self):
         onb = self.mesh.vertex_on_boundary()
         if self.vertex_nodes is None:
@@ -552,14 +555,29 @@ class FunctionSpace:
         return id(self)
 
 
+class _ShardView:
+    """A layout seen as pgdrome_amd/dist.py sees a mesh: `.part` and `.num_vertices()` in DOFS (a vector-valued space on a sharded
+    mesh has ncomp times the rows of its mesh)."""
+
+    def __init__(self, lay):
+        self.lay = lay
+
+    @property
+    def part(self):
+        return self.lay.part
+
+    def num_vertices(self):
+        return self.lay.n
+
+
 class BlockLayout:
     """Degrees of freedom of a VECTOR-valued Lagrange space: dof (node i, component c) = ncomp i + c over a
     scalar DofLayout.  The device sees it as a layout of its own (pgd_mesh_blocked); its atoms are scalar
     atoms of the base layout embedded in a (test component, trial component) block (pgd_atom_embed)."""
 
     def __init__(self, base, ncomp):
-        if base.part is not None:
-            raise NotImplementedError("vector-valued space on a sharded mesh")
+        if base.part is not None and base.degree != 1:
+            raise NotImplementedError("vector-valued P2 space on a sharded mesh")
         self.base, self.ncomp = base, int(ncomp)
         self.mesh, self.degree = base.mesh, base.degree
         self.n = base.n * self.ncomp
@@ -568,10 +586,28 @@ class BlockLayout:
         self._handles, self._atoms = {}, {}
         self._ones = self._space = None
 
-    part = None
+    @property
+    def part(self):
+        """Row-sharded base (P1 on z-slabs): dof (node i, component c) = ncomp i + c keeps a slab's dofs contiguous - ghost dofs
+        below, owned dofs, ghost dofs above - so the partition of the nodes, times ncomp, is the partition of the dofs."""
+        bp = self.base.part
+        if bp is None:
+            return None
+        if self._part is None or self._part[0] is not bp:
+            nc = self.ncomp
+            self._part = (bp, Partition(bp.comm, nc * bp.own0, nc * bp.own1, nc * bp.n_global, nc * bp.lo_ghost, nc * bp.hi_ghost,
+                                        nc * bp.global_offset))
+        return self._part[1]
+
+    _part = None
 
     def owned_range(self):
-        return (0, self.n)
+        part = self.part
+        return (part.own0, part.own1) if part is not None else (0, self.n)
+
+    def shard_view(self):
+        """What the communicator's solvers and halo exchanges take for "the mesh" of this layout: its partition and its length."""
+        return _ShardView(self)
 
     def on_boundary(self):
         return np.repeat(self.base.on_boundary(), self.ncomp)
@@ -2164,7 +2200,7 @@ def _matvec_cached(lay, atom, g):
 
 def _halo(lay, vec):
     if lay.part is not None:
-        lay.part.comm.halo_exchange(lay.mesh, vec)
+        lay.part.comm.halo_exchange(lay.shard_view(), vec)
 
 
 _SYMMETRIC_KINDS = (MASS, STIFF, WMASS, WSTIFF)
@@ -3053,8 +3089,10 @@ def _solve_linear(A, b, x, prm):
     n = A.lay.n
     op = A.op()
     info = {}
+    # the rows' partition and what the communicator takes for "the mesh": the layout's (a vector-valued space has ncomp rows per vertex)
+    part, view = A.lay.part, (A.lay.shard_view() if A.lay.part is not None else mesh)
     try:
-        use_direct = mesh.topology().dim() == 1 and n <= SMALL_DIRECT_N and mesh.part is None
+        use_direct = mesh.topology().dim() == 1 and n <= SMALL_DIRECT_N and part is None
         nonsym = not use_direct and not A.is_symmetric()
         if use_direct:
             be.band_solve(op, b.dev(), x.dev_for_write())
@@ -3068,10 +3106,10 @@ def _solve_linear(A, b, x, prm):
             atol = float(prm.get("absolute_tolerance", 0.0)) if not isinstance(prm.get("absolute_tolerance"), _Params) else 0.0
             maxit = int(prm.get("maximum_iterations", 20000)) if not isinstance(prm.get("maximum_iterations"), _Params) else 20000
             t_solve = time.perf_counter()
-            if mesh.part is not None:
+            if part is not None:
                 # (row-sharded: the same recurrence driven over the communicator - pgdrome_amd/dist.py::TorchComm.bicgstab;
                 # is_symmetric() reads the forms' coefficients, which are all-reduced numbers: every rank takes this branch or none)
-                it, rel = mesh.part.comm.bicgstab(mesh, op, b, x, rtol, atol, maxit)
+                it, rel = part.comm.bicgstab(view, op, b, x, rtol, atol, maxit)
             else:
                 it, rel = be.bicgstab(op, b.dev(), x.dev(), rtol, atol, maxit)
             x.touched_dev()
@@ -3103,21 +3141,21 @@ def _solve_linear(A, b, x, prm):
             # counters; every other value is the Jacobi-PCG.  The row-sharded solve has the Jacobi form only.
             prec = prm.get("preconditioner", "default")
             asks_mg = (not isinstance(prec, _Params)) and str(prec).lower() in MULTIGRID_NAMES
-            want_mg = asks_mg and mesh.part is None
+            want_mg = asks_mg and part is None
             mg0 = None
             used = 0
             if want_mg and hasattr(be, "precondition"):
                 mg0 = be.precondition(1)
             try:
-                if mesh.part is not None:
+                if part is not None:
                     # a row-sharded lattice: the V-cycle with level 0 on the slabs and levels >= 1 replicated (dist.pcg_mg);
                     # where it does not apply on some rank every rank takes the Jacobi-PCG (decided by an all-reduce)
-                    got = mesh.part.comm.pcg_mg(mesh, op, b, x, rtol, atol, maxit) if asks_mg and hasattr(mesh.part.comm, "pcg_mg") else None
+                    got = part.comm.pcg_mg(view, op, b, x, rtol, atol, maxit) if asks_mg and hasattr(part.comm, "pcg_mg") else None
                     if got is not None:
                         it, rel = got
                         used = 1
                     else:
-                        it, rel = mesh.part.comm.pcg(mesh, op, b, x, rtol, atol, maxit)
+                        it, rel = part.comm.pcg(view, op, b, x, rtol, atol, maxit)
                 else:
                     it, rel = be.pcg(op, b.dev(), x.dev(), rtol, atol, maxit)
                     x.touched_dev()

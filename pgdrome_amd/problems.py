@@ -301,6 +301,61 @@ def convection_diffusion(space_mesh, n_k=9, n_w=9, beta=(12.0, -5.0, 3.0), k_ran
                 PGD_nmax=PGD_nmax, PGD_tol=PGD_tol)
 
 
+def elastic_block(space_mesh, n_e=9, e_range=(0.5, 2.0), nu=0.3, k_found=2.0, PGD_nmax=3, PGD_tol=1e-8):
+    """A 3-D block clamped at x = 0 on an elastic foundation under its own weight: VECTOR-valued P1 displacement u(X; e), Young's
+    modulus factor e as the second PGD variable.   int eps(v) : (e C(nu)) eps(u) + k v . u dX = int g . v dX,  g = (0, 0, -1);
+    u = sum_m U_m(X) W_m(e).
+    (Voigt strain as in the reference's elastic test, /root/reference/tests/integration/test_solver_problem.py:59-75, which is 2-D
+    and P2; this one exists to carry a vector-valued space through the row-sharded solve.)"""
+    lam, mu = nu / ((1.0 + nu) * (1.0 - 2.0 * nu)), 1.0 / (2.0 * (1.0 + nu))
+    C = fem.as_matrix([[lam + 2 * mu, lam, lam, 0, 0, 0], [lam, lam + 2 * mu, lam, 0, 0, 0], [lam, lam, lam + 2 * mu, 0, 0, 0],
+                       [0, 0, 0, mu, 0, 0], [0, 0, 0, 0, mu, 0], [0, 0, 0, 0, 0, mu]])
+    g = fem.Constant((0.0, 0.0, -1.0))
+    meshes = [space_mesh, fem.IntervalMesh(n_e - 1, e_range[0], e_range[1])]
+    Vs = [fem.VectorFunctionSpace(meshes[0], "CG", 1), fem.FunctionSpace(meshes[1], "CG", 1)]
+    param = {"e": fem.interpolate(fem.Expression("x[0]", degree=1), Vs[1])}
+
+    def strain(w):
+        return fem.as_vector([w[0].dx(0), w[1].dx(1), w[2].dx(2), w[1].dx(2) + w[2].dx(1), w[0].dx(2) + w[2].dx(0), w[0].dx(1) + w[1].dx(0)])
+
+    def clamped(x, on_boundary):
+        return on_boundary and fem.near(x[0], 0.0)
+
+    def bc_fct(Vs, dom, param):
+        return [fem.DirichletBC(Vs[0], fem.Constant((0.0, 0.0, 0.0)), clamped), 0]
+
+    def op_form(t, j, a, b, meshes, param):
+        """term t of the operator on dimension j: t = 0 the strain energy x e-weighted mass, t = 1 the foundation x mass"""
+        if j == 0:
+            return (fem.inner(C * strain(a), strain(b)) if t == 0 else fem.Constant(k_found) * fem.inner(a, b)) * fem.dx(meshes[0])
+        return (param["e"] * a * b if t == 0 else a * b) * fem.dx(meshes[1])
+
+    def load_form(j, b, meshes):
+        if j == 0:
+            return fem.dot(g, b) * fem.dx(meshes[0])
+        return b * fem.dx(meshes[1])
+
+    def lhs_fct(u, v, Fs, meshes, dom, param, typ, dim):
+        d = 0 if typ == "x" else 1
+        a = 0
+        for t in (0, 1):
+            c = fem.assemble(op_form(t, 1 - d, Fs[1 - d], Fs[1 - d], meshes, param))
+            a = a + fem.Constant(c) * op_form(t, d, u, v, meshes, param)
+        return a
+
+    def rhs_fct(u, v, Fs, meshes, dom, param, Q, PGD_func, typ, nE, dim):
+        d = 0 if typ == "x" else 1
+        l = fem.Constant(fem.assemble(load_form(1 - d, Fs[1 - d], meshes))) * load_form(d, v, meshes)
+        for old in range(nE):
+            for t in (0, 1):
+                c = fem.assemble(op_form(t, 1 - d, PGD_func[1 - d][old], Fs[1 - d], meshes, param))
+                l = l - fem.Constant(c) * op_form(t, d, PGD_func[d][old], v, meshes, param)
+        return l
+
+    return dict(name="elastic_block", name_coord=["X", "e"], modes_info=["U", "Node", "Vector"], Vs=Vs, bc_fct=bc_fct, load=[],
+                param=param, rhs_fct=rhs_fct, lhs_fct=lhs_fct, probs=["x", "e"], PGD_nmax=PGD_nmax, PGD_tol=PGD_tol)
+
+
 def make_problem(spec, cls):
     """PGDProblem(**spec) for either implementation of the class."""
     return cls(**spec)
