@@ -532,7 +532,7 @@ def ghost_rank_rehearsal():
     try:
         env = _own_world_env()
         r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_self_periodic.py"), "--json"], capture_output=True,
-                           timeout=240, env=env, cwd=ROOT)
+                           timeout=120, env=env, cwd=ROOT)
         line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
             return None
@@ -555,7 +555,7 @@ def sharded_v_cycle_rank(args):
         env = _own_world_env()
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--dist-driver", "--python-driver", "--preconditioner", "amg",
                             "--steps", "6", "--warmup", "2", "--n", str(args.n), "--n-mu", str(args.n_mu), "--no-cpu-baseline", "--no-pmc",
-                            "--no-csr-section", "--no-general-paths"], capture_output=True, timeout=300, env=env, cwd=ROOT)
+                            "--no-csr-section", "--no-general-paths"], capture_output=True, timeout=120, env=env, cwd=ROOT)
         line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
         if r.returncode != 0 or not line:
             return None
@@ -804,7 +804,7 @@ def pmc_traffic(own_bytes, upd_bytes):
                 d = tempfile.mkdtemp(prefix="pgd_pmc_", dir="/tmp")
                 subprocess.run([rp, "--pmc", counter, "--output-format", "csv", "-d", d, "--", sys.executable,
                                 os.path.join(ROOT, "tools", "pmc_spmv_sym.py"), "256", "grid", "0"],
-                               check=True, timeout=180, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                               check=True, timeout=75, env=env, cwd="/tmp", stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 got = {k: [] for k in kernels}
                 for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                     with open(f) as fh:
