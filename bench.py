@@ -408,7 +408,10 @@ def main():
                    "halo_overlap": (bool(be.comm_overlap(-2)) if sharded and getattr(comm, "in_library", None) == "rccl" else (False if sharded else None)),
                    "halo_overlap_available": (bool(getattr(comm, "halo_overlap", False)) if sharded else None),
                    "direct_halo": ({"attached_on_every_rank": bool(getattr(comm, "direct_halo", False)),
-                                    "used_by_the_last_solve": bool(be.comm_push(-2)) if comm.in_library else False} if sharded else None),
+                                    "used_by_the_last_solve": bool(be.comm_push(-2)) if comm.in_library else False,
+                                    "direct_allreduce_attached_on_every_rank": bool(getattr(comm, "direct_allreduce", False)),
+                                    "direct_allreduce_used_by_the_last_solve": bool(be.comm_allreduce_direct(-2)) if comm.in_library else False}
+                                   if sharded else None),
                    "rccl_world": (be.comm_info()["world"] if sharded and comm.in_library == "rccl" else
                                   (dist.get_world_size() if sharded else None)),
                    "pcg_iterations_per_step": pcg_its / K, "modes_completed": len(prob.num_fp_it),

@@ -294,6 +294,13 @@ int pgd_comm_push_export(pgd_handle ctx, int64_t n, int64_t own0, int64_t own1, 
                          uint8_t *blob /* PGD_PUSH_BLOB_BYTES */);
 int pgd_comm_push_attach(pgd_handle ctx, const uint8_t *lower_blob, const uint8_t *upper_blob, int *state);
 int pgd_comm_push(pgd_handle ctx, int mode, int *state);
+/* DIRECT ALL-REDUCE of the loop's five sums (same opt-in, behind pgd_comm_push_export): all_blobs = every rank's export blob in rank
+ * order (world x PGD_PUSH_BLOB_BYTES, world <= 16).  Every rank maps every rank's flag block; in the loop ONE kernel forms the
+ * iteration's local sums, stores them into all mailboxes, posts, waits for everybody's and adds the contributions in rank order
+ * (the same bits on every rank): neither k_pcg1_sums nor an RCCL kernel is left in the iteration.  Collective, ends with a checked
+ * exchange; used by a solve only if every rank voted for it.  pgd_comm_allreduce_direct: mode as pgd_comm_push. */
+int pgd_comm_allreduce_attach(pgd_handle ctx, const uint8_t *all_blobs, int *state);
+int pgd_comm_allreduce_direct(pgd_handle ctx, int mode, int *state);
 /* Jacobi-PCG on the rows [own0, own1) of this rank's slab of A (replaces the KSP solve of
  * solver.py:636,716 for the row-partitioned spatial dimension); b, x are local slab vectors, x holds
  * the start value and returns with current ghost planes.  iters / rel_res are global.            */

@@ -108,6 +108,8 @@ SIGNATURES = {
     "pgd_comm_push_export": (C.c_int, [H, I64, I64, I64, I64, I64, PU8]),
     "pgd_comm_push_attach": (C.c_int, [H, PU8, PU8, C.POINTER(C.c_int)]),
     "pgd_comm_push": (C.c_int, [H, C.c_int, C.POINTER(C.c_int)]),
+    "pgd_comm_allreduce_attach": (C.c_int, [H, PU8, C.POINTER(C.c_int)]),
+    "pgd_comm_allreduce_direct": (C.c_int, [H, C.c_int, C.POINTER(C.c_int)]),
     "pgd_pcg_solve_sharded": (C.c_int, [H, H, H, H, I64, I64, I64, I64, F64, F64, C.c_int, C.POINTER(C.c_int), PD]),
     "pgd_op_symmetrize": (C.c_int, [H, H, C.POINTER(C.c_int)]),
     "pgd_op_classify": (C.c_int, [H, H, C.POINTER(C.c_int)]),
@@ -614,6 +616,21 @@ class Context:
             return (C.c_uint8 * self.PUSH_BLOB_BYTES).from_buffer_copy(b)
         st = C.c_int(0)
         self._ck(self.lib.pgd_comm_push_attach(self.h, arr(lower), arr(upper), C.byref(st)))
+        return bool(st.value)
+
+    def comm_allreduce_attach(self, blobs):
+        """Direct all-reduce (collective over ALL ranks): every rank's export blob in rank order.  True if usable here."""
+        data = b"".join(blobs)
+        if len(data) != self.PUSH_BLOB_BYTES * len(blobs):
+            raise ValueError("comm_allreduce_attach: blobs of %d bytes each" % self.PUSH_BLOB_BYTES)
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        st = C.c_int(0)
+        self._ck(self.lib.pgd_comm_allreduce_attach(self.h, buf, C.byref(st)))
+        return bool(st.value)
+
+    def comm_allreduce_direct(self, mode=-1):
+        st = C.c_int(0)
+        self._ck(self.lib.pgd_comm_allreduce_direct(self.h, int(mode), C.byref(st)))
         return bool(st.value)
 
     def comm_push(self, mode=-1):

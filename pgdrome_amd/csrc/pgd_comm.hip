@@ -83,6 +83,9 @@ static void push_drop(Ctx *c) {
     Comm &k = c->comm;
     for (void *&m : k.push_mapped) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
     if (k.push_flags) { (void)hipFree(k.push_flags); k.push_flags = nullptr; }
+    for (void *&m : k.ar_mapped) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
+    for (auto &q : k.ar_peer) q = nullptr;
+    k.ar = k.ar_used = false;
     k.push = k.push_used = false;
     k.push_peer[0] = k.push_peer[1] = nullptr;
     k.push_peer_flags[0] = k.push_peer_flags[1] = nullptr;
@@ -220,6 +223,106 @@ static int comm_push_halo(Ctx *c, double *v, int *flags) {
     const int grid = (int)std::min<int64_t>(std::max<int64_t>((most + 511) / 512, 1), 128);
     k_halo_push<<<grid, 256, 0, c->stream>>>(src_lo, dst_lo, n_lo, src_hi, dst_hi, n_hi, T.post_lo, T.post_hi, T.wait_a, T.wait_b, k.push_seq,
                                              k.push_flags + 2, push_ticks(k), flags);
+    PGD_LAUNCH_CHECK(c);
+    return PGD_OK;
+}
+
+// ---- direct all-reduce of the single-sync loop's sums (opt-in with the direct halo)
+// ONE workgroup: (1) the iteration's local sums exactly as k_pcg1_sums forms them (same lanes, same order) - or, `from_slots`, the
+// five numbers another kernel has left in slots[base ..]; (2) lane t < world stores them into rank t's mailbox and posts the sequence
+// number behind them; (3) lane t waits for rank t's number in this rank's block; (4) the contributions are added in RANK ORDER into
+// slots[base .. base + 4]: every rank gets the same bits.  A launch that finds the solve done (every rank alike) only posts - a rank
+// that failed locally and never sees the flag is not left waiting - and a rank that failed locally sends NaNs (`poison`), which is how
+// the others learn of it, as with the binding's all-reduce.
+struct ArArgs {
+    unsigned long long *peer[PUSH_AR_MAXW];
+    unsigned long long *own;
+    int rank, world;
+    unsigned long long seq;
+    long long ticks;
+};
+
+__global__ __launch_bounds__(1024) void k_allreduce_direct(const double *__restrict__ prod, int nprod, const double *__restrict__ vecp, int nvec,
+                                                           double *__restrict__ slots, int base, int *__restrict__ flags, int from_slots,
+                                                           int poison, ArArgs A) {
+    __shared__ double s_w[16];
+    __shared__ double s_v[8];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (flags[0]) {
+        if (tid < A.world) __hip_atomic_store(A.peer[tid] + PUSH_AR_FLAG0 + A.rank, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        return;
+    }
+    if (tid == 0) s_bad = 0;
+    if (!from_slots && !poison) {
+        const int v = wv >> 2, t = tid & 255;
+        const double *src = v < 2 ? prod : vecp;
+        const int n = v < 2 ? nprod : nvec, off = v & 1;
+        double a8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int i = t;
+        for (; i + 7 * 256 < n; i += 8 * 256) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a8[u] += src[2 * (int64_t)(i + u * 256) + off];
+        }
+        for (int u = 0; i < n; i += 256, ++u) a8[u & 7] += src[2 * (int64_t)i + off];
+        const double acc = wave_sum(((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7])));
+        if (lane == 0) s_w[wv] = acc;
+    }
+    __syncthreads();
+    if (tid < 5) {
+        double v;
+        if (poison) v = __longlong_as_double(0x7ff8000000000000ll);
+        else if (from_slots) v = slots[base + tid];
+        else v = tid < 4 ? (s_w[4 * tid] + s_w[4 * tid + 1]) + (s_w[4 * tid + 2] + s_w[4 * tid + 3]) : 0.0;
+        s_v[tid] = v;
+    }
+    __syncthreads();
+    const int par = (int)(A.seq & 1ull);
+    if (tid < A.world) {
+        double *box = reinterpret_cast<double *>(reinterpret_cast<char *>(A.peer[tid]) + PUSH_BOX_OFF) + ((int64_t)par * PUSH_AR_MAXW + A.rank) * 8;
+#pragma unroll
+        for (int j = 0; j < 5; ++j)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(box) + j, (unsigned long long)__double_as_longlong(s_v[j]), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_s_waitcnt(0);
+        __hip_atomic_store(A.peer[tid] + PUSH_AR_FLAG0 + A.rank, A.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(A.own + PUSH_AR_FLAG0 + tid, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < A.seq) {
+            if (wall_clock64() - t0 > A.ticks) { s_bad = 1; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    __syncthreads();
+    if (s_bad) {
+        if (tid == 0) { flags[2] = PGD_ERR_TIMEOUT; flags[0] = 1; }
+        return;
+    }
+    if (tid < 5) {
+        const double *box = reinterpret_cast<const double *>(reinterpret_cast<const char *>(A.own) + PUSH_BOX_OFF) + (int64_t)par * PUSH_AR_MAXW * 8;
+        double sum = 0.0;
+        for (int r = 0; r < A.world; ++r)
+            sum += __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long *>(box + r * 8) + tid, __ATOMIC_RELAXED,
+                                                                      __HIP_MEMORY_SCOPE_SYSTEM));
+        slots[base + tid] = sum;
+    }
+}
+
+// nprod < 0: the five local numbers are in slots[base ..] already
+static int comm_allreduce_direct(Ctx *c, int nprod, int nvec, int base, bool poison) {
+    Comm &k = c->comm;
+    if (!k.ar) return fail(c, PGD_ERR_INVALID, "direct all-reduce: not attached");
+    const double *prod = c->partials;
+    int from_slots = nprod < 0 ? 1 : 0;
+    if (!poison && nprod > 8192) {          // (k_pcg1_sums reduces that many pairs in two stages: let it, and exchange its result)
+        PGD_TRY(pcg1_sums(c, nprod, nvec, base));
+        from_slots = 1;
+    }
+    k.ar_seq += 1;
+    ArArgs A;
+    for (int r = 0; r < PUSH_AR_MAXW; ++r) A.peer[r] = r < k.world ? k.ar_peer[r] : nullptr;
+    A.own = k.push_flags; A.rank = k.rank; A.world = k.world; A.seq = k.ar_seq; A.ticks = push_ticks(k);
+    k_allreduce_direct<<<1, 1024, 0, c->stream>>>(prod, from_slots ? 0 : nprod, c->work[6], from_slots ? 0 : nvec, c->slots, base, c->flags, from_slots,
+                                                  poison ? 1 : 0, A);
     PGD_LAUNCH_CHECK(c);
     return PGD_OK;
 }
@@ -483,9 +586,9 @@ int pgd_comm_push_export(pgd_handle h, int64_t n, int64_t own0, int64_t own1, in
         k.work_n = n;
     }
     void *fl = nullptr;
-    PGD_HIP(c, hipMalloc(&fl, 64));
+    PGD_HIP(c, hipMalloc(&fl, PUSH_BLOCK_BYTES));      // flag words of the halo, of the all-reduce, and its mailbox (pgd_internal.h)
     k.push_flags = static_cast<unsigned long long *>(fl);
-    PGD_HIP(c, hipMemsetAsync(fl, 0, 64, c->stream));
+    PGD_HIP(c, hipMemsetAsync(fl, 0, PUSH_BLOCK_BYTES, c->stream));
     double *pv = get_vec(c, k.work[3])->d;
     // (the ghost planes start from a value no rank sends in the checked exchange of the attach step; set HERE, before any neighbour
     // can have the blob: a neighbour's planes may arrive while this rank is still attaching)
@@ -508,6 +611,7 @@ int pgd_comm_push_export(pgd_handle h, int64_t n, int64_t own0, int64_t own1, in
     memcpy(blob, &b, sizeof b);
     k.push_n = n; k.push_own0 = own0; k.push_own1 = own1; k.push_lo_g = lo_g; k.push_hi_g = hi_g;
     k.push_seq = 0;
+    k.ar_seq = 0;
     return PGD_OK;
 }
 
@@ -602,6 +706,86 @@ int pgd_comm_push(pgd_handle h, int mode, int *state) {
     else if (mode == 1) k.push = k.push_peer[0] != nullptr || k.push_peer[1] != nullptr || (k.push_n > 0 && !k.push_lo_g && !k.push_hi_g && k.push_flags);
     else if (mode != -1 && mode != -2) return fail(c, PGD_ERR_INVALID, "comm_push: mode must be 1, 0, -1 (read) or -2 (what the last solve did)");
     if (state) *state = mode == -2 ? (k.push_used ? 1 : 0) : (k.push ? 1 : 0);
+    return PGD_OK;
+}
+
+// The direct all-reduce: `blobs` = the export blobs of ALL ranks in rank order (world x PGD_PUSH_BLOB_BYTES; world <= 16).  Maps every
+// rank's flag block (a neighbour's is mapped already) and ends with a checked exchange: the sum of rank + 1 over the ranks.
+// Collective over all ranks; *state = 1 if usable here.  The solves vote on it like on the direct halo.
+int pgd_comm_allreduce_attach(pgd_handle h, const uint8_t *blobs, int *state) {
+    PGD_CTX(c, h);
+    Comm &k = c->comm;
+    if (state) *state = 0;
+    if (!k.push_flags || !k.push_n) return fail(c, PGD_ERR_INVALID, "comm_allreduce_attach: pgd_comm_push_export first");
+    if (!blobs || k.world > PUSH_AR_MAXW) return fail(c, PGD_ERR_INVALID, "comm_allreduce_attach: no blobs, or more than %d ranks", PUSH_AR_MAXW);
+    const bool self = k.self_periodic && k.world == 1;
+    bool ok = true;
+    for (int r = 0; r < k.world && ok; ++r) {
+        PushBlob b;
+        memcpy(&b, blobs + (size_t)r * PGD_PUSH_BLOB_BYTES, sizeof b);
+        if (r == k.rank || b.pid == (int64_t)getpid()) {
+            k.ar_peer[r] = r == k.rank ? k.push_flags : reinterpret_cast<unsigned long long *>(b.flags_ptr);
+        } else if (!self && r == k.rank - 1 && k.push_peer_flags[0]) {
+            k.ar_peer[r] = k.push_peer_flags[0];              // (the halo's attach has mapped the neighbours' blocks)
+        } else if (!self && r == k.rank + 1 && k.push_peer_flags[1]) {
+            k.ar_peer[r] = k.push_peer_flags[1];
+        } else {
+            void *pf = nullptr;
+            if (hipIpcOpenMemHandle(&pf, b.flags, hipIpcMemLazyEnablePeerAccess) != hipSuccess) { ok = false; break; }
+            k.ar_mapped[r] = pf;
+            k.ar_peer[r] = static_cast<unsigned long long *>(pf);
+        }
+    }
+    (void)hipGetLastError();
+    if (!ok) {
+        for (void *&m : k.ar_mapped) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
+        for (auto &q : k.ar_peer) q = nullptr;
+        (void)hipGetLastError();
+        return PGD_OK;
+    }
+    // checked exchange: slots[48] = rank + 1 -> the sum over the ranks (a 2 s deadline: a rank that could not map posts nothing)
+    k.ar = true;
+    const double keep_timeout = k.timeout_s;
+    k.timeout_s = 2.0;
+    PGD_TRY(ensure_work(c, 5, 16));
+    int *tflags = reinterpret_cast<int *>(c->work[5]);
+    (void)hipMemsetAsync(tflags, 0, 4 * sizeof(int), c->stream);
+    const double mine[5] = {k.rank + 1.0, 0.0, 0.0, 0.0, 0.0};
+    int rc = pgd_slots_upload(h, mine, 48, 5);
+    if (rc == PGD_OK) {
+        k.ar_seq += 1;
+        ArArgs A;
+        for (int r = 0; r < PUSH_AR_MAXW; ++r) A.peer[r] = r < k.world ? k.ar_peer[r] : nullptr;
+        A.own = k.push_flags; A.rank = k.rank; A.world = k.world; A.seq = k.ar_seq; A.ticks = push_ticks(k);
+        k_allreduce_direct<<<1, 1024, 0, c->stream>>>(nullptr, 0, nullptr, 0, c->slots, 48, tflags, 1, 0, A);
+        rc = hipGetLastError() == hipSuccess ? PGD_OK : PGD_ERR_HIP;
+    }
+    k.timeout_s = keep_timeout;
+    double got = 0.0;
+    int tf[4] = {0, 0, 0, 0};
+    if (rc == PGD_OK) rc = pgd_slots_download(h, &got, 48, 1);
+    if (rc == PGD_OK) rc = hipMemcpy(tf, tflags, sizeof tf, hipMemcpyDeviceToHost) == hipSuccess ? PGD_OK : PGD_ERR_HIP;
+    (void)hipGetLastError();
+    const bool good = rc == PGD_OK && tf[0] == 0 && got == 0.5 * k.world * (k.world + 1.0);
+    if (!good) {
+        for (void *&m : k.ar_mapped) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
+        for (auto &q : k.ar_peer) q = nullptr;
+        k.ar = false;
+        (void)hipGetLastError();
+        return PGD_OK;
+    }
+    if (state) *state = 1;
+    return PGD_OK;
+}
+
+// mode 1 / 0: on (if attached) / off; -1 reads the state; -2 what the last solve did
+int pgd_comm_allreduce_direct(pgd_handle h, int mode, int *state) {
+    PGD_CTX(c, h);
+    Comm &k = c->comm;
+    if (mode == 0) k.ar = false;
+    else if (mode == 1) k.ar = k.ar_peer[k.rank] != nullptr;
+    else if (mode != -1 && mode != -2) return fail(c, PGD_ERR_INVALID, "comm_allreduce_direct: mode must be 1, 0, -1 or -2");
+    if (state) *state = mode == -2 ? (k.ar_used ? 1 : 0) : (k.ar ? 1 : 0);
     return PGD_OK;
 }
 
@@ -777,7 +961,7 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     // ---- phase A: everything that can fail on ONE rank before the first collective (allocations, the symmetric copy), and
     // the choice of recurrence, are agreed on with one all-reduce: a rank whose operator did not qualify for the symmetric
     // storage must not take another branch (the scaled recurrence has one more halo exchange) than its neighbours.
-    bool sym = false, ss_all = false, push_all = false;
+    bool sym = false, ss_all = false, push_all = false, ar_all = false;
     double rows_all = 0.0;
     auto setup = [&]() -> int {
         if (!m) return fail(c, PGD_ERR_INVALID, "pcg_solve_sharded: operator without a mesh");
@@ -805,12 +989,12 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         // products takes the second stream)
         // (the fifth: the direct halo is attached here for exactly this vector - used only if it is on every rank)
         const bool can_push = k.push && k.push_n == n && k.push_own0 == own0 && k.push_own1 == own1 && k.push_lo_g == lo_g && k.push_hi_g == hi_g;
-        const double vote[5] = {rc_setup != PGD_OK ? 1.0 : 0.0, (rc_setup == PGD_OK && sym && c->pcg_scaled) ? 0.0 : 1.0, can_ss ? 0.0 : 1.0,
-                                (double)(own1 - own0), can_push ? 0.0 : 1.0};
-        double got[5] = {1.0, 1.0, 1.0, 0.0, 1.0};
-        int rc = pgd_slots_upload(h, vote, B, 5);
-        if (rc == PGD_OK) rc = comm_allreduce(c, B, 5);
-        if (rc == PGD_OK) rc = pgd_slots_download(h, got, B, 5);
+        const double vote[6] = {rc_setup != PGD_OK ? 1.0 : 0.0, (rc_setup == PGD_OK && sym && c->pcg_scaled) ? 0.0 : 1.0, can_ss ? 0.0 : 1.0,
+                                (double)(own1 - own0), can_push ? 0.0 : 1.0, k.ar ? 0.0 : 1.0};      // (the sixth: the direct all-reduce)
+        double got[6] = {1.0, 1.0, 1.0, 0.0, 1.0, 1.0};
+        int rc = pgd_slots_upload(h, vote, B, 6);
+        if (rc == PGD_OK) rc = comm_allreduce(c, B, 6);
+        if (rc == PGD_OK) rc = pgd_slots_download(h, got, B, 6);
         if (rc_setup != PGD_OK) { c->err = err_setup; return rc_setup; }
         if (rc != PGD_OK) return rc;
         if (got[0] != 0.0) return fail(c, PGD_ERR_PEER, "pcg_solve_sharded: the setup failed on another rank");
@@ -818,6 +1002,7 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
         ss_all = got[2] == 0.0;                         // ... and the single-sync recurrence only if every rank's slab is a grid
         rows_all = got[3];
         push_all = got[4] == 0.0;
+        ar_all = got[5] == 0.0;
     }
     const double dbg_t1 = dbg_now();
     const bool scaled = sym && c->pcg_scaled;
@@ -885,6 +1070,10 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
     // nobody overwrites ghost planes that are still being read), in stream order
     const bool pushing = push_all && ss && !async;
     k.push_used = pushing;
+    // ... and the loop's five sums travel through the ranks' mailboxes (formed by the same kernel) instead of k_pcg1_sums + the binding's
+    // all-reduce - still a full exchange: it completes on a rank only when every rank has contributed
+    const bool direct_ar = ar_all && ss;
+    k.ar_used = direct_ar;
     hipEvent_t *marks = nullptr;                                     // phase timing of the iteration being queued (or none)
     auto mark = [&](int i) { if (marks) (void)hipEventRecord(marks[i], c->stream); };
     // ... and leaves from the update kernel of the iteration before where that launch can carry it (fold, even rows and plane sizes):
@@ -1029,9 +1218,16 @@ int pgd_pcg_solve_sharded(pgd_handle h, pgd_handle oh, pgd_handle bh, pgd_handle
             const int rc = product(mv, pd, qd, true, &np);
             c->spmv_qq = 0;
             PGD_TRY(rc);
-            SH_LOCAL(S, pcg1_sums(c, np, gvec, B));
-            mark(4);
-            PGD_TRY(sh_allreduce(S, B, 5, "all-reduce of the iteration"));
+            if (direct_ar) {
+                mark(4);
+                S.last = "direct all-reduce of the iteration";
+                S.ncoll += 1;
+                PGD_TRY(comm_allreduce_direct(c, np, gvec, B, S.poisoned()));
+            } else {
+                SH_LOCAL(S, pcg1_sums(c, np, gvec, B));
+                mark(4);
+                PGD_TRY(sh_allreduce(S, B, 5, "all-reduce of the iteration"));
+            }
             mark(5);
             // stop test, alpha, beta: by every workgroup of the update (fold), or by k_pcg1_finish in a launch of its own
             if (!fold) SH_LOCAL(S, pcg1_finish_slots(c, B));

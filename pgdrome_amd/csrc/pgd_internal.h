@@ -205,7 +205,18 @@ struct Comm {
     unsigned long long *push_peer_flags[2] = {nullptr, nullptr};
     void *push_mapped[4] = {nullptr, nullptr, nullptr, nullptr};   // what hipIpcOpenMemHandle returned (to close)
     unsigned long long push_seq = 0;
+    // DIRECT all-reduce of the loop's five sums (pgd_comm_allreduce_attach; same opt-in, same flag block): every rank stores its sums
+    // into every rank's mailbox - block + PUSH_BOX_OFF bytes: [parity][source rank][8 doubles] - posts the sequence number into
+    // word PUSH_AR_FLAG0 + its rank of that block, waits for everybody's number in its own, and adds the contributions in rank
+    // order: the same bits on every rank.  The iteration's local sums (k_pcg1_sums) are formed by the same kernel.
+    bool ar = false, ar_used = false;
+    unsigned long long *ar_peer[16] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    void *ar_mapped[16] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    unsigned long long ar_seq = 0;
 };
+constexpr int PUSH_BLOCK_BYTES = 4096, PUSH_AR_FLAG0 = 8, PUSH_BOX_OFF = 512, PUSH_AR_MAXW = 16;
 
 struct Ctx {
     int device = 0;

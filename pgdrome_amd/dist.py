@@ -124,6 +124,7 @@ class TorchComm:
                           "through torch.distributed instead" % (why or "another rank failed"))
 
     direct_halo = False
+    direct_allreduce = False
 
     def enable_direct_halo(self, n, own0, own1, lo_g, hi_g):
         """Direct halo of the in-library loop (opt-in: PGD_HALO_DIRECT=1, or called by hand): the boundary planes of the search
@@ -158,6 +159,23 @@ class TorchComm:
                 pass
             LOG.warning("direct halo not available on every rank (%s): the exchange stays with the binding", why or "another rank")
         self.direct_halo = ok
+        # ... and the all-reduce of the loop's sums through the ranks' mailboxes (every rank maps every rank; PGD_ALLREDUCE_DIRECT=0
+        # keeps the binding's): collective, all ranks must succeed
+        self.direct_allreduce = False
+        if ok and self.world <= 16 and os.environ.get("PGD_ALLREDUCE_DIRECT", "1") != "0":
+            ar = 0.0
+            try:
+                ar = 1.0 if be.comm_allreduce_attach(blobs) else 0.0
+            except Exception as e:          # noqa: BLE001
+                why = str(e)
+            ar_ok = float(self.allreduce_array([1.0 - ar])[0]) == 0.0
+            if not ar_ok:
+                try:
+                    be.comm_allreduce_direct(0)
+                except Exception:           # noqa: BLE001
+                    pass
+                LOG.warning("direct all-reduce not available on every rank (%s): the loop's sums stay with the binding", why or "another rank")
+            self.direct_allreduce = ar_ok
         return ok
 
     def _cb_halo(self, vec, own0, own1, lo_g, hi_g):

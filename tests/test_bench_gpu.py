@@ -107,7 +107,7 @@ def test_two_ranks_of_the_bench_on_one_gpu(extra):
     c = d["config"]
     assert c["parallelism"].endswith("x2") and c["pcg_iterations_per_step"] > 3
     if "--direct-halo" in extra:
-        assert c["direct_halo"] == {"attached_on_every_rank": True, "used_by_the_last_solve": True}
+        assert all(c["direct_halo"].values()), c["direct_halo"]
     elif extra:
         assert c["sharded_v_cycle_solves"] > 0
     else:

@@ -239,7 +239,9 @@ def _shared_gpu_worker(rank, world, port, shape, q, in_library, problem="reactio
         if rank == 0:
             q.put(dict(num_fp_it=p.num_fp_it, pcg_iterations=fem.STATS["pcg_iterations"], bicgstab_iterations=fem.STATS.get("bicgstab_iterations", 0), amplitude=p.amplitude, modes_x=modes_x, stats=dict(comm.stats),
                        kernels=be.ctx.kernel_counts(), direct_halo=bool(comm.direct_halo),
-                       direct_halo_used=bool(be.comm_push(-2)) if comm.in_library else False))
+                       direct_halo_used=bool(be.comm_push(-2)) if comm.in_library else False,
+                       direct_allreduce=bool(comm.direct_allreduce),
+                       direct_allreduce_used=bool(be.comm_allreduce_direct(-2)) if comm.in_library else False))
     finally:
         dist.barrier()
         dist.destroy_process_group()
@@ -431,8 +433,9 @@ def test_nonsymmetric_spatial_systems_on_a_sharded_mesh_on_the_gpu():
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-6 * np.linalg.norm(ref_x[m])
 
 
-@pytest.mark.parametrize("world,shape,tune", [(2, (127, 127, 99), ""), (2, (127, 127, 99), "49=0"), (3, (24, 20, 29), "")])
-def test_direct_halo_between_processes_on_one_gpu(world, shape, tune, monkeypatch):
+@pytest.mark.parametrize("world,shape,tune,ar", [(2, (127, 127, 99), "", "1"), (2, (127, 127, 99), "49=0", "0"), (3, (24, 20, 29), "", "0"),
+                                                  (3, (24, 20, 29), "", "1")])
+def test_direct_halo_between_processes_on_one_gpu(world, shape, tune, ar, monkeypatch):
     """PGD_HALO_DIRECT=1: the boundary planes of the search direction go straight into the NEIGHBOUR PROCESS's ghost planes through
     hipIpcMemHandle-mapped pointers, a sequence number is posted behind them and the product waits for its own (pgd_comm_push_*) -
     `world` processes on GPU 0, everything else of the exchange over gloo as in the tests above.  Only the transport of the planes
@@ -441,6 +444,9 @@ def test_direct_halo_between_processes_on_one_gpu(world, shape, tune, monkeypatc
     import torch.multiprocessing as mp
     if tune:
         monkeypatch.setenv("PGD_TUNE", tune)
+    # (ar = "1": the loop's five sums through the ranks' IPC-mapped mailboxes as well - pgd_comm_allreduce_attach - added in rank order:
+    # with two ranks the same bits as any all-reduce, with three equal to rounding)
+    monkeypatch.setenv("PGD_ALLREDUCE_DIRECT", ar)
     ctx = mp.get_context("spawn")
     outs = {}
     saved = os.environ.get("PGD_HALO_DIRECT")
@@ -460,9 +466,18 @@ def test_direct_halo_between_processes_on_one_gpu(world, shape, tune, monkeypatc
     assert not a["direct_halo"] and not a["direct_halo_used"]
     assert b["direct_halo"] and b["direct_halo_used"], b
     assert b["stats"]["halo"] < a["stats"]["halo"] - 100           # the products' exchanges no longer come through the callback
-    assert a["num_fp_it"] == b["num_fp_it"] and a["amplitude"] == b["amplitude"]
-    for xa, xb in zip(a["modes_x"], b["modes_x"]):
-        assert np.array_equal(xa, xb)
+    assert b["direct_allreduce"] == (ar == "1") and b["direct_allreduce_used"] == (ar == "1")
+    if ar == "1":
+        assert b["stats"]["allreduce"] < a["stats"]["allreduce"] - 100    # ... nor the iterations' all-reduces
+    assert a["num_fp_it"] == b["num_fp_it"]
+    if ar == "0" or world == 2:
+        assert a["amplitude"] == b["amplitude"]
+        for xa, xb in zip(a["modes_x"], b["modes_x"]):
+            assert np.array_equal(xa, xb)
+    else:
+        np.testing.assert_allclose(a["amplitude"], b["amplitude"], rtol=1e-9)
+        for xa, xb in zip(a["modes_x"], b["modes_x"]):
+            assert np.linalg.norm(xa - xb) <= 1e-8 * np.linalg.norm(xa)
 
 
 FAULT_CASES = (("iteration 7", 15, 7), ("stage 1", 33, 1), ("stage 2", 33, 2), ("stage 3", 33, 3), ("stage 4", 33, 4))

@@ -42,7 +42,9 @@ VARIANTS = (("stream_ordered_one_march", ((45, 1 << 40), (46, 1))), ("stream_ord
             # the boundary planes stored straight into the ghost planes + a posted sequence number (pgd_comm_push_*): no RCCL kernel
             ("direct_halo_one_march", ((45, 1 << 40), (46, 1), (49, 1), ("push", 1))),
             # (49 = 0: the planes leave from a launch of their own, k_halo_push, instead of the update kernel)
-            ("direct_halo_push_kernel", ((45, 1 << 40), (46, 1), (49, 0), ("push", 1))))
+            ("direct_halo_push_kernel", ((45, 1 << 40), (46, 1), (49, 0), ("push", 1))),
+            # ... and the loop's sums through the mailbox kernel (pgd_comm_allreduce_attach): neither k_pcg1_sums nor an all-reduce of the binding
+            ("direct_halo_and_allreduce", ((45, 1 << 40), (46, 1), (49, 1), ("push", 1), ("ar", 1))))
 
 
 def slab(planes):
@@ -71,6 +73,8 @@ def timed(S, variants):
             if knob == "push":
                 blob = ctx.comm_push_export(n, own0, own1, plane, plane)
                 pushing = ctx.comm_push_attach(blob, blob)
+            elif knob == "ar":
+                ar_ok = ctx.comm_allreduce_attach([blob])
             else:
                 ctx.tune(knob, value)
         best = None
@@ -90,6 +94,8 @@ def timed(S, variants):
                 best = dt
         res[variant] = {"us_per_iteration": 1e6 * best / max(it, 1), "iterations": it, "second_stream_used": bool(ctx.comm_overlap(-2)),
                         "second_stream_available": bool(ok)}
+        if variant.endswith("_and_allreduce"):
+            res[variant].update(direct_allreduce_attached=bool(ar_ok), direct_allreduce_used=bool(ctx.comm_allreduce_direct(-2)))
         if variant.startswith("direct_halo"):
             res[variant].update(direct_halo_attached=bool(pushing), direct_halo_used=bool(ctx.comm_push(-2)),
                                 same_bits_as_the_rccl_exchange=bool("stream_ordered_one_march" in xs and
