@@ -60,6 +60,9 @@ def parse():
                     help="N > 1: the boundary planes of the PCG loop's search direction go straight into the neighbours' ghost planes "
                          "through IPC-mapped pointers (PGD_HALO_DIRECT=1, pgd_comm_push_*) instead of RCCL send / receive; opt-in - "
                          "never run between two different GPUs so far")
+    ap.add_argument("--no-direct-probe", action="store_true",
+                    help="N > 1 without --direct-halo: do not attach and check the direct halo / all-reduce (they are only CHECKED by default - "
+                         "the solves use RCCL - so that a run on real multi-GPU hardware says whether they would work there)")
     ap.add_argument("--share-one-gpu", action="store_true",
                     help="REHEARSAL on a one-GPU box, never a measurement: the N ranks all use GPU 0, the exchange steps go through gloo "
                          "(RCCL refuses two ranks on one device) and the library's sharded loop through its callback binding; the "
@@ -232,6 +235,10 @@ def main():
         from pgdrome_amd import dist as pdist
         if args.direct_halo:
             os.environ["PGD_HALO_DIRECT"] = "1"         # read by pdist.sharded_box_mesh
+        elif world > 1 and not args.no_direct_probe:
+            # the solves keep RCCL; the direct paths are attached, put through their checked exchanges on THIS hardware (a second or
+            # so, every wait bounded by a 2 s deadline) and switched off again: config.direct_halo.probe says what they found
+            os.environ["PGD_HALO_DIRECT"] = "probe"
         comm = pdist.TorchComm(dist, be, True if args.single_reduction else None, in_library=not args.python_driver)
         space = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), n - 1, n - 1, n - 1)
     else:
@@ -410,7 +417,8 @@ def main():
                    "direct_halo": ({"attached_on_every_rank": bool(getattr(comm, "direct_halo", False)),
                                     "used_by_the_last_solve": bool(be.comm_push(-2)) if comm.in_library else False,
                                     "direct_allreduce_attached_on_every_rank": bool(getattr(comm, "direct_allreduce", False)),
-                                    "direct_allreduce_used_by_the_last_solve": bool(be.comm_allreduce_direct(-2)) if comm.in_library else False}
+                                    "direct_allreduce_used_by_the_last_solve": bool(be.comm_allreduce_direct(-2)) if comm.in_library else False,
+                                    "probe": getattr(comm, "direct_probe", None)}
                                    if sharded else None),
                    "rccl_world": (be.comm_info()["world"] if sharded and comm.in_library == "rccl" else
                                   (dist.get_world_size() if sharded else None)),

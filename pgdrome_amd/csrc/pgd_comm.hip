@@ -399,6 +399,13 @@ static int comm_allreduce(Ctx *c, int first, int count) {
     return PGD_OK;
 }
 
+constexpr int PUSH_TEST_ROUNDS = 8;
+// entries of p[0, n) that differ from v are counted in *bad
+__global__ void k_comm_compare(const double *p, int64_t n, double v, int *bad) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && p[i] != v) atomicAdd(bad, 1);
+}
+
 __global__ void k_comm_fill(double *p, int n, double v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -661,14 +668,12 @@ int pgd_comm_push_attach(pgd_handle h, const uint8_t *lower, const uint8_t *uppe
         (void)hipGetLastError();
         return PGD_OK;
     }
-    // checked exchange, exactly as a solve does it
+    // checked exchanges, exactly as a solve does them - PUSH_TEST_ROUNDS of them with data that changes from round to round (a ghost
+    // plane served from a stale cache line shows up as the previous round's value) and EVERY ghost entry compared on the device by a
+    // kernel of its own, the way the product reads them.  Between two rounds the planes are pushed once more, unchanged, as an
+    // acknowledgement: a neighbour fills its next pattern only after this rank has compared the current one.
     double *pv = get_vec(c, k.work[3])->d;
     const int64_t n = k.push_n;
-    if (k.push_own1 > k.push_own0) {      // the OWNED rows only: the ghost planes belong to the neighbours from the export on
-        const int64_t rows = k.push_own1 - k.push_own0;
-        k_comm_fill<<<(int)((rows + 255) / 256), 256, 0, c->stream>>>(pv + k.push_own0, (int)rows, 1000.0 + k.rank);
-        PGD_LAUNCH_CHECK(c);
-    }
     k.push = true;
     const double keep_timeout = k.timeout_s;
     k.timeout_s = 2.0;
@@ -676,16 +681,29 @@ int pgd_comm_push_attach(pgd_handle h, const uint8_t *lower, const uint8_t *uppe
     PGD_TRY(ensure_work(c, 5, 16));
     tflags = reinterpret_cast<int *>(c->work[5]);
     (void)hipMemsetAsync(tflags, 0, 4 * sizeof(int), c->stream);
-    int rc = comm_push_halo(c, pv, tflags);
-    k.timeout_s = keep_timeout;
-    double got[2] = {0.0, 0.0};
+    int rc = PGD_OK;
     int tf[4] = {0, 0, 0, 0};
-    if (rc == PGD_OK && k.push_lo_g) rc = hipMemcpyAsync(&got[0], pv, sizeof(double), hipMemcpyDeviceToHost, c->stream) == hipSuccess ? PGD_OK : PGD_ERR_HIP;
-    if (rc == PGD_OK && k.push_hi_g) rc = hipMemcpyAsync(&got[1], pv + n - 1, sizeof(double), hipMemcpyDeviceToHost, c->stream) == hipSuccess ? PGD_OK : PGD_ERR_HIP;
-    if (rc == PGD_OK) rc = hipMemcpyAsync(tf, tflags, sizeof tf, hipMemcpyDeviceToHost, c->stream) == hipSuccess ? PGD_OK : PGD_ERR_HIP;
-    if (rc == PGD_OK) rc = hipStreamSynchronize(c->stream) == hipSuccess ? PGD_OK : PGD_ERR_HIP;
-    const double below = 1000.0 + (self ? k.rank : k.rank - 1), above = 1000.0 + (self ? k.rank : k.rank + 1);
-    const bool good = rc == PGD_OK && tf[0] == 0 && (!k.push_lo_g || got[0] == below) && (!k.push_hi_g || got[1] == above);
+    for (int round = 0; round < PUSH_TEST_ROUNDS && rc == PGD_OK; ++round) {
+        const double base = 1000.0 * (round + 1);
+        if (k.push_own1 > k.push_own0) {      // the OWNED rows only: the ghost planes belong to the neighbours from the export on
+            const int64_t rows = k.push_own1 - k.push_own0;
+            k_comm_fill<<<(int)((rows + 255) / 256), 256, 0, c->stream>>>(pv + k.push_own0, (int)rows, base + k.rank);
+        }
+        rc = comm_push_halo(c, pv, tflags);
+        if (rc != PGD_OK) break;
+        const double below = base + (self ? k.rank : k.rank - 1), above = base + (self ? k.rank : k.rank + 1);
+        if (k.push_lo_g) k_comm_compare<<<(int)((k.push_lo_g + 255) / 256), 256, 0, c->stream>>>(pv, k.push_lo_g, below, tflags + 1);
+        if (k.push_hi_g) k_comm_compare<<<(int)((k.push_hi_g + 255) / 256), 256, 0, c->stream>>>(pv + k.push_own1, k.push_hi_g, above, tflags + 1);
+        rc = comm_push_halo(c, pv, tflags);                                   // the acknowledgement
+        if (hipGetLastError() != hipSuccess) rc = PGD_ERR_HIP;
+        // (a deadline that passed - a neighbour could not map this rank - ends the rounds: no point in waiting 2 s sixteen times)
+        if (rc == PGD_OK) rc = hipMemcpyAsync(tf, tflags, sizeof tf, hipMemcpyDeviceToHost, c->stream) == hipSuccess ? PGD_OK : PGD_ERR_HIP;
+        if (rc == PGD_OK) rc = hipStreamSynchronize(c->stream) == hipSuccess ? PGD_OK : PGD_ERR_HIP;
+        if (tf[0] || tf[1]) break;
+    }
+    k.timeout_s = keep_timeout;
+    (void)n;
+    const bool good = rc == PGD_OK && tf[0] == 0 && tf[1] == 0;               // no deadline passed, no entry differed
     (void)hipGetLastError();
     if (!good) {
         for (void *&m : k.push_mapped) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
@@ -750,23 +768,28 @@ int pgd_comm_allreduce_attach(pgd_handle h, const uint8_t *blobs, int *state) {
     PGD_TRY(ensure_work(c, 5, 16));
     int *tflags = reinterpret_cast<int *>(c->work[5]);
     (void)hipMemsetAsync(tflags, 0, 4 * sizeof(int), c->stream);
-    const double mine[5] = {k.rank + 1.0, 0.0, 0.0, 0.0, 0.0};
-    int rc = pgd_slots_upload(h, mine, 48, 5);
-    if (rc == PGD_OK) {
+    // (rounds with changing numbers, both parities of the mailbox several times: slot 48 = (rank + 1) (round + 1) -> its sum over the ranks)
+    int rc = PGD_OK;
+    bool sums_ok = true;
+    for (int round = 0; round < PUSH_TEST_ROUNDS && rc == PGD_OK; ++round) {
+        const double mine[5] = {(k.rank + 1.0) * (round + 1.0), 0.0, 0.0, 0.0, 0.0};
+        rc = pgd_slots_upload(h, mine, 48, 5);
+        if (rc != PGD_OK) break;
         k.ar_seq += 1;
         ArArgs A;
         for (int r = 0; r < PUSH_AR_MAXW; ++r) A.peer[r] = r < k.world ? k.ar_peer[r] : nullptr;
         A.own = k.push_flags; A.rank = k.rank; A.world = k.world; A.seq = k.ar_seq; A.ticks = push_ticks(k);
         k_allreduce_direct<<<1, 1024, 0, c->stream>>>(nullptr, 0, nullptr, 0, c->slots, 48, tflags, 1, 0, A);
         rc = hipGetLastError() == hipSuccess ? PGD_OK : PGD_ERR_HIP;
+        double got = 0.0;
+        if (rc == PGD_OK) rc = pgd_slots_download(h, &got, 48, 1);
+        sums_ok = sums_ok && got == 0.5 * k.world * (k.world + 1.0) * (round + 1.0);
     }
     k.timeout_s = keep_timeout;
-    double got = 0.0;
     int tf[4] = {0, 0, 0, 0};
-    if (rc == PGD_OK) rc = pgd_slots_download(h, &got, 48, 1);
     if (rc == PGD_OK) rc = hipMemcpy(tf, tflags, sizeof tf, hipMemcpyDeviceToHost) == hipSuccess ? PGD_OK : PGD_ERR_HIP;
     (void)hipGetLastError();
-    const bool good = rc == PGD_OK && tf[0] == 0 && got == 0.5 * k.world * (k.world + 1.0);
+    const bool good = rc == PGD_OK && tf[0] == 0 && sums_ok;
     if (!good) {
         for (void *&m : k.ar_mapped) if (m) { (void)hipIpcCloseMemHandle(m); m = nullptr; }
         for (auto &q : k.ar_peer) q = nullptr;

@@ -126,7 +126,9 @@ class TorchComm:
     direct_halo = False
     direct_allreduce = False
 
-    def enable_direct_halo(self, n, own0, own1, lo_g, hi_g):
+    direct_probe = None
+
+    def enable_direct_halo(self, n, own0, own1, lo_g, hi_g, use=True):
         """Direct halo of the in-library loop (opt-in: PGD_HALO_DIRECT=1, or called by hand): the boundary planes of the search
         direction are stored straight into the neighbours' ghost planes through IPC-mapped pointers and the product waits for a
         posted sequence number - no send / receive kernel in the iteration (include/pgd_amd.h, pgd_comm_push_*).  Collective:
@@ -176,6 +178,17 @@ class TorchComm:
                     pass
                 LOG.warning("direct all-reduce not available on every rank (%s): the loop's sums stay with the binding", why or "another rank")
             self.direct_allreduce = ar_ok
+        # what the attach steps' checked exchanges (eight rounds each, every ghost entry compared) said on THIS hardware
+        self.direct_probe = {"direct_halo_passed_its_checks_on_every_rank": bool(self.direct_halo),
+                             "direct_allreduce_passed_its_checks_on_every_rank": bool(self.direct_allreduce)}
+        if not use:
+            # PROBE only (PGD_HALO_DIRECT=probe; bench.py at N > 1): the solves keep the binding's exchange and all-reduce
+            for switch in (be.comm_push, be.comm_allreduce_direct):
+                try:
+                    switch(0)
+                except Exception:           # noqa: BLE001
+                    pass
+            self.direct_halo = self.direct_allreduce = False
         return ok
 
     def _cb_halo(self, vec, own0, own1, lo_g, hi_g):
@@ -647,8 +660,8 @@ def sharded_box_mesh(comm, p0, p1, nx, ny, nz):
     own1 = own0 + (z1 - z0) * plane
     part = fem.Partition(comm, own0, own1, plane * (nz + 1), lo_g, hi_g, zf * plane)
     part.plane = plane                                         # vertices per z-plane (the slab V-cycle needs the lattice)
-    if os.environ.get("PGD_HALO_DIRECT", "0") == "1" and hasattr(comm, "enable_direct_halo") and getattr(comm.be, "name", "") == "hip":
-        comm.enable_direct_halo(own1 + hi_g, own0, own1, lo_g, hi_g)
+    if os.environ.get("PGD_HALO_DIRECT", "0") in ("1", "probe") and hasattr(comm, "enable_direct_halo") and getattr(comm.be, "name", "") == "hip":
+        comm.enable_direct_halo(own1 + hi_g, own0, own1, lo_g, hi_g, use=os.environ["PGD_HALO_DIRECT"] == "1")
     mesh = fem.Mesh(coords, cells, part)
     mesh._on_boundary = fem.box_hull_mask(nx, ny, nz, zf, zl)
     assert mesh.num_vertices() == own1 + hi_g

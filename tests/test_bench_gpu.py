@@ -107,8 +107,10 @@ def test_two_ranks_of_the_bench_on_one_gpu(extra):
     c = d["config"]
     assert c["parallelism"].endswith("x2") and c["pcg_iterations_per_step"] > 3
     if "--direct-halo" in extra:
-        assert all(c["direct_halo"].values()), c["direct_halo"]
+        assert all(v for k, v in c["direct_halo"].items() if k != "probe") and all(c["direct_halo"]["probe"].values()), c["direct_halo"]
     elif extra:
         assert c["sharded_v_cycle_solves"] > 0
     else:
         assert c["spectral_start"]["vectors"] > 0 and c["sharded_iteration_phases"]
+        # (without --direct-halo the direct paths are only probed: attached, checked, switched off)
+        assert all(c["direct_halo"]["probe"].values()) and not c["direct_halo"]["used_by_the_last_solve"], c["direct_halo"]
