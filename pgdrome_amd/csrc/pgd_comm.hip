@@ -674,12 +674,12 @@ int pgd_comm_push_attach(pgd_handle h, const uint8_t *lower, const uint8_t *uppe
     // acknowledgement: a neighbour fills its next pattern only after this rank has compared the current one.
     double *pv = get_vec(c, k.work[3])->d;
     const int64_t n = k.push_n;
+    int *tflags = nullptr;
+    PGD_TRY(ensure_work(c, 5, 16));              // (before anything is switched: an early return must leave the binding as it was)
+    tflags = reinterpret_cast<int *>(c->work[5]);
     k.push = true;
     const double keep_timeout = k.timeout_s;
     k.timeout_s = 2.0;
-    int *tflags = nullptr;
-    PGD_TRY(ensure_work(c, 5, 16));
-    tflags = reinterpret_cast<int *>(c->work[5]);
     (void)hipMemsetAsync(tflags, 0, 4 * sizeof(int), c->stream);
     int rc = PGD_OK;
     int tf[4] = {0, 0, 0, 0};
@@ -762,11 +762,11 @@ int pgd_comm_allreduce_attach(pgd_handle h, const uint8_t *blobs, int *state) {
         return PGD_OK;
     }
     // checked exchange: slots[48] = rank + 1 -> the sum over the ranks (a 2 s deadline: a rank that could not map posts nothing)
+    PGD_TRY(ensure_work(c, 5, 16));
+    int *tflags = reinterpret_cast<int *>(c->work[5]);
     k.ar = true;
     const double keep_timeout = k.timeout_s;
     k.timeout_s = 2.0;
-    PGD_TRY(ensure_work(c, 5, 16));
-    int *tflags = reinterpret_cast<int *>(c->work[5]);
     (void)hipMemsetAsync(tflags, 0, 4 * sizeof(int), c->stream);
     // (rounds with changing numbers, both parities of the mailbox several times: slot 48 = (rank + 1) (round + 1) -> its sum over the ranks)
     int rc = PGD_OK;
