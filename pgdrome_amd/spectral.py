@@ -42,6 +42,7 @@ STATS = {"harvests": 0, "harvest_seconds": 0.0, "corrections": 0, "dropped_reque
 _SPACES = {}      # (id(layout), Dirichlet signature) -> SpectralStart | None (None: asked for, not available)
 
 
+GS_PASSES = int(os.environ.get("PGD_SPECTRAL_GS_PASSES", "2"))            # re-orthogonalisation passes per Lanczos step of the harvest
 AUTO_K = 32                 # settings["spectral_start"] = "auto": this many vectors ...
 AUTO_AFTER = 48             # ... harvested when a space has seen this many large SPD solves (the harvest pays back after ~65 passes: short runs never pay)
 _AUTO_SOLVES = {}
@@ -219,7 +220,7 @@ def harvest(fem, A, b, k, steps=None):
         if j == 0 and info.get("method") != "mg_pcg" and not any_solver:
             raise _Unavailable("the multigrid preconditioner does not apply here (%s): a harvest through Jacobi-PCG solves would "
                                "cost %d cold solves; PGD_SPECTRAL_ANY_SOLVER=1 accepts that" % (info.get("method"), m))
-        for _ in range(2):                                 # classical Gram-Schmidt, twice: w -= Q (Q'w), eight vectors per pass
+        for _ in range(GS_PASSES):                         # classical Gram-Schmidt, twice: w -= Q (Q'w), eight vectors per pass
             h = _multidot(fem, lay, w, Q)
             out = fem.Vector(V)
             be.vec_lincomb(out.dev_for_write(), [w.dev()] + [q.dev() for q in Q], [1.0] + [-float(hj) for hj in h])
