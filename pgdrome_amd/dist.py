@@ -261,14 +261,14 @@ class TorchComm:
     def _halo_ops(self, mesh, t):
         part, P2P, d = mesh.part, self.dist.P2POp, self.dist
         ops = []
+        # (what goes down / up has the NEIGHBOUR's ghost size: the same as this rank's on P1 slabs, not on P2 ones - fem.Partition)
+        send_lo, send_hi = getattr(part, "send_lo", part.lo_ghost), getattr(part, "send_hi", part.hi_ghost)
         if part.lo_ghost:
-            g = part.lo_ghost
-            ops.append(P2P(d.isend, t[part.own0:part.own0 + g], self.rank - 1))
-            ops.append(P2P(d.irecv, t[0:g], self.rank - 1))
+            ops.append(P2P(d.isend, t[part.own0:part.own0 + send_lo], self.rank - 1))
+            ops.append(P2P(d.irecv, t[0:part.lo_ghost], self.rank - 1))
         if part.hi_ghost:
-            g = part.hi_ghost
-            ops.append(P2P(d.isend, t[part.own1 - g:part.own1], self.rank + 1))
-            ops.append(P2P(d.irecv, t[part.own1:part.own1 + g], self.rank + 1))
+            ops.append(P2P(d.isend, t[part.own1 - send_hi:part.own1], self.rank + 1))
+            ops.append(P2P(d.irecv, t[part.own1:part.own1 + part.hi_ghost], self.rank + 1))
         return ops
 
     def halo_exchange_raw(self, mesh, handle, cache_view=False):
@@ -578,7 +578,10 @@ class TorchComm:
         return iters, (float(np.sqrt(rr / bb)) if bb > 0 else 0.0)
 
     def pcg(self, mesh, op, b, x, rtol, atol, maxit):
-        if self.in_library:
+        # (a partition whose send sizes differ from its ghost sizes - P2 slabs - takes the loop below: its exchanges are sized per
+        # direction, and it multiplies only after the exchange; the same on every rank, the geometry being global knowledge)
+        symmetric = getattr(mesh.part, "symmetric", True)
+        if self.in_library and symmetric:
             part = mesh.part
             self._check_stream()
             try:
@@ -593,7 +596,7 @@ class TorchComm:
             x._host_ok = False
             x._halo_version = x.version      # the library returned x with current ghost planes
             return iters, rel
-        if self.single_reduction:
+        if self.single_reduction and symmetric:
             return self.pcg_single_reduction(mesh, op, b, x, rtol, atol, maxit)
         be, part = self.be, mesh.part
         self._check_stream()
@@ -664,6 +667,10 @@ def sharded_box_mesh(comm, p0, p1, nx, ny, nz):
         comm.enable_direct_halo(own1 + hi_g, own0, own1, lo_g, hi_g, use=os.environ["PGD_HALO_DIRECT"] == "1")
     mesh = fem.Mesh(coords, cells, part)
     mesh._on_boundary = fem.box_hull_mask(nx, ny, nz, zf, zl)
+    lo_c = np.array([p0.x(), p0.y(), p0.z()]) if hasattr(p0, "x") else np.asarray(p0, dtype=float)
+    hi_c = np.array([p1.x(), p1.y(), p1.z()]) if hasattr(p1, "x") else np.asarray(p1, dtype=float)
+    tol = 1e-9 * float(np.max(np.abs(hi_c - lo_c)))
+    mesh._hull_test = lambda X: np.any((np.abs(X - lo_c) <= tol) | (np.abs(X - hi_c) <= tol), axis=1)      # points on the hull of the WHOLE box
     assert mesh.num_vertices() == own1 + hi_g
     return mesh
 

@@ -101,11 +101,11 @@ def reaction_direct_param(n_x=33, n_e=17, e_range=(1.0, 20.0), PGD_nmax=4, PGD_t
 
 
 # ------------------------------------- configs 2 and 4: -Laplace(u) + mu u = 1, u(x; mu)
-def reaction_diffusion(space_mesh, n_mu=128, mu_range=(1.0, 10.0), PGD_nmax=10, PGD_tol=1e-8):
-    """Space (2-D or 3-D, P1) x 1-D parameter mu: atoms K_x (x) M_mu + M_x (x) Mw_mu, w = mu."""
+def reaction_diffusion(space_mesh, n_mu=128, mu_range=(1.0, 10.0), PGD_nmax=10, PGD_tol=1e-8, degree=1):
+    """Space (2-D or 3-D, P1 - or P2: `degree`) x 1-D parameter mu: atoms K_x (x) M_mu + M_x (x) Mw_mu, w = mu."""
     mu_mesh = fem.IntervalMesh(n_mu - 1, mu_range[0], mu_range[1])
     meshes = [space_mesh, mu_mesh]
-    Vs = [fem.FunctionSpace(m, "CG", 1) for m in meshes]
+    Vs = [fem.FunctionSpace(space_mesh, "CG", int(degree)), fem.FunctionSpace(mu_mesh, "CG", 1)]
     load = [[fem.interpolate(fem.Expression("1.0", degree=1), Vs[0])],
             [fem.interpolate(fem.Expression("1.0", degree=1), Vs[1])]]
     param = {"mu": fem.interpolate(fem.Expression("x[0]", degree=1), Vs[1])}
@@ -301,7 +301,7 @@ def convection_diffusion(space_mesh, n_k=9, n_w=9, beta=(12.0, -5.0, 3.0), k_ran
                 PGD_nmax=PGD_nmax, PGD_tol=PGD_tol)
 
 
-def elastic_block(space_mesh, n_e=9, e_range=(0.5, 2.0), nu=0.3, k_found=2.0, PGD_nmax=3, PGD_tol=1e-8):
+def elastic_block(space_mesh, n_e=9, e_range=(0.5, 2.0), nu=0.3, k_found=2.0, PGD_nmax=3, PGD_tol=1e-8, degree=1):
     """A 3-D block clamped at x = 0 on an elastic foundation under its own weight: VECTOR-valued P1 displacement u(X; e), Young's
     modulus factor e as the second PGD variable.   int eps(v) : (e C(nu)) eps(u) + k v . u dX = int g . v dX,  g = (0, 0, -1);
     u = sum_m U_m(X) W_m(e).
@@ -312,7 +312,7 @@ def elastic_block(space_mesh, n_e=9, e_range=(0.5, 2.0), nu=0.3, k_found=2.0, PG
                        [0, 0, 0, mu, 0, 0], [0, 0, 0, 0, mu, 0], [0, 0, 0, 0, 0, mu]])
     g = fem.Constant((0.0, 0.0, -1.0))
     meshes = [space_mesh, fem.IntervalMesh(n_e - 1, e_range[0], e_range[1])]
-    Vs = [fem.VectorFunctionSpace(meshes[0], "CG", 1), fem.FunctionSpace(meshes[1], "CG", 1)]
+    Vs = [fem.VectorFunctionSpace(meshes[0], "CG", int(degree)), fem.FunctionSpace(meshes[1], "CG", 1)]
     param = {"e": fem.interpolate(fem.Expression("x[0]", degree=1), Vs[1])}
 
     def strain(w):

@@ -444,7 +444,7 @@ def test_nonsymmetric_spatial_systems_on_a_sharded_mesh(world):
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-6 * np.linalg.norm(ref_x[m])
 
 
-def _vector_worker(rank, world, port, shape, q):
+def _vector_worker(rank, world, port, shape, q, degree=1):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -457,11 +457,13 @@ def _vector_worker(rank, world, port, shape, q):
         comm = pdist.TorchComm(dist, be, True)
         P = fem.Point
         mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(2, 1, 1), *shape)
-        p = PGDProblem(**problems.elastic_block(mesh, 7, PGD_nmax=3))
+        p = PGDProblem(**problems.elastic_block(mesh, 7, PGD_nmax=3, degree=degree))
         p.solve_PGD(_problem="linear", settings={"relative_tolerance": 1e-11})
-        V = p.V[0]
-        view = fem._block_layout(mesh, 1, 3).shard_view()
-        modes_x = [pdist.gather_owned(comm, view, f.vector()[:]) for f in p.PGD_func[0]]
+        if degree == 1:
+            view = fem._block_layout(mesh, 1, 3).shard_view()
+            modes_x = [pdist.gather_owned(comm, view, f.vector()[:]) for f in p.PGD_func[0]]
+        else:       # (P2: the slab numbers its nodes plane by plane - compare at the vertices)
+            modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values().reshape(3, -1).T.copy()).T.ravel() for f in p.PGD_func[0]]
         if rank == 0:
             q.put(dict(num_fp_it=p.num_fp_it, amplitude=p.amplitude, modes_x=modes_x, its=fem.STATS["pcg_iterations"], halo=comm.stats["halo"]))
     finally:
@@ -469,8 +471,8 @@ def _vector_worker(rank, world, port, shape, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_vector_valued_space_on_a_sharded_mesh(world):
+@pytest.mark.parametrize("world,degree", [(2, 1), (3, 1), (2, 2)])
+def test_vector_valued_space_on_a_sharded_mesh(world, degree):
     """A VECTOR-valued P1 space on the row-sharded box (problems.elastic_block: 3-D elasticity on a foundation x modulus factor): dof
     (node, component) = 3 node + component keeps every slab's dofs contiguous, the partition of the dofs is the partition of the nodes
     times three, and the sharded Jacobi-PCG, its halo exchanges and the all-reduced functionals run on it unchanged.  Must reproduce the
@@ -484,16 +486,16 @@ def test_vector_valued_space_on_a_sharded_mesh(world):
     fem.clear_caches()
     try:
         P = fem.Point
-        ref = PGDProblem(**problems.elastic_block(fem.BoxMesh(P(0, 0, 0), P(2, 1, 1), *shape), 7, PGD_nmax=3))
+        ref = PGDProblem(**problems.elastic_block(fem.BoxMesh(P(0, 0, 0), P(2, 1, 1), *shape), 7, PGD_nmax=3, degree=degree))
         ref.solve_PGD(_problem="linear", settings={"relative_tolerance": 1e-11})
-        ref_x = [f.vector()[:].copy() for f in ref.PGD_func[0]]
+        ref_x = [(f.vector()[:].copy() if degree == 1 else f.compute_vertex_values().copy()) for f in ref.PGD_func[0]]
     finally:
         fem.set_backend(old)
         fem.clear_caches()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_vector_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    procs = [ctx.Process(target=_vector_worker, args=(r, world, port, shape, q, degree)) for r in range(world)]
     for pr in procs:
         pr.start()
     out = q.get(timeout=600)
@@ -505,4 +507,67 @@ def test_vector_valued_space_on_a_sharded_mesh(world):
     np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-7)
     for m in range(ref.PGD_modes):
         assert out["modes_x"][m].shape == ref_x[m].shape
+        assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-6 * np.linalg.norm(ref_x[m])
+
+
+def _p2_worker(rank, world, port, shape, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.backend_numpy import NumpyBackend
+        from pgdrome_amd import dist as pdist, fem, problems
+        from pgdrome_amd.solver import PGDProblem
+        be = fem.set_backend(NumpyBackend())
+        comm = pdist.TorchComm(dist, be, True)
+        P = fem.Point
+        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+        p = PGDProblem(**problems.reaction_diffusion(mesh, 9, PGD_nmax=3, degree=2))
+        p.solve_PGD(_problem="linear", settings={"relative_tolerance": 1e-11})
+        lay = p.V[0].mesh().layout(2)
+        part = lay.part
+        modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values()) for f in p.PGD_func[0]]
+        if rank == 0:
+            q.put(dict(num_fp_it=p.num_fp_it, amplitude=p.amplitude, modes_x=modes_x, its=fem.STATS["pcg_iterations"],
+                       sizes=(part.lo_ghost, part.hi_ghost, part.send_lo, part.send_hi, lay.n), symmetric=part.symmetric))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_p2_on_a_sharded_mesh(world):
+    """P2 on the row-sharded box: nodes numbered plane by plane ([vertices | in-plane edge nodes | edge nodes up to the next plane]) so
+    that the halo is two contiguous ranges per neighbour - of DIFFERENT sizes per direction (Partition.send_lo / send_hi) - and the
+    loop driven from Python solves on it.  Must reproduce the unsharded P2 run (compared at the vertices)."""
+    from oracle.backend_numpy import NumpyBackend
+    from pgdrome_amd import fem, problems
+    from pgdrome_amd.solver import PGDProblem
+    shape = (4, 3, 7)
+    old = fem._backend
+    fem.set_backend(NumpyBackend())
+    fem.clear_caches()
+    try:
+        P = fem.Point
+        ref = PGDProblem(**problems.reaction_diffusion(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape), 9, PGD_nmax=3, degree=2))
+        ref.solve_PGD(_problem="linear", settings={"relative_tolerance": 1e-11})
+        ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
+    finally:
+        fem.set_backend(old)
+        fem.clear_caches()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_p2_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    out = q.get(timeout=600)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert out["its"] > 20 and not out["symmetric"] and out["sizes"][1] < out["sizes"][3]      # rank 0: sends a whole block up, receives less
+    assert out["num_fp_it"] == ref.num_fp_it
+    np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-7)
+    for m in range(ref.PGD_modes):
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-6 * np.linalg.norm(ref_x[m])
