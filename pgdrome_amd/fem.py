@@ -217,7 +217,13 @@ class Mesh:
                 for j in range(1, k - 1):
                     key = key * nv + loc[:, j]
                 uk, idx, cnt = np.unique(key, return_index=True, return_counts=True)
-                self._facets = (loc[idx], cnt == 1)
+                ext = cnt == 1
+                test = getattr(self, "_hull_test", None)
+                if self.part is not None and test is not None and ext.any():
+                    # a slab's cut planes are facets of one cell too: exterior is what lies on the hull of the WHOLE mesh (builder's test)
+                    fv = loc[idx]
+                    ext = ext & test(self._coords[fv].mean(axis=1))
+                self._facets = (loc[idx], ext)
         return self._facets
 
     def num_facets(self):
@@ -2973,12 +2979,21 @@ def _ds_scalar(term, lay, measure):
     test, coefs = _ds_split(term, lay)
     if test is not None:
         raise ValueError("scalar assemble of a form with arguments")
+    part = lay.part
     if len(coefs) == 0:
-        return term.coef * float(_boundary_load(lay.base if isinstance(lay, BlockLayout) else lay, measure).sum())
+        scalar = lay.base if isinstance(lay, BlockLayout) else lay
+        L0 = _boundary_load(scalar, measure)
+        if part is None:
+            return term.coef * float(L0.sum())
+        lo0, hi0 = scalar.owned_range()              # row-sharded: this rank's rows, summed over the ranks
+        return term.coef * part.comm.allreduce_sum(float(L0[lo0:hi0].sum()))
     if len(coefs) != 1:
         raise NotImplementedError("ds functional of a product of functions")
     c = coefs[0]
     f, L = _coef_vec(c.leaf, lay), _ds_load_vector(lay, measure, c.comp)
+    if part is not None:
+        lo, hi = lay.owned_range()
+        return term.coef * part.comm.allreduce_sum(get_backend().vec_dot(f.dev(), L.dev(), lo, hi))
     if f._small():
         return term.coef * float(f.host() @ L.host())
     return term.coef * get_backend().vec_dot(f.dev(), L.dev())

@@ -301,7 +301,7 @@ def convection_diffusion(space_mesh, n_k=9, n_w=9, beta=(12.0, -5.0, 3.0), k_ran
                 PGD_nmax=PGD_nmax, PGD_tol=PGD_tol)
 
 
-def elastic_block(space_mesh, n_e=9, e_range=(0.5, 2.0), nu=0.3, k_found=2.0, PGD_nmax=3, PGD_tol=1e-8, degree=1):
+def elastic_block(space_mesh, n_e=9, e_range=(0.5, 2.0), nu=0.3, k_found=2.0, PGD_nmax=3, PGD_tol=1e-8, degree=1, traction=None):
     """A 3-D block clamped at x = 0 on an elastic foundation under its own weight: VECTOR-valued P1 displacement u(X; e), Young's
     modulus factor e as the second PGD variable.   int eps(v) : (e C(nu)) eps(u) + k v . u dX = int g . v dX,  g = (0, 0, -1);
     u = sum_m U_m(X) W_m(e).
@@ -332,7 +332,10 @@ def elastic_block(space_mesh, n_e=9, e_range=(0.5, 2.0), nu=0.3, k_found=2.0, PG
 
     def load_form(j, b, meshes):
         if j == 0:
-            return fem.dot(g, b) * fem.dx(meshes[0])
+            l = fem.dot(g, b) * fem.dx(meshes[0])
+            if traction is not None:          # (a surface load on the whole boundary - exterior-facet integrals, `ds`)
+                l = l + fem.dot(fem.Constant(tuple(traction)), b) * fem.ds(meshes[0])
+            return l
         return b * fem.dx(meshes[1])
 
     def lhs_fct(u, v, Fs, meshes, dom, param, typ, dim):

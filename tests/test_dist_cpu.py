@@ -444,7 +444,7 @@ def test_nonsymmetric_spatial_systems_on_a_sharded_mesh(world):
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-6 * np.linalg.norm(ref_x[m])
 
 
-def _vector_worker(rank, world, port, shape, q, degree=1):
+def _vector_worker(rank, world, port, shape, q, degree=1, traction=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -457,7 +457,7 @@ def _vector_worker(rank, world, port, shape, q, degree=1):
         comm = pdist.TorchComm(dist, be, True)
         P = fem.Point
         mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(2, 1, 1), *shape)
-        p = PGDProblem(**problems.elastic_block(mesh, 7, PGD_nmax=3, degree=degree))
+        p = PGDProblem(**problems.elastic_block(mesh, 7, PGD_nmax=3, degree=degree, traction=traction))
         p.solve_PGD(_problem="linear", settings={"relative_tolerance": 1e-11})
         if degree == 1:
             view = fem._block_layout(mesh, 1, 3).shard_view()
@@ -471,8 +471,8 @@ def _vector_worker(rank, world, port, shape, q, degree=1):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,degree", [(2, 1), (3, 1), (2, 2)])
-def test_vector_valued_space_on_a_sharded_mesh(world, degree):
+@pytest.mark.parametrize("world,degree,traction", [(2, 1, None), (3, 1, None), (2, 2, None), (3, 1, (0.3, -0.2, 0.5))])
+def test_vector_valued_space_on_a_sharded_mesh(world, degree, traction):
     """A VECTOR-valued P1 space on the row-sharded box (problems.elastic_block: 3-D elasticity on a foundation x modulus factor): dof
     (node, component) = 3 node + component keeps every slab's dofs contiguous, the partition of the dofs is the partition of the nodes
     times three, and the sharded Jacobi-PCG, its halo exchanges and the all-reduced functionals run on it unchanged.  Must reproduce the
@@ -486,7 +486,8 @@ def test_vector_valued_space_on_a_sharded_mesh(world, degree):
     fem.clear_caches()
     try:
         P = fem.Point
-        ref = PGDProblem(**problems.elastic_block(fem.BoxMesh(P(0, 0, 0), P(2, 1, 1), *shape), 7, PGD_nmax=3, degree=degree))
+        # (traction: a surface load through `ds` - on a slab the exterior facets are those on the hull of the WHOLE box, not its cut planes)
+        ref = PGDProblem(**problems.elastic_block(fem.BoxMesh(P(0, 0, 0), P(2, 1, 1), *shape), 7, PGD_nmax=3, degree=degree, traction=traction))
         ref.solve_PGD(_problem="linear", settings={"relative_tolerance": 1e-11})
         ref_x = [(f.vector()[:].copy() if degree == 1 else f.compute_vertex_values().copy()) for f in ref.PGD_func[0]]
     finally:
@@ -495,7 +496,7 @@ def test_vector_valued_space_on_a_sharded_mesh(world, degree):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_vector_worker, args=(r, world, port, shape, q, degree)) for r in range(world)]
+    procs = [ctx.Process(target=_vector_worker, args=(r, world, port, shape, q, degree, traction)) for r in range(world)]
     for pr in procs:
         pr.start()
     out = q.get(timeout=600)
