@@ -288,7 +288,7 @@ int pgd_comm_allreduce_slots(pgd_handle ctx, int first_slot, int count);
  * checked exchange; *state = 1 if the direct halo is usable on this rank.  pgd_pcg_solve_sharded uses it when EVERY rank has it
  * for exactly that partition (its setup vote) and the single-sync recurrence runs; otherwise the binding's exchange.  A number that
  * does not arrive within pgd_comm_timeout ends the solve with PGD_ERR_TIMEOUT.  pgd_comm_push: mode 1 / 0 switch it on / off,
- * -1 reads the state, -2 what the last solve did. */
+ * -1 reads the state, -2 what the last solve did, 2 queues ONE exchange of the loop's search direction as it stands (probes: timing). */
 #define PGD_PUSH_BLOB_BYTES 256
 int pgd_comm_push_export(pgd_handle ctx, int64_t n, int64_t own0, int64_t own1, int64_t lo_ghost, int64_t hi_ghost,
                          uint8_t *blob /* PGD_PUSH_BLOB_BYTES */);
@@ -298,7 +298,8 @@ int pgd_comm_push(pgd_handle ctx, int mode, int *state);
  * order (world x PGD_PUSH_BLOB_BYTES, world <= 16).  Every rank maps every rank's flag block; in the loop ONE kernel forms the
  * iteration's local sums, stores them into all mailboxes, posts, waits for everybody's and adds the contributions in rank order
  * (the same bits on every rank): neither k_pcg1_sums nor an RCCL kernel is left in the iteration.  Collective, ends with a checked
- * exchange; used by a solve only if every rank voted for it.  pgd_comm_allreduce_direct: mode as pgd_comm_push. */
+ * exchange; used by a solve only if every rank voted for it.  pgd_comm_allreduce_direct: mode as pgd_comm_push (2: one direct
+ * all-reduce of slots 48 .. 52). */
 int pgd_comm_allreduce_attach(pgd_handle ctx, const uint8_t *all_blobs, int *state);
 int pgd_comm_allreduce_direct(pgd_handle ctx, int mode, int *state);
 /* Jacobi-PCG on the rows [own0, own1) of this rank's slab of A (replaces the KSP solve of

@@ -720,9 +720,15 @@ int pgd_comm_push_attach(pgd_handle h, const uint8_t *lower, const uint8_t *uppe
 int pgd_comm_push(pgd_handle h, int mode, int *state) {
     PGD_CTX(c, h);
     Comm &k = c->comm;
+    if (mode == 2) {          // probes: ONE exchange of the loop's search direction as it stands, queued on the stream (collective)
+        if (!k.push) return fail(c, PGD_ERR_INVALID, "comm_push: not attached");
+        PGD_TRY(comm_push_halo(c, get_vec(c, k.work[3])->d, nullptr));
+        if (state) *state = 1;
+        return PGD_OK;
+    }
     if (mode == 0) k.push = false;
     else if (mode == 1) k.push = k.push_peer[0] != nullptr || k.push_peer[1] != nullptr || (k.push_n > 0 && !k.push_lo_g && !k.push_hi_g && k.push_flags);
-    else if (mode != -1 && mode != -2) return fail(c, PGD_ERR_INVALID, "comm_push: mode must be 1, 0, -1 (read) or -2 (what the last solve did)");
+    else if (mode != -1 && mode != -2) return fail(c, PGD_ERR_INVALID, "comm_push: mode must be 2 (one exchange), 1, 0, -1 (read) or -2 (what the last solve did)");
     if (state) *state = mode == -2 ? (k.push_used ? 1 : 0) : (k.push ? 1 : 0);
     return PGD_OK;
 }
@@ -805,9 +811,23 @@ int pgd_comm_allreduce_attach(pgd_handle h, const uint8_t *blobs, int *state) {
 int pgd_comm_allreduce_direct(pgd_handle h, int mode, int *state) {
     PGD_CTX(c, h);
     Comm &k = c->comm;
+    if (mode == 2) {          // probes: ONE direct all-reduce of slots 48 .. 52, queued on the stream (collective)
+        if (!k.ar) return fail(c, PGD_ERR_INVALID, "comm_allreduce_direct: not attached");
+        PGD_TRY(ensure_work(c, 5, 16));
+        int *tflags = reinterpret_cast<int *>(c->work[5]);
+        PGD_HIP(c, hipMemsetAsync(tflags, 0, 4 * sizeof(int), c->stream));
+        k.ar_seq += 1;
+        ArArgs A;
+        for (int r = 0; r < PUSH_AR_MAXW; ++r) A.peer[r] = r < k.world ? k.ar_peer[r] : nullptr;
+        A.own = k.push_flags; A.rank = k.rank; A.world = k.world; A.seq = k.ar_seq; A.ticks = push_ticks(k);
+        k_allreduce_direct<<<1, 1024, 0, c->stream>>>(nullptr, 0, nullptr, 0, c->slots, 48, tflags, 1, 0, A);
+        PGD_LAUNCH_CHECK(c);
+        if (state) *state = 1;
+        return PGD_OK;
+    }
     if (mode == 0) k.ar = false;
     else if (mode == 1) k.ar = k.ar_peer[k.rank] != nullptr;
-    else if (mode != -1 && mode != -2) return fail(c, PGD_ERR_INVALID, "comm_allreduce_direct: mode must be 1, 0, -1 or -2");
+    else if (mode != -1 && mode != -2) return fail(c, PGD_ERR_INVALID, "comm_allreduce_direct: mode must be 2 (one all-reduce), 1, 0, -1 or -2");
     if (state) *state = mode == -2 ? (k.ar_used ? 1 : 0) : (k.ar ? 1 : 0);
     return PGD_OK;
 }

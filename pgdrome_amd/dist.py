@@ -181,6 +181,11 @@ class TorchComm:
         # what the attach steps' checked exchanges (eight rounds each, every ghost entry compared) said on THIS hardware
         self.direct_probe = {"direct_halo_passed_its_checks_on_every_rank": bool(self.direct_halo),
                              "direct_allreduce_passed_its_checks_on_every_rank": bool(self.direct_allreduce)}
+        # ... and what one exchange / one all-reduce of five numbers costs either way here: 50 back to back, one synchronisation
+        try:
+            self.direct_probe["microseconds"] = self._time_exchanges(n, own0, own1, lo_g, hi_g)
+        except Exception as e:              # noqa: BLE001 - a probe must not end the run
+            self.direct_probe["microseconds"] = {"error": str(e)[:200]}
         if not use:
             # PROBE only (PGD_HALO_DIRECT=probe; bench.py at N > 1): the solves keep the binding's exchange and all-reduce
             for switch in (be.comm_push, be.comm_allreduce_direct):
@@ -190,6 +195,34 @@ class TorchComm:
                     pass
             self.direct_halo = self.direct_allreduce = False
         return ok
+
+    def _time_exchanges(self, n, own0, own1, lo_g, hi_g, reps=50):
+        """Microseconds per halo exchange of one vector and per all-reduce of five scalars: through the binding (RCCL, or the
+        callbacks) and - where attached - through the direct paths.  Collective: every rank issues the same sequence."""
+        import time
+        be, out = self.be, {}
+        v = be.vec_zeros(n)
+
+        def timed(fn):
+            fn()
+            be.sync()
+            self.dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            be.sync()
+            return 1e6 * (time.perf_counter() - t0) / reps
+        try:
+            if self.in_library:
+                out["halo_through_the_binding"] = timed(lambda: be.comm_halo(v, own0, own1, lo_g, hi_g))
+                out["allreduce_through_the_binding"] = timed(lambda: be.comm_allreduce_slots(48, 5))
+            if self.direct_halo:
+                out["direct_halo"] = timed(lambda: be.comm_push(2))
+            if self.direct_allreduce:
+                out["direct_allreduce"] = timed(lambda: be.comm_allreduce_direct(2))
+        finally:
+            be.vec_free(v)
+        return out
 
     def _cb_halo(self, vec, own0, own1, lo_g, hi_g):
         from types import SimpleNamespace
