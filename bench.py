@@ -235,10 +235,7 @@ def main():
         from pgdrome_amd import dist as pdist
         if args.direct_halo:
             os.environ["PGD_HALO_DIRECT"] = "1"         # read by pdist.sharded_box_mesh
-        elif world > 1 and not args.no_direct_probe:
-            # the solves keep RCCL; the direct paths are attached, put through their checked exchanges on THIS hardware (a second or
-            # so, every wait bounded by a 2 s deadline) and switched off again: config.direct_halo.probe says what they found
-            os.environ["PGD_HALO_DIRECT"] = "probe"
+
         comm = pdist.TorchComm(dist, be, True if args.single_reduction else None, in_library=not args.python_driver)
         space = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), n - 1, n - 1, n - 1)
     else:
@@ -512,6 +509,11 @@ def main():
         plain = out["config"].get("without_spectral_start") or {}
         _note("cpu_baseline")
         out["cpu_baseline"] = cpu_baseline(prob, spec, be, plain.get("pcg_iterations_per_pass", pcg_its / K), args)
+    if sharded and world > 1 and not args.no_direct_probe and not args.direct_halo:
+        _note("probe of the direct halo / all-reduce (child processes)")
+        probe = direct_probe(args, comm, space, dist, rank, world, local_rank)
+        if rank == 0:
+            out["config"]["direct_halo"]["probe"] = probe
     _note("done")
     if rank == 0:
         sys.stdout.flush()
@@ -522,6 +524,35 @@ def main():
         if args.watchdog_seconds > 0:
             import faulthandler
             faulthandler.cancel_dump_traceback_later()
+
+
+def direct_probe(args, comm, space, dist, rank, world, local_rank):
+    """N > 1, the solves on RCCL: what would the direct halo / direct all-reduce (pgd_comm_push_*, pgd_comm_allreduce_*) do on THIS
+    hardware?  Their checked exchanges and a timing of 50 exchanges run in CHILD processes - one per rank, on the rank's GPU, a world of
+    their own over gloo (tools/probe_direct.py) - after the timed region, with a deadline: nothing they do can touch the measurement or
+    this process.  The same exchanges through the binding are timed here (they are what the solves have been doing all along).  Returns
+    what rank 0's child printed + the binding's microseconds; {"error": ...} if a child failed."""
+    import subprocess
+    part = space.part
+    n = space.num_vertices()
+    res = {}
+    try:
+        res["microseconds_through_the_binding"] = comm._time_exchanges(n, part.own0, part.own1, part.lo_ghost, part.hi_ghost)
+    except Exception as e:          # noqa: BLE001 - a probe never ends the run
+        res["microseconds_through_the_binding"] = {"error": repr(e)[:200]}
+    box = [_free_port() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "probe_direct.py")] + [str(int(t)) for t in (
+        rank, world, box[0], 0 if args.share_one_gpu else local_rank, n, part.own0, part.own1, part.lo_ghost, part.hi_ghost)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, timeout=150, env=_own_world_env(MASTER_PORT=str(box[0])), cwd=ROOT)
+        line = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+        if rank == 0:
+            res.update(json.loads(line[-1]) if (r.returncode == 0 and line) else
+                       {"error": "the probe's child ended with status %d: %s" % (r.returncode, r.stderr.decode()[-300:])})
+    except Exception as e:          # noqa: BLE001
+        res["error"] = repr(e)[:300]
+    return res
 
 
 def _own_world_env(**more):

@@ -128,7 +128,7 @@ class TorchComm:
 
     direct_probe = None
 
-    def enable_direct_halo(self, n, own0, own1, lo_g, hi_g, use=True):
+    def enable_direct_halo(self, n, own0, own1, lo_g, hi_g, use=True, time_binding=True):
         """Direct halo of the in-library loop (opt-in: PGD_HALO_DIRECT=1, or called by hand): the boundary planes of the search
         direction are stored straight into the neighbours' ghost planes through IPC-mapped pointers and the product waits for a
         posted sequence number - no send / receive kernel in the iteration (include/pgd_amd.h, pgd_comm_push_*).  Collective:
@@ -183,7 +183,7 @@ class TorchComm:
                              "direct_allreduce_passed_its_checks_on_every_rank": bool(self.direct_allreduce)}
         # ... and what one exchange / one all-reduce of five numbers costs either way here: 50 back to back, one synchronisation
         try:
-            self.direct_probe["microseconds"] = self._time_exchanges(n, own0, own1, lo_g, hi_g)
+            self.direct_probe["microseconds"] = self._time_exchanges(n, own0, own1, lo_g, hi_g, binding=time_binding)
         except Exception as e:              # noqa: BLE001 - a probe must not end the run
             self.direct_probe["microseconds"] = {"error": str(e)[:200]}
         if not use:
@@ -196,7 +196,7 @@ class TorchComm:
             self.direct_halo = self.direct_allreduce = False
         return ok
 
-    def _time_exchanges(self, n, own0, own1, lo_g, hi_g, reps=50):
+    def _time_exchanges(self, n, own0, own1, lo_g, hi_g, reps=50, binding=True):
         """Microseconds per halo exchange of one vector and per all-reduce of five scalars: through the binding (RCCL, or the
         callbacks) and - where attached - through the direct paths.  Collective: every rank issues the same sequence."""
         import time
@@ -213,7 +213,7 @@ class TorchComm:
             be.sync()
             return 1e6 * (time.perf_counter() - t0) / reps
         try:
-            if self.in_library:
+            if self.in_library and binding:
                 out["halo_through_the_binding"] = timed(lambda: be.comm_halo(v, own0, own1, lo_g, hi_g))
                 out["allreduce_through_the_binding"] = timed(lambda: be.comm_allreduce_slots(48, 5))
             if self.direct_halo:

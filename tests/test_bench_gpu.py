@@ -112,5 +112,8 @@ def test_two_ranks_of_the_bench_on_one_gpu(extra):
         assert c["sharded_v_cycle_solves"] > 0
     else:
         assert c["spectral_start"]["vectors"] > 0 and c["sharded_iteration_phases"]
-        # (without --direct-halo the direct paths are only probed: attached, checked, switched off)
-        assert all(c["direct_halo"]["probe"].values()) and not c["direct_halo"]["used_by_the_last_solve"], c["direct_halo"]
+        # (without --direct-halo the direct paths are only PROBED - in child processes, after the timed region)
+        pr = c["direct_halo"]["probe"]
+        assert "error" not in pr and pr["direct_halo_passed_its_checks_on_every_rank"] and pr["direct_allreduce_passed_its_checks_on_every_rank"], pr
+        assert pr["microseconds"]["direct_halo"] > 0 and pr["microseconds_through_the_binding"]["halo_through_the_binding"] > 0, pr
+        assert not c["direct_halo"]["used_by_the_last_solve"], c["direct_halo"]
