@@ -572,3 +572,67 @@ def test_p2_on_a_sharded_mesh(world):
     np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-7)
     for m in range(ref.PGD_modes):
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-6 * np.linalg.norm(ref_x[m])
+
+
+def _fourway_worker(rank, world, port, shape, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.backend_numpy import NumpyBackend
+        from pgdrome_amd import dist as pdist, fem, problems
+        from pgdrome_amd.solver import PGDProblem
+        be = fem.set_backend(NumpyBackend())
+        comm = pdist.TorchComm(dist, be, True)
+        P = fem.Point
+        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+        p = PGDProblem(**problems.transient_heat(mesh, 9, 5, PGD_nmax=4))
+        p.solve_PGD(_problem="linear", settings={"relative_tolerance": 1e-11})
+        modes_x = [pdist.gather_owned(comm, mesh, f.compute_vertex_values()) for f in p.PGD_func[0]]
+        others = [[np.asarray(f.vector()[:]).copy() for f in p.PGD_func[d]] for d in (1, 2, 3)]
+        if rank == 0:
+            q.put(dict(num_fp_it=p.num_fp_it, amplitude=p.amplitude, modes_x=modes_x, others=others, its=fem.STATS["pcg_iterations"]))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_four_way_separation_with_a_sharded_space(world):
+    """BASELINE config 5 in small: space x time x two parameters (problems.transient_heat with n_p: 4-way separated), the spatial
+    dimension row-sharded, the time dimension (non-symmetric, banded direct solve) and the parameters whole on every rank.  Must
+    reproduce the unsharded run: pass counts, amplitudes, the modes of all four dimensions."""
+    from oracle.backend_numpy import NumpyBackend
+    from pgdrome_amd import fem, problems
+    from pgdrome_amd.solver import PGDProblem
+    shape = (5, 4, 8)
+    old = fem._backend
+    fem.set_backend(NumpyBackend())
+    fem.clear_caches()
+    try:
+        P = fem.Point
+        ref = PGDProblem(**problems.transient_heat(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape), 9, 5, PGD_nmax=4))
+        ref.solve_PGD(_problem="linear", settings={"relative_tolerance": 1e-11})
+        ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
+        ref_others = [[np.asarray(f.vector()[:]).copy() for f in ref.PGD_func[d]] for d in (1, 2, 3)]
+    finally:
+        fem.set_backend(old)
+        fem.clear_caches()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fourway_worker, args=(r, world, port, shape, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    out = q.get(timeout=600)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert out["its"] > 20
+    assert out["num_fp_it"] == ref.num_fp_it
+    np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-7)
+    for m in range(ref.PGD_modes):
+        assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-6 * np.linalg.norm(ref_x[m])
+        for d in range(3):
+            assert np.linalg.norm(out["others"][d][m] - ref_others[d][m]) <= 1e-6 * np.linalg.norm(ref_others[d][m])
