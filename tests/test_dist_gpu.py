@@ -228,6 +228,8 @@ def _shared_gpu_worker(rank, world, port, shape, q, in_library, problem="reactio
             p = PGDProblem(**problems.convection_diffusion(mesh, 7, 6, PGD_nmax=3))
         elif problem == "elastic":
             p = PGDProblem(**problems.elastic_block(mesh, 7, PGD_nmax=3))
+        elif problem == "heat4":
+            p = PGDProblem(**problems.transient_heat(mesh, 9, 5, PGD_nmax=4))
         elif problem == "p2":
             p = PGDProblem(**problems.reaction_diffusion(mesh, 9, PGD_nmax=3, degree=2))
         else:
@@ -369,6 +371,37 @@ def test_sharded_solve_on_slabs_of_the_bench_plane():
     np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-8)
     for m in range(ref.PGD_modes):
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-7 * np.linalg.norm(ref_x[m])
+
+
+def test_four_way_separation_with_a_sharded_space_on_the_gpu():
+    """BASELINE config 5 in small with the HIP kernels: space x time x two parameters, the space row-sharded over two processes on GPU 0
+    (in-library loop), the other three dimensions whole on every rank.  Must reproduce the unsharded run."""
+    import torch.multiprocessing as mp
+    from pgdrome_amd import fem, problems
+    from pgdrome_amd.hip_backend import HipBackend
+    from pgdrome_amd.solver import PGDProblem
+    shape = (12, 10, 15)
+    old = fem._backend
+    fem.set_backend(HipBackend(0))
+    fem.clear_caches()
+    try:
+        P = fem.Point
+        ref = PGDProblem(**problems.transient_heat(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape), 9, 5, PGD_nmax=4))
+        ref.solve_PGD(_problem="linear")
+        ref_x = [f.compute_vertex_values() for f in ref.PGD_func[0]]
+    finally:
+        fem.set_backend(old)
+        fem.clear_caches()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_shared_gpu_worker, args=(r, 2, port, shape, q, True, "heat4")) for r in range(2)]
+    out = _collect(procs, q, 1, 600)[0]
+    assert out["pcg_iterations"] > 50
+    assert out["num_fp_it"] == ref.num_fp_it
+    np.testing.assert_allclose(out["amplitude"], ref.amplitude, rtol=1e-7)
+    for m in range(ref.PGD_modes):
+        assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-6 * np.linalg.norm(ref_x[m])
 
 
 def test_p2_on_a_sharded_mesh_on_the_gpu():
