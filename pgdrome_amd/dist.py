@@ -699,6 +699,7 @@ def sharded_box_mesh(comm, p0, p1, nx, ny, nz):
     if os.environ.get("PGD_HALO_DIRECT", "0") in ("1", "probe") and hasattr(comm, "enable_direct_halo") and getattr(comm.be, "name", "") == "hip":
         comm.enable_direct_halo(own1 + hi_g, own0, own1, lo_g, hi_g, use=os.environ["PGD_HALO_DIRECT"] == "1")
     mesh = fem.Mesh(coords, cells, part)
+    mesh._global_box = (p0, p1, nx, ny, nz)                    # what unshard() rebuilds the whole mesh from
     mesh._on_boundary = fem.box_hull_mask(nx, ny, nz, zf, zl)
     lo_c = np.array([p0.x(), p0.y(), p0.z()]) if hasattr(p0, "x") else np.asarray(p0, dtype=float)
     hi_c = np.array([p1.x(), p1.y(), p1.z()]) if hasattr(p1, "x") else np.asarray(p1, dtype=float)
@@ -718,3 +719,47 @@ def gather_owned(comm, mesh, local_values):
     out = [None] * comm.world
     dist.all_gather_object(out, mine)
     return np.concatenate(out)
+
+
+def unshard(problem, root=0):
+    """After solve_PGD with a row-sharded spatial mesh: on rank `root` the sharded dimension of `problem` is replaced by the WHOLE
+    mesh with the modes gathered from the ranks, so that everything downstream of the solve - return_PGD(), PGD.evaluate, the error
+    computation, the result files (pgdrome_amd/model.py, io.py: /root/reference/pgdrome/model.py:162-575, 724-953) - works as after a
+    one-process run.  Output only: the gathered modes live on the host / on root's GPU (0.13 GB per mode at 256^3).  P1 spaces, scalar
+    or vector-valued (a slab numbers its P2 nodes plane by plane: not gathered).  Collective; returns True on `root`, False elsewhere
+    (where the problem is left as it was)."""
+    done = False
+    for d, V in enumerate(problem.V):
+        mesh = V.mesh()
+        part = getattr(mesh, "part", None)
+        if part is None:
+            continue
+        if V.ufl_element().degree() != 1:
+            raise NotImplementedError("unshard: P2 on a sharded mesh is not gathered")
+        comm, nc = part.comm, int(getattr(V, "_ncomp", 1))
+        gathered = []
+        for f in problem.PGD_func[d]:
+            mine = np.ascontiguousarray(np.asarray(f.vector()[:])[nc * part.own0:nc * part.own1])
+            box = [None] * comm.world if comm.rank == root else None
+            comm.dist.gather_object(mine, box, dst=root)
+            gathered.append(np.concatenate(box) if comm.rank == root else None)
+        if comm.rank != root:
+            continue
+        p0, p1, nx, ny, nz = mesh._global_box
+        whole = fem.BoxMesh(p0, p1, nx, ny, nz)
+        gV = fem.VectorFunctionSpace(whole, "CG", 1, dim=nc) if nc > 1 else fem.FunctionSpace(whole, "CG", 1)
+        funcs = []
+        for old, values in zip(problem.PGD_func[d], gathered):
+            g = fem.Function(gV)
+            g.vector()[:] = values
+            if hasattr(old, "name") and callable(getattr(old, "rename", None)):
+                try:
+                    g.rename(old.name(), old.name())
+                except Exception:       # noqa: BLE001 - a label only
+                    pass
+            funcs.append(g)
+        problem.PGD_func[d] = funcs
+        problem.V[d] = gV
+        problem.meshes[d] = whole
+        done = True
+    return done

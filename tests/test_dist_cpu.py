@@ -636,3 +636,64 @@ def test_four_way_separation_with_a_sharded_space(world):
         assert np.linalg.norm(out["modes_x"][m] - ref_x[m]) <= 1e-6 * np.linalg.norm(ref_x[m])
         for d in range(3):
             assert np.linalg.norm(out["others"][d][m] - ref_others[d][m]) <= 1e-6 * np.linalg.norm(ref_others[d][m])
+
+
+def _unshard_worker(rank, world, port, shape, q, tmp):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle.backend_numpy import NumpyBackend
+        from pgdrome_amd import dist as pdist, fem
+        from pgdrome_amd.solver import PGDProblem
+        be = fem.set_backend(NumpyBackend())
+        comm = pdist.TorchComm(dist, be, True)
+        P = fem.Point
+        mesh = pdist.sharded_box_mesh(comm, P(0, 0, 0), P(1, 1, 1), *shape)
+        p = PGDProblem(**_problem(mesh))
+        p.solve_PGD(_problem="linear")
+        on_root = pdist.unshard(p)
+        assert on_root == (rank == 0)
+        if rank == 0:
+            sol = p.return_PGD()
+            u = sol.evaluate(0, [1], [4.2], 0)
+            path = os.path.join(tmp, "sharded_run")
+            os.makedirs(path, exist_ok=True)
+            sol.write_pxdmf(path)
+            q.put(dict(u=np.asarray(u.compute_vertex_values()), nv=p.meshes[0].num_vertices(), files=sorted(os.listdir(path))))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_results_of_a_sharded_run_on_the_whole_mesh(tmp_path):
+    """pdist.unshard: after a solve with a row-sharded space, rank 0 holds the problem on the WHOLE mesh - modes gathered - and what
+    comes after the solve in the reference (return_PGD, PGD.evaluate, the result files; model.py:162-575, 724-953) works unchanged."""
+    from oracle.backend_numpy import NumpyBackend
+    from pgdrome_amd import fem
+    from pgdrome_amd.solver import PGDProblem
+    shape = (5, 4, 8)
+    old = fem._backend
+    fem.set_backend(NumpyBackend())
+    fem.clear_caches()
+    try:
+        P = fem.Point
+        ref = PGDProblem(**_problem(fem.BoxMesh(P(0, 0, 0), P(1, 1, 1), *shape)))
+        ref.solve_PGD(_problem="linear")
+        u_ref = np.asarray(ref.return_PGD().evaluate(0, [1], [4.2], 0).compute_vertex_values())
+    finally:
+        fem.set_backend(old)
+        fem.clear_caches()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_unshard_worker, args=(r, 2, port, shape, q, str(tmp_path))) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    out = q.get(timeout=120)
+    for pr in procs:
+        pr.join(timeout=120)
+        assert pr.exitcode == 0
+    assert out["nv"] == u_ref.size and np.linalg.norm(out["u"] - u_ref) <= 1e-7 * np.linalg.norm(u_ref)
+    assert any(f.endswith(".pxdmf") for f in out["files"]) and any(f.endswith(".h5") for f in out["files"]), out["files"]
