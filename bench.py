@@ -509,7 +509,8 @@ def main():
         plain = out["config"].get("without_spectral_start") or {}
         _note("cpu_baseline")
         out["cpu_baseline"] = cpu_baseline(prob, spec, be, plain.get("pcg_iterations_per_pass", pcg_its / K), args)
-    if sharded and world > 1 and not args.no_direct_probe and not args.direct_halo:
+    # (a rehearsal with all ranks on ONE card: ranks + probe children must stay within the box's six processes per card)
+    if sharded and world > 1 and not args.no_direct_probe and not args.direct_halo and not (args.share_one_gpu and 2 * world > 6):
         _note("probe of the direct halo / all-reduce (child processes)")
         probe = direct_probe(args, comm, space, dist, rank, world, local_rank)
         if rank == 0:
