@@ -88,6 +88,7 @@ struct Mesh : Obj {
         uint8_t *codes = nullptr; int *same = nullptr; int *reps = nullptr; size_t bytes = 0;
         bool st_ok = false; int ident = -1, base = -1, zm0 = 0, zm1 = 0;
         uint8_t zero_pat[256];      // per class: bit s = slot s is an exact zero (a coupling to an eliminated node / the rim)
+        uint8_t in_range[256];      // per class: it occurs on the verified planes [z_lo, z_hi) (a slab's ghost rows carry classes of their own)
         uint64_t used = 0;
     };
     mutable std::vector<ClsCache> cls_cache;

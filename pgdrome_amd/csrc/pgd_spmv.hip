@@ -1902,12 +1902,14 @@ struct ZeroPat { uint8_t b[256]; };
 
 // the class-level relations of the stencil form for known codes: the identity tuple, and every class = the base tuple with
 // exact zeros where (and only where) the structure - verified row by row when the codes were first seen - has them
-__global__ void k_stencil_known(const double *__restrict__ table, int ncls, int ident, int base, ZeroPat pat, StencilInfo *S) {
+// (`use`: the classes that occur on the verified planes - the incomplete ghost rows of a sharded slab have tuples of their own, which
+// the full classification never holds against the stencil either: k_stencil_verify walks the verified planes only)
+__global__ void k_stencil_known(const double *__restrict__ table, int ncls, int ident, int base, ZeroPat pat, ZeroPat use, StencilInfo *S) {
     __shared__ int s_bad;
     if (threadIdx.x == 0) s_bad = 0;
     __syncthreads();
     const int k = threadIdx.x;
-    if (k < ncls) {
+    if (k < ncls && use.b[k]) {
         bool good = true;
         if (k == ident) {
             good = table[k * 8 + cls_pos(0)] == 1.0;
@@ -1990,7 +1992,9 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
             if (E.st_ok) {
                 ZeroPat zp;
                 memcpy(zp.b, E.zero_pat, sizeof zp.b);
-                k_stencil_known<<<1, 256, 0, st>>>(a->cls_table, E.ncls, E.ident, E.base, zp, SI);
+                ZeroPat use;
+                memcpy(use.b, E.in_range, sizeof use.b);
+                k_stencil_known<<<1, 256, 0, st>>>(a->cls_table, E.ncls, E.ident, E.base, zp, use, SI);
                 k_stencil_ghost_init<<<1, 1, 0, st>>>(SI, z_lo, z_hi, nzp, E.zm0, E.zm1);
                 if (z_lo > 0 || z_hi < nzp) k_stencil_ghost<<<(int)((plane + TPB - 1) / TPB), TPB, 0, st>>>(a->cls, a->cls_table, m->sym_nx, m->sym_ny, z_lo, z_hi, E.zm0, SI);
             }
@@ -1999,6 +2003,9 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
             if (E.st_ok) PGD_HIP(c, hipMemcpyAsync(&host.si, SI, sizeof(StencilInfo), hipMemcpyDeviceToHost, st));
             PGD_HIP(c, hipStreamSynchronize(st));
             PGD_LAUNCH_CHECK(c);
+            if (getenv("PGD_DEBUG_CLS"))
+                fprintf(stderr, "[dia_classify] known structure %zu of %zu: z %d..%d mismatches %d (info %d %d %d %d) stencil %d -> %d\n", e, m->cls_cache.size(),
+                        z_lo, z_hi, host.info[1], host.info[0], host.info[1], host.info[2], host.info[3], (int)E.st_ok, host.si.ok);
             if (host.info[1] != 0 || (E.st_ok && !host.si.ok)) {          // not that structure after all: forget it, classify in full
                 (void)hipFree(E.same);
                 m->cls_cache.erase(m->cls_cache.begin() + (long)e);
@@ -2080,6 +2087,15 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
             bool okc = hipMemcpyAsync(E.codes, a->cls, (size_t)m->nv, hipMemcpyDeviceToDevice, st) == hipSuccess &&
                        hipMemcpyAsync(E.same, a->cls_same, (size_t)nzp * sizeof(int), hipMemcpyDeviceToDevice, st) == hipSuccess &&
                        hipMemsetAsync(E.reps, 0x7f, reps_b, st) == hipSuccess;
+            int reps_rng[256];
+            if (okc) {
+                // (first the classes that occur on the verified planes - representatives within them, through the same kernel on
+                // that range - then the representatives of ALL classes, which is what the entry keeps)
+                const int64_t r0 = (int64_t)z_lo * plane, r1 = std::min<int64_t>((int64_t)z_hi * plane, m->nv);
+                if (r1 > r0) k_cls_reps<<<(int)((r1 - r0 + TPB - 1) / TPB), TPB, 0, st>>>(a->cls + r0, r1 - r0, E.reps);
+                okc = hipMemcpyAsync(reps_rng, E.reps, sizeof reps_rng, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                      hipStreamSynchronize(st) == hipSuccess && hipMemsetAsync(E.reps, 0x7f, reps_b, st) == hipSuccess;
+            }
             if (okc) {
                 k_cls_reps<<<g, TPB, 0, st>>>(a->cls, m->nv, E.reps);
                 okc = hipMemcpyAsync(tab, a->cls_table, (size_t)(ncls + 1) * 8 * sizeof(double), hipMemcpyDeviceToHost, st) == hipSuccess &&
@@ -2087,6 +2103,7 @@ int dia_classify(Ctx *c, const Mesh *m, Csr *a, int zrange_lo, int zrange_hi) {
             }
             if (okc) {
                 E.st_ok = a->st_ok; E.ident = a->st_ident; E.base = try_stencil ? host.si.base : -1; E.zm0 = a->st_zm0; E.zm1 = a->st_zm1;
+                for (int k = 0; k < 256; ++k) E.in_range[k] = (k < ncls && reps_rng[k] >= 0 && reps_rng[k] < 0x7f000000) ? 1 : 0;
                 for (int k = 0; k < 256; ++k) {
                     uint8_t b = 0;
                     if (k < ncls) for (int s2 = 1; s2 < 8; ++s2) if (tab[k * 8 + cls_pos(s2)] == 0.0) b |= (uint8_t)(1u << s2);
